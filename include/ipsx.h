@@ -1,0 +1,190 @@
+/*
+ * ipsx.h - C ABI of libipsx.so: the MI355X (gfx950) implementation of the
+ * Iterative-Patch-Selection no-grad hot path of benbergner/ips.
+ *
+ * Everything here is plain C: device pointers, sizes, an opaque stream handle
+ * (a hipStream_t passed as void*; NULL = the null stream).  No torch types.  All
+ * functions enqueue asynchronously on `stream`, never synchronise, never allocate
+ * device memory (workspaces are caller-owned) and return 0 on success or a
+ * negative IPSX_E* code; ipsx_last_error() gives the message for the calling
+ * thread.  Buffers are contiguous fp32 (int64 for indices) unless stated.
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the reference repo benbergner/ips).
+ *
+ * Arithmetic contract (restated on the CPU in oracle/ips_oracle.cpp):
+ *   - every contraction (convolution taps x channels, Linear rows, q.k, attn.v)
+ *     is ONE fp32 fused-multiply-add chain in ascending index order, which is
+ *     what v_mfma_f32_32x32x2_f32 computes bit for bit;
+ *   - convolution K order is tap-major: k = (ky*KW + kx)*C_in + c;
+ *   - eval BatchNorm is the affine y = fma(acc, alpha, shift) with
+ *     alpha = gamma * (1/sqrt(var+eps)), shift = beta - mean*alpha;
+ *   - exp() is ipsx's own fma polynomial (identical bits on host and device);
+ *   - row sums (softmax denominators, LayerNorm moments) are 64 strided partial
+ *     sums combined by an xor butterfly (the wavefront reduction order).
+ */
+#ifndef IPSX_H
+#define IPSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPSX_VERSION 100          /* 0.1.0 */
+
+#define IPSX_OK            0
+#define IPSX_EINVAL       -1      /* bad argument / unsupported shape */
+#define IPSX_EHIP         -2      /* HIP runtime error (launch failed ...) */
+#define IPSX_EWORKSPACE   -3      /* workspace too small */
+
+int ipsx_version(void);
+const char* ipsx_last_error(void);
+/* number of GPUs visible, and whether device `dev` is a gfx950 part (1/0) */
+int ipsx_device_count(void);
+int ipsx_device_is_gfx950(int dev);
+
+/* ------------------------------------------------------------------ encoder
+ * Replaces IPSNet.encoder as built by get_conv_patch_enc
+ * (architecture/ips_net.py:17-52; called at :209, :227, :273).            */
+
+/* elements of the packed form of an OIHW weight (C_out padded to 32, K to 8) */
+size_t ipsx_packed_conv_weight_elems(int c_out, int c_in, int kh, int kw);
+
+/* OIHW fp32 -> MFMA B-operand stream [C_out/32][K/8][64 lanes][4], tap-major K */
+int ipsx_pack_conv_weight(const float* w_oihw, int c_out, int c_in, int kh, int kw,
+                          float* packed, void* stream);
+
+/* eval-mode BatchNorm (nn.BatchNorm2d/1d with running stats) -> per-channel affine.
+ * lin_bias (or NULL): bias of a Linear feeding the BatchNorm, folded in as
+ * shift = fma(lin_bias, alpha, shift)                                        */
+int ipsx_bn_affine(const float* gamma, const float* beta, const float* mean,
+                   const float* var, const float* lin_bias, float eps, int c,
+                   float* alpha, float* shift, void* stream);
+
+typedef struct ipsx_conv {
+    int c_in, c_out, kh, kw, stride, pad;
+    const float* w_packed;        /* ipsx_pack_conv_weight output            */
+    const float* alpha;           /* c_out, BatchNorm scale (or NULL = 1)    */
+    const float* shift;           /* c_out, BatchNorm shift / bias (or NULL) */
+} ipsx_conv;
+
+/* one residual block: BasicBlock (n_conv = 2) or Bottleneck (n_conv = 3)     */
+typedef struct ipsx_block {
+    int n_conv;
+    ipsx_conv conv[3];
+    int has_down;                 /* 1x1 strided projection on the shortcut  */
+    ipsx_conv down;
+} ipsx_block;
+
+/* the nn.Sequential of ips_net.py:35-50: stem conv 7x7/2 + BN + ReLU,
+ * max-pool 3x3/2, residual blocks, global average pool                      */
+typedef struct ipsx_trunk {
+    int c_in, h, w;               /* patch shape (C, h, w)                    */
+    ipsx_conv stem;
+    int n_block;
+    const ipsx_block* blocks;     /* HOST array of n_block descriptors        */
+} ipsx_trunk;
+
+/* y = act(affine(conv(x)) [+ residual]); x (n,c_in,h,w), y (n,c_out,ho,wo) NCHW */
+int ipsx_conv2d_affine(const ipsx_conv* cv, const float* x, const float* residual,
+                       float* y, int64_t n, int h, int w, int relu, void* stream);
+/* nn.MaxPool2d(3, 2, 1) */
+int ipsx_maxpool_3x3s2(const float* x, float* y, int64_t n, int c, int h, int w, void* stream);
+/* nn.AdaptiveAvgPool2d(1): (n,c,hw) -> (n,c) */
+int ipsx_avgpool(const float* x, float* y, int64_t n, int c, int hw, void* stream);
+
+size_t ipsx_trunk_workspace_bytes(const ipsx_trunk* t, int64_t n_patch);
+/* patches (n_patch, c_in, h, w) -> emb (n_patch, D); picks the fused LDS-resident
+ * kernel when the trunk matches it, the layer-by-layer kernels otherwise       */
+int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n_patch,
+                      float* emb, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces IPSNet.encoder as built by get_projector (ips_net.py:54-60):
+ * ReLU(BN1d(Linear(LayerNorm_noaffine(x)))); x (n,f) -> out (n,d).
+ * `lin` is the Linear packed as a 1x1 conv (c_in=f, c_out=d) whose alpha/shift
+ * hold the BatchNorm affine with the Linear bias folded into shift
+ * (shift' = fma(bias, alpha, shift)).  workspace: n*f floats.                */
+int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps,
+                   float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------- scorer
+ * Replaces MultiHeadCrossAttention.get_attn + ScaledDotProductAttention.
+ * compute_attn + Transformer.get_scores (architecture/transformer.py:29-34,
+ * 71-83, 143-148) and IPSNet.score_and_select (ips_net.py:136-155).          */
+
+/* qs[t][o] = (sum_c q[t][c]*wq[o][c]) / temperature; q (T,D), wq (H*Dk,D)
+ * (transformer.py:76 and the division of :31)                               */
+int ipsx_query_proj(const float* q, const float* wq, float temperature,
+                    int n_token, int d, int hdk, float* qs, void* stream);
+
+/* per-patch attention logits, computed ONCE per patch:
+ *   x = emb[r] (+ pos[r]);  k = wk . x;  logits[r][h*T+t] = qs[t][h,:] . k[h,:]
+ * emb/pos/logits are (b, n, *) with explicit batch strides in ELEMENTS so that a
+ * column slice of a larger (b, N, *) buffer can be passed; pos_bstride = 0
+ * broadcasts one (n, d) table over the batch; pos may be NULL (use_pos false). */
+int ipsx_logits(const float* emb, int64_t emb_bstride,
+                const float* pos, int64_t pos_bstride,
+                const float* wk, const float* qs,
+                int b, int64_t n, int d, int h, int dk, int n_token,
+                float* logits, int64_t logits_bstride, void* stream);
+
+/* The chunk loop of IPSNet.ips (ips_net.py:213-241) on cached logits
+ * (b, n, h*T): memory = first m patches; for every chunk of `i` further
+ * patches: candidates = memory ++ chunk, per-(h,t) softmax over candidates,
+ * mean over h then t, keep top m (score descending, ties: earlier candidate
+ * position first).  One workgroup per image, one launch for the whole loop.
+ * mem_idx (b,m) int64 = selected patch indices in final score order;
+ * mem_score (b,m) or NULL; tie_flag (b) int32 or NULL: set when two candidates
+ * straddling a top-m boundary had bit-equal scores (the reference's own order is
+ * then implementation-defined, ips_net.py:199).                               */
+int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+              int64_t* mem_idx, float* mem_score, int32_t* tie_flag, void* stream);
+
+/* Transformer.get_scores on arbitrary embeddings x (b,l,d) -> scores (b,l);
+ * attn (b,h,T,l) optionally written too (get_attn).                          */
+int ipsx_scores(const float* x, const float* wk, const float* qs,
+                int b, int l, int d, int h, int dk, int n_token,
+                float* scores, float* attn, void* workspace, size_t workspace_bytes,
+                void* stream);
+size_t ipsx_scores_workspace_bytes(int b, int l, int h, int n_token);
+
+/* torch.topk(scores, m, dim=-1)[1] (ips_net.py:148): (b,l) -> (b,m) int64 */
+int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_idx,
+              int32_t* tie_flag, void* stream);
+
+/* ------------------------------------------------------------------- gather
+ * Replaces the torch.gather calls of ips_net.py:245-250: dst[b][j] = src[b][idx[b][j]]
+ * for rows of row_bytes bytes (multiple of 4).  src_bstride_rows = rows between
+ * batches of src (0 = one table shared by all batches).                       */
+int ipsx_gather_rows(const void* src, const int64_t* idx, void* dst,
+                     int b, int64_t n_rows, int m, int64_t row_bytes,
+                     int64_t src_bstride_rows, void* stream);
+
+/* --------------------------------------------------------------- aggregation
+ * Replaces Transformer.forward (transformer.py:85-109,122-132,150-152) and the
+ * task heads (ips_net.py:72-81,157-166) in eval / no-grad mode.               */
+typedef struct ipsx_transf {
+    int n_token, h, d, dk, dv, d_inner;
+    const float *q, *wq, *wk, *wv, *fc;          /* (T,D) (HDk,D) (HDk,D) (HDv,D) (D,HDv) */
+    const float *ln1_g, *ln1_b;                  /* LayerNorm after attention, eps 1e-6   */
+    const float *w1, *b1, *w2, *b2;              /* (Dinner,D) (Dinner) (D,Dinner) (D)    */
+    const float *ln2_g, *ln2_b;
+    float temperature, ln_eps;
+} ipsx_transf;
+
+size_t ipsx_aggregate_workspace_bytes(const ipsx_transf* t, int b, int m);
+/* x (b,m,d) -> out (b,T,d) */
+int ipsx_aggregate(const ipsx_transf* t, const float* x, int b, int m, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* out[b][c] = act(w[c,:] . emb[b][token,:] + bias[c]); act 0 = softmax, 1 = sigmoid */
+int ipsx_head(const float* emb, int b, int n_token, int d, int token,
+              const float* w, const float* bias, int n_class, int act,
+              float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPSX_H */

@@ -1,0 +1,254 @@
+"""IPSNet: patch encoder + Iterative Patch Selection + aggregation + task heads.
+
+Drop-in mirror of /root/reference/architecture/ips_net.py:11-283: same class
+name, ``IPSNet(device, conf)`` constructor, ``ips(patches) -> (mem_patch,
+mem_pos)`` and ``forward(mem_patch, mem_pos=None) -> {task: probs}`` signatures,
+same sub-module / parameter names (``encoder.N...``, ``transf...``,
+``output_layers.<task>.0``), so the reference's ``main.py`` and
+``training/iterative.py`` drive it unchanged and state-dicts interchange.
+
+What is different is how ``ips()`` executes on a ROCm device.  The reference
+runs a Python loop of ~75 stock kernels per chunk.  In eval / no-grad mode the
+encoder is a pure per-patch function (BatchNorm uses running statistics,
+reference :191-193) and a patch's attention logits do not depend on which other
+patches are in the candidate set (only the softmax denominator does), so the
+HIP path is three launches' worth of work:
+
+  1. ``encode``   every patch once (fused ResNet trunk / projector kernels),
+  2. ``logits``   K-projection and q.k per patch, once,
+  3. ``scan``     one persistent workgroup per image replays the reference's
+                  chunk loop on the cached logits: softmax over memory+chunk,
+                  mean over heads and tokens, top-M, repeat,
+
+followed by row gathers of the M winners.  Results are those of the reference
+loop: same candidate order (memory first, reference :231-232), same arithmetic
+order per patch.  ``last_mem_idx`` exposes the selected indices (the reference
+only returns the gathered patches).
+"""
+
+import math
+
+import torch
+from torch import nn
+
+from .. import hip
+from ..shuffle import shuffle_batch, shuffle_instance
+from .resnet import resnet18_trunk, resnet50_trunk
+from .transformer import Transformer, pos_enc_1d
+
+
+class IPSNet(nn.Module):
+    """Patch encoder, IPS, cross-attention aggregator and classification heads."""
+
+    # ---------------------------------------------------------------- construction
+    def get_conv_patch_enc(self, enc_type, pretrained, n_chan_in, n_res_blocks):
+        """ResNet stem + 2 or 4 residual stages + global average pool (reference :17-52)."""
+        if pretrained:
+            raise RuntimeError(
+                "pretrained=True needs torchvision's ImageNet checkpoint, which this offline "
+                "image cannot fetch; load it yourself with net.encoder.load_state_dict(...)")
+        if enc_type == 'resnet18':
+            trunk = resnet18_trunk()
+        elif enc_type == 'resnet50':
+            trunk = resnet50_trunk()
+        else:
+            raise ValueError("unknown enc_type {!r}".format(enc_type))
+        if n_chan_in == 1:
+            # the reference swaps the 3-channel stem for a fresh 1-channel one (:29-31)
+            trunk.conv1 = nn.Conv2d(n_chan_in, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        stages = [trunk.conv1, trunk.bn1, trunk.relu, trunk.maxpool, trunk.layer1, trunk.layer2]
+        if n_res_blocks == 4:
+            stages += [trunk.layer3, trunk.layer4]
+        stages.append(trunk.avgpool)
+        return nn.Sequential(*stages)
+
+    def get_projector(self, n_chan_in, D):
+        """LN(no affine) -> Linear -> BatchNorm1d -> ReLU for pre-extracted features (:54-60)."""
+        return nn.Sequential(
+            nn.LayerNorm(n_chan_in, eps=1e-05, elementwise_affine=False),
+            nn.Linear(n_chan_in, D),
+            nn.BatchNorm1d(D),
+            nn.ReLU(),
+        )
+
+    def get_output_layers(self, tasks):
+        """One ``Linear(D, n_class) -> softmax|sigmoid`` head per task (:62-83)."""
+        heads = nn.ModuleDict()
+        for task in tasks.values():
+            act = {'softmax': lambda: nn.Softmax(dim=-1), 'sigmoid': nn.Sigmoid}[task['act_fn']]()
+            heads[task['name']] = nn.Sequential(nn.Linear(self.D, self.n_class), act)
+        return heads
+
+    def __init__(self, device, conf):
+        super().__init__()
+        self.device = device
+        self.n_class = conf.n_class
+        self.M, self.I, self.D = conf.M, conf.I, conf.D
+        self.use_pos = conf.use_pos
+        self.tasks = conf.tasks
+        self.shuffle = conf.shuffle
+        self.shuffle_style = conf.shuffle_style
+        self.is_image = conf.is_image
+
+        if self.is_image:
+            self.encoder = self.get_conv_patch_enc(conf.enc_type, conf.pretrained,
+                                                   conf.n_chan_in, conf.n_res_blocks)
+        else:
+            self.encoder = self.get_projector(conf.n_chan_in, self.D)
+
+        self.transf = Transformer(conf.n_token, conf.H, conf.D, conf.D_k, conf.D_v,
+                                  conf.D_inner, conf.attn_dropout, conf.dropout)
+
+        # plain tensor attribute, not a buffer - exactly as the reference (:110-113)
+        self.pos_enc = pos_enc_1d(conf.D, conf.N).unsqueeze(0).to(device) if conf.use_pos else None
+
+        self.output_layers = self.get_output_layers(conf.tasks)
+
+        # additions that do not change the drop-in surface
+        self.last_mem_idx = None      # (B, M) int64 indices chosen by the last ips() call
+        self._plan = None             # packed-weight cache of the HIP encoder
+
+    # ---------------------------------------------------------------- small pieces
+    def do_shuffle(self, patches, pos_enc):
+        """Permute the patch axis (and pos_enc identically) to randomise ties (:118-134)."""
+        if self.shuffle_style == 'batch':
+            patches, perm = shuffle_batch(patches)
+            if torch.is_tensor(pos_enc):
+                pos_enc, _ = shuffle_batch(pos_enc, perm)
+        elif self.shuffle_style == 'instance':
+            patches, perm = shuffle_instance(patches, 1)
+            if torch.is_tensor(pos_enc):
+                pos_enc, _ = shuffle_instance(pos_enc, 1, perm)
+        return patches, pos_enc
+
+    def score_and_select(self, emb, emb_pos, M, idx):
+        """Score ``L`` candidates, keep the top ``M`` (:136-155).
+
+        Scores come from ``emb_pos`` when given, the gathered memory from ``emb``.
+        """
+        scored = emb_pos if torch.is_tensor(emb_pos) else emb
+        if hip.on_device(scored):
+            top = hip.topm(self.transf.get_scores(scored), M)
+        else:
+            top = torch.topk(self.transf.get_scores(scored), M, dim=-1)[1]
+        mem_emb = torch.gather(emb, 1, top.unsqueeze(-1).expand(-1, -1, emb.shape[2]))
+        return mem_emb, torch.gather(idx, 1, top)
+
+    def get_preds(self, embeddings):
+        """Task ``t`` reads aggregated token ``t_id`` (:157-166)."""
+        return {task['name']: self.output_layers[task['name']](embeddings[:, task['id']])
+                for task in self.tasks.values()}
+
+    def _embed(self, x):
+        """(P, C, h, w) | (P, F)  ->  (P, D) with the encoder's CURRENT mode."""
+        if hip.on_device(x) and not self.encoder.training and not (
+                torch.is_grad_enabled() and any(p.requires_grad for p in self.encoder.parameters())):
+            if self._plan is None:
+                self._plan = hip.EncoderPlan(self.encoder, self.is_image)
+            return self._plan.encode(x)
+        return self.encoder(x).flatten(1)
+
+    # ---------------------------------------------------------------- IPS
+    @torch.no_grad()
+    def ips(self, patches):
+        """Iterative Patch Selection (reference :169-262).
+
+        ``patches``: (B, N, C, h, w) images or (B, N, F) features, on the device
+        (eager loading) or on the host (lazy loading).  Returns the M selected
+        patches ``(B, M, ...)`` and their positional encodings ``(B, M, D)`` (or
+        ``None``), both on ``self.device``, ordered by score of the last round.
+        """
+        M, device, pos_enc = self.M, self.device, self.pos_enc
+        B, N = patches.shape[:2]
+
+        if M >= N:  # nothing to select (:185-188)
+            self.last_mem_idx = None
+            return patches.to(device), (pos_enc.expand(B, -1, -1) if self.use_pos else None)
+
+        was_training = self.training
+        if was_training:  # IPS always scores with running BN statistics and no dropout
+            self.encoder.eval()
+            self.transf.eval()
+        try:
+            if self.use_pos:
+                pos_enc = pos_enc.expand(B, -1, -1)
+            if self.shuffle:
+                patches, pos_enc = self.do_shuffle(patches, pos_enc)
+
+            if hip.on_device(device):
+                mem_idx = self._select_hip(patches, pos_enc)
+            else:
+                mem_idx = self._select_aten(patches, pos_enc)
+
+            mem_patch = self._take(patches, mem_idx).to(device)
+            mem_pos = self._take(pos_enc, mem_idx) if self.use_pos else None
+        finally:
+            if was_training:
+                self.encoder.train()
+                self.transf.train()
+
+        self.last_mem_idx = mem_idx
+        return mem_patch, mem_pos
+
+    def _chunks(self, N):
+        """[0, M) then ceil((N-M)/I) chunks of I (last one ragged) - reference :206,217-221."""
+        yield 0, self.M
+        for start in range(self.M, N, self.I):
+            yield start, min(start + self.I, N)
+
+    @staticmethod
+    def _take(src, idx):
+        """``src[b, idx[b, m]]`` on the device ``src`` lives on."""
+        if hip.on_device(src):
+            return hip.gather_rows(src, idx)
+        idx = idx.to(src.device)
+        view = idx.view(*idx.shape, *(1,) * (src.dim() - 2)).expand(-1, -1, *src.shape[2:])
+        return torch.gather(src.expand(idx.shape[0], *src.shape[1:]), 1, view)
+
+    def _select_hip(self, patches, pos_enc):
+        """encode-all -> logits -> one scan launch.  Patches may still be on the host."""
+        B, N = patches.shape[:2]
+        ca = self.transf.crs_attn
+        qs = ca.scaled_query()
+        n_ht = ca.H * ca.n_token
+        logits = torch.empty((B, N, n_ht), dtype=torch.float32, device=self.device)
+        lazy = not patches.is_cuda
+        # eager: one encoder pass over all B*N patches.  lazy: the reference's chunking
+        # bounds device memory, so keep it (H2D per chunk, reference :206,223).
+        spans = self._chunks(N) if lazy else [(0, N)]
+        for lo, hi in spans:
+            part = patches[:, lo:hi]
+            part = part.to(self.device, non_blocking=True) if lazy else part
+            emb = self._embed(part.reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
+            pos = pos_enc[:, lo:hi] if self.use_pos else None
+            hip.logits(emb, pos, ca.k_w.weight, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
+        return hip.scan(logits, self.M, self.I, ca.H, ca.n_token)
+
+    def _select_aten(self, patches, pos_enc):
+        """The reference's loop on stock ATen ops (CPU plumbing path)."""
+        B, N = patches.shape[:2]
+        D, device = self.D, self.device
+        order = torch.arange(N, dtype=torch.int64, device=device).unsqueeze(0).expand(B, -1)
+        mem_emb = mem_idx = None
+        for lo, hi in self._chunks(N):
+            part = patches[:, lo:hi].to(device)
+            emb = self._embed(part.reshape(-1, *patches.shape[2:])).view(B, hi - lo, D)
+            if mem_emb is None:
+                mem_emb, mem_idx = emb, order[:, lo:hi]
+                continue
+            cand_emb = torch.cat((mem_emb, emb), dim=1)          # memory first, chunk after
+            cand_idx = torch.cat((mem_idx, order[:, lo:hi]), dim=1)
+            cand_pos = None
+            if self.use_pos:
+                cand_pos = cand_emb + torch.gather(pos_enc, 1, cand_idx.unsqueeze(-1).expand(-1, -1, D))
+            mem_emb, mem_idx = self.score_and_select(cand_emb, cand_pos, self.M, cand_idx)
+        return mem_idx
+
+    # ---------------------------------------------------------------- aggregation
+    def forward(self, mem_patch, mem_pos=None):
+        """Embed the M selected patches, aggregate, classify (reference :264-283)."""
+        B, M = mem_patch.shape[:2]
+        mem_emb = self._embed(mem_patch.reshape(-1, *mem_patch.shape[2:])).view(B, M, -1)
+        if torch.is_tensor(mem_pos):
+            mem_emb = mem_emb + mem_pos
+        return self.get_preds(self.transf(mem_emb))

@@ -1,0 +1,166 @@
+"""Learned-query cross-attention: the IPS patch scorer and the patch aggregator.
+
+Drop-in mirror of /root/reference/architecture/transformer.py - same public
+names (``pos_enc_1d``, ``ScaledDotProductAttention``, ``MultiHeadCrossAttention``,
+``MLP``, ``Transformer``), constructor arguments, parameter names and shapes, so
+state-dicts interchange with the reference.
+
+Two execution paths live behind that interface:
+
+* tensors on a ROCm device, autograd off  ->  the hand-written gfx950 kernels in
+  ``ips_amd/csrc`` through the C ABI of ``include/ipsx.h`` (``ips_amd.hip``).
+  There is no fallback: if ``libipsx.so`` is missing the call raises.
+* everything else (CPU tensors, or autograd on for the training ``forward``)
+  ->  stock ATen ops, which is what the reference itself dispatches.
+"""
+
+import math
+
+import torch
+from torch import nn
+
+from .. import hip
+
+
+def pos_enc_1d(D, len_seq):
+    """Sinusoidal table ``(len_seq, D)``; reference transformer.py:6-18.
+
+    Built with the same ATen ops in the same order as the reference so the
+    table is bit-identical to it on CPU (it is data for the kernels, which
+    gather rows of it by patch index).
+    """
+    if D % 2:
+        raise ValueError("Cannot use sin/cos positional encoding with "
+                         "odd dim (got dim={:d})".format(D))
+    freq = torch.exp(torch.arange(0, D, 2, dtype=torch.float) * -(math.log(10000.0) / D))
+    phase = torch.arange(0, len_seq).unsqueeze(1).float() * freq
+    table = torch.zeros(len_seq, D)
+    table[:, 0::2] = torch.sin(phase)
+    table[:, 1::2] = torch.cos(phase)
+    return table
+
+
+def _use_hip(*tensors):
+    """HIP kernels run when data is on the GPU and no autograd graph is wanted."""
+    if not tensors[0].is_cuda:
+        return False
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors if t is not None):
+        return False
+    return hip.backend() == "hip"
+
+
+class ScaledDotProductAttention(nn.Module):
+    """softmax(q/temperature . k^T) [. v]; reference transformer.py:20-41."""
+
+    def __init__(self, temperature, attn_dropout=0.1):
+        super().__init__()
+        self.temperature = temperature
+        self.dropout = nn.Dropout(attn_dropout)
+
+    def compute_attn(self, q, k):
+        # the division is applied to q BEFORE the contraction (reference :31)
+        logits = torch.matmul(q / self.temperature, k.transpose(2, 3))
+        return self.dropout(torch.softmax(logits, dim=-1))
+
+    def forward(self, q, k, v):
+        return torch.matmul(self.compute_attn(q, k), v)
+
+
+class MultiHeadCrossAttention(nn.Module):
+    """``n_token`` learned queries attend over the patch embeddings.
+
+    Reference transformer.py:43-109.  Parameters: ``q`` (1, n_token, D) and
+    bias-free ``q_w``, ``k_w`` (H*D_k, D), ``v_w`` (H*D_v, D), ``fc`` (D, H*D_v),
+    ``layer_norm`` (eps 1e-6).
+    """
+
+    def __init__(self, n_token, H, D, D_k, D_v, attn_dropout=0.1, dropout=0.1):
+        super().__init__()
+        self.n_token, self.H, self.D_k, self.D_v = n_token, H, D_k, D_v
+
+        self.q = nn.Parameter(torch.empty((1, n_token, D)))
+        bound = math.sqrt(1 / D_k)
+        nn.init.uniform_(self.q, a=-bound, b=bound)
+
+        self.q_w = nn.Linear(D, H * D_k, bias=False)
+        self.k_w = nn.Linear(D, H * D_k, bias=False)
+        self.v_w = nn.Linear(D, H * D_v, bias=False)
+        self.fc = nn.Linear(H * D_v, D, bias=False)
+
+        self.attention = ScaledDotProductAttention(temperature=D_k ** 0.5, attn_dropout=attn_dropout)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(D, eps=1e-6)
+
+    def _heads(self, proj, x, width):
+        b, length = x.shape[:2]
+        return proj(x).view(b, length, self.H, width).transpose(1, 2)
+
+    def scaled_query(self):
+        """(n_token, H*D_k) query projection already divided by the temperature.
+
+        Constant for a whole ``ips()`` call; the HIP scan keeps it in LDS.
+        """
+        return hip.query_proj(self.q[0], self.q_w.weight, self.attention.temperature)
+
+    def get_attn(self, x):
+        """Attention map ``(B, H, n_token, L)`` of the queries over ``x`` (B, L, D)."""
+        if _use_hip(x, self.q, self.q_w.weight, self.k_w.weight) and not self._drops():
+            return hip.attn_map(x, self.scaled_query(), self.k_w.weight, self.H, self.D_k, self.n_token)
+        q = self._heads(self.q_w, self.q, self.D_k)
+        k = self._heads(self.k_w, x, self.D_k)
+        return self.attention.compute_attn(q, k)
+
+    def _drops(self):
+        return self.training and (self.dropout.p > 0 or self.attention.dropout.p > 0)
+
+    def forward(self, x):
+        b = x.shape[0]
+        q = self._heads(self.q_w, self.q, self.D_k)
+        k = self._heads(self.k_w, x, self.D_k)
+        v = self._heads(self.v_w, x, self.D_v)
+        ctx = self.attention(q, k, v)                        # (B, H, n_token, D_v)
+        ctx = ctx.transpose(1, 2).contiguous().view(b, self.n_token, -1)
+        out = self.dropout(self.fc(ctx))
+        out += self.q                                        # residual on the learned queries
+        return self.layer_norm(out)
+
+
+class MLP(nn.Module):
+    """D -> D_inner -> D feed-forward with residual + LayerNorm; reference :111-132."""
+
+    def __init__(self, D, D_inner, dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Linear(D, D_inner)
+        self.w_2 = nn.Linear(D_inner, D)
+        self.layer_norm = nn.LayerNorm(D, eps=1e-6)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        y = self.dropout(self.w_2(torch.relu(self.w_1(x))))
+        y += x
+        return self.layer_norm(y)
+
+
+class Transformer(nn.Module):
+    """Cross-attention block + MLP; reference transformer.py:134-152."""
+
+    def __init__(self, n_token, H, D, D_k, D_v, D_inner, attn_dropout=0.1, dropout=0.1):
+        super().__init__()
+        self.crs_attn = MultiHeadCrossAttention(n_token, H, D, D_k, D_v,
+                                                attn_dropout=attn_dropout, dropout=dropout)
+        self.mlp = MLP(D, D_inner, dropout=dropout)
+
+    def get_scores(self, x):
+        """Per-patch score ``(B, L)``: attention averaged over heads, then over tokens."""
+        ca = self.crs_attn
+        if _use_hip(x, ca.q, ca.q_w.weight, ca.k_w.weight) and not ca._drops():
+            return hip.scores(x, ca.scaled_query(), ca.k_w.weight, ca.H, ca.D_k, ca.n_token)
+        attn = ca.get_attn(x)
+        return attn.mean(dim=1).transpose(1, 2).mean(-1)
+
+    def forward(self, x):
+        """Aggregate ``x`` (B, M, D) into ``(B, n_token, D)``."""
+        ca = self.crs_attn
+        if _use_hip(x, *self.parameters()) and not self.training:
+            return hip.aggregate(self, x)
+        return self.mlp(self.crs_attn(x))

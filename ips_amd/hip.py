@@ -1,0 +1,390 @@
+"""ctypes binding of libipsx.so (include/ipsx.h) for torch tensors on a ROCm device.
+
+PyTorch is plumbing here: it owns device memory and the stream; every function
+below hands raw device pointers to the C ABI, which launches the hand-written
+gfx950 kernels of ips_amd/csrc on ``torch.cuda.current_stream()``.
+
+There is NO fallback in this module: if the shared library cannot be loaded, or a
+call returns an error code, a RuntimeError is raised.  ``IPSX_BACKEND=aten``
+(explicit opt-out, e.g. to time stock PyTorch-ROCm ops on the same GPU) makes
+``on_device`` report False so callers keep to ATen; the default is ``hip``.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "lib", "libipsx.so")
+_LIB = None
+
+f32p = C.c_void_p  # device pointers travel as integers
+
+
+def backend():
+    b = os.environ.get("IPSX_BACKEND", "hip").lower()
+    if b not in ("hip", "aten"):
+        raise ValueError("IPSX_BACKEND must be 'hip' or 'aten', got {!r}".format(b))
+    return b
+
+
+def on_device(x):
+    """True when ``x`` (tensor / device / str) is a GPU and the HIP backend is selected."""
+    if torch.is_tensor(x):
+        dev = x.device
+    else:
+        dev = torch.device(x)
+    return dev.type == "cuda" and backend() == "hip"
+
+
+# ------------------------------------------------------------------ C structs
+class Conv(C.Structure):
+    _fields_ = [("c_in", C.c_int), ("c_out", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("stride", C.c_int), ("pad", C.c_int),
+                ("w_packed", C.c_void_p), ("alpha", C.c_void_p), ("shift", C.c_void_p)]
+
+
+class Block(C.Structure):
+    _fields_ = [("n_conv", C.c_int), ("conv", Conv * 3), ("has_down", C.c_int), ("down", Conv)]
+
+
+class Trunk(C.Structure):
+    _fields_ = [("c_in", C.c_int), ("h", C.c_int), ("w", C.c_int), ("stem", Conv),
+                ("n_block", C.c_int), ("blocks", C.POINTER(Block))]
+
+
+class Transf(C.Structure):
+    _fields_ = [("n_token", C.c_int), ("h", C.c_int), ("d", C.c_int), ("dk", C.c_int),
+                ("dv", C.c_int), ("d_inner", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("q", "wq", "wk", "wv", "fc", "ln1_g", "ln1_b", "w1", "b1",
+                                          "w2", "b2", "ln2_g", "ln2_b")] + \
+               [("temperature", C.c_float), ("ln_eps", C.c_float)]
+
+
+_EXPORTS = {
+    # name: (restype, argtypes)
+    "ipsx_version": (C.c_int, []),
+    "ipsx_last_error": (C.c_char_p, []),
+    "ipsx_device_count": (C.c_int, []),
+    "ipsx_device_is_gfx950": (C.c_int, [C.c_int]),
+    "ipsx_packed_conv_weight_elems": (C.c_size_t, [C.c_int] * 4),
+    "ipsx_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_bn_affine": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_conv2d_affine": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_maxpool_3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_avgpool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_trunk_workspace_bytes": (C.c_size_t, [C.POINTER(Trunk), C.c_int64]),
+    "ipsx_trunk_encode": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
+    "ipsx_projector": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p]),
+    "ipsx_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                              C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_void_p, C.c_int64, C.c_void_p]),
+    "ipsx_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_scores_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "ipsx_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
+                    [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_topm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                   C.c_int64, C.c_int64, C.c_void_p]),
+    "ipsx_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(Transf), C.c_int, C.c_int]),
+    "ipsx_aggregate": (C.c_int, [C.POINTER(Transf), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                            C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+
+def library_path():
+    return _SO
+
+
+def build(verbose=False):
+    """Compile ips_amd/csrc for gfx950 into ips_amd/lib/libipsx.so (in-tree)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc")] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(
+                "libipsx.so not found at {} - build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C ips_amd/csrc`; the HIP backend has no fallback".format(_SO))
+        L = C.CDLL(_SO)
+        for name, (res, args) in _EXPORTS.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if L.ipsx_version() // 100 != 1:
+            raise RuntimeError("libipsx.so ABI version {} != 1.x".format(L.ipsx_version()))
+        _LIB = L
+    return _LIB
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise RuntimeError("{} failed ({}): {}".format(what, rc, lib().ipsx_last_error().decode()))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got {}".format(t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------ encoder plan
+def _bn_affine(bn, bias=None):
+    """Per-channel (alpha, shift) of an eval-mode BatchNorm, on the device."""
+    c = bn.num_features
+    out = torch.empty((2, c), dtype=torch.float32, device=bn.weight.device)
+    lin_bias = _f32(bias.detach()) if bias is not None else None
+    _ck(lib().ipsx_bn_affine(_p(_f32(bn.weight.detach())), _p(_f32(bn.bias.detach())),
+                             _p(_f32(bn.running_mean)), _p(_f32(bn.running_var)), _p(lin_bias),
+                             C.c_float(bn.eps), c, _p(out[0]), _p(out[1]), _stream()), "ipsx_bn_affine")
+    return out
+
+
+def _pack_conv(weight):
+    co, ci, kh, kw = weight.shape
+    n = lib().ipsx_packed_conv_weight_elems(co, ci, kh, kw)
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    _ck(lib().ipsx_pack_conv_weight(_p(_f32(weight.detach())), co, ci, kh, kw, _p(packed), _stream()),
+        "ipsx_pack_conv_weight")
+    return packed
+
+
+class EncoderPlan:
+    """Device-side description of ``IPSNet.encoder``: packed weights + BN affines.
+
+    Parameters change every optimiser step and BatchNorm running statistics move
+    in every training-mode forward, so the plan is keyed on the tensors'
+    ``_version`` counters / storage pointers and re-packed when any moved.
+    """
+
+    def __init__(self, encoder, is_image):
+        self.encoder, self.is_image = encoder, is_image
+        self._sig = None
+        self._keep = []
+        self._ws = None
+
+    def _signature(self):
+        sig = []
+        for t in list(self.encoder.parameters()) + list(self.encoder.buffers()):
+            sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
+
+    def _conv(self, conv, bn):
+        packed = _pack_conv(conv.weight)
+        aff = _bn_affine(bn)
+        self._keep += [packed, aff]
+        return Conv(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
+                    conv.stride[0], conv.padding[0], _p(packed), _p(aff[0]), _p(aff[1]))
+
+    def _rebuild(self):
+        self._keep = []
+        enc = self.encoder
+        if self.is_image:
+            mods = list(enc.children())
+            blocks = []
+            for stage in mods[4:-1]:
+                for blk in stage.children():
+                    b = Block()
+                    pairs = [(getattr(blk, "conv%d" % i), getattr(blk, "bn%d" % i))
+                             for i in (1, 2, 3) if hasattr(blk, "conv%d" % i)]
+                    b.n_conv = len(pairs)
+                    for j, (cv, bn) in enumerate(pairs):
+                        b.conv[j] = self._conv(cv, bn)
+                    b.has_down = int(blk.downsample is not None)
+                    if b.has_down:
+                        b.down = self._conv(blk.downsample[0], blk.downsample[1])
+                    blocks.append(b)
+            self._blocks = (Block * len(blocks))(*blocks)
+            t = Trunk()
+            t.stem = self._conv(mods[0], mods[1])
+            t.c_in = mods[0].in_channels
+            t.n_block = len(blocks)
+            t.blocks = C.cast(self._blocks, C.POINTER(Block))
+            self.trunk = t
+            self.d_out = blocks[-1].conv[blocks[-1].n_conv - 1].c_out
+        else:
+            ln, lin, bn = enc[0], enc[1], enc[2]
+            w = lin.weight.detach()
+            packed = _pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1))
+            aff = _bn_affine(bn, bias=lin.bias)
+            self._keep += [packed, aff]
+            self.lin = Conv(w.shape[1], w.shape[0], 1, 1, 1, 0, _p(packed), _p(aff[0]), _p(aff[1]))
+            self.ln_eps = float(ln.eps)
+            self.d_out = w.shape[0]
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def encode(self, x):
+        """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D)."""
+        sig = self._signature()
+        if sig != self._sig:
+            self._rebuild()
+            self._sig = sig
+        x = _f32(x)
+        n = x.shape[0]
+        out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
+        if n == 0:
+            return out
+        if self.is_image:
+            self.trunk.h, self.trunk.w = x.shape[2], x.shape[3]
+            if x.shape[1] != self.trunk.c_in:
+                raise ValueError("patches have {} channels, encoder expects {}".format(x.shape[1], self.trunk.c_in))
+            nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), n)
+            ws = self._workspace(nb, x.device)
+            _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()),
+                "ipsx_trunk_encode")
+        else:
+            nb = n * x.shape[1] * 4
+            ws = self._workspace(nb, x.device)
+            _ck(lib().ipsx_projector(C.byref(self.lin), _p(x), n, C.c_float(self.ln_eps), _p(out),
+                                     _p(ws), nb, _stream()), "ipsx_projector")
+        return out
+
+
+# ------------------------------------------------------------------ scorer
+def query_proj(q, wq, temperature):
+    """(T, D) queries, (H*Dk, D) weight -> (T, H*Dk) = (q @ wq.T) / temperature."""
+    q, wq = _f32(q.detach()), _f32(wq.detach())
+    out = torch.empty((q.shape[0], wq.shape[0]), dtype=torch.float32, device=q.device)
+    _ck(lib().ipsx_query_proj(_p(q), _p(wq), C.c_float(temperature), q.shape[0], q.shape[1],
+                              wq.shape[0], _p(out), _stream()), "ipsx_query_proj")
+    return out
+
+
+def logits(emb, pos, wk, qs, H, Dk, T, out=None):
+    """Per-patch attention logits (B, n, H*T); ``out`` may be a column slice of (B, N, H*T)."""
+    B, n, D = emb.shape
+    emb = _f32(emb)
+    wk = _f32(wk.detach())
+    if out is None:
+        out = torch.empty((B, n, H * T), dtype=torch.float32, device=emb.device)
+    if out.stride(2) != 1 or out.stride(1) != H * T:
+        raise ValueError("logits output must be row-contiguous")
+    pos_bs = 0
+    if pos is not None:
+        if pos.stride(2) != 1 or pos.stride(1) != D:
+            pos = pos.contiguous()
+        pos_bs = pos.stride(0) if pos.shape[0] > 1 else 0
+    _ck(lib().ipsx_logits(_p(emb), n * D, _p(pos), pos_bs, _p(wk), _p(qs), B, n, D, H, Dk, T,
+                          _p(out), out.stride(0), _stream()), "ipsx_logits")
+    return out
+
+
+def scan(lg, M, I, H, T, want_scores=False):
+    """The IPS chunk loop on cached logits (B, N, H*T) -> mem_idx (B, M) int64."""
+    lg = _f32(lg)
+    B, N = lg.shape[:2]
+    mem_idx = torch.empty((B, M), dtype=torch.int64, device=lg.device)
+    sc = torch.empty((B, M), dtype=torch.float32, device=lg.device) if want_scores else None
+    tie = torch.zeros((B,), dtype=torch.int32, device=lg.device)
+    _ck(lib().ipsx_scan(_p(lg), B, N, M, I, H, T, _p(mem_idx), _p(sc), _p(tie), _stream()), "ipsx_scan")
+    scan.last_tie = tie
+    return (mem_idx, sc) if want_scores else mem_idx
+
+
+def _scores_impl(x, qs, wk, H, Dk, T, want_attn):
+    x = _f32(x)
+    B, L, D = x.shape
+    sc = torch.empty((B, L), dtype=torch.float32, device=x.device)
+    attn = torch.empty((B, H, T, L), dtype=torch.float32, device=x.device) if want_attn else None
+    nb = lib().ipsx_scores_workspace_bytes(B, L, H, T)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
+    _ck(lib().ipsx_scores(_p(x), _p(_f32(wk.detach())), _p(qs), B, L, D, H, Dk, T, _p(sc), _p(attn),
+                          _p(ws), nb, _stream()), "ipsx_scores")
+    return sc, attn
+
+
+def scores(x, qs, wk, H, Dk, T):
+    return _scores_impl(x, qs, wk, H, Dk, T, False)[0]
+
+
+def attn_map(x, qs, wk, H, Dk, T):
+    return _scores_impl(x, qs, wk, H, Dk, T, True)[1]
+
+
+def topm(sc, M):
+    sc = _f32(sc)
+    B, L = sc.shape
+    top = torch.empty((B, M), dtype=torch.int64, device=sc.device)
+    tie = torch.zeros((B,), dtype=torch.int32, device=sc.device)
+    _ck(lib().ipsx_topm(_p(sc), B, L, M, _p(top), _p(tie), _stream()), "ipsx_topm")
+    return top
+
+
+def gather_rows(src, idx):
+    """src (B|1, N, ...) on the GPU, idx (B, M) int64 -> (B, M, ...)."""
+    B, M = idx.shape
+    if src.stride(0) == 0 and src.shape[0] > 1:      # expanded broadcast table
+        src = src[:1]
+    src = src if src.is_contiguous() else src.contiguous()
+    idx = idx if idx.is_contiguous() else idx.contiguous()
+    N = src.shape[1]
+    row_bytes = src[0, 0].numel() * src.element_size()
+    if row_bytes % 4:
+        raise ValueError("row size must be a multiple of 4 bytes")
+    out = torch.empty((B, M) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    bstride = N if src.shape[0] > 1 else 0
+    _ck(lib().ipsx_gather_rows(_p(src), _p(idx), _p(out), B, N, M, row_bytes, bstride, _stream()),
+        "ipsx_gather_rows")
+    return out
+
+
+# ------------------------------------------------------------------ aggregation
+def aggregate(transf, x):
+    """Transformer.forward in eval / no-grad mode: x (B, M, D) -> (B, n_token, D)."""
+    ca, mlp = transf.crs_attn, transf.mlp
+    x = _f32(x)
+    B, M, D = x.shape
+    t = Transf()
+    t.n_token, t.h, t.d, t.dk, t.dv, t.d_inner = ca.n_token, ca.H, D, ca.D_k, ca.D_v, mlp.w_1.out_features
+    keep = []
+    for name, src in (("q", ca.q[0]), ("wq", ca.q_w.weight), ("wk", ca.k_w.weight), ("wv", ca.v_w.weight),
+                      ("fc", ca.fc.weight), ("ln1_g", ca.layer_norm.weight), ("ln1_b", ca.layer_norm.bias),
+                      ("w1", mlp.w_1.weight), ("b1", mlp.w_1.bias), ("w2", mlp.w_2.weight),
+                      ("b2", mlp.w_2.bias), ("ln2_g", mlp.layer_norm.weight), ("ln2_b", mlp.layer_norm.bias)):
+        s = _f32(src.detach())
+        keep.append(s)
+        setattr(t, name, s.data_ptr())
+    t.temperature = float(ca.attention.temperature)
+    t.ln_eps = float(ca.layer_norm.eps)
+    out = torch.empty((B, ca.n_token, D), dtype=torch.float32, device=x.device)
+    nb = lib().ipsx_aggregate_workspace_bytes(C.byref(t), B, M)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
+    _ck(lib().ipsx_aggregate(C.byref(t), _p(x), B, M, _p(out), _p(ws), nb, _stream()), "ipsx_aggregate")
+    return out
+
+
+def head(emb, token, linear, act):
+    """act(Linear(emb[:, token])) with act in {'softmax', 'sigmoid'}: (B, T, D) -> (B, n_class)."""
+    emb = _f32(emb)
+    B, T, D = emb.shape
+    w, b = _f32(linear.weight.detach()), _f32(linear.bias.detach())
+    out = torch.empty((B, w.shape[0]), dtype=torch.float32, device=emb.device)
+    _ck(lib().ipsx_head(_p(emb), B, T, D, token, _p(w), _p(b), w.shape[0],
+                        {"softmax": 0, "sigmoid": 1}[act], _p(out), _stream()), "ipsx_head")
+    return out
