@@ -124,10 +124,11 @@ int ipsx_query_proj(const float* q, const float* wq, float temperature,
  *   x = emb[r] (+ pos[r]);  k = wk . x;  logits[r][h*T+t] = qs[t][h,:] . k[h,:]
  * emb/pos/logits are (b, n, *) with explicit batch strides in ELEMENTS so that a
  * column slice of a larger (b, N, *) buffer can be passed; pos_bstride = 0
- * broadcasts one (n, d) table over the batch; pos may be NULL (use_pos false). */
+ * broadcasts one (n, d) table over the batch; pos may be NULL (use_pos false).
+ * wk_packed = ipsx_pack_conv_weight of k_w.weight viewed as (H*Dk, D, 1, 1).    */
 int ipsx_logits(const float* emb, int64_t emb_bstride,
                 const float* pos, int64_t pos_bstride,
-                const float* wk, const float* qs,
+                const float* wk_packed, const float* qs,
                 int b, int64_t n, int d, int h, int dk, int n_token,
                 float* logits, int64_t logits_bstride, void* stream);
 
@@ -145,7 +146,7 @@ int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_
 
 /* Transformer.get_scores on arbitrary embeddings x (b,l,d) -> scores (b,l);
  * attn (b,h,T,l) optionally written too (get_attn).                          */
-int ipsx_scores(const float* x, const float* wk, const float* qs,
+int ipsx_scores(const float* x, const float* wk_packed, const float* qs,
                 int b, int l, int d, int h, int dk, int n_token,
                 float* scores, float* attn, void* workspace, size_t workspace_bytes,
                 void* stream);

@@ -136,8 +136,17 @@ class IPSNet(nn.Module):
 
     def get_preds(self, embeddings):
         """Task ``t`` reads aggregated token ``t_id`` (:157-166)."""
-        return {task['name']: self.output_layers[task['name']](embeddings[:, task['id']])
-                for task in self.tasks.values()}
+        fused = hip.on_device(embeddings) and not (
+            torch.is_grad_enabled() and (embeddings.requires_grad or
+                                         any(p.requires_grad for p in self.output_layers.parameters())))
+        preds = {}
+        for task in self.tasks.values():
+            layer = self.output_layers[task['name']]
+            if fused:   # Linear + softmax|sigmoid in one kernel
+                preds[task['name']] = hip.head(embeddings, task['id'], layer[0], task['act_fn'])
+            else:
+                preds[task['name']] = layer(embeddings[:, task['id']])
+        return preds
 
     def _embed(self, x):
         """(P, C, h, w) | (P, F)  ->  (P, D) with the encoder's CURRENT mode."""
@@ -210,6 +219,7 @@ class IPSNet(nn.Module):
         B, N = patches.shape[:2]
         ca = self.transf.crs_attn
         qs = ca.scaled_query()
+        wk = hip.pack_linear(ca.k_w.weight)
         n_ht = ca.H * ca.n_token
         logits = torch.empty((B, N, n_ht), dtype=torch.float32, device=self.device)
         lazy = not patches.is_cuda
@@ -221,7 +231,7 @@ class IPSNet(nn.Module):
             part = part.to(self.device, non_blocking=True) if lazy else part
             emb = self._embed(part.reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
-            hip.logits(emb, pos, ca.k_w.weight, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
+            hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
         return hip.scan(logits, self.M, self.I, ca.H, ca.n_token)
 
     def _select_aten(self, patches, pos_enc):

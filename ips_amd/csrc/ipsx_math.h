@@ -1,0 +1,88 @@
+// ipsx_math.h - device arithmetic shared by every kernel of libipsx.
+//
+// The sequences here are the "arithmetic contract" of include/ipsx.h and are
+// restated operation for operation in oracle/ips_oracle.cpp (det_expf, wave_sum64,
+// rank_key).  Every operation is an exactly rounded IEEE fp32 operation, the
+// library is compiled with -ffp-contract=off and without fast-math, so host and
+// device produce identical bits.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IPSX_WAVE 64
+
+namespace ipsx {
+
+__device__ __forceinline__ float as_float(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t as_u32(float f) { return __float_as_uint(f); }
+
+// exp(): Cody-Waite reduction by ln2 = C1 + C2, degree-5 Horner polynomial,
+// exponent rebuilt from bits (two-step scaling in the subnormal range).
+__device__ __forceinline__ float det_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72f) return __builtin_huge_valf();
+    if (x < -104.0f) return 0.0f;
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r);
+    y = y + 1.0f;
+    int ni = (int)n;
+    if (ni < -126) {
+        y = y * as_float((uint32_t)(ni + 127 + 64) << 23);
+        return y * 5.42101086242752217e-20f;  // 2^-64
+    }
+    if (ni > 127) {
+        y = y * as_float((uint32_t)(ni + 126) << 23);
+        return y * 2.0f;
+    }
+    return y * as_float((uint32_t)(ni + 127) << 23);
+}
+
+// xor-butterfly sum over the 64 lanes, offsets 32,16,...,1: every lane ends with
+// the same total (the second half of wave_sum64 of the oracle).
+__device__ __forceinline__ float wave_butterfly_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+// max over the wave with the oracle's NaN rule (a NaN wins)
+__device__ __forceinline__ float nanmax(float a, float b) { return (b > a || b != b) ? b : a; }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = nanmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ranking key: score descending, NaN first, -0 == +0, ties -> earlier position
+__device__ __forceinline__ uint64_t rank_key(float s, uint32_t pos) {
+    uint32_t u;
+    if (s != s) {
+        u = 0xFFFFFFFFu;
+    } else {
+        s = s + 0.0f;
+        u = as_u32(s);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - pos);
+}
+
+__device__ __forceinline__ uint32_t key_pos(uint64_t key) { return 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull); }
+
+__device__ __forceinline__ float key_score(uint64_t key) {
+    uint32_t u = (uint32_t)(key >> 32);
+    if (u == 0xFFFFFFFFu) return as_float(0x7FC00000u);
+    return as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+}  // namespace ipsx

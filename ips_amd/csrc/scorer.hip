@@ -1,0 +1,420 @@
+// scorer.hip - the cross-attention patch scorer and the IPS selection loop.
+//
+// Reference: MultiHeadCrossAttention.get_attn (architecture/transformer.py:71-83),
+// ScaledDotProductAttention.compute_attn (:29-34), Transformer.get_scores (:143-148),
+// IPSNet.score_and_select (architecture/ips_net.py:136-155) and the chunk loop of
+// IPSNet.ips (:213-241).
+//
+// A patch's logits  l[h,t] = (q_w q)[t,h,:]/sqrt(Dk) . (k_w (emb+pos))[h,:]  depend on
+// that patch alone; only the softmax denominator depends on the candidate set.  So
+//   logits_kernel  computes them once per patch (K projection on the fp32 matrix
+//                  cores, q.k reduction from LDS), and
+//   scan_kernel    replays the reference loop on those cached logits with ONE
+//                  persistent workgroup per image: stage the candidates' logits in
+//                  LDS, per-(h,t) softmax statistics by wavefront reductions, mean over
+//                  heads then tokens, rank, keep the top M - no host round trips.
+// Arithmetic order is the oracle's (oracle/ips_oracle.cpp orc_logits,
+// orc_scores_from_logits, orc_topm).
+//
+// Algorithmic bytes of the scan: R*4 bytes of logits per patch (R = H*n_token), read
+// once per iteration it takes part in.
+
+#include <algorithm>
+
+#include "ipsx_common.h"
+#include "ipsx_math.h"
+
+namespace ipsx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ query projection
+__global__ void query_proj_kernel(const float* __restrict__ q, const float* __restrict__ wq, float temperature,
+                                  int n_token, int d, int hdk, float* __restrict__ qs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_token * hdk) return;
+    const int t = i / hdk, o = i - t * hdk;
+    float a = 0.0f;
+    for (int c = 0; c < d; ++c) a = __builtin_fmaf(q[t * d + c], wq[(size_t)o * d + c], a);
+    qs[i] = a / temperature;
+}
+
+// ------------------------------------------------------------------ logits
+struct LogitsArgs {
+    const float* emb; long long emb_bs;
+    const float* pos; long long pos_bs;
+    const float* wkp;            // k_w.weight packed as a 1x1 conv (ipsx_pack_conv_weight)
+    const float* qs;             // (T, H*Dk)
+    long long n;
+    int d, h, dk, T, kgs;
+    float* out; long long out_bs;
+};
+
+// One workgroup = 32 rows x all H*Dk columns.  Wave w owns n-tiles w, w+4, ... (NTW of them).
+template <int NTW>
+__global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float kbuf[];   // [32][hdk + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int hdk = a.h * a.dk, ntiles = (hdk + 31) >> 5, ld = hdk + 1;
+    const long long r0 = (long long)blockIdx.x * 32;
+    const int bi = blockIdx.y;
+    const long long row = r0 + (lane & 31);
+    const bool rv = row < a.n;
+    const float* e = a.emb + (size_t)bi * a.emb_bs + (size_t)(rv ? row : 0) * a.d + half;
+    const float* p = a.pos ? a.pos + (size_t)bi * a.pos_bs + (size_t)(rv ? row : 0) * a.d + half : nullptr;
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const float4* wp = reinterpret_cast<const float4*>(a.wkp) + lane;
+    for (int kg = 0; kg < a.kgs; ++kg) {
+        float av[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = kg * 8 + 2 * j;          // + half is in the base pointers
+            float v = (c + half < a.d) ? e[c] : 0.0f;
+            if (p) v = v + ((c + half < a.d) ? p[c] : 0.0f);
+            av[j] = rv ? v : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int nt = wave + 4 * i;
+            if (nt < ntiles) {                      // wave-uniform
+                const float4 b = wp[((size_t)nt * a.kgs + kg) * 64];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], b.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], b.w, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    // K tile -> LDS (row = pixel row of the C layout, column = output feature)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + 4 * i;
+        if (nt < ntiles) {
+            const int o = nt * 32 + (lane & 31);
+            if (o < hdk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    kbuf[rr * ld + o] = acc[i][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int R = a.h * a.T;
+    for (int idx = threadIdx.x; idx < 32 * R; idx += 256) {
+        const int rr = idx / R, r = idx - rr * R;
+        const int hh = r / a.T, t = r - hh * a.T;
+        if (r0 + rr >= a.n) continue;
+        const float* kq = a.qs + (size_t)t * hdk + hh * a.dk;
+        const float* kk = kbuf + rr * ld + hh * a.dk;
+        float s = 0.0f;
+        for (int j = 0; j < a.dk; ++j) s = __builtin_fmaf(kq[j], kk[j], s);
+        a.out[(size_t)bi * a.out_bs + (size_t)(r0 + rr) * R + r] = s;
+    }
+}
+
+// ------------------------------------------------------------------ scoring of a candidate set
+// Candidate logits either staged in LDS (cl, row stride R+1) or read through `cand`
+// from the global (n, R) table of one image.
+struct CandView {
+    const float* cl;       // LDS staging or nullptr
+    const float* lg;       // global logits of this image, (n, R)
+    const int* cand;       // LDS: candidate -> patch index (nullptr = identity)
+    int R;
+    __device__ __forceinline__ float get(int l, int r) const {
+        if (cl) return cl[l * (R + 1) + r];
+        const size_t row = cand ? (size_t)cand[l] : (size_t)l;
+        return lg[row * R + r];
+    }
+};
+
+// per-(h,t) row maximum and softmax denominator over L candidates (wave per row)
+__device__ __forceinline__ void row_stats(const CandView& v, int L, float* rmax, float* rden) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = wave; r < v.R; r += nw) {
+        float m = -__builtin_huge_valf();
+        for (int i = lane; i < L; i += 64) m = nanmax(m, v.get(i, r));
+        m = wave_max(m);
+        float s = 0.0f;
+        for (int i = lane; i < L; i += 64) s = s + det_expf(v.get(i, r) - m);
+        s = wave_butterfly_sum(s);
+        if (lane == 0) { rmax[r] = m; rden[r] = s; }
+    }
+}
+
+// score of candidate l: mean over heads, then over tokens, of its attention weights
+__device__ __forceinline__ float cand_score(const CandView& v, int l, int h, int T, const float* rmax,
+                                            const float* rden, float* attn, int L) {
+    float st = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        float sh = 0.0f;
+        for (int hh = 0; hh < h; ++hh) {
+            const int r = hh * T + t;
+            const float a = det_expf(v.get(l, r) - rmax[r]) / rden[r];
+            if (attn) attn[((size_t)hh * T + t) * L + l] = a;
+            sh = sh + a;
+        }
+        st = st + sh / (float)h;
+    }
+    return st / (float)T;
+}
+
+// Sort `n2` (power of two) keys descending.  src holds the keys; the sorted keys end
+// up in the returned buffer (src or tmp).  Keys are unique.  Must be called by all
+// threads of the workgroup; contains barriers.
+__device__ __forceinline__ uint64_t* sort_desc(uint64_t* src, uint64_t* tmp, int L, int n2) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (L <= 512) {
+        // rank by counting: rank = number of larger keys (LDS broadcast reads, no barriers inside)
+        __syncthreads();
+        for (int l = tid; l < L; l += nt) {
+            const uint64_t k = src[l];
+            int rank = 0;
+            for (int j = 0; j < L; ++j) rank += (src[j] > k) ? 1 : 0;
+            tmp[rank] = k;
+        }
+        __syncthreads();
+        return tmp;
+    }
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < n2; i += nt) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = src[i], y = src[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { src[i] = y; src[ixj] = x; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return src;
+}
+
+struct ScanArgs {
+    const float* lg;       // (b, n, R)
+    long long n;
+    int m, i, h, T, n2, use_lds;
+    long long* mem_idx;
+    float* mem_score;
+    int* tie;
+};
+
+__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = a.h * a.T, Lmax = a.m + a.i;
+    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* keyB = keyA + a.n2;
+    int* candA = reinterpret_cast<int*>(keyB + a.n2);
+    int* candB = candA + Lmax;
+    float* rmax = reinterpret_cast<float*>(candB + Lmax);
+    float* rden = rmax + R;
+    float* cl = a.use_lds ? rden + R : nullptr;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const float* lg = a.lg + (size_t)b * a.n * R;
+
+    int* cand = candA;
+    int* cnew = candB;
+    for (int j = tid; j < a.m; j += 256) cand[j] = j;
+    int tie = 0;
+    uint64_t* sorted = keyA;
+    const long long n_iter = (a.n - a.m + a.i - 1) / a.i;
+    for (long long it = 0; it < n_iter; ++it) {
+        const long long lo = it * a.i + a.m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+        const int L = a.m + cnt;
+        for (int j = tid; j < cnt; j += 256) cand[a.m + j] = (int)(lo + j);
+        __syncthreads();
+        CandView v;
+        v.cl = cl; v.lg = lg; v.cand = cand; v.R = R;
+        if (cl) {
+            for (int e = tid; e < L * R; e += 256) {
+                const int l = e / R, r = e - l * R;
+                cl[l * (R + 1) + r] = lg[(size_t)cand[l] * R + r];
+            }
+            __syncthreads();
+        }
+        row_stats(v, L, rmax, rden);
+        __syncthreads();
+        for (int l = tid; l < a.n2; l += 256)
+            keyA[l] = l < L ? rank_key(cand_score(v, l, a.h, a.T, rmax, rden, nullptr, L), (uint32_t)l) : 0ull;
+        sorted = sort_desc(keyA, keyB, L, a.n2);
+        for (int j = tid; j < a.m; j += 256) cnew[j] = cand[key_pos(sorted[j])];
+        if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
+        __syncthreads();
+        int* t = cand; cand = cnew; cnew = t;
+    }
+    for (int j = tid; j < a.m; j += 256) {
+        a.mem_idx[(size_t)b * a.m + j] = cand[j];
+        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
+    }
+    if (a.tie && tid == 0) a.tie[b] = tie;
+}
+
+// Transformer.get_scores on the logits (b, L, R) of arbitrary embeddings
+struct ScoresArgs {
+    const float* lg;
+    int L, h, T, use_lds;
+    float* scores;    // (b, L)
+    float* attn;      // (b, h, T, L) or nullptr
+};
+
+__global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = a.h * a.T;
+    float* rmax = reinterpret_cast<float*>(smem);
+    float* rden = rmax + R;
+    float* cl = a.use_lds ? rden + R : nullptr;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* lg = a.lg + (size_t)b * a.L * R;
+    CandView v;
+    v.cl = cl; v.lg = lg; v.cand = nullptr; v.R = R;
+    if (cl) {
+        for (int e = tid; e < a.L * R; e += 256) {
+            const int l = e / R, r = e - l * R;
+            cl[l * (R + 1) + r] = lg[e];
+        }
+        __syncthreads();
+    }
+    row_stats(v, a.L, rmax, rden);
+    __syncthreads();
+    float* attn = a.attn ? a.attn + (size_t)b * R * a.L : nullptr;
+    for (int l = tid; l < a.L; l += 256)
+        a.scores[(size_t)b * a.L + l] = cand_score(v, l, a.h, a.T, rmax, rden, attn, a.L);
+}
+
+struct TopmArgs {
+    const float* scores;
+    int L, m, n2;
+    long long* top;
+    int* tie;
+};
+
+__global__ __launch_bounds__(256) void topm_kernel(TopmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* keyB = keyA + a.n2;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int l = tid; l < a.n2; l += 256)
+        keyA[l] = l < a.L ? rank_key(a.scores[(size_t)b * a.L + l], (uint32_t)l) : 0ull;
+    uint64_t* sorted = sort_desc(keyA, keyB, a.L, a.n2);
+    for (int j = tid; j < a.m; j += 256) a.top[(size_t)b * a.m + j] = key_pos(sorted[j]);
+    if (a.tie && tid == 0)
+        a.tie[b] = (a.L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) ? 1 : 0;
+}
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static const size_t kLdsLimit = 160 * 1024;
+
+static int launch_logits(const LogitsArgs& a, int b, hipStream_t s) {
+    const int hdk = a.h * a.dk;
+    const int ntiles = (hdk + 31) / 32;
+    const size_t lds = (size_t)32 * (hdk + 1) * sizeof(float);
+    IPSX_REQUIRE(ntiles <= 16, "logits: H*Dk = %d > 512 not supported", hdk);
+    dim3 grid((unsigned)cdiv(a.n, 32), (unsigned)b);
+    const int ntw = (ntiles + 3) / 4;
+    if (ntw == 1) logits_kernel<1><<<grid, dim3(256), lds, s>>>(a);
+    else if (ntw == 2) logits_kernel<2><<<grid, dim3(256), lds, s>>>(a);
+    else if (ntw == 3) logits_kernel<3><<<grid, dim3(256), lds, s>>>(a);
+    else logits_kernel<4><<<grid, dim3(256), lds, s>>>(a);
+    return launched("logits");
+}
+
+}  // namespace ipsx
+
+using namespace ipsx;
+
+IPSX_API int ipsx_query_proj(const float* q, const float* wq, float temperature, int n_token, int d, int hdk,
+                             float* qs, void* stream) {
+    IPSX_REQUIRE(q && wq && qs && n_token > 0 && d > 0 && hdk > 0, "query_proj: bad arguments");
+    query_proj_kernel<<<dim3((unsigned)cdiv(n_token * hdk, 256)), dim3(256), 0, as_stream(stream)>>>(
+        q, wq, temperature, n_token, d, hdk, qs);
+    return launched("query_proj");
+}
+
+IPSX_API int ipsx_logits(const float* emb, int64_t emb_bstride, const float* pos, int64_t pos_bstride,
+                         const float* wk_packed, const float* qs, int b, int64_t n, int d, int h, int dk,
+                         int n_token, float* logits, int64_t logits_bstride, void* stream) {
+    IPSX_REQUIRE(emb && wk_packed && qs && logits, "logits: null pointer");
+    IPSX_REQUIRE(b > 0 && n >= 0 && d > 0 && h > 0 && dk > 0 && n_token > 0, "logits: bad sizes");
+    if (n == 0) return IPSX_OK;
+    LogitsArgs a;
+    a.emb = emb; a.emb_bs = emb_bstride; a.pos = pos; a.pos_bs = pos_bstride;
+    a.wkp = wk_packed; a.qs = qs; a.n = n; a.d = d; a.h = h; a.dk = dk; a.T = n_token;
+    a.kgs = (int)cdiv(d, 8);
+    a.out = logits; a.out_bs = logits_bstride;
+    return launch_logits(a, b, as_stream(stream));
+}
+
+IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                       int64_t* mem_idx, float* mem_score, int32_t* tie_flag, void* stream) {
+    IPSX_REQUIRE(logits && mem_idx, "scan: null pointer");
+    IPSX_REQUIRE(b > 0 && m > 0 && i > 0 && h > 0 && n_token > 0, "scan: bad sizes");
+    IPSX_REQUIRE(n > m, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
+    IPSX_REQUIRE(n < ((int64_t)1 << 31), "scan: too many patches");
+    const int R = h * n_token, Lmax = m + i, n2 = next_pow2(Lmax);
+    size_t base = (size_t)n2 * 16 + (size_t)Lmax * 8 + (size_t)R * 8;
+    base = (base + 15) & ~(size_t)15;
+    const size_t stage = (size_t)Lmax * (R + 1) * 4;
+    IPSX_REQUIRE(base <= kLdsLimit, "scan: M+I = %d candidates do not fit the 160 KiB LDS", Lmax);
+    const int use_lds = base + stage <= kLdsLimit;
+    ScanArgs a;
+    a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2; a.use_lds = use_lds;
+    a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
+    const size_t lds = base + (use_lds ? stage : 0);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    scan_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
+    return launched("scan");
+}
+
+IPSX_API size_t ipsx_scores_workspace_bytes(int b, int l, int h, int n_token) {
+    return (size_t)b * l * h * n_token * sizeof(float);
+}
+
+IPSX_API int ipsx_scores(const float* x, const float* wk_packed, const float* qs, int b, int l, int d, int h,
+                         int dk, int n_token, float* scores, float* attn, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    IPSX_REQUIRE(x && wk_packed && qs && scores, "scores: null pointer");
+    IPSX_REQUIRE(b > 0 && l > 0 && d > 0 && h > 0 && dk > 0 && n_token > 0, "scores: bad sizes");
+    const size_t need = ipsx_scores_workspace_bytes(b, l, h, n_token);
+    if (!workspace || workspace_bytes < need)
+        return fail(IPSX_EWORKSPACE, "scores: workspace %zu B < %zu B", workspace_bytes, need);
+    const int R = h * n_token;
+    float* lg = static_cast<float*>(workspace);
+    IPSX_TRY(ipsx_logits(x, (int64_t)l * d, nullptr, 0, wk_packed, qs, b, l, d, h, dk, n_token, lg,
+                         (int64_t)l * R, stream));
+    ScoresArgs a;
+    const size_t base = (size_t)R * 8, stage = (size_t)l * (R + 1) * 4;
+    a.lg = lg; a.L = l; a.h = h; a.T = n_token; a.use_lds = base + stage <= kLdsLimit;
+    a.scores = scores; a.attn = attn;
+    const size_t lds = base + (a.use_lds ? stage : 0);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scores_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    scores_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
+    return launched("scores");
+}
+
+IPSX_API int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_idx, int32_t* tie_flag,
+                       void* stream) {
+    IPSX_REQUIRE(scores && top_idx && b > 0 && l > 0 && m > 0 && m <= l, "topm: bad arguments (l=%d m=%d)", l, m);
+    TopmArgs a;
+    a.scores = scores; a.L = l; a.m = m; a.n2 = next_pow2(l);
+    a.top = reinterpret_cast<long long*>(top_idx); a.tie = tie_flag;
+    const size_t lds = (size_t)a.n2 * 16;
+    IPSX_REQUIRE(lds <= kLdsLimit, "topm: %d candidates do not fit the 160 KiB LDS", l);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    topm_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
+    return launched("topm");
+}

@@ -1,0 +1,134 @@
+// trunk.hip - walks the nn.Sequential of IPSNet.get_conv_patch_enc (reference
+// architecture/ips_net.py:35-50) over a batch of patches: stem conv 7x7/2 + BN +
+// ReLU, max-pool 3x3/2, residual blocks, global average pool.
+//
+// Host-side runtime only: it sequences the kernels of conv.hip (or the fused
+// LDS-resident kernel of fused_trunk.hip when the trunk matches it) on the
+// caller's stream, in chunks of patches so the activation workspace stays bounded.
+
+#include <algorithm>
+
+#include "ipsx_common.h"
+
+namespace ipsx {
+
+// fused_trunk.hip
+bool fused_trunk_supported(const ipsx_trunk* t);
+int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s);
+
+struct TrunkGeom {
+    size_t max_elems;   // largest per-patch activation (floats) of any layer
+    int d_out;
+};
+
+static int trunk_geom(const ipsx_trunk* t, TrunkGeom* g) {
+    IPSX_REQUIRE(t && t->n_block >= 0 && (t->n_block == 0 || t->blocks), "trunk: missing blocks");
+    IPSX_REQUIRE(t->c_in > 0 && t->h > 0 && t->w > 0, "trunk: bad patch shape %dx%dx%d", t->c_in, t->h, t->w);
+    IPSX_REQUIRE(t->stem.c_in == t->c_in, "trunk: stem expects %d channels, patches have %d", t->stem.c_in, t->c_in);
+    int h = conv_out(t->h, t->stem.kh, t->stem.stride, t->stem.pad);
+    int w = conv_out(t->w, t->stem.kw, t->stem.stride, t->stem.pad);
+    IPSX_REQUIRE(h > 0 && w > 0, "trunk: patch too small");
+    int c = t->stem.c_out;
+    size_t mx = (size_t)c * h * w;
+    h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
+    for (int b = 0; b < t->n_block; ++b) {
+        const ipsx_block& B = t->blocks[b];
+        IPSX_REQUIRE(B.n_conv == 2 || B.n_conv == 3, "trunk: block %d has %d convs", b, B.n_conv);
+        int ch = h, cw = w, cc = c;
+        for (int j = 0; j < B.n_conv; ++j) {
+            const ipsx_conv& cv = B.conv[j];
+            IPSX_REQUIRE(cv.c_in == cc, "trunk: block %d conv %d expects %d channels, gets %d", b, j, cv.c_in, cc);
+            ch = conv_out(ch, cv.kh, cv.stride, cv.pad); cw = conv_out(cw, cv.kw, cv.stride, cv.pad);
+            IPSX_REQUIRE(ch > 0 && cw > 0, "trunk: feature map vanished in block %d", b);
+            cc = cv.c_out;
+            mx = std::max(mx, (size_t)cc * ch * cw);
+        }
+        if (B.has_down) {
+            IPSX_REQUIRE(B.down.c_in == c && B.down.c_out == cc, "trunk: block %d shortcut shape", b);
+            IPSX_REQUIRE(conv_out(h, B.down.kh, B.down.stride, B.down.pad) == ch, "trunk: block %d shortcut size", b);
+        } else {
+            IPSX_REQUIRE(cc == c && ch == h && cw == w, "trunk: block %d needs a projection shortcut", b);
+        }
+        h = ch; w = cw; c = cc;
+    }
+    g->max_elems = mx;
+    g->d_out = c;
+    return IPSX_OK;
+}
+
+// patches per chunk: 4 activation buffers of chunk*max_elems floats, <= ~2 GiB in all
+static int64_t trunk_chunk(const TrunkGeom& g, int64_t n) {
+    const size_t budget = (size_t)2 << 30;
+    int64_t cap = (int64_t)(budget / (4 * g.max_elems * sizeof(float)));
+    cap = std::max<int64_t>(cap, 1);
+    return std::min<int64_t>(n, cap);
+}
+
+}  // namespace ipsx
+
+using namespace ipsx;
+
+IPSX_API size_t ipsx_trunk_workspace_bytes(const ipsx_trunk* t, int64_t n_patch) {
+    TrunkGeom g;
+    if (trunk_geom(t, &g) != IPSX_OK || n_patch <= 0) return 0;
+    if (fused_trunk_supported(t)) return 0;
+    return (size_t)trunk_chunk(g, n_patch) * g.max_elems * sizeof(float) * 4;
+}
+
+IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    TrunkGeom g;
+    IPSX_TRY(trunk_geom(t, &g));
+    IPSX_REQUIRE(patches && emb && n_patch >= 0, "trunk_encode: bad arguments");
+    if (n_patch == 0) return IPSX_OK;
+    if (fused_trunk_supported(t)) return fused_trunk_encode(t, patches, n_patch, emb, as_stream(stream));
+
+    const int64_t chunk = trunk_chunk(g, n_patch);
+    const size_t buf_elems = (size_t)chunk * g.max_elems;
+    if (!workspace || workspace_bytes < buf_elems * sizeof(float) * 4)
+        return fail(IPSX_EWORKSPACE, "trunk_encode: workspace %zu B < %zu B", workspace_bytes,
+                    buf_elems * sizeof(float) * 4);
+    float* buf[4];
+    for (int i = 0; i < 4; ++i) buf[i] = static_cast<float*>(workspace) + i * buf_elems;
+    const size_t patch_elems = (size_t)t->c_in * t->h * t->w;
+
+    for (int64_t p0 = 0; p0 < n_patch; p0 += chunk) {
+        const int64_t n = std::min(chunk, n_patch - p0);
+        int h = conv_out(t->h, t->stem.kh, t->stem.stride, t->stem.pad);
+        int w = conv_out(t->w, t->stem.kw, t->stem.stride, t->stem.pad);
+        int c = t->stem.c_out;
+        IPSX_TRY(ipsx_conv2d_affine(&t->stem, patches + p0 * patch_elems, nullptr, buf[0], n, t->h, t->w, 1, stream));
+        IPSX_TRY(ipsx_maxpool_3x3s2(buf[0], buf[1], n, c, h, w, stream));
+        h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
+        int cur = 1;                                   // buf[cur] holds the block input
+        for (int b = 0; b < t->n_block; ++b) {
+            const ipsx_block& B = t->blocks[b];
+            // free buffers: the three that are not `cur`
+            int fr[3], k = 0;
+            for (int i = 0; i < 4; ++i) if (i != cur) fr[k++] = i;
+            const float* src = buf[cur];
+            int ch = h, cw = w, si = -1;
+            for (int j = 0; j < B.n_conv - 1; ++j) {   // conv -> BN -> ReLU
+                const ipsx_conv& cv = B.conv[j];
+                const int di = (si == fr[0]) ? fr[1] : fr[0];
+                IPSX_TRY(ipsx_conv2d_affine(&cv, src, nullptr, buf[di], n, ch, cw, 1, stream));
+                ch = conv_out(ch, cv.kh, cv.stride, cv.pad); cw = conv_out(cw, cv.kw, cv.stride, cv.pad);
+                src = buf[di]; si = di;
+            }
+            const ipsx_conv& last = B.conv[B.n_conv - 1];
+            const float* shortcut = buf[cur];
+            if (B.has_down) {                          // 1x1 strided conv + BN on the identity path
+                IPSX_TRY(ipsx_conv2d_affine(&B.down, buf[cur], nullptr, buf[fr[2]], n, h, w, 0, stream));
+                shortcut = buf[fr[2]];
+            }
+            const int oi = (si == fr[0]) ? fr[1] : fr[0];
+            // last conv -> BN -> += identity -> ReLU
+            IPSX_TRY(ipsx_conv2d_affine(&last, src, shortcut, buf[oi], n, ch, cw, 1, stream));
+            h = conv_out(ch, last.kh, last.stride, last.pad); w = conv_out(cw, last.kw, last.stride, last.pad);
+            c = last.c_out;
+            cur = oi;
+        }
+        IPSX_TRY(ipsx_avgpool(buf[cur], emb + (size_t)p0 * g.d_out, n, c, h * w, stream));
+    }
+    return IPSX_OK;
+}

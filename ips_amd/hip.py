@@ -276,11 +276,17 @@ def query_proj(q, wq, temperature):
     return out
 
 
-def logits(emb, pos, wk, qs, H, Dk, T, out=None):
+def pack_linear(weight):
+    """nn.Linear weight (out, in) -> MFMA B-operand stream (a 1x1 convolution)."""
+    w = weight.detach()
+    return _pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1))
+
+
+def logits(emb, pos, wk_packed, qs, H, Dk, T, out=None):
     """Per-patch attention logits (B, n, H*T); ``out`` may be a column slice of (B, N, H*T)."""
     B, n, D = emb.shape
     emb = _f32(emb)
-    wk = _f32(wk.detach())
+    wk = wk_packed
     if out is None:
         out = torch.empty((B, n, H * T), dtype=torch.float32, device=emb.device)
     if out.stride(2) != 1 or out.stride(1) != H * T:
@@ -314,7 +320,8 @@ def _scores_impl(x, qs, wk, H, Dk, T, want_attn):
     attn = torch.empty((B, H, T, L), dtype=torch.float32, device=x.device) if want_attn else None
     nb = lib().ipsx_scores_workspace_bytes(B, L, H, T)
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
-    _ck(lib().ipsx_scores(_p(x), _p(_f32(wk.detach())), _p(qs), B, L, D, H, Dk, T, _p(sc), _p(attn),
+    wkp = pack_linear(wk)
+    _ck(lib().ipsx_scores(_p(x), _p(wkp), _p(qs), B, L, D, H, Dk, T, _p(sc), _p(attn),
                           _p(ws), nb, _stream()), "ipsx_scores")
     return sc, attn
 

@@ -1,0 +1,150 @@
+"""End-to-end parity of IPSNet.ips / IPSNet.forward on the MI355X.
+
+Against (1) the golden fixtures recorded from the reference itself - selected indices
+must be IDENTICAL, final outputs within 1e-4 (north_star) - and (2) the CPU oracle on
+the same inputs - indices identical, embeddings and outputs bit for bit.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from ips_amd import hip, synth
+from ips_amd.architecture import IPSNet
+from oracle import oracle as orc
+from tests.util import Golden, GOLDEN_CASES, ulp_diff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PRED_TOL = 1e-4      # tolerance north_star states for the final fp32 outputs
+
+
+@pytest.mark.parametrize("case", [c for c in GOLDEN_CASES if "shuffle_instance" not in c])
+def test_ips_and_forward_match_reference_fixture(case):
+    g = Golden(case)
+    net = g.net(DEV)
+    x = g.patches().to(DEV)                              # eager loading: patches resident on the GPU
+    torch.manual_seed(g.torch_seed)                      # 'batch' shuffle draws randperm on the CPU generator
+    mem_patch, mem_pos = net.ips(x)
+    assert mem_patch.is_cuda and mem_patch.shape[:2] == (g.B, g.conf.M)
+    assert np.array_equal(net.last_mem_idx.cpu().numpy(), g.mem_idx), "indices differ from the reference"
+    s = mem_patch.double().sum(dim=tuple(range(2, mem_patch.dim()))).cpu().numpy()
+    assert np.allclose(s, g.mem_patch_sum, rtol=1e-12, atol=1e-9)
+    if g.mem_pos_sum is not None:
+        # the table is built by the HOST's sin/cos (reference transformer.py:6-18), which differs in
+        # the last ulp between CPU models; the selection of rows is exact, the values are host-made
+        assert np.allclose(mem_pos.double().sum(-1).cpu().numpy(), g.mem_pos_sum, rtol=1e-6)
+        assert torch.equal(mem_pos, torch.stack([net.pos_enc[0][net.last_mem_idx[b]] for b in range(g.B)])) \
+            or g.perm is not None
+    with torch.no_grad():
+        preds = net(mem_patch, mem_pos)
+    for k, v in g.preds.items():
+        assert np.abs(preds[k].cpu().numpy() - v).max() < PRED_TOL, k
+
+
+@pytest.mark.parametrize("case", ["mnist_mini", "mnist_ragged", "mnist_onechunk", "mnist_tok1", "cam_b2",
+                                  "traffic_tiny", "mnist_full"])
+def test_ips_and_forward_bit_exact_vs_oracle(case):
+    g = Golden(case)
+    net = g.net(DEV)
+    o = orc.Oracle(g.net("cpu"))
+    x = g.patches()
+    pos = g.net("cpu").pos_enc.numpy() if g.conf.use_pos else None
+    want = o.ips(x.numpy(), pos)
+    mem_patch, mem_pos = net.ips(x.to(DEV))
+    assert np.array_equal(net.last_mem_idx.cpu().numpy(), want["mem_idx"])
+    assert np.array_equal(mem_patch.cpu().numpy(), want["mem_patch"])
+    if pos is not None:
+        assert np.array_equal(mem_pos.cpu().numpy(), want["mem_pos"])
+    with torch.no_grad():
+        preds = net(mem_patch, mem_pos)
+    wp = o.forward(want["mem_patch"], want["mem_pos"])
+    for k in wp:
+        assert ulp_diff(preds[k].cpu().numpy(), wp[k]) == 0, k
+
+
+def test_lazy_loading_equals_eager():
+    """patches left on the host (reference ips_net.py:204-206,223,245-247)."""
+    g = Golden("mnist_ragged")
+    net = g.net(DEV)
+    x = g.patches()
+    mp_lazy, pos_lazy = net.ips(x)                       # CPU tensor in, device tensors out
+    idx_lazy = net.last_mem_idx.clone()
+    mp_eager, pos_eager = net.ips(x.to(DEV))
+    assert mp_lazy.is_cuda and torch.equal(idx_lazy, net.last_mem_idx)
+    assert torch.equal(mp_lazy, mp_eager) and torch.equal(pos_lazy, pos_eager)
+    assert np.array_equal(idx_lazy.cpu().numpy(), g.mem_idx)
+
+
+def test_instance_shuffle_against_oracle():
+    """shuffle_style='instance' draws on the device generator; check against the oracle fed the same order."""
+    g = Golden("mnist_shuffle_instance")
+    net = g.net(DEV)
+    x = g.patches().to(DEV)
+    seen = {}
+    orig = net.do_shuffle
+
+    def spy(patches, pos_enc):
+        p, pe = orig(patches, pos_enc)
+        seen["p"], seen["pe"] = p, pe
+        return p, pe
+
+    net.do_shuffle = spy
+    torch.manual_seed(3)
+    mem_patch, mem_pos = net.ips(x)
+    o = orc.Oracle(g.net("cpu"))
+    want = o.ips(seen["p"].cpu().numpy(), seen["pe"].cpu().numpy())
+    assert np.array_equal(net.last_mem_idx.cpu().numpy(), want["mem_idx"])
+    assert np.array_equal(mem_patch.cpu().numpy(), want["mem_patch"])
+    assert np.array_equal(mem_pos.cpu().numpy(), want["mem_pos"])
+
+
+def test_reference_style_chunk_loop_equals_fused_scan():
+    """score_and_select per chunk (the reference's structure, through get_scores + topm kernels)
+    selects exactly what the single-launch scan selects."""
+    g = Golden("mnist_ragged")
+    net = g.net(DEV)
+    x = g.patches().to(DEV)
+    net.ips(x)
+    fused = net.last_mem_idx.clone()
+    B, N = x.shape[:2]
+    D, M, I = g.conf.D, g.conf.M, g.conf.I
+    pos = net.pos_enc.expand(B, -1, -1)
+    order = torch.arange(N, device=DEV).unsqueeze(0).expand(B, -1)
+    with torch.no_grad():
+        emb = net._embed(x.reshape(-1, *x.shape[2:])).view(B, N, D)
+        mem_emb, mem_idx = emb[:, :M], order[:, :M]
+        for lo in range(M, N, I):
+            hi = min(lo + I, N)
+            ce = torch.cat((mem_emb, emb[:, lo:hi]), 1)
+            ci = torch.cat((mem_idx, order[:, lo:hi]), 1)
+            cp = ce + torch.gather(pos, 1, ci.unsqueeze(-1).expand(-1, -1, D))
+            mem_emb, mem_idx = net.score_and_select(ce, cp, M, ci)
+    assert torch.equal(mem_idx, fused)
+    assert np.array_equal(fused.cpu().numpy(), g.mem_idx)
+
+
+def test_full_size_properties_b16():
+    """BASELINE configs[1] at the benchmark batch (16 x 2500 patches): size-independent properties."""
+    conf = synth.mnist_conf(N=2500, M=64, I=64)
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 7).to(DEV).eval()
+    x = synth.make_patches(conf, 16, seed=21).to(DEV)
+    mp1, pos1 = net.ips(x)
+    idx1 = net.last_mem_idx.clone()
+    mp2, _ = net.ips(x)
+    assert torch.equal(idx1, net.last_mem_idx) and torch.equal(mp1, mp2)          # deterministic
+    idx = idx1.cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 2500
+    assert all(len(set(r)) == 64 for r in idx)                                       # a patch is kept once
+    assert torch.equal(mp1, torch.stack([x[b][idx1[b]] for b in range(16)]))         # gather is exact
+    assert torch.equal(pos1, torch.stack([net.pos_enc[0][idx1[b]] for b in range(16)]))
+    assert int(hip.scan.last_tie.sum()) == 0
+    # batch independence: image 3 alone selects the same patches
+    net.ips(x[3:4])
+    assert torch.equal(net.last_mem_idx[0], idx1[3])
+    # image 0 of this batch is the mnist_full fixture's input/weights -> the reference's indices
+    g = Golden("mnist_full")
+    netg = g.net(DEV)
+    xg = torch.cat([g.patches().to(DEV), x[:3]], 0)
+    netg.ips(xg)
+    assert np.array_equal(netg.last_mem_idx[0].cpu().numpy(), g.mem_idx[0])

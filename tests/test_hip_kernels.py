@@ -1,0 +1,235 @@
+"""Kernel-level parity: every entry point of libipsx.so, called through the C ABI
+(ips_amd.hip -> ctypes), against the CPU oracle on the same seeded inputs.
+
+The kernels restate the oracle's arithmetic order exactly (fp32 MFMA = ordered fma
+chain; own exp; wave-order sums), so floating-point results are compared BIT FOR BIT
+(ulp distance 0); indices are compared exactly.
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from ips_amd import hip, synth
+from oracle import oracle as orc
+from tests.util import Golden, ulp_diff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def test_device_is_gfx950_and_library_loaded():
+    L = hip.lib()
+    assert L.ipsx_device_count() >= 1
+    assert L.ipsx_device_is_gfx950(0) == 1
+
+
+def test_det_expf_and_wave_sum_bits_via_head_kernel():
+    """softmax head = det_expf + wave butterfly on device; must equal the oracle bit for bit."""
+    B, T, D, ncls = 5, 4, 128, 10
+    emb, w, b = rnd((B, T, D), 1), rnd((ncls, D), 2, 0.3), rnd((ncls,), 3)
+    lin = torch.nn.Linear(D, ncls)
+    lin.weight.data, lin.bias.data = torch.from_numpy(w), torch.from_numpy(b)
+    lin = lin.to(DEV)
+    for act, code in (("softmax", 0), ("sigmoid", 1)):
+        got = hip.head(dev(emb), 2, lin, act).cpu().numpy()
+        want = np.empty_like(got)
+        for i in range(B):
+            orc.lib().orc_head(orc._f(emb[i, 2])[1], D, orc._f(w)[1], orc._f(b)[1], ncls, code,
+                               want[i].ctypes.data_as(orc.f32p))
+        assert ulp_diff(got, want) == 0, act
+
+
+@pytest.mark.parametrize("c_in,c_out,k,stride,pad,h,w,n,res,relu", [
+    (64, 64, 3, 1, 1, 8, 8, 5, True, True),        # layer1 conv2 shape (MNIST-32)
+    (64, 128, 3, 2, 1, 8, 8, 7, False, True),      # layer2.0.conv1
+    (64, 128, 1, 2, 0, 8, 8, 3, False, False),     # layer2.0.downsample
+    (128, 128, 3, 1, 1, 4, 4, 9, True, True),      # layer2 convs, 4x4 maps
+    (1, 64, 7, 2, 3, 32, 32, 3, False, True),      # 1-channel stem
+    (3, 64, 7, 2, 3, 37, 29, 2, False, True),      # 3-channel stem, odd sizes
+    (64, 64, 3, 1, 1, 13, 13, 3, True, True),      # 50-px patches: 13x13 maps (no vec4 stores)
+    (16, 32, 3, 1, 1, 5, 7, 4, False, False),      # C_out = 32: one n-tile only
+])
+def test_conv2d_affine_bit_exact(c_in, c_out, k, stride, pad, h, w, n, res, relu):
+    x = rnd((n, c_in, h, w), 10)
+    wt = rnd((c_out, c_in, k, k), 11, (2.0 / (c_in * k * k)) ** 0.5)
+    alpha, shift = (1 + 0.2 * rnd((c_out,), 12)), rnd((c_out,), 13, 0.1)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = rnd((n, c_out, ho, wo), 14) if res else None
+    # oracle
+    cv = orc._Conv(c_in, c_out, k, k, stride, pad, orc._f(wt)[1], orc._f(alpha)[1], orc._f(shift)[1])
+    want = np.empty((n, c_out, ho, wo), dtype=np.float32)
+    orc.lib().orc_conv2d_affine(C.byref(cv), orc._f(x)[1], orc._f(r)[1] if res else None,
+                                want.ctypes.data_as(orc.f32p), C.c_int64(n), h, w, int(relu))
+    # device
+    packed = hip._pack_conv(dev(wt))
+    a, s = dev(alpha), dev(shift)
+    hcv = hip.Conv(c_in, c_out, k, k, stride, pad, packed.data_ptr(), a.data_ptr(), s.data_ptr())
+    y = torch.full((n, c_out, ho, wo), float("nan"), device=DEV)
+    xd, rd = dev(x), (dev(r) if res else None)
+    hip._ck(hip.lib().ipsx_conv2d_affine(C.byref(hcv), hip._p(xd), hip._p(rd), hip._p(y), n, h, w, int(relu),
+                                         hip._stream()), "conv")
+    got = y.cpu().numpy()
+    assert not np.isnan(got).any(), "kernel left outputs unwritten"
+    assert ulp_diff(got, want) == 0, "max abs diff %g" % np.abs(got - want).max()
+
+
+def test_bn_affine_and_pools_bit_exact():
+    c = 64
+    bn = torch.nn.BatchNorm2d(c)
+    g = np.random.default_rng(5)
+    bn.weight.data = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+    bn.bias.data = torch.from_numpy(rnd((c,), 6, 0.1))
+    bn.running_mean = torch.from_numpy(rnd((c,), 7, 0.1))
+    bn.running_var = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+    want = orc.bn_affine(bn)
+    got = hip._bn_affine(bn.to(DEV)).cpu().numpy()
+    assert ulp_diff(got[0], want[0]) == 0 and ulp_diff(got[1], want[1]) == 0
+
+    x = rnd((3, c, 16, 16), 8)
+    y = torch.empty((3, c, 8, 8), device=DEV)
+    xd = dev(x)
+    hip._ck(hip.lib().ipsx_maxpool_3x3s2(hip._p(xd), hip._p(y), 3, c, 16, 16, hip._stream()), "maxpool")
+    ref = torch.nn.functional.max_pool2d(torch.from_numpy(x), 3, 2, 1).numpy()
+    assert np.array_equal(y.cpu().numpy(), ref)
+    x2 = rnd((3, c, 13, 13), 9)                      # odd size -> ho = 7
+    y2 = torch.empty((3, c, 7, 7), device=DEV)
+    x2d = dev(x2)
+    hip._ck(hip.lib().ipsx_maxpool_3x3s2(hip._p(x2d), hip._p(y2), 3, c, 13, 13, hip._stream()), "maxpool")
+    assert np.array_equal(y2.cpu().numpy(), torch.nn.functional.max_pool2d(torch.from_numpy(x2), 3, 2, 1).numpy())
+
+    z = torch.empty((3, c), device=DEV)
+    hip._ck(hip.lib().ipsx_avgpool(hip._p(xd), hip._p(z), 3, c, 256, hip._stream()), "avgpool")
+    want = np.empty((3, c), dtype=np.float32)
+    orc.lib().orc_avgpool(orc._f(x)[1], want.ctypes.data_as(orc.f32p), C.c_int64(3), c, 256)
+    assert ulp_diff(z.cpu().numpy(), want) == 0
+
+
+@pytest.mark.parametrize("case,n", [("mnist_mini", 70), ("traffic_tiny", 5), ("mnist_native50", 6),
+                                    ("cam_b2", 300)])
+def test_encoder_bit_exact(case, n):
+    g = Golden(case)
+    net = g.net(DEV)
+    x = g.patches()[0, :n]
+    plan = hip.EncoderPlan(net.encoder, g.conf.is_image)
+    got = plan.encode(x.to(DEV)).cpu().numpy()
+    want = orc.Oracle(g.net("cpu")).encode(x.numpy())
+    assert got.shape == want.shape
+    assert ulp_diff(got, want) == 0, "max abs diff %g" % np.abs(got - want).max()
+
+
+def test_encoder_plan_tracks_weight_updates():
+    g = Golden("mnist_mini")
+    net = g.net(DEV)
+    x = g.patches()[0, :8].to(DEV)
+    plan = hip.EncoderPlan(net.encoder, True)
+    a = plan.encode(x).clone()
+    with torch.no_grad():
+        net.encoder[0].weight.mul_(1.5)              # what optimizer.step() does: in-place update
+        net.encoder[1].running_mean.add_(0.05)       # what a training-mode forward does
+    b = plan.encode(x)
+    assert not torch.equal(a, b)
+    want = orc.Oracle(net.cpu()).encode(x.cpu().numpy())
+    assert ulp_diff(b.cpu().numpy(), want) == 0
+
+
+@pytest.mark.parametrize("case", ["mnist_mini", "mnist_tok1", "cam_b2", "traffic_tiny"])
+def test_logits_scores_attn_bit_exact(case):
+    g = Golden(case)
+    net = g.net(DEV)
+    o = orc.Oracle(g.net("cpu"))
+    ca = net.transf.crs_attn
+    D = g.conf.D
+    B, L = 2, 53
+    x = rnd((B, L, D), 21)
+    qs = ca.scaled_query()
+    assert ulp_diff(qs.cpu().numpy(), o.qs) == 0
+    pos = rnd((B, L, D), 22)
+    wkp = hip._pack_conv(ca.k_w.weight.detach().reshape(ca.H * ca.D_k, D, 1, 1))
+    got = hip.logits(dev(x), dev(pos), wkp, qs, ca.H, ca.D_k, ca.n_token).cpu().numpy()
+    for b in range(B):
+        assert ulp_diff(got[b], o.logits(x[b], pos[b])) == 0
+    # broadcast positional table (batch stride 0) and no table at all
+    got = hip.logits(dev(x), dev(pos[:1]), wkp, qs, ca.H, ca.D_k, ca.n_token).cpu().numpy()
+    assert ulp_diff(got[1], o.logits(x[1], pos[0])) == 0
+    got = hip.logits(dev(x), None, wkp, qs, ca.H, ca.D_k, ca.n_token).cpu().numpy()
+    assert ulp_diff(got[1], o.logits(x[1])) == 0
+    # Transformer.get_scores / get_attn through the module API
+    with torch.no_grad():
+        sc = net.transf.get_scores(dev(x)).cpu().numpy()
+        attn = ca.get_attn(dev(x)).cpu().numpy()
+    for b in range(B):
+        ws, wa = o.scores(x[b], want_attn=True)
+        assert ulp_diff(sc[b], ws) == 0
+        assert ulp_diff(attn[b], wa) == 0
+
+
+@pytest.mark.parametrize("L,M", [(128, 64), (48, 16), (512, 256), (600, 100), (2000, 64), (7, 7)])
+def test_topm_matches_oracle_and_torch(L, M):
+    g = np.random.default_rng(L)
+    s = np.stack([g.permutation(L), g.permutation(L)]).astype(np.float32) / L
+    top = hip.topm(dev(s), M).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(top[b], orc.topm(s[b], M)[0])
+        assert np.array_equal(top[b], torch.topk(torch.from_numpy(s[b]), M)[1].numpy())
+    # exact ties: canonical rule = earlier position first
+    t = np.zeros((1, L), dtype=np.float32)
+    t[0, ::3] = 1.0
+    top = hip.topm(dev(t), M).cpu().numpy()[0]
+    assert np.array_equal(top, orc.topm(t[0], M)[0])
+
+
+@pytest.mark.parametrize("N,M,I,H,T", [(300, 16, 16, 8, 4), (301, 16, 24, 8, 4), (40, 16, 64, 8, 4),
+                                       (1000, 32, 48, 8, 1), (2500, 64, 64, 8, 4), (3000, 256, 256, 8, 1),
+                                       (5000, 900, 900, 8, 1)])
+def test_scan_matches_oracle(N, M, I, H, T):
+    """The persistent scan kernel against the reference-faithful loop of the oracle."""
+    B, R = 2, H * T
+    lg = rnd((B, N, R), N + M, 3.0)
+    mem, sc = hip.scan(dev(lg), M, I, H, T, want_scores=True)
+    mem, sc = mem.cpu().numpy(), sc.cpu().numpy()
+    L = orc.lib()
+    for b in range(B):
+        cur = np.arange(M, dtype=np.int64)
+        for lo in range(M, N, I):
+            cand = np.concatenate([cur, np.arange(lo, min(lo + I, N), dtype=np.int64)])
+            s = np.empty(len(cand), dtype=np.float32)
+            L.orc_scores_from_logits(orc._f(lg[b][cand])[1], len(cand), H, T, s.ctypes.data_as(orc.f32p), None)
+            top, tie = orc.topm(s, M)
+            cur, last = cand[top], s[top]
+        assert np.array_equal(mem[b], cur)
+        assert ulp_diff(sc[b], last) == 0
+
+
+def test_gather_rows():
+    B, N, M = 3, 50, 7
+    src = rnd((B, N, 1, 32, 32), 30)
+    idx = np.random.default_rng(31).integers(0, N, (B, M))
+    got = hip.gather_rows(dev(src), dev(idx)).cpu().numpy()
+    assert np.array_equal(got, np.stack([src[b][idx[b]] for b in range(B)]))
+    tab = rnd((1, N, 130), 32)                       # shared table, row not a multiple of 16 bytes
+    got = hip.gather_rows(dev(tab).expand(B, -1, -1), dev(idx)).cpu().numpy()
+    assert np.array_equal(got, np.stack([tab[0][idx[b]] for b in range(B)]))
+
+
+@pytest.mark.parametrize("case", ["mnist_mini", "cam_b2", "traffic_tiny"])
+def test_aggregate_and_heads_bit_exact(case):
+    g = Golden(case)
+    net = g.net(DEV)
+    o = orc.Oracle(g.net("cpu"))
+    B, M, D = 3, g.conf.M, g.conf.D
+    x = rnd((B, M, D), 40)
+    with torch.no_grad():
+        got = net.transf(dev(x)).cpu().numpy()
+    want = o.aggregate(x)
+    assert ulp_diff(got, want) == 0, "max abs diff %g" % np.abs(got - want).max()

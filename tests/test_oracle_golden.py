@@ -1,0 +1,46 @@
+"""Pins the CPU oracle (oracle/ips_oracle.cpp) against the reference's own outputs.
+
+tests/golden/*.npz were produced by tools/gen_golden.py by running the reference
+(/root/reference, imported in the build container).  The oracle must select the same
+patch indices in every iteration, and agree on values to well inside the 1e-4 the
+task allows (its summation order differs from oneDNN/MKL, so not bit for bit).
+"""
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests.util import Golden, ORACLE_FAST_CASES, max_rel
+
+VALUE_TOL = 1e-4     # oracle vs reference, relative: the tolerance north_star states for fp32
+
+
+@pytest.mark.parametrize("case", ORACLE_FAST_CASES)
+def test_oracle_reproduces_reference(case):
+    g = Golden(case)
+    net = g.net("cpu")
+    orc = Oracle(net)
+    x = g.shuffled(g.patches()).numpy()
+    pos = None
+    if g.conf.use_pos:
+        pos = net.pos_enc.numpy()
+        if g.perm is not None:
+            pos = np.stack([pos[0][g.perm[b]] for b in range(g.B)])
+    out = orc.ips(x, pos)
+    # indices: every iteration, same order
+    assert np.array_equal(out["trace_idx"], g.trace_idx), "selected indices differ from the reference"
+    assert out["tie"].sum() == 0
+    # scores the selection was based on
+    assert max_rel(out["trace_score"], g.trace_score) < VALUE_TOL
+    # encoder values
+    head = g.patches()[0, :8].numpy()          # emb_head is recorded for the UNshuffled first 8 patches
+    assert max_rel(orc.encode(head), g.emb_head) < VALUE_TOL
+    # gathered outputs
+    ps = out["mem_patch"].astype(np.float64).sum(axis=tuple(range(2, out["mem_patch"].ndim)))
+    assert np.allclose(ps, g.mem_patch_sum, rtol=1e-12, atol=1e-9)
+    if g.mem_pos_sum is not None:
+        assert np.allclose(out["mem_pos"].astype(np.float64).sum(-1), g.mem_pos_sum, rtol=1e-6)  # host sin/cos
+    # final outputs ("logits" of the north star = the preds dict)
+    preds = orc.forward(out["mem_patch"], out["mem_pos"])
+    for k, v in g.preds.items():
+        assert np.abs(preds[k] - v).max() < 1e-5, k
