@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py - patches scored / second of the IPS no-grad hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``IPSNet.ips(patches)`` call (no-grad, eval, eager loading: the patch
+tensor is resident in HBM when the timed region starts): embed every patch, score,
+run the whole selection loop, gather the M winners.  Workload at N = 1: BASELINE.json
+configs[1], Megapixel-MNIST 1500 (2500 patches of 1x32x32 per image, M = I = 64, 4
+query tokens, positional encoding on) at the reference's batch size B = 16
+(config/mnist_config.yml B_seq).  At N > 1 the patch axis is sharded (ips_amd/dist.py):
+every GPU holds 2500 patches of each of the 16 images (weak scaling: the image grows
+with the node, N = 4 is the 3000x3000 / 10000-patch case of configs[2]); value counts
+the patches all ranks scored.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline      encoder launch(es) timed with HIP events on the launch stream inside the
+                timed region; achieved = algorithmic FLOP (37,257,216 per 32-px patch,
+                SURVEY.md 8 d-4) / that time, against the 157.3 TFLOP/s fp32 MFMA peak;
+  cpu_baseline  oracle/ips_torch.py (the reference's ATen CPU path restated) on this host's
+                cores, on a bounded sample of the same workload.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+FLOP_PER_PATCH_MNIST32 = 37_257_216      # encoder MACs*2, SURVEY.md section 8 d-4
+FP32_MFMA_PEAK_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PATCHES_PER_GPU = 2500
+BATCH = 16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(conf, budget_s):
+    """The reference's CPU path (ATen restatement) on a bounded sample of the same workload."""
+    from ips_amd import synth
+    from ips_amd.architecture import IPSNet
+    from oracle import ips_torch
+
+    c1 = conf.clone(N=PATCHES_PER_GPU)
+    net = synth.fill_weights(IPSNet(torch.device("cpu"), c1), 7).eval()
+    sd = dict(net.state_dict())
+    B = 2
+    x = synth.make_patches(c1, B, seed=21)
+    # The reference loop feeds the encoder 64 patches per image per call: too little work for every
+    # core of a big host (256 threads measured 14 patches/s).  Probe a few thread counts on a 300-patch
+    # prefix and keep the fastest - that is the reference's best case on this host.
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best, probe = None, conf.clone(N=320)
+    for thr in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
+        torch.set_num_threads(thr)
+        ips_torch.ips(sd, probe, x[:1, :320], net.pos_enc[:, :320])
+        t0 = time.perf_counter()
+        ips_torch.ips(sd, probe, x[:1, :320], net.pos_enc[:, :320])
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (thr, dt)
+        if dt > 4 * best[1]:
+            break
+    torch.set_num_threads(best[0])
+    ips_torch.ips(sd, c1, x, net.pos_enc)                      # warm-up (oneDNN primitive cache)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        ips_torch.ips(sd, c1, x, net.pos_enc)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or reps >= 50:
+            break
+    return {"value": B * PATCHES_PER_GPU * reps / dt, "unit": "patches/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d x ips() on %d images x %d patches (oracle/ips_torch.py, ATen/oneDNN, %.1f s)"
+                      % (reps, B, PATCHES_PER_GPU, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ips_amd import hip, synth
+    from ips_amd import dist as ipsd
+    from ips_amd.architecture import IPSNet
+
+    hip.lib()                                                   # fail loudly if the extension is missing
+    n_total = PATCHES_PER_GPU * world
+    conf = synth.mnist_conf(N=n_total, M=64, I=64)
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    x = synth.make_patches(conf, args.batch, seed=21 + rank, N=PATCHES_PER_GPU).to(dev)   # resident in HBM
+
+    if world == 1:
+        def step():
+            return net.ips(x)
+    else:
+        def step():
+            return ipsd.ips_sharded(net, x, n_total)
+
+    for _ in range(max(args.warmup, 1)):                        # also builds the encoder plan
+        step()
+    # time the encoder launches with HIP events on the stream they run on
+    enc_events = []
+    plan_encode = net._plan.encode
+
+    def timed_encode(t):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = plan_encode(t)
+        b.record()
+        enc_events.append((a, b, t.shape[0]))
+        return out
+
+    net._plan.encode = timed_encode
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    enc_ms = sum(a.elapsed_time(b) for a, b, _ in enc_events)
+    enc_patches = sum(n for _, _, n in enc_events)
+    achieved = enc_patches * FLOP_PER_PATCH_MNIST32 / (enc_ms * 1e-3) / 1e12
+    patches_per_step = args.batch * n_total
+
+    if rank == 0:
+        out = {
+            "metric": "patches scored/sec (no-grad IPS loop)",
+            "value": patches_per_step * args.steps / elapsed,
+            "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Megapixel-MNIST %d patches of 1x32x32 per image (%d per GPU), B=%d, M=I=64, "
+                                   "n_token=4, use_pos, eager" % (n_total, PATCHES_PER_GPU, args.batch),
+                       "parallelism": "patch-sharded x%d, one all-gather of logits" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": hip.encoder_kernel_name(net._plan),
+                         "launch_ms": enc_ms / max(len(enc_events), 1),
+                         "patches_per_launch": enc_patches / max(len(enc_events), 1)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(conf, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

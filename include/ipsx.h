@@ -97,6 +97,8 @@ int ipsx_maxpool_3x3s2(const float* x, float* y, int64_t n, int c, int h, int w,
 int ipsx_avgpool(const float* x, float* y, int64_t n, int c, int hw, void* stream);
 
 size_t ipsx_trunk_workspace_bytes(const ipsx_trunk* t, int64_t n_patch);
+/* name of the kernel family ipsx_trunk_encode will use for this trunk (static string) */
+const char* ipsx_trunk_kernel(const ipsx_trunk* t);
 /* patches (n_patch, c_in, h, w) -> emb (n_patch, D); picks the fused LDS-resident
  * kernel when the trunk matches it, the layer-by-layer kernels otherwise       */
 int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n_patch,

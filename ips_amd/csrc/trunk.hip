@@ -75,6 +75,10 @@ IPSX_API size_t ipsx_trunk_workspace_bytes(const ipsx_trunk* t, int64_t n_patch)
     return (size_t)trunk_chunk(g, n_patch) * g.max_elems * sizeof(float) * 4;
 }
 
+IPSX_API const char* ipsx_trunk_kernel(const ipsx_trunk* t) {
+    return (t && fused_trunk_supported(t)) ? "fused_trunk_kernel" : "conv_c8_kernel (layer by layer)";
+}
+
 IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb,
                                void* workspace, size_t workspace_bytes, void* stream) {
     TrunkGeom g;

@@ -77,6 +77,7 @@ _EXPORTS = {
     "ipsx_maxpool_3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_avgpool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_trunk_workspace_bytes": (C.c_size_t, [C.POINTER(Trunk), C.c_int64]),
+    "ipsx_trunk_kernel": (C.c_char_p, [C.POINTER(Trunk)]),
     "ipsx_trunk_encode": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
     "ipsx_projector": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
@@ -264,6 +265,15 @@ class EncoderPlan:
             _ck(lib().ipsx_projector(C.byref(self.lin), _p(x), n, C.c_float(self.ln_eps), _p(out),
                                      _p(ws), nb, _stream()), "ipsx_projector")
         return out
+
+
+def encoder_kernel_name(plan):
+    """Which kernel family the plan's encode() launches (for bench.py's roofline record)."""
+    if plan is None or plan._sig is None:
+        return None
+    if not plan.is_image:
+        return "layernorm_rows_kernel + conv_c8_kernel (projector)"
+    return lib().ipsx_trunk_kernel(C.byref(plan.trunk)).decode()
 
 
 # ------------------------------------------------------------------ scorer

@@ -33,9 +33,10 @@ def test_ips_and_forward_match_reference_fixture(case):
     if g.mem_pos_sum is not None:
         # the table is built by the HOST's sin/cos (reference transformer.py:6-18), which differs in
         # the last ulp between CPU models; the selection of rows is exact, the values are host-made
-        assert np.allclose(mem_pos.double().sum(-1).cpu().numpy(), g.mem_pos_sum, rtol=1e-6)
-        assert torch.equal(mem_pos, torch.stack([net.pos_enc[0][net.last_mem_idx[b]] for b in range(g.B)])) \
-            or g.perm is not None
+        # (exp() for the frequencies differs by an ulp, multiplied by positions up to N: ~1e-4 absolute)
+        assert np.allclose(mem_pos.double().sum(-1).cpu().numpy(), g.mem_pos_sum, atol=2e-2, rtol=0)
+        if g.perm is None:
+            assert torch.equal(mem_pos, torch.stack([net.pos_enc[0][net.last_mem_idx[b]] for b in range(g.B)]))
     with torch.no_grad():
         preds = net(mem_patch, mem_pos)
     for k, v in g.preds.items():
