@@ -128,6 +128,23 @@ def test_encoder_bit_exact(case, n):
     assert ulp_diff(got, want) == 0, "max abs diff %g" % np.abs(got - want).max()
 
 
+def test_fused_trunk_equals_layered_kernels(monkeypatch):
+    """The LDS-resident fused trunk (1x32x32 patches) vs the layer-by-layer kernels vs the oracle."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    x = g.patches()[0, :203].to(DEV)                 # 203 = 50*4 + 3: exercises the tail workgroup
+    plan = hip.EncoderPlan(net.encoder, True)
+    fused = plan.encode(x)
+    assert hip.encoder_kernel_name(plan) == "fused_trunk_kernel"
+    monkeypatch.setenv("IPSX_NO_FUSED", "1")
+    layered = plan.encode(x)
+    assert hip.encoder_kernel_name(plan).startswith("conv_c8_kernel")
+    monkeypatch.delenv("IPSX_NO_FUSED")
+    assert torch.equal(fused, layered)
+    want = orc.Oracle(g.net("cpu")).encode(x.cpu().numpy())
+    assert ulp_diff(fused.cpu().numpy(), want) == 0
+
+
 def test_encoder_plan_tracks_weight_updates():
     g = Golden("mnist_mini")
     net = g.net(DEV)
