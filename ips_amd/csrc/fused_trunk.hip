@@ -49,6 +49,12 @@ struct FusedArgs {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Ordering point for a slab that only ONE wavefront touches (stem and 8x8 stage: wave = patch).
+// DS operations of a wavefront are executed in issue order, so a later ds_read of another lane
+// sees an earlier ds_write; what is needed is that the compiler keeps the order and that reads
+// issued before are complete before the slab is overwritten.
+__device__ __forceinline__ void wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ void zero(f32x16& v) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = 0.0f;
@@ -182,34 +188,47 @@ __device__ __forceinline__ void store_l1(float* S, const f32x16 (&v)[2][2], int 
 
 // ------------------------------------------------------------------ 8x8 stage, wave = patch
 // acc = conv3x3(S) over K = 9*64 in tap-major order.  wp: packed weights (2 n-tiles x 72 k-groups).
-// Two-stage software pipeline over k-groups (8 k = 4 MFMA steps = 16 MFMAs = 1024 matrix-pipe
-// cycles): the LDS reads and the 2 KiB weight fetch of group g+1 are issued before the MFMAs of
-// group g; sched_barrier keeps the compiler from sinking them back next to their uses.
+//
+// Software pipeline over k-groups (8 k = 4 MFMA steps = 16 MFMAs = 1024 matrix-pipe cycles):
+// the LDS reads and the 2 KiB weight fetch of group g+1 are issued before the MFMAs of group g;
+// sched_barrier keeps the compiler from sinking them back next to their uses.  Everything that
+// depends only on the tap (halo mask, source pixel) is computed once per tap; inside a tap every
+// address is base + immediate.
+struct L1Tap {
+    const float* s0;    // slab pointer of this lane's source pixel, m-tile 0 (halo -> pixel 0)
+    const float* s1;    // m-tile 1
+    bool ok0, ok1;
+};
+
 struct L1Stage {
     float a[2][4];      // raw A values [m-tile][k-step]
-    bool ok[2];         // halo validity of this lane's pixel for the group's tap
+    bool ok0, ok1;
     float4 b[2];        // weights of the two n-tiles
 };
 
-__device__ __forceinline__ void l1_load(L1Stage& st, int g, const float4* wp0, const float4* wp1, const float* S,
-                                        int i, int half) {
-    g = g < 72 ? g : 71;
-    const int tap = g >> 3, cg = g & 7;
+__device__ __forceinline__ L1Tap l1_tap(int tap, const float* S, int i, int half) {
     const int t3 = tap / 3;
     const int dy = t3 - 1, dx = tap - 3 * t3 - 1;
     const int x = i & 7, y0 = i >> 3;
     const bool okx = (unsigned)(x + dx) < 8u;
-    st.ok[0] = okx && (unsigned)(y0 + dy) < 8u;
-    st.ok[1] = okx && (unsigned)(y0 + 4 + dy) < 8u;
+    L1Tap d;
+    d.ok0 = okx && (unsigned)(y0 + dy) < 8u;
+    d.ok1 = okx && (unsigned)(y0 + 4 + dy) < 8u;
     const int p0 = i + dy * 8 + dx;
-    const float* s0 = S + (half + cg * 8) * CS1 + (st.ok[0] ? p0 : 0);
-    const float* s1 = S + (half + cg * 8) * CS1 + (st.ok[1] ? p0 + 32 : 0);
-    st.b[0] = wp0[g * 64];
-    st.b[1] = wp1[g * 64];
+    d.s0 = S + half * CS1 + (d.ok0 ? p0 : 0);
+    d.s1 = S + half * CS1 + (d.ok1 ? p0 + 32 : 0);
+    return d;
+}
+
+template <int CG>
+__device__ __forceinline__ void l1_load(L1Stage& st, const L1Tap& d, const float4* w) {
+    st.ok0 = d.ok0; st.ok1 = d.ok1;
+    st.b[0] = w[CG * 64];
+    st.b[1] = w[72 * 64 + CG * 64];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        st.a[0][j] = s0[2 * j * CS1];
-        st.a[1][j] = s1[2 * j * CS1];
+        st.a[0][j] = d.s0[(CG * 8 + 2 * j) * CS1];
+        st.a[1][j] = d.s1[(CG * 8 + 2 * j) * CS1];
     }
 }
 
@@ -218,8 +237,8 @@ __device__ __forceinline__ void l1_mma(const L1Stage& st, f32x16 (&acc)[2][2]) {
     const float bb1[4] = {st.b[1].x, st.b[1].y, st.b[1].z, st.b[1].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float a0 = st.ok[0] ? st.a[0][j] : 0.0f;
-        const float a1 = st.ok[1] ? st.a[1][j] : 0.0f;
+        const float a0 = st.ok0 ? st.a[0][j] : 0.0f;
+        const float a1 = st.ok1 ? st.a[1][j] : 0.0f;
         acc[0][0] = MFMA(a0, bb0[j], acc[0][0]);
         acc[0][1] = MFMA(a0, bb1[j], acc[0][1]);
         acc[1][0] = MFMA(a1, bb0[j], acc[1][0]);
@@ -227,26 +246,32 @@ __device__ __forceinline__ void l1_mma(const L1Stage& st, f32x16 (&acc)[2][2]) {
     }
 }
 
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
 __device__ __forceinline__ void conv_l1(const float* __restrict__ wp, const float* S, f32x16 (&acc)[2][2], int lane) {
     const int i = lane & 31, half = lane >> 5;
-    const float4* wp0 = reinterpret_cast<const float4*>(wp) + lane;
-    const float4* wp1 = wp0 + 72 * 64;
+    const float4* w = reinterpret_cast<const float4*>(wp) + lane;      // advances 8 k-groups per tap
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) zero(acc[mt][nt]);
-    L1Stage s0, s1;
-    l1_load(s0, 0, wp0, wp1, S, i, half);
+    L1Tap cur = l1_tap(0, S, i, half);
+    L1Stage sa, sb;
+    l1_load<0>(sa, cur, w);
 #pragma unroll 1
-    for (int g = 0; g < 72; g += 2) {
-        l1_load(s1, g + 1, wp0, wp1, S, i, half);
-        __builtin_amdgcn_sched_barrier(0);
-        l1_mma(s0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        l1_load(s0, g + 2, wp0, wp1, S, i, half);
-        __builtin_amdgcn_sched_barrier(0);
-        l1_mma(s1, acc);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int tap = 0; tap < 9; ++tap) {
+        const L1Tap nxt = l1_tap(tap < 8 ? tap + 1 : 8, S, i, half);
+        const float4* wn = tap < 8 ? w + 8 * 64 : w;                   // last prefetch re-reads valid memory
+        l1_load<1>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
+        l1_load<2>(sa, cur, w); SB(); l1_mma(sb, acc); SB();
+        l1_load<3>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
+        l1_load<4>(sa, cur, w); SB(); l1_mma(sb, acc); SB();
+        l1_load<5>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
+        l1_load<6>(sa, cur, w); SB(); l1_mma(sb, acc); SB();
+        l1_load<7>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
+        l1_load<0>(sa, nxt, wn); SB(); l1_mma(sb, acc); SB();
+        cur = nxt;
+        w = wn;
     }
 }
 
@@ -254,28 +279,40 @@ __device__ __forceinline__ void conv_l1(const float* __restrict__ wp, const floa
 // M rows: tile mt = patches 2mt, 2mt+1; row i -> patch 2mt + (i>>4), pixel i & 15.
 // Wave `wave` accumulates output channels 32*wave .. 32*wave+31 for both tiles.
 // Input: CIN channels of WIN x WIN pixels with channel stride CS in every patch slab.
+// Same pipeline, stage = 2 packed k-groups (8 MFMA steps x 2 tiles = 16 MFMAs).
+struct L2Tap {
+    const float* s0;    // tile 0 source (patch i>>4), halo -> pixel 0
+    const float* s1;    // tile 1 source (patch 2 + (i>>4))
+    bool ok;
+};
+
 struct L2Stage {
-    float a[2][8];      // raw A values [m-tile][k-step], 8 steps = 2 packed k-groups
+    float a[2][8];
     bool ok;
     float4 b[2];
 };
 
-template <int CIN, int WIN, int CS, int STRIDE, int KS>
-__device__ __forceinline__ void l2_load(L2Stage& st, int g2, const float4* wq, const float* S0, const float* S1,
-                                        int oy, int ox) {
-    constexpr int G2 = KS * KS * CIN / 16, PER_TAP = CIN / 16, PAD = KS / 2;
-    g2 = g2 < G2 ? g2 : G2 - 1;
-    const int tap = g2 / PER_TAP, cg2 = g2 - tap * PER_TAP;
+template <int WIN, int STRIDE, int KS>
+__device__ __forceinline__ L2Tap l2_tap(int tap, const float* S0, int oy, int ox) {
+    constexpr int PAD = KS / 2;
     const int ky = tap / KS, kx = tap - ky * KS;
     const int iy = oy * STRIDE + ky - PAD, ix = ox * STRIDE + kx - PAD;
-    st.ok = (unsigned)iy < (unsigned)WIN && (unsigned)ix < (unsigned)WIN;
-    const int off = (st.ok ? iy * WIN + ix : 0) + cg2 * 16 * CS;
-    st.b[0] = wq[(2 * g2) * 64];
-    st.b[1] = wq[(2 * g2 + 1) * 64];
+    L2Tap d;
+    d.ok = (unsigned)iy < (unsigned)WIN && (unsigned)ix < (unsigned)WIN;
+    d.s0 = S0 + (d.ok ? iy * WIN + ix : 0);
+    d.s1 = d.s0 + 2 * SLAB;
+    return d;
+}
+
+template <int CS, int C2>
+__device__ __forceinline__ void l2_load(L2Stage& st, const L2Tap& d, const float4* w) {
+    st.ok = d.ok;
+    st.b[0] = w[(2 * C2) * 64];
+    st.b[1] = w[(2 * C2 + 1) * 64];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        st.a[0][j] = S0[off + 2 * j * CS];
-        st.a[1][j] = S1[off + 2 * j * CS];
+        st.a[0][j] = d.s0[(C2 * 16 + 2 * j) * CS];
+        st.a[1][j] = d.s1[(C2 * 16 + 2 * j) * CS];
     }
 }
 
@@ -293,26 +330,32 @@ __device__ __forceinline__ void l2_mma(const L2Stage& st, f32x16 (&acc)[2]) {
 template <int CIN, int WIN, int CS, int STRIDE, int KS>
 __device__ __forceinline__ void conv_l2(const float* __restrict__ wp, const float* lds, f32x16 (&acc)[2], int lane,
                                         int wave) {
-    constexpr int KGS = KS * KS * CIN / 8, G2 = KGS / 2;
-    static_assert(G2 % 2 == 0 && CIN % 16 == 0, "pipeline needs an even number of k-group pairs per conv");
+    constexpr int KGS = KS * KS * CIN / 8, PER_TAP = CIN / 16, TAPS = KS * KS;
+    static_assert(PER_TAP == 4 || PER_TAP == 8, "stage schedule is written for 64 or 128 input channels");
     const int i = lane & 31, half = lane >> 5;
     const int pix = i & 15, oy = pix >> 2, ox = pix & 3;
-    const float* S0 = lds + (i >> 4) * SLAB + half * CS;     // tile 0: patch (i>>4); tile 1: patch 2 + (i>>4)
-    const float* S1 = S0 + 2 * SLAB;
-    const float4* wq = reinterpret_cast<const float4*>(wp) + (size_t)wave * KGS * 64 + lane;
+    const float* S0 = lds + (i >> 4) * SLAB + half * CS;
+    const float4* w = reinterpret_cast<const float4*>(wp) + (size_t)wave * KGS * 64 + lane;   // +2*PER_TAP groups per tap
     zero(acc[0]); zero(acc[1]);
-    L2Stage s0, s1;
-    l2_load<CIN, WIN, CS, STRIDE, KS>(s0, 0, wq, S0, S1, oy, ox);
+    L2Tap cur = l2_tap<WIN, STRIDE, KS>(0, S0, oy, ox);
+    L2Stage sa, sb;
+    l2_load<CS, 0>(sa, cur, w);
 #pragma unroll 1
-    for (int g = 0; g < G2; g += 2) {
-        l2_load<CIN, WIN, CS, STRIDE, KS>(s1, g + 1, wq, S0, S1, oy, ox);
-        __builtin_amdgcn_sched_barrier(0);
-        l2_mma(s0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        l2_load<CIN, WIN, CS, STRIDE, KS>(s0, g + 2, wq, S0, S1, oy, ox);
-        __builtin_amdgcn_sched_barrier(0);
-        l2_mma(s1, acc);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const L2Tap nxt = l2_tap<WIN, STRIDE, KS>(tap < TAPS - 1 ? tap + 1 : TAPS - 1, S0, oy, ox);
+        const float4* wn = tap < TAPS - 1 ? w + 2 * PER_TAP * 64 : w;
+        l2_load<CS, 1>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
+        l2_load<CS, 2>(sa, cur, w); SB(); l2_mma(sb, acc); SB();
+        l2_load<CS, 3>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
+        if (PER_TAP == 8) {
+            l2_load<CS, 4>(sa, cur, w); SB(); l2_mma(sb, acc); SB();
+            l2_load<CS, 5>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
+            l2_load<CS, 6>(sa, cur, w); SB(); l2_mma(sb, acc); SB();
+            l2_load<CS, 7>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
+        }
+        l2_load<CS, 0>(sa, nxt, wn); SB(); l2_mma(sb, acc); SB();
+        cur = nxt;
+        w = wn;
     }
 }
 
@@ -342,14 +385,14 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
     const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
 #pragma unroll
     for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(S)[k * 64 + lane] = src[k * 64 + lane];
-    __syncthreads();
+    wave_fence();
 
     // ---- stem + pool: result in registers = identity of block 1
     f32x16 idn[2][2], acc[2][2];
     stem_pool(a, S, idn, lane);
-    __syncthreads();                                                      // the input is dead
+    wave_fence();                                                      // the input is dead
     store_l1(S, idn, lane);
-    __syncthreads();
+    wave_fence();
 
     // ---- layer1: two BasicBlocks at 8x8, wave = patch
 #pragma unroll 1
@@ -371,9 +414,9 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
                     }
             }
         }
-        __syncthreads();
+        wave_fence();
         store_l1(S, acc, lane);
-        __syncthreads();
+        wave_fence();
         // conv2 -> BN -> += identity -> ReLU
         conv_l1(a.w[2 * blk + 1], S, acc, lane);
         {
@@ -392,9 +435,9 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
                     }
             }
         }
-        __syncthreads();
+        wave_fence();
         store_l1(S, idn, lane);
-        __syncthreads();
+        __syncthreads();                                                  // layer2 reads all four slabs
     }
 
     // ---- layer2 block 0: conv3x3/2 (64->128) and the 1x1/2 projection read the 8x8 stage
