@@ -14,9 +14,13 @@
  *
  * Arithmetic contract (restated on the CPU in oracle/ips_oracle.cpp):
  *   - every contraction (convolution taps x channels, Linear rows, q.k, attn.v)
- *     is ONE fp32 fused-multiply-add chain in ascending index order, which is
- *     what v_mfma_f32_32x32x2_f32 computes bit for bit;
- *   - convolution K order is tap-major: k = (ky*KW + kx)*C_in + c;
+ *     is ONE fp32 fused-multiply-add chain, which is what
+ *     v_mfma_f32_32x32x2_f32 computes bit for bit;
+ *   - convolution K index is tap-major: k = (ky*KW + kx)*C_in + c;
+ *   - chains that run on the matrix cores (convolutions, projector Linear, K and V
+ *     projections) visit every aligned group of 8 k in the order 0,4,1,5,2,6,3,7
+ *     (the MFMA consumes k in (lane-half 0, lane-half 1) pairs and a lane half
+ *     fetches 4 consecutive k with one 16-byte load); all others ascend;
  *   - eval BatchNorm is the affine y = fma(acc, alpha, shift) with
  *     alpha = gamma * (1/sqrt(var+eps)), shift = beta - mean*alpha;
  *   - exp() is ipsx's own fma polynomial (identical bits on host and device);
@@ -53,7 +57,8 @@ int ipsx_device_is_gfx950(int dev);
 /* elements of the packed form of an OIHW weight (C_out padded to 32, K to 8) */
 size_t ipsx_packed_conv_weight_elems(int c_out, int c_in, int kh, int kw);
 
-/* OIHW fp32 -> MFMA B-operand stream [C_out/32][K/8][64 lanes][4], tap-major K */
+/* OIHW fp32 -> MFMA B-operand stream [C_out/32][K/8][64 lanes][4], tap-major K;
+ * element j of lane l holds k = 8*group + 4*(l>>5) + j, output channel 32*tile + (l&31) */
 int ipsx_pack_conv_weight(const float* w_oihw, int c_out, int c_in, int kh, int kw,
                           float* packed, void* stream);
 

@@ -9,7 +9,7 @@
 // bit for bit.
 //
 //  * A operand (activations, NCHW fp32): lane l holds pixel (l & 31) of the tile
-//    and k = 2*step + (l >> 5); it is fetched straight from global/L2 with the tap
+//    and, in step j of k-group g, k = 8g + 4*(l >> 5) + j; it is fetched straight from global/L2 with the tap
 //    offset applied (im2col on the fly); padded taps read a valid address and are
 //    zeroed by a select, so there is no divergent control flow around the MFMAs.
 //  * B operand (weights): pre-packed by ipsx_pack_conv_weight into the exact
@@ -52,7 +52,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int c_out, 
     const int kg = (int)(g % kgs);
     const int nt = (int)(g / kgs);
     const int n = nt * 32 + (lane & 31);
-    const int k = kg * 8 + 2 * j + (lane >> 5);
+    const int k = kg * 8 + 4 * (lane >> 5) + j;          // lane half h, step j  <->  k = 8g + 4h + j
     const int K = kh * kw * c_in;
     float v = 0.0f;
     if (n < c_out && k < K) {
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a) {
             const bool ok0 = p0.valid && (unsigned)iy_0 < (unsigned)a.h && (unsigned)ix_0 < (unsigned)a.w;
             const bool ok1 = p1.valid && (unsigned)iy_1 < (unsigned)a.h && (unsigned)ix_1 < (unsigned)a.w;
             // padded taps load element 0 of the patch (always mapped) and are zeroed below
-            const float* s0 = p0.base + (ok0 ? iy_0 * a.w + ix_0 : 0) + half * hw;
-            const float* s1 = p1.base + (ok1 ? iy_1 * a.w + ix_1 : 0) + half * hw;
+            const float* s0 = p0.base + (ok0 ? iy_0 * a.w + ix_0 : 0) + 4 * half * hw;
+            const float* s1 = p1.base + (ok1 ? iy_1 * a.w + ix_1 : 0) + 4 * half * hw;
 #pragma unroll 2
             for (int cg = 0; cg < cgs; ++cg) {
                 const float4 b0 = *wp0;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a) {
                 const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int coff = (cg * 8 + 2 * j) * hw;
+                    const int coff = (cg * 8 + j) * hw;          // channel cg*8 + 4*half + j
                     float a0 = s0[coff], a1 = s1[coff];
                     a0 = ok0 ? a0 : 0.0f;
                     a1 = ok1 ? a1 : 0.0f;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_any_kernel(ConvArgs a) {
         const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = kg * 8 + 2 * j + half;
+            const int k = kg * 8 + 4 * half + j;
             const bool kin = k < K;
             const int kk = kin ? k : 0;
             const int tap = kk / a.c_in, c = kk - tap * a.c_in;

@@ -7,19 +7,28 @@
 // 18,628,608 MAC per patch; 4 KiB in, 512 B out: arithmetic intensity ~8 kFLOP/B, so the
 // bound is the fp32 matrix pipe (157 TFLOP/s), not HBM.
 //
-// One workgroup = 4 wavefronts = 4 patches, 68 KiB of LDS (one 17 KiB slab per patch), two
-// workgroups per CU (2 waves per SIMD).  Every contraction is v_mfma_f32_32x32x2_f32 in the
-// canonical k order, so the embeddings are bit-identical to the layer-by-layer kernels of
-// conv.hip and to the oracle.
+// One workgroup = 4 wavefronts = 4 patches, 69 KiB of LDS (one 17.3 KiB slab per patch), two
+// workgroups per CU.  Every contraction is v_mfma_f32_32x32x2_f32 in the contract's k order, so
+// the embeddings are bit-identical to the layer-by-layer kernels of conv.hip and to the oracle.
 //
-//   stem      wave = patch.  The 32x32 input sits in the slab; 8 tiles of 2 output rows
-//             (32 px) x 64 channels; BN+ReLU in registers; the 3x3/2 max-pool is done ON
-//             the accumulators (one lane-half exchange), and its output lands in exactly the
-//             register layout of the 8x8 stage's MFMA C tile - it is the first block's identity.
-//   layer1    wave = patch: 64 px x 64 ch = 2x2 accumulators.  A from the slab ([c][pix],
-//             channel stride 68 floats, halo by select), B = pre-packed weights streamed from
-//             L2 (16 B per lane per 4 k-steps).  conv1 output overwrites the slab in place
-//             (its input is dead: the identity lives in registers).
+// What the instruction stream is shaped by (measured, tools/ubench): for the fp32 MFMA every
+// OTHER instruction a wave issues costs matrix-pipe time (~8-10 cycles each, wherever it is
+// placed), and a VALU write to a register that an MFMA issued just before reads as SrcA/B stalls
+// for that MFMA.  So the kernel minimises instructions per MFMA:
+//   * the LDS image of a stage is PIXEL-major, [pix][channel] with 4 floats of row padding, so a
+//     lane fetches the 4 consecutive k of its half of an 8-group with ONE ds_read_b128
+//     (that is why the contract's k order inside a group is 0,4,1,5,2,6,3,7);
+//   * one extra all-zero pixel row per slab: halo lanes point at it - no select anywhere;
+//   * weights come pre-packed from L2, 16 B per lane per 4 k-steps, through a 4-slot register
+//     ring refilled two stages (2 x 1024 pipe cycles) ahead; LDS operands one stage ahead;
+//     sched_barrier pins loads-then-16-MFMAs per stage.
+//
+//   stem      wave = patch.  The zero-padded 38x38 input sits in the slab; 8 tiles of 2 output rows
+//             (32 px) x 64 channels; BN+ReLU in registers; the 3x3/2 max-pool is done ON the
+//             accumulators (one lane-half exchange of column maxima), and its output lands in
+//             exactly the register layout of the 8x8 stage's MFMA C tile - the first block's identity.
+//   layer1    wave = patch: 64 px x 64 ch = 2x2 accumulators, no workgroup barriers (the slab is
+//             wave-private).  conv1 output overwrites the slab in place (the identity lives in registers).
 //   layer2    the 4 waves share the 4 patches: M = 4 x 16 px = 2 tiles, wave w owns output
 //             channels 32w..32w+31, so each weight is fetched once per workgroup.
 //   avgpool   sequential 16-term sums from the slab (the oracle's order).
@@ -34,9 +43,11 @@ namespace ipsx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CS1 = 68;              // channel stride of the 64ch x 8x8 stage (floats)
-constexpr int CS2 = 20;              // channel stride of the 128ch x 4x4 stage
-constexpr int SLAB = 64 * CS1;       // floats per patch slab (17,408 B); >= 128*CS2 and >= 1024
+constexpr int PS1 = 68;              // floats per pixel row of the 8x8 stage: 64 channels + 4 pad
+constexpr int ZP1 = 64;              // index of its all-zero pixel row
+constexpr int PS2 = 132;             // 4x4 stage: 128 channels + 4 pad
+constexpr int ZP2 = 16;
+constexpr int SLAB = (ZP1 + 1) * PS1;   // floats per patch slab (17,680 B); >= (ZP2+1)*PS2 and >= 38*38
 
 struct FusedArgs {
     const float* patches;
@@ -61,102 +72,91 @@ __device__ __forceinline__ void zero(f32x16& v) {
 }
 
 // ------------------------------------------------------------------ stem + max-pool
-// S: this wave's slab holding the 32x32 input at [0, 1024).  On return idn[mt][nt] holds the
-// pooled 8x8x64 activation in MFMA C layout (lane = channel, rows = pixels).
+// S: this wave's slab holding the ZERO-PADDED input as P[38][38] (image at rows/cols 3..34), so
+// every tap address is base + immediate and needs no halo mask.  On return idn[mt][nt] holds
+// the pooled 8x8x64 activation in MFMA C layout (lane = channel, rows = pixels).
+constexpr int PW = 38;               // padded input width
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 __device__ __forceinline__ void stem_pool(const FusedArgs& a, const float* S, f32x16 (&idn)[2][2], int lane) {
     const int i = lane & 31, half = lane >> 5;
     const int ox = i & 15;
     const float4* wp0 = reinterpret_cast<const float4*>(a.w_stem) + lane;      // n-tile 0, 7 k-groups
     const float4* wp1 = wp0 + 7 * 64;
-    const float al0 = a.a_stem[i], sh0 = a.s_stem[i], al1 = a.a_stem[32 + i], sh1 = a.s_stem[32 + i];
-    // column validity of the 7 taps for this lane's output column (tile independent)
-    unsigned colmask = 0;
+    float bw0[28], bw1[28];                                                    // weights of the 28 k-steps
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx) colmask |= ((unsigned)(2 * ox + kx - 3) < 32u ? 1u : 0u) << kx;
+    for (int kg = 0; kg < 7; ++kg) {
+        const float4 v0 = wp0[kg * 64], v1 = wp1[kg * 64];
+        bw0[4 * kg] = v0.x; bw0[4 * kg + 1] = v0.y; bw0[4 * kg + 2] = v0.z; bw0[4 * kg + 3] = v0.w;
+        bw1[4 * kg] = v1.x; bw1[4 * kg + 1] = v1.y; bw1[4 * kg + 2] = v1.z; bw1[4 * kg + 3] = v1.w;
+    }
+    const float al0 = a.a_stem[i], sh0 = a.s_stem[i], al1 = a.a_stem[32 + i], sh1 = a.s_stem[32 + i];
 
-    float prev[2][16];                                                         // stem row 2t-1, per n-tile
+    // previous stem row (2t-1) of this lane's 8 own columns, per n-tile; row -1 is padding (-inf)
+    float prev[2][8];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int x = 0; x < 16; ++x) prev[nt][x] = -__builtin_huge_valf();
+        for (int x = 0; x < 8; ++x) prev[nt][x] = -__builtin_huge_valf();
 
 #pragma unroll 1
     for (int t = 0; t < 8; ++t) {
+        // lane's output pixel: row 2t + (i>>4), col ox.  Step (kg, j) of the contract feeds
+        // k = 8kg + 4*half + j -> tap (k/7, k%7): the upper half's tap is 4 columns right of the
+        // lower half's, or, when that leaves the 7-wide row (kx0 >= 3), 3 columns left one row down.
         const int oy = 2 * t + (i >> 4);
-        unsigned rowmask = 0;
+        const float* base = S + (2 * oy) * PW + 2 * ox;
+        const float* baseN = base + half * 4;
+        const float* baseW = base + half * (PW - 3);
+        float av[25];
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) rowmask |= ((unsigned)(2 * oy + ky - 3) < 32u ? 1u : 0u) << ky;
-        const int base = (2 * oy - 3) * 32 + (2 * ox - 3);
-        // the 3.5 KiB of stem weights are re-read per tile (L1/L2 resident) instead of pinning 56
-        // VGPRs across the pooling code; the opaque zero keeps the loads inside the loop
-        int opq = 0;
-        asm volatile("" : "+s"(opq));
-        float bw0[28], bw1[28];
-#pragma unroll
-        for (int kg = 0; kg < 7; ++kg) {
-            const float4 v0 = wp0[(kg + opq) * 64], v1 = wp1[(kg + opq) * 64];
-            bw0[4 * kg] = v0.x; bw0[4 * kg + 1] = v0.y; bw0[4 * kg + 2] = v0.z; bw0[4 * kg + 3] = v0.w;
-            bw1[4 * kg] = v1.x; bw1[4 * kg + 1] = v1.y; bw1[4 * kg + 2] = v1.z; bw1[4 * kg + 3] = v1.w;
+        for (int st = 0; st < 25; ++st) {                  // steps 0..23: k-groups 0..5; step 24: k = 48 (+ padding)
+            const int k0 = 8 * (st >> 2) + (st & 3), ky0 = k0 / 7, kx0 = k0 % 7;
+            av[st] = (kx0 <= 2) ? baseN[ky0 * PW + kx0] : baseW[ky0 * PW + kx0];
         }
+        av[24] = half ? 0.0f : av[24];                     // k = 52 does not exist (zero weight): feed a clean 0
+        __builtin_amdgcn_sched_barrier(0);                 // all 25 LDS reads in flight before the MFMAs
         f32x16 acc0, acc1;
         zero(acc0); zero(acc1);
-        float av[25];
-        bool okv[25];
 #pragma unroll
-        for (int s = 0; s < 25; ++s) {                    // k = 2s + half; k = 49 is zero padding
-            const int k0 = 2 * s, k1 = 2 * s + 1;
-            const int ky0 = k0 / 7, kx0 = k0 % 7;
-            const int ky1 = k1 < 49 ? k1 / 7 : 0, kx1 = k1 < 49 ? k1 % 7 : 0;
-            const int ky = half ? ky1 : ky0, kx = half ? kx1 : kx0;
-            bool ok = ((rowmask >> ky) & (colmask >> kx) & 1u) != 0;
-            if (k1 >= 49) ok = ok && !half;
-            okv[s] = ok;
-            av[s] = S[ok ? base + ky * 32 + kx : 0];
+        for (int st = 0; st < 25; ++st) {
+            acc0 = MFMA(av[st], bw0[st], acc0);
+            acc1 = MFMA(av[st], bw1[st], acc1);
         }
-        __builtin_amdgcn_sched_barrier(0);                 // all 25 LDS reads in flight before the MFMAs
-#pragma unroll
-        for (int s = 0; s < 25; ++s) {
-            const float v = okv[s] ? av[s] : 0.0f;
-            acc0 = MFMA(v, bw0[s], acc0);
-            acc1 = MFMA(v, bw1[s], acc1);
-        }
-        // BN + ReLU, then give every lane all 32 pixels of its channel (swap lane halves)
-        float own[2][16], oth[2][16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v0 = __builtin_fmaf(acc0[r], al0, sh0), v1 = __builtin_fmaf(acc1[r], al1, sh1);
-            own[0][r] = v0 > 0.0f ? v0 : 0.0f;
-            own[1][r] = v1 > 0.0f ? v1 : 0.0f;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oth[nt][r] = __shfl_xor(own[nt][r], 32, 64);
+        // BN + ReLU; column maxima over stem rows {2t-1, 2t, 2t+1} for the 8 columns this lane holds:
+        // C reg r -> tile row r>>3, column (r&3) + 8*((r>>2)&1) + 4*half.
         float pooled[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            // tile pixel p (0..31): row = p >> 4, col = p & 15; C row p lives in lane-half (p>>2)&1, reg (p&3)+4*(p>>3)
-            float row0[16], row1[16];
+            float v[16];
 #pragma unroll
-            for (int p = 0; p < 32; ++p) {
-                const int reg = (p & 3) + 4 * (p >> 3), hp = (p >> 2) & 1;
-                const float v = (hp == half) ? own[nt][reg] : oth[nt][reg];
-                if (p < 16) row0[p] = v; else row1[p - 16] = v;
+            for (int r = 0; r < 16; ++r) {
+                const float x = nt ? __builtin_fmaf(acc1[r], al1, sh1) : __builtin_fmaf(acc0[r], al0, sh0);
+                v[r] = x > 0.0f ? x : 0.0f;
             }
-            // pooled row t, columns 4*half .. 4*half+3: max over rows {2t-1, 2t, 2t+1} x cols {2x-1, 2x, 2x+1}
+            float own[8], oth[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float m0 = -__builtin_huge_valf(), m1 = m0;          // the two candidates for px = q and px = 4+q
-#pragma unroll
-                for (int d = -1; d <= 1; ++d) {
-                    const int c0 = 2 * q + d, c1 = 2 * (4 + q) + d;
-                    if (c0 >= 0) { m0 = nanmax(m0, prev[nt][c0]); m0 = nanmax(m0, row0[c0]); m0 = nanmax(m0, row1[c0]); }
-                    if (c1 < 16) { m1 = nanmax(m1, prev[nt][c1]); m1 = nanmax(m1, row0[c1]); m1 = nanmax(m1, row1[c1]); }
-                }
-                pooled[nt][q] = half ? m1 : m0;
+            for (int j = 0; j < 4; ++j) {
+                own[j] = max3(prev[nt][j], v[j], v[8 + j]);                 // columns 4*half + j
+                own[4 + j] = max3(prev[nt][4 + j], v[4 + j], v[12 + j]);    // columns 8 + 4*half + j
+                prev[nt][j] = v[8 + j];
+                prev[nt][4 + j] = v[12 + j];
             }
 #pragma unroll
-            for (int x = 0; x < 16; ++x) prev[nt][x] = row1[x];
+            for (int j = 0; j < 8; ++j) oth[j] = __shfl_xor(own[j], 32, 64);
+            // pooled columns 4*half + q need stem columns 8*half - 1 .. 8*half + 7:
+            //   half 0: [-inf, own0..3 (cols 0-3), oth0..3 (cols 4-7)]
+            //   half 1: [own3 (col 7), oth4..7 (cols 8-11), own4..7 (cols 12-15)]
+            float L[9];
+            L[0] = half ? own[3] : -__builtin_huge_valf();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                L[1 + j] = half ? oth[4 + j] : own[j];
+                L[5 + j] = half ? own[4 + j] : oth[j];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pooled[nt][q] = max3(L[2 * q], L[2 * q + 1], L[2 * q + 2]);
         }
         // pooled row t -> C-layout registers of the 8x8 stage: pix = 8t + 4*half + q  <=>  [mt = t>>2][reg = 4*(t&3)+q]
 #pragma unroll
@@ -171,7 +171,7 @@ __device__ __forceinline__ void stem_pool(const FusedArgs& a, const float* S, f3
     }
 }
 
-// write a 64px x 64ch wave tile (C layout) into the slab as [c][pix], 16 B per store
+// write a 64px x 64ch wave tile (C layout: lane = channel, regs = pixels) into the slab as [pix][c]
 __device__ __forceinline__ void store_l1(float* S, const f32x16 (&v)[2][2], int lane) {
     const int i = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -179,31 +179,24 @@ __device__ __forceinline__ void store_l1(float* S, const f32x16 (&v)[2][2], int 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float* d = S + (nt * 32 + i) * CS1 + mt * 32 + 8 * q + 4 * half;
-                *reinterpret_cast<float4*>(d) =
-                    make_float4(v[mt][nt][4 * q], v[mt][nt][4 * q + 1], v[mt][nt][4 * q + 2], v[mt][nt][4 * q + 3]);
+            for (int r = 0; r < 16; ++r) {
+                const int pix = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                S[pix * PS1 + nt * 32 + i] = v[mt][nt][r];
             }
 }
 
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
 // ------------------------------------------------------------------ 8x8 stage, wave = patch
-// acc = conv3x3(S) over K = 9*64 in tap-major order.  wp: packed weights (2 n-tiles x 72 k-groups).
-//
-// Software pipeline over k-groups (8 k = 4 MFMA steps = 16 MFMAs = 1024 matrix-pipe cycles):
-// the LDS reads and the 2 KiB weight fetch of group g+1 are issued before the MFMAs of group g;
-// sched_barrier keeps the compiler from sinking them back next to their uses.  Everything that
-// depends only on the tap (halo mask, source pixel) is computed once per tap; inside a tap every
-// address is base + immediate.
+// acc = conv3x3(S) over K = 9*64.  wp: packed weights (2 n-tiles x 72 k-groups).
+// Stage = one k-group (8 k = 4 MFMA steps x 2x2 tiles = 16 MFMAs = 1024 matrix-pipe cycles).
 struct L1Tap {
-    const float* s0;    // slab pointer of this lane's source pixel, m-tile 0 (halo -> pixel 0)
+    const float* s0;    // this lane's source pixel row (+ 4*half), m-tile 0; halo -> zero row
     const float* s1;    // m-tile 1
-    bool ok0, ok1;
 };
 
 struct L1Stage {
-    float a[2][4];      // raw A values [m-tile][k-step]
-    bool ok0, ok1;
-    float4 b[2];        // weights of the two n-tiles
+    float4 a0, a1;      // 4 consecutive k of this lane's half, per m-tile
 };
 
 __device__ __forceinline__ L1Tap l1_tap(int tap, const float* S, int i, int half) {
@@ -211,168 +204,195 @@ __device__ __forceinline__ L1Tap l1_tap(int tap, const float* S, int i, int half
     const int dy = t3 - 1, dx = tap - 3 * t3 - 1;
     const int x = i & 7, y0 = i >> 3;
     const bool okx = (unsigned)(x + dx) < 8u;
-    L1Tap d;
-    d.ok0 = okx && (unsigned)(y0 + dy) < 8u;
-    d.ok1 = okx && (unsigned)(y0 + 4 + dy) < 8u;
+    const bool ok0 = okx && (unsigned)(y0 + dy) < 8u;
+    const bool ok1 = okx && (unsigned)(y0 + 4 + dy) < 8u;
     const int p0 = i + dy * 8 + dx;
-    d.s0 = S + half * CS1 + (d.ok0 ? p0 : 0);
-    d.s1 = S + half * CS1 + (d.ok1 ? p0 + 32 : 0);
+    L1Tap d;
+    d.s0 = S + (ok0 ? p0 : ZP1) * PS1 + 4 * half;
+    d.s1 = S + (ok1 ? p0 + 32 : ZP1) * PS1 + 4 * half;
     return d;
 }
 
 template <int CG>
-__device__ __forceinline__ void l1_load(L1Stage& st, const L1Tap& d, const float4* w) {
-    st.ok0 = d.ok0; st.ok1 = d.ok1;
-    st.b[0] = w[CG * 64];
-    st.b[1] = w[72 * 64 + CG * 64];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        st.a[0][j] = d.s0[(CG * 8 + 2 * j) * CS1];
-        st.a[1][j] = d.s1[(CG * 8 + 2 * j) * CS1];
-    }
+__device__ __forceinline__ void l1_load(L1Stage& st, const L1Tap& d) {
+    st.a0 = *reinterpret_cast<const float4*>(d.s0 + CG * 8);
+    st.a1 = *reinterpret_cast<const float4*>(d.s1 + CG * 8);
 }
 
-__device__ __forceinline__ void l1_mma(const L1Stage& st, f32x16 (&acc)[2][2]) {
-    const float bb0[4] = {st.b[0].x, st.b[0].y, st.b[0].z, st.b[0].w};
-    const float bb1[4] = {st.b[1].x, st.b[1].y, st.b[1].z, st.b[1].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a0 = st.ok0 ? st.a[0][j] : 0.0f;
-        const float a1 = st.ok1 ? st.a[1][j] : 0.0f;
-        acc[0][0] = MFMA(a0, bb0[j], acc[0][0]);
-        acc[0][1] = MFMA(a0, bb1[j], acc[0][1]);
-        acc[1][0] = MFMA(a1, bb0[j], acc[1][0]);
-        acc[1][1] = MFMA(a1, bb1[j], acc[1][1]);
-    }
+// weights of k-group g (clamped: the tail prefetches re-read the last group) for both n-tiles.
+// wb is wave-uniform (scalar base + scalar group offset), loff = lane*16 the only vector part.
+__device__ __forceinline__ void l1_loadb(float4 (&b)[2], const char* wb, unsigned loff, int g) {
+    g = g < 72 ? g : 71;
+    const char* p = wb + (size_t)g * 1024;
+    b[0] = *reinterpret_cast<const float4*>(p + loff);
+    b[1] = *reinterpret_cast<const float4*>(p + 72 * 1024 + loff);
 }
 
-#define SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void l1_mma(const L1Stage& st, const float4 (&b)[2], f32x16 (&acc)[2][2]) {
+    const float a0[4] = {st.a0.x, st.a0.y, st.a0.z, st.a0.w}, a1[4] = {st.a1.x, st.a1.y, st.a1.z, st.a1.w};
+    const float bb0[4] = {b[0].x, b[0].y, b[0].z, b[0].w};
+    const float bb1[4] = {b[1].x, b[1].y, b[1].z, b[1].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc[0][0] = MFMA(a0[j], bb0[j], acc[0][0]);
+        acc[0][1] = MFMA(a0[j], bb1[j], acc[0][1]);
+        acc[1][0] = MFMA(a1[j], bb0[j], acc[1][0]);
+        acc[1][1] = MFMA(a1[j], bb1[j], acc[1][1]);
+    }
+}
 
 __device__ __forceinline__ void conv_l1(const float* __restrict__ wp, const float* S, f32x16 (&acc)[2][2], int lane) {
     const int i = lane & 31, half = lane >> 5;
-    const float4* w = reinterpret_cast<const float4*>(wp) + lane;      // advances 8 k-groups per tap
+    const char* w = reinterpret_cast<const char*>(wp);
+    const unsigned lo = lane * 16;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) zero(acc[mt][nt]);
     L1Tap cur = l1_tap(0, S, i, half);
     L1Stage sa, sb;
-    l1_load<0>(sa, cur, w);
+    float4 b0[2], b1[2], b2[2], b3[2];       // weight ring: slot = stage & 3, refilled 2 stages ahead
+    l1_loadb(b0, w, lo, 0);
+    l1_loadb(b1, w, lo, 1);
+    l1_load<0>(sa, cur);
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const L1Tap nxt = l1_tap(tap < 8 ? tap + 1 : 8, S, i, half);
-        const float4* wn = tap < 8 ? w + 8 * 64 : w;                   // last prefetch re-reads valid memory
-        l1_load<1>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
-        l1_load<2>(sa, cur, w); SB(); l1_mma(sb, acc); SB();
-        l1_load<3>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
-        l1_load<4>(sa, cur, w); SB(); l1_mma(sb, acc); SB();
-        l1_load<5>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
-        l1_load<6>(sa, cur, w); SB(); l1_mma(sb, acc); SB();
-        l1_load<7>(sb, cur, w); SB(); l1_mma(sa, acc); SB();
-        l1_load<0>(sa, nxt, wn); SB(); l1_mma(sb, acc); SB();
+        const int g = tap * 8;
+        l1_load<1>(sb, cur); l1_loadb(b2, w, lo, g + 2); SB(); l1_mma(sa, b0, acc); SB();
+        l1_load<2>(sa, cur); l1_loadb(b3, w, lo, g + 3); SB(); l1_mma(sb, b1, acc); SB();
+        l1_load<3>(sb, cur); l1_loadb(b0, w, lo, g + 4); SB(); l1_mma(sa, b2, acc); SB();
+        l1_load<4>(sa, cur); l1_loadb(b1, w, lo, g + 5); SB(); l1_mma(sb, b3, acc); SB();
+        l1_load<5>(sb, cur); l1_loadb(b2, w, lo, g + 6); SB(); l1_mma(sa, b0, acc); SB();
+        l1_load<6>(sa, cur); l1_loadb(b3, w, lo, g + 7); SB(); l1_mma(sb, b1, acc); SB();
+        l1_load<7>(sb, cur); l1_loadb(b0, w, lo, g + 8); SB(); l1_mma(sa, b2, acc); SB();
+        l1_load<0>(sa, nxt); l1_loadb(b1, w, lo, g + 9); SB(); l1_mma(sb, b3, acc); SB();
         cur = nxt;
-        w = wn;
     }
 }
 
 // ------------------------------------------------------------------ 4x4 stage, 4 waves x 4 patches
 // M rows: tile mt = patches 2mt, 2mt+1; row i -> patch 2mt + (i>>4), pixel i & 15.
 // Wave `wave` accumulates output channels 32*wave .. 32*wave+31 for both tiles.
-// Input: CIN channels of WIN x WIN pixels with channel stride CS in every patch slab.
-// Same pipeline, stage = 2 packed k-groups (8 MFMA steps x 2 tiles = 16 MFMAs).
+// Input: CIN channels of WIN x WIN pixels, pixel-major with row stride PS and zero row ZP.
+// Stage = 2 packed k-groups (16 k = 8 MFMA steps x 2 tiles = 16 MFMAs).
 struct L2Tap {
-    const float* s0;    // tile 0 source (patch i>>4), halo -> pixel 0
-    const float* s1;    // tile 1 source (patch 2 + (i>>4))
-    bool ok;
+    const float* s0;    // tile 0 source pixel row (+ 4*half), halo -> zero row
+    const float* s1;    // tile 1 (two slabs further)
 };
 
 struct L2Stage {
-    float a[2][8];
-    bool ok;
-    float4 b[2];
+    float4 a[2][2];     // [tile][k-group of the pair]
 };
 
-template <int WIN, int STRIDE, int KS>
+template <int WIN, int PS, int ZP, int STRIDE, int KS>
 __device__ __forceinline__ L2Tap l2_tap(int tap, const float* S0, int oy, int ox) {
     constexpr int PAD = KS / 2;
     const int ky = tap / KS, kx = tap - ky * KS;
     const int iy = oy * STRIDE + ky - PAD, ix = ox * STRIDE + kx - PAD;
+    const bool ok = (unsigned)iy < (unsigned)WIN && (unsigned)ix < (unsigned)WIN;
     L2Tap d;
-    d.ok = (unsigned)iy < (unsigned)WIN && (unsigned)ix < (unsigned)WIN;
-    d.s0 = S0 + (d.ok ? iy * WIN + ix : 0);
+    d.s0 = S0 + (ok ? iy * WIN + ix : ZP) * PS;
     d.s1 = d.s0 + 2 * SLAB;
     return d;
 }
 
-template <int CS, int C2>
-__device__ __forceinline__ void l2_load(L2Stage& st, const L2Tap& d, const float4* w) {
-    st.ok = d.ok;
-    st.b[0] = w[(2 * C2) * 64];
-    st.b[1] = w[(2 * C2 + 1) * 64];
+template <int C2>
+__device__ __forceinline__ void l2_load(L2Stage& st, const L2Tap& d) {
+    st.a[0][0] = *reinterpret_cast<const float4*>(d.s0 + C2 * 16);
+    st.a[0][1] = *reinterpret_cast<const float4*>(d.s0 + C2 * 16 + 8);
+    st.a[1][0] = *reinterpret_cast<const float4*>(d.s1 + C2 * 16);
+    st.a[1][1] = *reinterpret_cast<const float4*>(d.s1 + C2 * 16 + 8);
+}
+
+template <int G2>
+__device__ __forceinline__ void l2_loadb(float4 (&b)[2], const char* wb, unsigned loff, int g2) {
+    g2 = g2 < G2 ? g2 : G2 - 1;
+    const char* p = wb + (size_t)g2 * 2048;
+    b[0] = *reinterpret_cast<const float4*>(p + loff);
+    b[1] = *reinterpret_cast<const float4*>(p + 1024 + loff);
+}
+
+__device__ __forceinline__ void l2_mma(const L2Stage& st, const float4 (&b)[2], f32x16 (&acc)[2]) {
+    const float a0[8] = {st.a[0][0].x, st.a[0][0].y, st.a[0][0].z, st.a[0][0].w,
+                         st.a[0][1].x, st.a[0][1].y, st.a[0][1].z, st.a[0][1].w};
+    const float a1[8] = {st.a[1][0].x, st.a[1][0].y, st.a[1][0].z, st.a[1][0].w,
+                         st.a[1][1].x, st.a[1][1].y, st.a[1][1].z, st.a[1][1].w};
+    const float bb[8] = {b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, b[1].z, b[1].w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        st.a[0][j] = d.s0[(C2 * 16 + 2 * j) * CS];
-        st.a[1][j] = d.s1[(C2 * 16 + 2 * j) * CS];
+        acc[0] = MFMA(a0[j], bb[j], acc[0]);
+        acc[1] = MFMA(a1[j], bb[j], acc[1]);
     }
 }
 
-__device__ __forceinline__ void l2_mma(const L2Stage& st, f32x16 (&acc)[2]) {
-    const float bb[8] = {st.b[0].x, st.b[0].y, st.b[0].z, st.b[0].w, st.b[1].x, st.b[1].y, st.b[1].z, st.b[1].w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float a0 = st.ok ? st.a[0][j] : 0.0f;
-        const float a1 = st.ok ? st.a[1][j] : 0.0f;
-        acc[0] = MFMA(a0, bb[j], acc[0]);
-        acc[1] = MFMA(a1, bb[j], acc[1]);
-    }
-}
-
-template <int CIN, int WIN, int CS, int STRIDE, int KS>
+template <int CIN, int WIN, int PS, int ZP, int STRIDE, int KS>
 __device__ __forceinline__ void conv_l2(const float* __restrict__ wp, const float* lds, f32x16 (&acc)[2], int lane,
                                         int wave) {
-    constexpr int KGS = KS * KS * CIN / 8, PER_TAP = CIN / 16, TAPS = KS * KS;
+    constexpr int KGS = KS * KS * CIN / 8, G2 = KGS / 2, PER_TAP = CIN / 16, TAPS = KS * KS;
     static_assert(PER_TAP == 4 || PER_TAP == 8, "stage schedule is written for 64 or 128 input channels");
     const int i = lane & 31, half = lane >> 5;
     const int pix = i & 15, oy = pix >> 2, ox = pix & 3;
-    const float* S0 = lds + (i >> 4) * SLAB + half * CS;
-    const float4* w = reinterpret_cast<const float4*>(wp) + (size_t)wave * KGS * 64 + lane;   // +2*PER_TAP groups per tap
+    const float* S0 = lds + (i >> 4) * SLAB + 4 * half;
+    const char* w = reinterpret_cast<const char*>(wp) + (size_t)__builtin_amdgcn_readfirstlane(wave) * KGS * 1024;
+    const unsigned lo = lane * 16;
     zero(acc[0]); zero(acc[1]);
-    L2Tap cur = l2_tap<WIN, STRIDE, KS>(0, S0, oy, ox);
+    L2Tap cur = l2_tap<WIN, PS, ZP, STRIDE, KS>(0, S0, oy, ox);
     L2Stage sa, sb;
-    l2_load<CS, 0>(sa, cur, w);
+    float4 b0[2], b1[2], b2[2], b3[2];
+    l2_loadb<G2>(b0, w, lo, 0);
+    l2_loadb<G2>(b1, w, lo, 1);
+    l2_load<0>(sa, cur);
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
-        const L2Tap nxt = l2_tap<WIN, STRIDE, KS>(tap < TAPS - 1 ? tap + 1 : TAPS - 1, S0, oy, ox);
-        const float4* wn = tap < TAPS - 1 ? w + 2 * PER_TAP * 64 : w;
-        l2_load<CS, 1>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
-        l2_load<CS, 2>(sa, cur, w); SB(); l2_mma(sb, acc); SB();
-        l2_load<CS, 3>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
+        const L2Tap nxt = l2_tap<WIN, PS, ZP, STRIDE, KS>(tap < TAPS - 1 ? tap + 1 : TAPS - 1, S0, oy, ox);
+        const int g = tap * PER_TAP;
         if (PER_TAP == 8) {
-            l2_load<CS, 4>(sa, cur, w); SB(); l2_mma(sb, acc); SB();
-            l2_load<CS, 5>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
-            l2_load<CS, 6>(sa, cur, w); SB(); l2_mma(sb, acc); SB();
-            l2_load<CS, 7>(sb, cur, w); SB(); l2_mma(sa, acc); SB();
+            l2_load<1>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 2); SB(); l2_mma(sa, b0, acc); SB();
+            l2_load<2>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 3); SB(); l2_mma(sb, b1, acc); SB();
+            l2_load<3>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 4); SB(); l2_mma(sa, b2, acc); SB();
+            l2_load<4>(sa, cur); l2_loadb<G2>(b1, w, lo, g + 5); SB(); l2_mma(sb, b3, acc); SB();
+            l2_load<5>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 6); SB(); l2_mma(sa, b0, acc); SB();
+            l2_load<6>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 7); SB(); l2_mma(sb, b1, acc); SB();
+            l2_load<7>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 8); SB(); l2_mma(sa, b2, acc); SB();
+            l2_load<0>(sa, nxt); l2_loadb<G2>(b1, w, lo, g + 9); SB(); l2_mma(sb, b3, acc); SB();
+        } else {
+            l2_load<1>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 2); SB(); l2_mma(sa, b0, acc); SB();
+            l2_load<2>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 3); SB(); l2_mma(sb, b1, acc); SB();
+            l2_load<3>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 4); SB(); l2_mma(sa, b2, acc); SB();
+            l2_load<0>(sa, nxt); l2_loadb<G2>(b1, w, lo, g + 5); SB(); l2_mma(sb, b3, acc); SB();
         }
-        l2_load<CS, 0>(sa, nxt, wn); SB(); l2_mma(sb, acc); SB();
         cur = nxt;
-        w = wn;
     }
 }
 
-// write the wave's 2 tiles (C layout) into the slabs in 4x4-stage layout [c][pix] (stride CS2)
+// write the wave's 2 tiles (C layout) into the slabs in 4x4-stage layout [pix][c] (row stride PS2)
 __device__ __forceinline__ void store_l2(float* lds, const f32x16 (&v)[2], int lane, int wave) {
     const int i = lane & 31, half = lane >> 5;
     const int n = 32 * wave + i;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float* d = lds + (2 * mt + (q >> 1)) * SLAB + n * CS2 + 8 * (q & 1) + 4 * half;
-            *reinterpret_cast<float4*>(d) = make_float4(v[mt][4 * q], v[mt][4 * q + 1], v[mt][4 * q + 2], v[mt][4 * q + 3]);
+        for (int r = 0; r < 16; ++r) {
+            const int pl = 2 * mt + (r >> 3), pix = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+            lds[pl * SLAB + pix * PS2 + n] = v[mt][r];
         }
 }
 
-__global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
+// STAMP = true is the diagnostic build: every wavefront records s_memtime at its phase boundaries
+// into a buffer of its own (never into an output); the product launches STAMP = false.
+#define IPSX_STAMP(k)                                                                      \
+    do {                                                                                   \
+        if (STAMP) {                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+            if (lane == 0) stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (k)] = t_;        \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+        }                                                                                  \
+    } while (0)
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 slabs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31;
@@ -380,16 +400,30 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
     long long pi = p_first + wave;
     if (pi >= a.n) pi = a.n - 1;                                          // tail: recompute a valid patch, store nothing
     float* S = lds + wave * SLAB;
+    IPSX_STAMP(0);
 
-    // ---- input patch -> slab (coalesced 16 B loads)
-    const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
+    // ---- input patch -> slab as a zero-padded 38x38 image (coalesced 16 B global loads)
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
+        float4 px[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(S)[k * 64 + lane] = src[k * 64 + lane];
+        for (int k = 0; k < 4; ++k) px[k] = src[k * 64 + lane];
+        for (int z = lane; z < (PW * PW + 3) / 4; z += 64) reinterpret_cast<float4*>(S)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = lane; z < PS1; z += 64) S[ZP1 * PS1 + z] = 0.0f;          // zero pixel row of the 8x8 stage
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (k * 64 + lane) * 4, y = e >> 5, x = e & 31;       // 4 pixels of row y starting at x
+            float* d = S + (y + 3) * PW + x + 3;
+            d[0] = px[k].x; d[1] = px[k].y; d[2] = px[k].z; d[3] = px[k].w;
+        }
+    }
     wave_fence();
 
     // ---- stem + pool: result in registers = identity of block 1
     f32x16 idn[2][2], acc[2][2];
+    IPSX_STAMP(1);
     stem_pool(a, S, idn, lane);
+    IPSX_STAMP(2);
     wave_fence();                                                      // the input is dead
     store_l1(S, idn, lane);
     wave_fence();
@@ -399,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
     for (int blk = 0; blk < 2; ++blk) {
         // conv1 -> BN -> ReLU, written over its own input (identity is in registers)
         conv_l1(a.w[2 * blk], S, acc, lane);
+        IPSX_STAMP(3 + 4 * blk);
         {
             const float* al = a.al[2 * blk];
             const float* sh = a.sh[2 * blk];
@@ -417,8 +452,10 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
         wave_fence();
         store_l1(S, acc, lane);
         wave_fence();
+        IPSX_STAMP(4 + 4 * blk);
         // conv2 -> BN -> += identity -> ReLU
         conv_l1(a.w[2 * blk + 1], S, acc, lane);
+        IPSX_STAMP(5 + 4 * blk);
         {
             const float* al = a.al[2 * blk + 1];
             const float* sh = a.sh[2 * blk + 1];
@@ -438,13 +475,15 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
         wave_fence();
         store_l1(S, idn, lane);
         __syncthreads();                                                  // layer2 reads all four slabs
+        IPSX_STAMP(6 + 4 * blk);
     }
 
     // ---- layer2 block 0: conv3x3/2 (64->128) and the 1x1/2 projection read the 8x8 stage
     f32x16 t2[2], id2[2];
     const int n2 = 32 * wave + i;
-    conv_l2<64, 8, CS1, 2, 3>(a.w[4], lds, t2, lane, wave);
-    conv_l2<64, 8, CS1, 2, 1>(a.w_down, lds, id2, lane, wave);
+    conv_l2<64, 8, PS1, ZP1, 2, 3>(a.w[4], lds, t2, lane, wave);
+    conv_l2<64, 8, PS1, ZP1, 2, 1>(a.w_down, lds, id2, lane, wave);
+    IPSX_STAMP(11);
     {
         const float A = a.al[4][n2], B = a.sh[4][n2], Ad = a.a_down[n2], Bd = a.s_down[n2];
 #pragma unroll
@@ -458,11 +497,12 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
     }
     __syncthreads();
     store_l2(lds, t2, lane, wave);
+    for (int z = lane; z < PS2; z += 64) lds[wave * SLAB + ZP2 * PS2 + z] = 0.0f;   // zero pixel row of the 4x4 stage
     __syncthreads();
     // conv2 of block 0, then block 1 (conv1, conv2), all 128->128 at 4x4
 #pragma unroll 1
     for (int cv = 5; cv < 8; ++cv) {
-        conv_l2<128, 4, CS2, 1, 3>(a.w[cv], lds, t2, lane, wave);
+        conv_l2<128, 4, PS2, ZP2, 1, 3>(a.w[cv], lds, t2, lane, wave);
         const float A = a.al[cv][n2], B = a.sh[cv][n2];
         const bool plain = (cv == 6);                                     // block 1 conv1: BN + ReLU only
 #pragma unroll
@@ -478,17 +518,19 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a) {
         __syncthreads();
         store_l2(lds, t2, lane, wave);
         __syncthreads();
+        IPSX_STAMP(7 + cv);
     }
 
     // ---- global average pool over the 16 pixels, sequential order
     for (int o = threadIdx.x; o < 4 * 128; o += 256) {
         const int pl = o >> 7, n = o & 127;
-        const float* s = lds + pl * SLAB + n * CS2;
+        const float* s = lds + pl * SLAB + n;
         float sum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sum = sum + s[k];
+        for (int k = 0; k < 16; ++k) sum = sum + s[k * PS2];
         if (p_first + pl < a.n) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
     }
+    IPSX_STAMP(15);
 }
 
 static bool is_conv(const ipsx_conv& c, int ci, int co, int k, int s, int p) {
@@ -512,7 +554,8 @@ bool fused_trunk_supported(const ipsx_trunk* t) {
     return !(off && off[0] == '1');
 }
 
-int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s) {
+static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, float* emb,
+                        unsigned long long* stamps, hipStream_t s) {
     FusedArgs a;
     a.patches = patches; a.emb = emb; a.n = n;
     a.w_stem = t->stem.w_packed; a.a_stem = t->stem.alpha; a.s_stem = t->stem.shift;
@@ -526,12 +569,29 @@ int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, flo
     const size_t lds = (size_t)4 * SLAB * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    fused_trunk_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), lds, s>>>(a);
+    if (stamps)
+        fused_trunk_kernel<true><<<dim3((unsigned)cdiv(n, 4)), dim3(256), lds, s>>>(a, stamps);
+    else
+        fused_trunk_kernel<false><<<dim3((unsigned)cdiv(n, 4)), dim3(256), lds, s>>>(a, nullptr);
     return launched("fused_trunk");
 }
 
+int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s) {
+    return fused_launch(t, patches, n, emb, nullptr, s);
+}
+
 }  // namespace ipsx
+
+// Diagnostic entry point (not part of include/ipsx.h): the fused trunk with s_memtime stamps,
+// 16 x uint64 per wavefront = per patch, in launch order.  Used by tools/fused_stamps.py only.
+extern "C" __attribute__((visibility("default"))) int ipsx_dbg_fused_trunk_stamps(
+    const ipsx_trunk* t, const float* patches, int64_t n, float* emb, unsigned long long* stamps, void* stream) {
+    if (!ipsx::fused_trunk_supported(t)) return ipsx::fail(IPSX_EINVAL, "trunk is not the fused shape");
+    return ipsx::fused_launch(t, patches, n, emb, stamps, ipsx::as_stream(stream));
+}

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
     const int bi = blockIdx.y;
     const long long row = r0 + (lane & 31);
     const bool rv = row < a.n;
-    const float* e = a.emb + (size_t)bi * a.emb_bs + (size_t)(rv ? row : 0) * a.d + half;
-    const float* p = a.pos ? a.pos + (size_t)bi * a.pos_bs + (size_t)(rv ? row : 0) * a.d + half : nullptr;
+    const float* e = a.emb + (size_t)bi * a.emb_bs + (size_t)(rv ? row : 0) * a.d + 4 * half;
+    const float* p = a.pos ? a.pos + (size_t)bi * a.pos_bs + (size_t)(rv ? row : 0) * a.d + 4 * half : nullptr;
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
         float av[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = kg * 8 + 2 * j;          // + half is in the base pointers
-            float v = (c + half < a.d) ? e[c] : 0.0f;
-            if (p) v = v + ((c + half < a.d) ? p[c] : 0.0f);
+            const int c = kg * 8 + j;              // + 4*half is in the base pointers
+            float v = (c + 4 * half < a.d) ? e[c] : 0.0f;
+            if (p) v = v + ((c + 4 * half < a.d) ? p[c] : 0.0f);
             av[j] = rv ? v : 0.0f;
         }
 #pragma unroll
@@ -209,6 +209,8 @@ struct ScanArgs {
     int* tie;
 };
 
+// Generic scan (any M+I that fits the key arrays): candidates' logits are re-staged from global
+// memory every iteration (or read in place when even that does not fit).
 __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = a.h * a.T, Lmax = a.m + a.i;
@@ -253,6 +255,141 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
         if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
         __syncthreads();
         int* t = cand; cand = cnew; cnew = t;
+    }
+    for (int j = tid; j < a.m; j += 256) {
+        a.mem_idx[(size_t)b * a.m + j] = cand[j];
+        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
+    }
+    if (a.tie && tid == 0) a.tie[b] = tie;
+}
+
+// Resident scan: the logits of the M memory patches stay in LDS from one iteration to the next
+// (two candidate buffers of (M+I) rows, row stride R+1), so an iteration reads only its new chunk
+// from global memory - one contiguous, coalesced block that is prefetched into registers during
+// the previous iteration.  Row statistics of a wavefront's rows are computed interleaved (the
+// max / butterfly chains of 8 rows in flight together), scoring uses one work item per
+// (candidate, token).  Same arithmetic order as the generic kernel and the oracle.
+constexpr int SCAN_PF = 8;     // prefetch registers per thread: chunk <= 256 * 8 floats
+
+__global__ __launch_bounds__(256) void scan_resident_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = a.h * a.T, Lmax = a.m + a.i, ld = R + 1;
+    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* keyB = keyA + a.n2;
+    int* candA = reinterpret_cast<int*>(keyB + a.n2);
+    int* candB = candA + Lmax;
+    float* rmax = reinterpret_cast<float*>(candB + Lmax);
+    float* rden = rmax + R;
+    float* qbuf = rden + R;                       // Lmax * T per-(candidate, token) head means
+    float* clA = qbuf + (size_t)Lmax * a.T;
+    float* clB = clA + (size_t)Lmax * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float* lg = a.lg + (size_t)b * a.n * R;
+
+    int* cand = candA;
+    int* cnew = candB;
+    float* cl = clA;
+    float* clnew = clB;
+    // memory = first m patches: their logits are one contiguous block
+    for (int j = tid; j < a.m; j += 256) cand[j] = j;
+    for (int e = tid; e < a.m * R; e += 256) { const int l = e / R; cl[l * ld + (e - l * R)] = lg[e]; }
+    const long long n_iter = (a.n - a.m + a.i - 1) / a.i;
+    // prefetch chunk 0
+    float pf[SCAN_PF];
+    {
+        const long long lo = a.m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+#pragma unroll
+        for (int k = 0; k < SCAN_PF; ++k) {
+            const int e = tid + 256 * k;
+            pf[k] = (n_iter > 0 && e < cnt * R) ? lg[(size_t)lo * R + e] : 0.0f;
+        }
+    }
+    int tie = 0;
+    uint64_t* sorted = keyA;
+    for (long long it = 0; it < n_iter; ++it) {
+        const long long lo = it * a.i + a.m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+        const int L = a.m + cnt;
+        // chunk registers -> candidate rows m.., next chunk -> registers
+#pragma unroll
+        for (int k = 0; k < SCAN_PF; ++k) {
+            const int e = tid + 256 * k;
+            if (e < cnt * R) { const int l = e / R; cl[(a.m + l) * ld + (e - l * R)] = pf[k]; }
+        }
+        for (int j = tid; j < cnt; j += 256) cand[a.m + j] = (int)(lo + j);
+        {
+            const long long lo2 = lo + a.i;
+            const int cnt2 = (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2));
+#pragma unroll
+            for (int k = 0; k < SCAN_PF; ++k) {
+                const int e = tid + 256 * k;
+                pf[k] = e < cnt2 * R ? lg[(size_t)lo2 * R + e] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // row statistics, 8 rows of this wave in flight together
+        for (int r0 = wave * 8; r0 < R; r0 += 32) {
+            float mx[8], sm[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                mx[q] = -__builtin_huge_valf();
+                if (r0 + q < R)
+                    for (int i = lane; i < L; i += 64) mx[q] = nanmax(mx[q], cl[i * ld + r0 + q]);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mx[q] = nanmax(mx[q], __shfl_xor(mx[q], off, 64));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                sm[q] = 0.0f;
+                if (r0 + q < R)
+                    for (int i = lane; i < L; i += 64) sm[q] = sm[q] + det_expf(cl[i * ld + r0 + q] - mx[q]);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sm[q] = sm[q] + __shfl_xor(sm[q], off, 64);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (r0 + q < R) { rmax[r0 + q] = mx[q]; rden[r0 + q] = sm[q]; }
+            }
+        }
+        __syncthreads();
+        // per (candidate, token): mean over heads of the attention weights (ascending h)
+        for (int e = tid; e < L * a.T; e += 256) {
+            const int l = e / a.T, t = e - l * a.T;
+            float sh = 0.0f;
+            for (int hh = 0; hh < a.h; ++hh) {
+                const int r = hh * a.T + t;
+                sh = sh + det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
+            }
+            qbuf[e] = sh / (float)a.h;
+        }
+        __syncthreads();
+        for (int l = tid; l < a.n2; l += 256) {
+            uint64_t key = 0ull;
+            if (l < L) {
+                float st = 0.0f;
+                for (int t = 0; t < a.T; ++t) st = st + qbuf[l * a.T + t];
+                key = rank_key(st / (float)a.T, (uint32_t)l);
+            }
+            keyA[l] = key;
+        }
+        sorted = sort_desc(keyA, keyB, L, a.n2);
+        // new memory: indices and logit rows of the winners, into the other buffers
+        for (int j = tid; j < a.m; j += 256) cnew[j] = cand[key_pos(sorted[j])];
+        for (int e = tid; e < a.m * R; e += 256) {
+            const int j = e / R, r = e - j * R;
+            clnew[j * ld + r] = cl[key_pos(sorted[j]) * ld + r];
+        }
+        if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
+        __syncthreads();
+        { int* t = cand; cand = cnew; cnew = t; }
+        { float* t = cl; cl = clnew; clnew = t; }
     }
     for (int j = tid; j < a.m; j += 256) {
         a.mem_idx[(size_t)b * a.m + j] = cand[j];
@@ -367,11 +504,21 @@ IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int 
     base = (base + 15) & ~(size_t)15;
     const size_t stage = (size_t)Lmax * (R + 1) * 4;
     IPSX_REQUIRE(base <= kLdsLimit, "scan: M+I = %d candidates do not fit the 160 KiB LDS", Lmax);
-    const int use_lds = base + stage <= kLdsLimit;
     ScanArgs a;
-    a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2; a.use_lds = use_lds;
+    a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
-    const size_t lds = base + (use_lds ? stage : 0);
+    // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
+    const size_t resident = base + (size_t)Lmax * n_token * 4 + 2 * stage;
+    if (resident <= kLdsLimit && (size_t)i * R <= (size_t)256 * SCAN_PF) {
+        a.use_lds = 1;
+        if (resident > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
+        scan_resident_kernel<<<dim3((unsigned)b), dim3(256), resident, as_stream(stream)>>>(a);
+        return launched("scan");
+    }
+    a.use_lds = base + stage <= kLdsLimit;
+    const size_t lds = base + (a.use_lds ? stage : 0);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     scan_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);

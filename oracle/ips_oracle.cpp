@@ -7,8 +7,12 @@
 // (file:line cited at each function, relative to the reference repo), with the
 // arithmetic ORDER pinned down so that the gfx950 kernels can reproduce the same
 // bits (see include/ipsx.h "Arithmetic contract"):
-//   * contractions are single fp32 fma chains in ascending index order,
-//   * conv K order is tap-major  k = (ky*KW+kx)*C_in + c,
+//   * contractions are single fp32 fma chains; conv K index is tap-major k = (ky*KW+kx)*C_in + c;
+//   * contractions the device runs on the matrix cores (convolutions, the projector Linear,
+//     the K and V projections) visit each aligned group of 8 consecutive k in the order
+//     0,4,1,5,2,6,3,7 (mfma_order() below): v_mfma_f32_32x32x2_f32 consumes k in pairs
+//     (lane half 0, lane half 1) and a lane half fetches 4 CONSECUTIVE k with one 16-byte read;
+//     all other chains (q.k, attn.v, fc, MLP, heads) are in ascending index order,
 //   * exp is det_expf() below, row sums are wave_sum64() below.
 // The reference's own bits (oneDNN / MKL / Sleef on CPU) are not reproducible by
 // any GPU kernel; this oracle is pinned against the reference through the golden
@@ -80,6 +84,19 @@ static inline float wave_sum64(const float* x, int64_t n, int64_t stride = 1) {
     return part[0];
 }
 
+// chain order of a K-long contraction done on the matrix cores: per group of 8: 0,4,1,5,2,6,3,7
+static std::vector<int> mfma_order(int K) {
+    std::vector<int> ord;
+    ord.reserve(K);
+    for (int g = 0; g * 8 < K; ++g)
+        for (int j = 0; j < 4; ++j)
+            for (int h = 0; h < 2; ++h) {
+                const int k = g * 8 + 4 * h + j;
+                if (k < K) ord.push_back(k);
+            }
+    return ord;
+}
+
 ORC_API float orc_expf(float x) { return det_expf(x); }
 ORC_API float orc_wave_sum64(const float* x, int64_t n) { return wave_sum64(x, n); }
 ORC_API int orc_version(void) { return 100; }
@@ -110,12 +127,13 @@ static inline int out_dim(int in, int k, int s, int p) { return (in + 2 * p - k)
 
 // nn.Conv2d(bias=False) -> BatchNorm(eval) [-> += identity] [-> ReLU]
 // (torchvision BasicBlock.forward as composed by ips_net.py:35-50).
-// acc = fma chain over k = (ky,kx,c) ascending, zero for padded taps.
+// acc = fma chain over k = (ky,kx,c) in mfma_order(), zero for padded taps.
 ORC_API void orc_conv2d_affine(const orc_conv* cv, const float* x, const float* residual,
                                float* y, int64_t n, int h, int w, int relu) {
     const int ci = cv->c_in, co = cv->c_out, kh = cv->kh, kw = cv->kw;
     const int ho = out_dim(h, kh, cv->stride, cv->pad), wo = out_dim(w, kw, cv->stride, cv->pad);
     const int K = kh * kw * ci;
+    const std::vector<int> ord = mfma_order(K);
     // weights transposed to [k][o] so the chain vectorises over output channels
     std::vector<float> wt((size_t)K * co);
     for (int o = 0; o < co; ++o)
@@ -131,17 +149,17 @@ ORC_API void orc_conv2d_affine(const orc_conv* cv, const float* x, const float* 
                 for (int ox = 0; ox < wo; ++ox) {
                     std::fill(acc.begin(), acc.end(), 0.0f);
                     float* a = acc.data();
-                    for (int ky = 0; ky < kh; ++ky)
-                        for (int kx = 0; kx < kw; ++kx) {
-                            const int iy = oy * cv->stride + ky - cv->pad;
-                            const int ix = ox * cv->stride + kx - cv->pad;
-                            const bool in = iy >= 0 && iy < h && ix >= 0 && ix < w;
-                            for (int c = 0; c < ci; ++c) {
-                                const float v = in ? x[(((size_t)p * ci + c) * h + iy) * w + ix] : 0.0f;
-                                const float* wr = &wt[(size_t)((ky * kw + kx) * ci + c) * co];
-                                for (int o = 0; o < co; ++o) a[o] = __builtin_fmaf(v, wr[o], a[o]);
-                            }
-                        }
+                    for (int kk = 0; kk < K; ++kk) {
+                        const int k = ord[kk];
+                        const int tap = k / ci, c = k - tap * ci;
+                        const int ky = tap / kw, kx = tap - ky * kw;
+                        const int iy = oy * cv->stride + ky - cv->pad;
+                        const int ix = ox * cv->stride + kx - cv->pad;
+                        const bool in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                        const float v = in ? x[(((size_t)p * ci + c) * h + iy) * w + ix] : 0.0f;
+                        const float* wr = &wt[(size_t)k * co];
+                        for (int o = 0; o < co; ++o) a[o] = __builtin_fmaf(v, wr[o], a[o]);
+                    }
                     for (int o = 0; o < co; ++o) {
                         float v = a[o];
                         if (cv->alpha) v = __builtin_fmaf(v, cv->alpha[o], cv->shift ? cv->shift[o] : 0.0f);
@@ -260,22 +278,30 @@ ORC_API void orc_layernorm(const float* x, int64_t n, int d, float eps, const fl
 }
 
 // y[r][o] = (fma chain over c of x[r][c]*w[o][c]) [+ bias[o]]   (nn.Linear)
-ORC_API void orc_linear(const float* x, const float* w, const float* bias, int64_t n, int d_in,
-                        int d_out, float* y) {
+// mfma != 0: chain in mfma_order() (the device runs this Linear on the matrix cores)
+static void linear_impl(const float* x, const float* w, const float* bias, int64_t n, int d_in,
+                        int d_out, float* y, int mfma) {
     std::vector<float> wt((size_t)d_in * d_out);
+    const std::vector<int> ord = mfma_order(d_in);
     for (int o = 0; o < d_out; ++o)
         for (int c = 0; c < d_in; ++c) wt[(size_t)c * d_out + o] = w[(size_t)o * d_in + c];
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < n; ++r) {
         float* a = y + r * d_out;
         for (int o = 0; o < d_out; ++o) a[o] = 0.0f;
-        for (int c = 0; c < d_in; ++c) {
+        for (int cc = 0; cc < d_in; ++cc) {
+            const int c = mfma ? ord[cc] : cc;
             const float v = x[r * d_in + c];
             const float* wr = &wt[(size_t)c * d_out];
             for (int o = 0; o < d_out; ++o) a[o] = __builtin_fmaf(v, wr[o], a[o]);
         }
         if (bias) for (int o = 0; o < d_out; ++o) a[o] = a[o] + bias[o];
     }
+}
+
+ORC_API void orc_linear(const float* x, const float* w, const float* bias, int64_t n, int d_in,
+                        int d_out, float* y) {
+    linear_impl(x, w, bias, n, d_in, d_out, y, 0);
 }
 
 // IPSNet.encoder for features (ips_net.py:54-60): LN(eps 1e-5, no affine) ->
@@ -285,7 +311,7 @@ ORC_API void orc_projector(const float* x, int64_t n, int f, int d, float ln_eps
                            const float* bias, const float* alpha, const float* shift, float* out) {
     std::vector<float> xn((size_t)n * f);
     orc_layernorm(x, n, f, ln_eps, nullptr, nullptr, xn.data());
-    orc_linear(xn.data(), w, nullptr, n, f, d, out);
+    linear_impl(xn.data(), w, nullptr, n, f, d, out, 1);          // on the matrix cores
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < n; ++r)
         for (int o = 0; o < d; ++o) {
@@ -306,10 +332,11 @@ ORC_API void orc_query_proj(const float* q, const float* wq, float temperature, 
 // logits of one row: x = emb (+ pos); k = k_w(x); logit[h*T+t] = qs[t][h,:] . k[h,:]
 // (transformer.py:77,31 - matmul(q/temperature, k^T), before the softmax)
 static void logits_row(const float* emb, const float* pos, const float* wkT /*[c][o]*/, const float* qs,
-                       int d, int h, int dk, int T, float* k /*scratch hdk*/, float* out) {
+                       int d, int h, int dk, int T, float* k /*scratch hdk*/, float* out, const int* ord) {
     const int hdk = h * dk;
     for (int o = 0; o < hdk; ++o) k[o] = 0.0f;
-    for (int c = 0; c < d; ++c) {
+    for (int cc = 0; cc < d; ++cc) {                      // K projection: on the matrix cores
+        const int c = ord[cc];
         const float v = pos ? emb[c] + pos[c] : emb[c];
         const float* wr = wkT + (size_t)c * hdk;
         for (int o = 0; o < hdk; ++o) k[o] = __builtin_fmaf(v, wr[o], k[o]);
@@ -326,6 +353,7 @@ ORC_API void orc_logits(const float* emb, const float* pos, const float* wk, con
                         int64_t n, int d, int h, int dk, int T, float* logits) {
     const int hdk = h * dk;
     std::vector<float> wkT((size_t)d * hdk);
+    const std::vector<int> ord = mfma_order(d);
     for (int o = 0; o < hdk; ++o)
         for (int c = 0; c < d; ++c) wkT[(size_t)c * hdk + o] = wk[(size_t)o * d + c];
 #pragma omp parallel
@@ -334,7 +362,7 @@ ORC_API void orc_logits(const float* emb, const float* pos, const float* wk, con
 #pragma omp for schedule(static)
         for (int64_t r = 0; r < n; ++r)
             logits_row(emb + r * d, pos ? pos + r * d : nullptr, wkT.data(), qs, d, h, dk, T, k.data(),
-                       logits + r * h * T);
+                       logits + r * h * T, ord.data());
     }
 }
 
@@ -477,7 +505,7 @@ ORC_API void orc_aggregate(const orc_transf* t, const float* x, int M, float* ou
     orc_logits(x, nullptr, t->wk, qs.data(), M, d, h, dk, T, lg.data());
     orc_scores_from_logits(lg.data(), M, h, T, sc.data(), attn.data());
     std::vector<float> v((size_t)M * hdv), ctx((size_t)T * hdv), y((size_t)T * d), z((size_t)T * d);
-    orc_linear(x, t->wv, nullptr, M, d, hdv, v.data());
+    linear_impl(x, t->wv, nullptr, M, d, hdv, v.data(), 1);       // V projection: on the matrix cores
     for (int tt = 0; tt < T; ++tt)
         for (int hh = 0; hh < h; ++hh)
             for (int j = 0; j < dv; ++j) {
