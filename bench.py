@@ -37,6 +37,9 @@ import torch
 import torch.distributed as dist
 
 FLOP_PER_PATCH_MNIST32 = 37_257_216      # encoder MACs*2, SURVEY.md section 8 d-4
+# secondary workloads (--config): algorithmic encoder FLOP per patch, SURVEY.md section 8 d-4
+FLOP_PER_PATCH = {"mnist": 37_257_216, "b1": 37_257_216, "native50": 2 * 52_570_176,
+                  "traffic": 2 * 441_262_848, "cam": 2 * 1_048_576}
 FP32_MFMA_PEAK_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PATCHES_PER_GPU = 2500
 BATCH = 16
@@ -49,6 +52,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--config", default="mnist", choices=sorted(FLOP_PER_PATCH),
+                    help="mnist = the headline workload (BASELINE configs[1], B=16); the others are secondary "
+                         "single-GPU measurements: b1 (same, B=1), native50 (reference-native 900 patches of 50 px, "
+                         "M=I=100, B=16), traffic (192 patches of 3x100x100, ResNet-18 x4, M=16, I=32, B=16), "
+                         "cam (65536 x 2048 features, projector, M=I=256, B=1)")
     return ap.parse_args()
 
 
@@ -117,10 +125,30 @@ def main():
     from ips_amd.architecture import IPSNet
 
     hip.lib()                                                   # fail loudly if the extension is missing
-    n_total = PATCHES_PER_GPU * world
-    conf = synth.mnist_conf(N=n_total, M=64, I=64)
+    per_gpu = PATCHES_PER_GPU
+    if args.config != "mnist" and world > 1:
+        print("secondary configs are single-GPU measurements", file=sys.stderr)
+        sys.exit(2)
+    if args.config == "b1":
+        args.batch = 1
+    if args.config in ("mnist", "b1"):
+        conf = synth.mnist_conf(N=per_gpu * world, M=64, I=64)
+        label = "Megapixel-MNIST %d patches of 1x32x32 per image" % (per_gpu * world)
+    elif args.config == "native50":
+        per_gpu = 900
+        conf = synth.mnist_conf(N=900, M=100, I=100, patch=50)
+        label = "Megapixel-MNIST reference-native 900 patches of 1x50x50 per image, M=I=100"
+    elif args.config == "traffic":
+        per_gpu = 192
+        conf = synth.traffic_conf(N=192, M=16, I=32, patch=100)
+        label = "traffic signs 192 patches of 3x100x100 per image, ResNet-18 x4 stages, M=16, I=32"
+    else:
+        per_gpu, args.batch = 65536, 1
+        conf = synth.camelyon_conf(N=65536, M=256, I=256)
+        label = "CAMELYON 65536 x 2048 features per slide, projector, M=I=256"
+    n_total = per_gpu * world
     net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
-    x = synth.make_patches(conf, args.batch, seed=21 + rank, N=PATCHES_PER_GPU).to(dev)   # resident in HBM
+    x = synth.make_patches(conf, args.batch, seed=21 + rank, N=per_gpu).to(dev)   # resident in HBM
 
     if world == 1:
         def step():
@@ -164,8 +192,19 @@ def main():
 
     enc_ms = sum(a.elapsed_time(b) for a, b, _ in enc_events)
     enc_patches = sum(n for _, _, n in enc_events)
-    achieved = enc_patches * FLOP_PER_PATCH_MNIST32 / (enc_ms * 1e-3) / 1e12
+    achieved = enc_patches * FLOP_PER_PATCH[args.config] / (enc_ms * 1e-3) / 1e12
     patches_per_step = args.batch * n_total
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process;
+    # they are collected with separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this
+    # very command (tools/pmc_traffic.py, gfx950 correction applied) and committed under profiles/.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        if args.config == "mnist" and world == 1 and pmc["kernel"] in hip.encoder_kernel_name(net._plan) \
+                and args.batch * per_gpu == 40000:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         out = {
@@ -179,16 +218,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Megapixel-MNIST %d patches of 1x32x32 per image (%d per GPU), B=%d, M=I=64, "
-                                   "n_token=4, use_pos, eager" % (n_total, PATCHES_PER_GPU, args.batch),
+            "config": {"workload": "%s (%d per GPU), B=%d, M=%d, I=%d, n_token=%d, %s, eager"
+                                   % (label, per_gpu, args.batch, conf.M, conf.I, conf.n_token,
+                                      "use_pos" if conf.use_pos else "no pos-enc"),
                        "parallelism": "patch-sharded x%d, one all-gather of logits" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
+                         "algorithmic_bytes": enc_patches / max(len(enc_events), 1) * (conf.n_chan_in * (conf.patch_size[0] * conf.patch_size[1] if conf.is_image else 1) + conf.D) * 4,
                          "kernel": hip.encoder_kernel_name(net._plan),
                          "launch_ms": enc_ms / max(len(enc_events), 1),
                          "patches_per_launch": enc_patches / max(len(enc_events), 1)},
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and args.config == "mnist":
             out["cpu_baseline"] = cpu_baseline(conf, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -266,12 +266,30 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
 // Resident scan: the logits of the M memory patches stay in LDS from one iteration to the next
 // (two candidate buffers of (M+I) rows, row stride R+1), so an iteration reads only its new chunk
 // from global memory - one contiguous, coalesced block that is prefetched into registers during
-// the previous iteration.  Row statistics of a wavefront's rows are computed interleaved (the
-// max / butterfly chains of 8 rows in flight together), scoring uses one work item per
-// (candidate, token).  Same arithmetic order as the generic kernel and the oracle.
-constexpr int SCAN_PF = 8;     // prefetch registers per thread: chunk <= 256 * 8 floats
+// the previous iteration.  1024 threads (16 wavefronts) per image: the loop is a chain of short
+// VALU-bound phases (two exp + one division per candidate x (head, token)), and 4 waves per SIMD
+// give them 4x the issue slots of a 256-thread block.  Same arithmetic order as the generic
+// kernel and the oracle: wave-order row sums, ascending sums over heads then tokens.
+constexpr int SCAN_NT = 1024;
+constexpr int SCAN_PF = 4;     // prefetch registers per thread: chunk <= 1024 * 4 floats
 
-__global__ __launch_bounds__(256) void scan_resident_kernel(ScanArgs a) {
+// rank by counting with P lanes per candidate (P = power of two <= 64, P * L <= blockDim):
+// lane `part` counts the keys j = part, part+P, ... that are larger; partial counts are added by an
+// xor butterfly over the P lanes (integer adds: order-free).  Keys are unique.
+__device__ __forceinline__ void rank_scatter(const uint64_t* src, uint64_t* dst, int L, int P) {
+    const int tid = threadIdx.x;
+    const int l = tid / P, part = tid & (P - 1);
+    int cnt = 0;
+    uint64_t k = 0ull;
+    if (l < L) {
+        k = src[l];
+        for (int j = part; j < L; j += P) cnt += (src[j] > k) ? 1 : 0;
+    }
+    for (int off = P >> 1; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (l < L && part == 0) dst[cnt] = k;
+}
+
+__global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = a.h * a.T, Lmax = a.m + a.i, ld = R + 1;
     uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
@@ -280,8 +298,8 @@ __global__ __launch_bounds__(256) void scan_resident_kernel(ScanArgs a) {
     int* candB = candA + Lmax;
     float* rmax = reinterpret_cast<float*>(candB + Lmax);
     float* rden = rmax + R;
-    float* qbuf = rden + R;                       // Lmax * T per-(candidate, token) head means
-    float* clA = qbuf + (size_t)Lmax * a.T;
+    float* abuf = rden + R;                       // Lmax * R attention weights of the candidates
+    float* clA = abuf + (size_t)Lmax * R;
     float* clB = clA + (size_t)Lmax * ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
@@ -292,20 +310,22 @@ __global__ __launch_bounds__(256) void scan_resident_kernel(ScanArgs a) {
     float* cl = clA;
     float* clnew = clB;
     // memory = first m patches: their logits are one contiguous block
-    for (int j = tid; j < a.m; j += 256) cand[j] = j;
-    for (int e = tid; e < a.m * R; e += 256) { const int l = e / R; cl[l * ld + (e - l * R)] = lg[e]; }
+    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = j;
+    for (int e = tid; e < a.m * R; e += SCAN_NT) { const int l = e / R; cl[l * ld + (e - l * R)] = lg[e]; }
     const long long n_iter = (a.n - a.m + a.i - 1) / a.i;
-    // prefetch chunk 0
     float pf[SCAN_PF];
     {
         const long long lo = a.m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
 #pragma unroll
         for (int k = 0; k < SCAN_PF; ++k) {
-            const int e = tid + 256 * k;
+            const int e = tid + SCAN_NT * k;
             pf[k] = (n_iter > 0 && e < cnt * R) ? lg[(size_t)lo * R + e] : 0.0f;
         }
     }
+    // lanes per candidate for the ranking (uniform)
+    int P = 1;
+    while (P < 64 && 2 * P * Lmax <= SCAN_NT) P <<= 1;
     int tie = 0;
     uint64_t* sorted = keyA;
     for (long long it = 0; it < n_iter; ++it) {
@@ -315,83 +335,92 @@ __global__ __launch_bounds__(256) void scan_resident_kernel(ScanArgs a) {
         // chunk registers -> candidate rows m.., next chunk -> registers
 #pragma unroll
         for (int k = 0; k < SCAN_PF; ++k) {
-            const int e = tid + 256 * k;
+            const int e = tid + SCAN_NT * k;
             if (e < cnt * R) { const int l = e / R; cl[(a.m + l) * ld + (e - l * R)] = pf[k]; }
         }
-        for (int j = tid; j < cnt; j += 256) cand[a.m + j] = (int)(lo + j);
+        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
         {
             const long long lo2 = lo + a.i;
             const int cnt2 = (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2));
 #pragma unroll
             for (int k = 0; k < SCAN_PF; ++k) {
-                const int e = tid + 256 * k;
+                const int e = tid + SCAN_NT * k;
                 pf[k] = e < cnt2 * R ? lg[(size_t)lo2 * R + e] : 0.0f;
             }
         }
         __syncthreads();
-        // row statistics, 8 rows of this wave in flight together
-        for (int r0 = wave * 8; r0 < R; r0 += 32) {
-            float mx[8], sm[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                mx[q] = -__builtin_huge_valf();
-                if (r0 + q < R)
-                    for (int i = lane; i < L; i += 64) mx[q] = nanmax(mx[q], cl[i * ld + r0 + q]);
+        // row statistics: wave w owns rows w, w+16, ...; two rows in flight together
+        for (int r0 = wave; r0 < R; r0 += 32) {
+            const int r1 = r0 + 16;
+            const bool has1 = r1 < R;
+            float m0 = -__builtin_huge_valf(), m1 = m0;
+            for (int i = lane; i < L; i += 64) {
+                m0 = nanmax(m0, cl[i * ld + r0]);
+                if (has1) m1 = nanmax(m1, cl[i * ld + r1]);
             }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) mx[q] = nanmax(mx[q], __shfl_xor(mx[q], off, 64));
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                sm[q] = 0.0f;
-                if (r0 + q < R)
-                    for (int i = lane; i < L; i += 64) sm[q] = sm[q] + det_expf(cl[i * ld + r0 + q] - mx[q]);
+            for (int off = 32; off >= 1; off >>= 1) {
+                m0 = nanmax(m0, __shfl_xor(m0, off, 64));
+                m1 = nanmax(m1, __shfl_xor(m1, off, 64));
+            }
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int i = lane; i < L; i += 64) {
+                s0 = s0 + det_expf(cl[i * ld + r0] - m0);
+                if (has1) s1 = s1 + det_expf(cl[i * ld + r1] - m1);
             }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sm[q] = sm[q] + __shfl_xor(sm[q], off, 64);
+            for (int off = 32; off >= 1; off >>= 1) {
+                s0 = s0 + __shfl_xor(s0, off, 64);
+                s1 = s1 + __shfl_xor(s1, off, 64);
+            }
             if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (r0 + q < R) { rmax[r0 + q] = mx[q]; rden[r0 + q] = sm[q]; }
+                rmax[r0] = m0; rden[r0] = s0;
+                if (has1) { rmax[r1] = m1; rden[r1] = s1; }
             }
         }
         __syncthreads();
-        // per (candidate, token): mean over heads of the attention weights (ascending h)
-        for (int e = tid; e < L * a.T; e += 256) {
-            const int l = e / a.T, t = e - l * a.T;
-            float sh = 0.0f;
-            for (int hh = 0; hh < a.h; ++hh) {
-                const int r = hh * a.T + t;
-                sh = sh + det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
-            }
-            qbuf[e] = sh / (float)a.h;
+        // attention weight of every (candidate, head, token)
+        for (int e = tid; e < L * R; e += SCAN_NT) {
+            const int l = e / R, r = e - l * R;
+            abuf[e] = det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
         }
         __syncthreads();
-        for (int l = tid; l < a.n2; l += 256) {
+        // score = mean over tokens of (mean over heads), ascending sums; ranking key
+        for (int l = tid; l < a.n2; l += SCAN_NT) {
             uint64_t key = 0ull;
             if (l < L) {
                 float st = 0.0f;
-                for (int t = 0; t < a.T; ++t) st = st + qbuf[l * a.T + t];
+                for (int t = 0; t < a.T; ++t) {
+                    float sh = 0.0f;
+                    for (int hh = 0; hh < a.h; ++hh) sh = sh + abuf[l * R + hh * a.T + t];
+                    st = st + sh / (float)a.h;
+                }
                 key = rank_key(st / (float)a.T, (uint32_t)l);
             }
             keyA[l] = key;
         }
-        sorted = sort_desc(keyA, keyB, L, a.n2);
+        if (L <= 512) {
+            __syncthreads();
+            rank_scatter(keyA, keyB, L, P);
+            __syncthreads();
+            sorted = keyB;
+        } else {
+            sorted = sort_desc(keyA, keyB, L, a.n2);
+        }
         // new memory: indices and logit rows of the winners, into the other buffers
-        for (int j = tid; j < a.m; j += 256) cnew[j] = cand[key_pos(sorted[j])];
-        for (int e = tid; e < a.m * R; e += 256) {
+        for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
+        for (int e = tid; e < a.m * R; e += SCAN_NT) {
             const int j = e / R, r = e - j * R;
             clnew[j * ld + r] = cl[key_pos(sorted[j]) * ld + r];
         }
         if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
-        __syncthreads();
         { int* t = cand; cand = cnew; cnew = t; }
         { float* t = cl; cl = clnew; clnew = t; }
+        // no barrier here: the next iteration's first phase writes rows m.. of the new buffers only,
+        // and its barrier orders everything before the statistics pass
     }
-    for (int j = tid; j < a.m; j += 256) {
+    __syncthreads();
+    for (int j = tid; j < a.m; j += SCAN_NT) {
         a.mem_idx[(size_t)b * a.m + j] = cand[j];
         if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
     }
@@ -508,13 +537,13 @@ IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int 
     a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
-    const size_t resident = base + (size_t)Lmax * n_token * 4 + 2 * stage;
-    if (resident <= kLdsLimit && (size_t)i * R <= (size_t)256 * SCAN_PF) {
+    const size_t resident = base + (size_t)Lmax * R * 4 + 2 * stage;
+    if (resident <= kLdsLimit && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF) {
         a.use_lds = 1;
         if (resident > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
-        scan_resident_kernel<<<dim3((unsigned)b), dim3(256), resident, as_stream(stream)>>>(a);
+        scan_resident_kernel<<<dim3((unsigned)b), dim3(SCAN_NT), resident, as_stream(stream)>>>(a);
         return launched("scan");
     }
     a.use_lds = base + stage <= kLdsLimit;

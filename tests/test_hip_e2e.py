@@ -149,3 +149,26 @@ def test_full_size_properties_b16():
     xg = torch.cat([g.patches().to(DEV), x[:3]], 0)
     netg.ips(xg)
     assert np.array_equal(netg.last_mem_idx[0].cpu().numpy(), g.mem_idx[0])
+
+
+def test_sharded_path_on_gpu_single_rank_rccl():
+    """ips_amd.dist.ips_sharded over an RCCL (nccl) group of one rank: exercises the GPU branch
+    (logits into a padded slab, all_gather_into_tensor, scan, owner all_reduce) and must equal ips()."""
+    import os
+    import torch.distributed as dist
+    from ips_amd import dist as ipsd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        g = Golden("mnist_ragged")
+        net = g.net(DEV)
+        x = g.patches().to(DEV)
+        mp, pos, idx = ipsd.ips_sharded(net, x, x.shape[1])
+        full_patch, full_pos = net.ips(x)
+        assert torch.equal(idx, net.last_mem_idx) and np.array_equal(idx.cpu().numpy(), g.mem_idx)
+        assert torch.equal(mp, full_patch) and torch.equal(pos, full_pos)
+    finally:
+        dist.destroy_process_group()
