@@ -273,9 +273,9 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
 constexpr int SCAN_NT = 1024;
 constexpr int SCAN_PF = 4;     // prefetch registers per thread: chunk <= 1024 * 4 floats
 
-// rank by counting with P lanes per candidate (P = power of two <= 64, P * L <= blockDim):
-// lane `part` counts the keys j = part, part+P, ... that are larger; partial counts are added by an
-// xor butterfly over the P lanes (integer adds: order-free).  Keys are unique.
+// Small candidate sets: rank by counting with P lanes per candidate (P = power of two <= 64,
+// P * L <= blockDim): lane `part` counts the keys j = part, part+P, ... that are larger; the partial
+// counts are added by an xor butterfly over the P lanes (integer adds: order-free).  O(L^2 / P).
 __device__ __forceinline__ void rank_scatter(const uint64_t* src, uint64_t* dst, int L, int P) {
     const int tid = threadIdx.x;
     const int l = tid / P, part = tid & (P - 1);
@@ -289,8 +289,69 @@ __device__ __forceinline__ void rank_scatter(const uint64_t* src, uint64_t* dst,
     if (l < L && part == 0) dst[cnt] = k;
 }
 
-__global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a) {
+// Ranking of L <= 64 * (waves per block) unique keys, descending, without an O(L^2) pass:
+//   1. wave w bitonic-sorts keys [64w, 64w+64) in registers (lane shuffles, no barrier) and
+//      publishes the sorted run;
+//   2. every key's rank = its position in its own run + for each other run the number of
+//      larger keys there, found by a branch-free binary search (7 LDS reads per run, the
+//      searches of all runs in flight together).
+// src/dst hold L keys (dst gets them sorted); runs is scratch for 64 * ceil(L/64) keys.
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint64_t other = __shfl_xor(key, j, 64);
+            const bool take_max = ((lane & k) == 0) == ((lane & j) == 0);
+            const bool gt = key > other;
+            key = (take_max == gt) ? key : other;
+        }
+    }
+    return key;
+}
+
+__device__ __forceinline__ void rank_runs(const uint64_t* src, uint64_t* dst, uint64_t* runs, int L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nruns = (L + 63) >> 6;
+    uint64_t mine = 0ull;
+    if (wave < nruns) {
+        const int idx = wave * 64 + lane;
+        mine = wave_sort_desc(idx < L ? src[idx] : 0ull, lane);     // padding keys (0) sort last
+        runs[idx] = mine;
+    }
+    __syncthreads();
+    if (wave < nruns && mine != 0ull) {
+        int rank = lane;
+        int lo[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lo[r] = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r < nruns && r != wave) lo[r] += (runs[r * 64 + lo[r] + step - 1] > mine) ? step : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (r < nruns && r != wave) rank += lo[r] + ((runs[r * 64 + lo[r]] > mine) ? 1 : 0);
+        dst[rank] = mine;
+    }
+}
+
+// STAMP = true: diagnostic build, wave 0 accumulates s_memtime deltas per phase into stamps[b*8 + k]
+#define SCAN_STAMP(k)                                                              \
+    do {                                                                           \
+        if (STAMP) {                                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();            \
+            if (tid == 0) { tacc[k] += t_ - tlast; }                               \
+            tlast = t_;                                                            \
+        }                                                                          \
+    } while (0)
+
+template <bool STAMP>
+__global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     const int R = a.h * a.T, Lmax = a.m + a.i, ld = R + 1;
     uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
     uint64_t* keyB = keyA + a.n2;
@@ -323,9 +384,9 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a) {
             pf[k] = (n_iter > 0 && e < cnt * R) ? lg[(size_t)lo * R + e] : 0.0f;
         }
     }
-    // lanes per candidate for the ranking (uniform)
+    // lanes per candidate for the counting rank (uniform)
     int P = 1;
-    while (P < 64 && 2 * P * Lmax <= SCAN_NT) P <<= 1;
+    while (P < 64 && 2 * P * std::min(Lmax, 192) <= SCAN_NT) P <<= 1;
     int tie = 0;
     uint64_t* sorted = keyA;
     for (long long it = 0; it < n_iter; ++it) {
@@ -349,6 +410,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a) {
             }
         }
         __syncthreads();
+        SCAN_STAMP(0);
         // row statistics: wave w owns rows w, w+16, ...; two rows in flight together
         for (int r0 = wave; r0 < R; r0 += 32) {
             const int r1 = r0 + 16;
@@ -379,34 +441,66 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a) {
             }
         }
         __syncthreads();
+        SCAN_STAMP(1);
         // attention weight of every (candidate, head, token)
         for (int e = tid; e < L * R; e += SCAN_NT) {
             const int l = e / R, r = e - l * R;
             abuf[e] = det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
         }
         __syncthreads();
-        // score = mean over tokens of (mean over heads), ascending sums; ranking key
-        for (int l = tid; l < a.n2; l += SCAN_NT) {
-            uint64_t key = 0ull;
-            if (l < L) {
-                float st = 0.0f;
-                for (int t = 0; t < a.T; ++t) {
+        SCAN_STAMP(2);
+        // score = mean over tokens of (mean over heads), ascending sums; ranking key.
+        // One lane per (candidate, token) sums the heads (independent LDS reads, then the ascending
+        // chain); the T lanes of a candidate are adjacent, so the token sum is a few lane reads.
+        if ((a.T & (a.T - 1)) == 0 && a.T <= 64 && a.h <= 16) {
+            for (int e0 = 0; e0 < a.n2 * a.T; e0 += SCAN_NT) {
+                const int e = e0 + tid, l = e / a.T, t = e - l * a.T;
+                float q = 0.0f;
+                if (l < L) {
+                    float v[16];
+#pragma unroll
+                    for (int hh = 0; hh < 16; ++hh) v[hh] = hh < a.h ? abuf[l * R + hh * a.T + t] : 0.0f;
                     float sh = 0.0f;
-                    for (int hh = 0; hh < a.h; ++hh) sh = sh + abuf[l * R + hh * a.T + t];
-                    st = st + sh / (float)a.h;
+#pragma unroll
+                    for (int hh = 0; hh < 16; ++hh) if (hh < a.h) sh = sh + v[hh];
+                    q = sh / (float)a.h;
                 }
-                key = rank_key(st / (float)a.T, (uint32_t)l);
+                float st = 0.0f;
+                for (int tt = 0; tt < a.T; ++tt) st = st + __shfl(q, (lane & ~(a.T - 1)) + tt, 64);
+                if (t == 0 && l < a.n2) keyA[l] = l < L ? rank_key(st / (float)a.T, (uint32_t)l) : 0ull;
             }
-            keyA[l] = key;
+        } else {
+            for (int l = tid; l < a.n2; l += SCAN_NT) {
+                uint64_t key = 0ull;
+                if (l < L) {
+                    float st = 0.0f;
+                    for (int t = 0; t < a.T; ++t) {
+                        float sh = 0.0f;
+                        for (int hh = 0; hh < a.h; ++hh) sh = sh + abuf[l * R + hh * a.T + t];
+                        st = st + sh / (float)a.h;
+                    }
+                    key = rank_key(st / (float)a.T, (uint32_t)l);
+                }
+                keyA[l] = key;
+            }
         }
-        if (L <= 512) {
+        if (L <= 192) {                      // measured crossover of the two rankings (stamps): ~200 keys
             __syncthreads();
+            SCAN_STAMP(3);
             rank_scatter(keyA, keyB, L, P);
             __syncthreads();
             sorted = keyB;
+        } else if (L <= SCAN_NT) {
+            __syncthreads();
+            SCAN_STAMP(3);
+            rank_runs(keyA, keyB, reinterpret_cast<uint64_t*>(abuf), L);
+            __syncthreads();
+            sorted = keyB;
         } else {
+            SCAN_STAMP(3);
             sorted = sort_desc(keyA, keyB, L, a.n2);
         }
+        SCAN_STAMP(4);
         // new memory: indices and logit rows of the winners, into the other buffers
         for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
         for (int e = tid; e < a.m * R; e += SCAN_NT) {
@@ -416,6 +510,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a) {
         if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
         { int* t = cand; cand = cnew; cnew = t; }
         { float* t = cl; cl = clnew; clnew = t; }
+        SCAN_STAMP(5);
         // no barrier here: the next iteration's first phase writes rows m.. of the new buffers only,
         // and its barrier orders everything before the statistics pass
     }
@@ -425,6 +520,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a) {
         if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
     }
     if (a.tie && tid == 0) a.tie[b] = tie;
+    if (STAMP && tid == 0)
+        for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
 }
 
 // Transformer.get_scores on the logits (b, L, R) of arbitrary embeddings
@@ -478,6 +575,8 @@ __global__ __launch_bounds__(256) void topm_kernel(TopmArgs a) {
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) ? 1 : 0;
 }
+
+static unsigned long long* g_scan_stamps = nullptr;   // diagnostic only (ipsx_dbg_scan_stamps)
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static const size_t kLdsLimit = 160 * 1024;
@@ -538,12 +637,19 @@ IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int 
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
     const size_t resident = base + (size_t)Lmax * R * 4 + 2 * stage;
-    if (resident <= kLdsLimit && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF) {
+    const bool runs_fit = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)Lmax * R * 4;   // run scratch aliases the weight buffer
+    if (resident <= kLdsLimit && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && runs_fit) {
         a.use_lds = 1;
         if (resident > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
-        scan_resident_kernel<<<dim3((unsigned)b), dim3(SCAN_NT), resident, as_stream(stream)>>>(a);
+        if (g_scan_stamps) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
+            scan_resident_kernel<true><<<dim3((unsigned)b), dim3(SCAN_NT), resident, as_stream(stream)>>>(a, g_scan_stamps);
+        } else {
+            scan_resident_kernel<false><<<dim3((unsigned)b), dim3(SCAN_NT), resident, as_stream(stream)>>>(a, nullptr);
+        }
         return launched("scan");
     }
     a.use_lds = base + stage <= kLdsLimit;
@@ -593,4 +699,10 @@ IPSX_API int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_id
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     topm_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
     return launched("topm");
+}
+
+// Diagnostic entry point (not part of include/ipsx.h): when set to a device buffer of b*8 uint64, the next
+// resident scans accumulate per-phase s_memtime cycles there (tools/scan_stamps.py); NULL switches it off.
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_stamps(unsigned long long* buf) {
+    ipsx::g_scan_stamps = buf;
 }
