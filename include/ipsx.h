@@ -96,6 +96,13 @@ typedef struct ipsx_trunk {
 /* y = act(affine(conv(x)) [+ residual]); x (n,c_in,h,w), y (n,c_out,ho,wo) NCHW */
 int ipsx_conv2d_affine(const ipsx_conv* cv, const float* x, const float* residual,
                        float* y, int64_t n, int h, int w, int relu, void* stream);
+/* the same on channels-last activations: x (n,h,w,c_in), residual / y (n,ho,wo,c_out); C_in % 32 == 0.
+ * This is the fast layer-by-layer path (16-byte operand loads); a Linear over rows is h = w = 1. */
+int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* residual,
+                            float* y, int64_t n, int h, int w, int relu, void* stream);
+int ipsx_maxpool_3x3s2_nhwc(const float* x, float* y, int64_t n, int c, int h, int w, void* stream);
+/* (n,hw,c) -> (n,c) */
+int ipsx_avgpool_nhwc(const float* x, float* y, int64_t n, int c, int hw, void* stream);
 /* nn.MaxPool2d(3, 2, 1) */
 int ipsx_maxpool_3x3s2(const float* x, float* y, int64_t n, int c, int h, int w, void* stream);
 /* nn.AdaptiveAvgPool2d(1): (n,c,hw) -> (n,c) */

@@ -217,7 +217,7 @@ IPSX_API int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, flo
     layernorm_rows_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(
         x, n, lin->c_in, ln_eps, nullptr, nullptr, xn);
     IPSX_TRY(launched("projector layernorm"));
-    return ipsx_conv2d_affine(lin, xn, nullptr, out, n, 1, 1, 1, stream);
+    return ipsx_conv2d_affine_nhwc(lin, xn, nullptr, out, n, 1, 1, 1, stream);
 }
 
 IPSX_API size_t ipsx_aggregate_workspace_bytes(const ipsx_transf* t, int b, int m) {
@@ -251,7 +251,7 @@ IPSX_API int ipsx_aggregate(const ipsx_transf* t, const float* x, int b, int m, 
     ipsx_conv vproj;
     vproj.c_in = t->d; vproj.c_out = hdv; vproj.kh = vproj.kw = 1; vproj.stride = 1; vproj.pad = 0;
     vproj.w_packed = wvp; vproj.alpha = nullptr; vproj.shift = nullptr;
-    IPSX_TRY(ipsx_conv2d_affine(&vproj, x, nullptr, v, (int64_t)b * m, 1, 1, 0, stream));
+    IPSX_TRY(ipsx_conv2d_affine_nhwc(&vproj, x, nullptr, v, (int64_t)b * m, 1, 1, 0, stream));
 
     CtxArgs c;
     c.lg = lg; c.v = v; c.ctx = ctx; c.m = m; c.h = t->h; c.T = t->n_token; c.dv = t->dv;

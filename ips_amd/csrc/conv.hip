@@ -39,6 +39,7 @@ struct ConvArgs {
     unsigned m_total;     // n * ho * wo  (< 2^31, the driver chunks)
     int c_in, h, w, c_out, ho, wo, kh, kw, stride, pad, relu;
     int kgs;              // packed k-groups = ceil(K/8)
+    int out_nhwc;         // write y as [pixel][c_out] (channels-last) instead of NCHW
 };
 
 // ------------------------------------------------------------------ packing
@@ -99,7 +100,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
                                               int n_base, int lane) {
     const unsigned howo = (unsigned)(a.ho * a.wo);
     const int half = lane >> 5;
-    const bool vec4 = (howo & 3u) == 0;
+    const bool vec4 = (howo & 3u) == 0 && !a.out_nhwc;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n = n_base + nt * 32 + (lane & 31);
@@ -138,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
                         const unsigned m = m0 + r;
                         if (m >= a.m_total) continue;
                         const unsigned img = m / howo, pix = m - img * howo;
-                        const size_t idx = ((size_t)img * a.c_out + n) * howo + pix;
+                        const size_t idx = a.out_nhwc ? (size_t)m * a.c_out + n : ((size_t)img * a.c_out + n) * howo + pix;
                         float t = v[r];
                         if (a.res) t = t + a.res[idx];
                         if (a.relu) t = t > 0.0f ? t : 0.0f;
@@ -323,8 +324,18 @@ IPSX_API int ipsx_bn_affine(const float* gamma, const float* beta, const float* 
     return launched("bn_affine");
 }
 
+namespace ipsx {
+int conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* residual, float* y, int64_t n, int h,
+                       int w, int relu, int out_nhwc, void* stream);
+}
+
 IPSX_API int ipsx_conv2d_affine(const ipsx_conv* cv, const float* x, const float* residual, float* y,
                                 int64_t n, int h, int w, int relu, void* stream) {
+    return conv2d_affine_impl(cv, x, residual, y, n, h, w, relu, 0, stream);
+}
+
+int ipsx::conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* residual, float* y, int64_t n,
+                             int h, int w, int relu, int out_nhwc, void* stream) {
     IPSX_TRY(check_conv(cv));
     IPSX_REQUIRE(x && y && n >= 0 && h > 0 && w > 0, "conv2d_affine: bad arguments");
     if (n == 0) return IPSX_OK;
@@ -344,6 +355,7 @@ IPSX_API int ipsx_conv2d_affine(const ipsx_conv* cv, const float* x, const float
         a.c_in = cv->c_in; a.h = h; a.w = w; a.c_out = cv->c_out; a.ho = ho; a.wo = wo;
         a.kh = cv->kh; a.kw = cv->kw; a.stride = cv->stride; a.pad = cv->pad; a.relu = relu;
         a.kgs = (int)cdiv((int64_t)cv->kh * cv->kw * cv->c_in, 8);
+        a.out_nhwc = out_nhwc;
         dim3 grid((unsigned)cdiv(a.m_total, 256), (unsigned)cdiv(cv->c_out, 64));
         if (cv->c_in % 8 == 0)
             conv_c8_kernel<<<grid, dim3(256), 0, as_stream(stream)>>>(a);

@@ -1,0 +1,274 @@
+// conv_nhwc.hip - implicit-GEMM convolution on channels-last activations: the layer-by-layer
+// encoder path for every trunk the fused kernel does not cover (other patch sizes, ResNet-18 with
+// four stages, ResNet-50 bottlenecks) and the Linear layers that run on the matrix cores (projector,
+// V projection).
+//
+// Same arithmetic as conv.hip / the oracle (one fp32 fma chain per output in the contract's k
+// order).  What differs is the data path, shaped by what tools/ubench measured for the fp32 MFMA
+// (every non-MFMA instruction costs matrix-pipe time):
+//   * activations are pixel-major, x[pixel][C_in]: the 4 consecutive k a lane half needs per
+//     k-group are ONE 16-byte load;
+//   * operands are fetched with raw buffer loads: the per-lane pixel offset lives in a VGPR that
+//     changes once per tap, the channel / k-group offset is a scalar register, so a stage issues
+//     4 loads + 16 MFMAs and no address arithmetic on the vector pipe;
+//   * halo (padding) lanes carry an out-of-range offset: the buffer's hardware bounds check
+//     returns zeros - no select, no zero page;
+//   * 4-slot register ring, operands requested two stages (2 x 1024 matrix-pipe cycles) ahead.
+// Wave tile 64(M) x 64(N) = 2x2 accumulators; the 4 waves of a workgroup are arranged WM x WN
+// (along N for wide layers so the activation rows are fetched once per workgroup).
+//
+// Algorithmic cost: 2*K*C_out flop per output pixel; bytes: activations in + out once.
+
+#include <algorithm>
+
+#include "ipsx_common.h"
+#include "ipsx_math.h"
+
+namespace ipsx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+constexpr unsigned kOob = 0x80000000u;      // voffset of a padding lane: beyond any buffer we bind
+
+struct NhwcArgs {
+    const float* x;
+    const float* wp;
+    const float* alpha;
+    const float* shift;
+    const float* res;
+    float* y;
+    unsigned m_total;      // n * ho * wo
+    unsigned x_bytes, w_bytes;
+    int c_in, h, w, c_out, ho, wo, kh, kw, stride, pad, relu;
+    int spt;               // stages (k-groups) per tap = c_in / 8
+    int kgs;               // packed k-groups per n-tile = kh*kw*c_in / 8
+};
+
+struct NhwcStage {
+    f32x4 a0, a1, b0, b1;
+};
+
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+__device__ __forceinline__ void nhwc_mma(const NhwcStage& st, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc[0][0] = MFMA(st.a0[j], st.b0[j], acc[0][0]);
+        acc[0][1] = MFMA(st.a0[j], st.b1[j], acc[0][1]);
+        acc[1][0] = MFMA(st.a1[j], st.b0[j], acc[1][0]);
+        acc[1][1] = MFMA(st.a1[j], st.b1[j], acc[1][1]);
+    }
+}
+
+struct NhwcPixel {
+    int iy0, ix0;          // top-left input coordinate of the receptive field
+    unsigned img_pix;      // img * h * w
+    bool valid;
+};
+
+__device__ __forceinline__ NhwcPixel nhwc_pixel(const NhwcArgs& a, unsigned m) {
+    NhwcPixel p;
+    p.valid = m < a.m_total;
+    const unsigned howo = (unsigned)(a.ho * a.wo);
+    const unsigned mm = p.valid ? m : 0u;
+    const unsigned img = mm / howo, pix = mm - img * howo;
+    const unsigned oy = pix / (unsigned)a.wo, ox = pix - oy * (unsigned)a.wo;
+    p.iy0 = (int)oy * a.stride - a.pad;
+    p.ix0 = (int)ox * a.stride - a.pad;
+    p.img_pix = img * (unsigned)(a.h * a.w);
+    return p;
+}
+
+// byte offset of this lane's source pixel row (+ its half's 16 bytes) for a tap, or kOob
+__device__ __forceinline__ unsigned nhwc_voff(const NhwcArgs& a, const NhwcPixel& p, int tap, int half) {
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    const int iy = p.iy0 + ky, ix = p.ix0 + kx;
+    const bool ok = p.valid && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+    return ok ? ((p.img_pix + (unsigned)(iy * a.w + ix)) * (unsigned)a.c_in + 4u * half) * 4u : kOob;
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int wm = __builtin_amdgcn_readfirstlane(wave % WM), wn = __builtin_amdgcn_readfirstlane(wave / WM);
+    const unsigned m_base = (blockIdx.x * WM + wm) * 64u;
+    const int nt0 = (blockIdx.y * WN + wn) * 2;                     // first of this wave's two n-tiles
+    if (m_base >= a.m_total || nt0 * 32 >= a.c_out) return;         // wave-uniform
+    const bool n1 = (nt0 + 1) * 32 < a.c_out;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)a.w_bytes, 0x00020000);
+    const NhwcPixel p0 = nhwc_pixel(a, m_base + (lane & 31));
+    const NhwcPixel p1 = nhwc_pixel(a, m_base + 32 + (lane & 31));
+    const unsigned lb = lane * 16u;
+    const unsigned wb0 = (unsigned)nt0 * (unsigned)a.kgs * 1024u;   // byte offset of n-tile nt0's stream
+    const unsigned wb1 = n1 ? wb0 + (unsigned)a.kgs * 1024u : wb0;
+    const int taps = a.kh * a.kw, total = taps * a.spt;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // prefetch stream state: stage gp = (tap pt, k-group pc); pv0/pv1 = pixel offsets of tap pt
+    int gp = 0, pt = 0, pc = 0;
+    unsigned pv0 = nhwc_voff(a, p0, 0, half), pv1 = nhwc_voff(a, p1, 0, half);
+    NhwcStage s0, s1, s2, s3;
+#define NHWC_LOAD(S)                                                        \
+    do {                                                                    \
+        const unsigned ca = (unsigned)pc * 32u, cb = (unsigned)gp * 1024u;  \
+        S.a0 = bufload(rx, pv0, ca);                                        \
+        S.a1 = bufload(rx, pv1, ca);                                        \
+        S.b0 = bufload(rw, lb, wb0 + cb);                                   \
+        S.b1 = bufload(rw, lb, wb1 + cb);                                   \
+        if (gp + 1 < total) {                                               \
+            ++gp;                                                           \
+            if (++pc == a.spt) {                                            \
+                pc = 0; ++pt;                                               \
+                pv0 = nhwc_voff(a, p0, pt, half);                           \
+                pv1 = nhwc_voff(a, p1, pt, half);                           \
+            }                                                               \
+        }                                                                   \
+    } while (0)
+    NHWC_LOAD(s0);
+    NHWC_LOAD(s1);
+#pragma unroll 1
+    for (int g = 0; g < total; g += 4) {       // total is a multiple of 4 (C_in % 32 == 0)
+        NHWC_LOAD(s2); SB(); nhwc_mma(s0, acc); SB();
+        NHWC_LOAD(s3); SB(); nhwc_mma(s1, acc); SB();
+        NHWC_LOAD(s0); SB(); nhwc_mma(s2, acc); SB();
+        NHWC_LOAD(s1); SB(); nhwc_mma(s3, acc); SB();
+    }
+#undef NHWC_LOAD
+
+    // epilogue: BatchNorm affine, residual, ReLU; lanes of a store are 32 consecutive channels
+    const int i = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = (nt0 + nt) * 32 + i;
+        if (n >= a.c_out) continue;
+        const float al = a.alpha ? a.alpha[n] : 1.0f;
+        const float sh = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned m = m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= a.m_total) continue;
+                const size_t idx = (size_t)m * a.c_out + n;
+                float v = acc[mt][nt][r];
+                if (a.alpha) v = __builtin_fmaf(v, al, sh);
+                else if (a.shift) v = v + sh;
+                if (a.res) v = v + a.res[idx];
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                a.y[idx] = v;
+            }
+    }
+}
+
+// nn.MaxPool2d(3, 2, 1) on channels-last activations: one thread per (output pixel, 4 channels)
+__global__ void maxpool_3x3s2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total4, int c4,
+                                          int h, int w, int ho, int wo) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int cq = (int)(i % c4);
+    size_t t = i / c4;
+    const int ox = (int)(t % wo); t /= wo;
+    const int oy = (int)(t % ho);
+    const size_t img = t / ho;
+    const float4* src = reinterpret_cast<const float4*>(x) + img * (size_t)h * w * c4 + cq;
+    float4 m = make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf());
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
+            if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+            const float4 v = src[(size_t)(iy * w + ix) * c4];
+            m.x = nanmax(m.x, v.x); m.y = nanmax(m.y, v.y); m.z = nanmax(m.z, v.z); m.w = nanmax(m.w, v.w);
+        }
+    reinterpret_cast<float4*>(y)[i] = m;
+}
+
+// nn.AdaptiveAvgPool2d(1) on channels-last activations: (n, hw, c) -> (n, c), sequential sum over pixels
+__global__ void avgpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int c, int hw) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t img = i / c;
+    const int ch = (int)(i - img * c);
+    const float* src = x + img * (size_t)hw * c + ch;
+    float s = 0.0f;
+    for (int j = 0; j < hw; ++j) s = s + src[(size_t)j * c];
+    y[i] = s / (float)hw;
+}
+
+}  // namespace ipsx
+
+using namespace ipsx;
+
+IPSX_API int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* residual, float* y,
+                                     int64_t n, int h, int w, int relu, void* stream) {
+    IPSX_REQUIRE(cv && cv->w_packed && x && y && n >= 0 && h > 0 && w > 0, "conv2d_affine_nhwc: bad arguments");
+    IPSX_REQUIRE(cv->c_in % 32 == 0, "conv2d_affine_nhwc: C_in = %d is not a multiple of 32", cv->c_in);
+    if (n == 0) return IPSX_OK;
+    const int ho = conv_out(h, cv->kh, cv->stride, cv->pad), wo = conv_out(w, cv->kw, cv->stride, cv->pad);
+    IPSX_REQUIRE(ho > 0 && wo > 0, "conv2d_affine_nhwc: empty output");
+    const int64_t howo = (int64_t)ho * wo;
+    const int kgs = cv->kh * cv->kw * cv->c_in / 8;
+    const int64_t w_bytes = (int64_t)cdiv(cv->c_out, 32) * kgs * 1024;
+    IPSX_REQUIRE(w_bytes < ((int64_t)1 << 31), "conv2d_affine_nhwc: weights too large for one buffer");
+    // per launch: input below 2 GiB (buffer range + the out-of-range marker), output pixels below 2^31
+    const int64_t in_img = (int64_t)h * w * cv->c_in * 4;
+    int64_t per = std::min<int64_t>(n, std::max<int64_t>(1, (((int64_t)1 << 31) - 65536) / in_img));
+    per = std::min<int64_t>(per, std::max<int64_t>(1, ((int64_t)1 << 30) / howo));
+    for (int64_t i0 = 0; i0 < n; i0 += per) {
+        const int64_t cnt = std::min(per, n - i0);
+        NhwcArgs a;
+        a.x = x + (size_t)i0 * h * w * cv->c_in;
+        a.y = y + (size_t)i0 * howo * cv->c_out;
+        a.res = residual ? residual + (size_t)i0 * howo * cv->c_out : nullptr;
+        a.wp = cv->w_packed; a.alpha = cv->alpha; a.shift = cv->shift;
+        a.m_total = (unsigned)(cnt * howo);
+        a.x_bytes = (unsigned)(cnt * in_img);
+        a.w_bytes = (unsigned)w_bytes;
+        a.c_in = cv->c_in; a.h = h; a.w = w; a.c_out = cv->c_out; a.ho = ho; a.wo = wo;
+        a.kh = cv->kh; a.kw = cv->kw; a.stride = cv->stride; a.pad = cv->pad; a.relu = relu;
+        a.spt = cv->c_in / 8; a.kgs = kgs;
+        const unsigned mt64 = (unsigned)cdiv(a.m_total, 64), nt64 = (unsigned)cdiv(cv->c_out, 64);
+        hipStream_t s = as_stream(stream);
+        if (cv->c_out >= 256)        // wide layer: the 4 waves share the activation rows
+            conv_nhwc_kernel<1, 4><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
+        else if (cv->c_out > 64)
+            conv_nhwc_kernel<2, 2><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
+        else
+            conv_nhwc_kernel<4, 1><<<dim3((unsigned)cdiv(mt64, 4), nt64), dim3(256), 0, s>>>(a);
+        IPSX_TRY(launched("conv2d_affine_nhwc"));
+    }
+    return IPSX_OK;
+}
+
+IPSX_API int ipsx_maxpool_3x3s2_nhwc(const float* x, float* y, int64_t n, int c, int h, int w, void* stream) {
+    IPSX_REQUIRE(x && y && n >= 0 && c > 0 && c % 4 == 0 && h > 0 && w > 0, "maxpool_nhwc: bad arguments");
+    const int ho = conv_out(h, 3, 2, 1), wo = conv_out(w, 3, 2, 1);
+    const size_t total4 = (size_t)n * ho * wo * (c / 4);
+    if (!total4) return IPSX_OK;
+    maxpool_3x3s2_nhwc_kernel<<<dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, as_stream(stream)>>>(
+        x, y, total4, c / 4, h, w, ho, wo);
+    return launched("maxpool_nhwc");
+}
+
+IPSX_API int ipsx_avgpool_nhwc(const float* x, float* y, int64_t n, int c, int hw, void* stream) {
+    IPSX_REQUIRE(x && y && n >= 0 && c > 0 && hw > 0, "avgpool_nhwc: bad arguments");
+    const size_t total = (size_t)n * c;
+    if (!total) return IPSX_OK;
+    avgpool_nhwc_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream)>>>(x, y, total, c, hw);
+    return launched("avgpool_nhwc");
+}

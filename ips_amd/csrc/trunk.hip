@@ -12,6 +12,9 @@
 
 namespace ipsx {
 
+// conv.hip
+int conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* residual, float* y, int64_t n, int h,
+                       int w, int relu, int out_nhwc, void* stream);
 // fused_trunk.hip
 bool fused_trunk_supported(const ipsx_trunk* t);
 int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s);
@@ -38,6 +41,7 @@ static int trunk_geom(const ipsx_trunk* t, TrunkGeom* g) {
         for (int j = 0; j < B.n_conv; ++j) {
             const ipsx_conv& cv = B.conv[j];
             IPSX_REQUIRE(cv.c_in == cc, "trunk: block %d conv %d expects %d channels, gets %d", b, j, cv.c_in, cc);
+            IPSX_REQUIRE(cv.c_in % 32 == 0, "trunk: block %d conv %d has %d input channels (need a multiple of 32)", b, j, cv.c_in);
             ch = conv_out(ch, cv.kh, cv.stride, cv.pad); cw = conv_out(cw, cv.kw, cv.stride, cv.pad);
             IPSX_REQUIRE(ch > 0 && cw > 0, "trunk: feature map vanished in block %d", b);
             cc = cv.c_out;
@@ -76,7 +80,7 @@ IPSX_API size_t ipsx_trunk_workspace_bytes(const ipsx_trunk* t, int64_t n_patch)
 }
 
 IPSX_API const char* ipsx_trunk_kernel(const ipsx_trunk* t) {
-    return (t && fused_trunk_supported(t)) ? "fused_trunk_kernel" : "conv_c8_kernel (layer by layer)";
+    return (t && fused_trunk_supported(t)) ? "fused_trunk_kernel" : "conv_nhwc_kernel (layer by layer)";
 }
 
 IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb,
@@ -101,8 +105,9 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
         int h = conv_out(t->h, t->stem.kh, t->stem.stride, t->stem.pad);
         int w = conv_out(t->w, t->stem.kw, t->stem.stride, t->stem.pad);
         int c = t->stem.c_out;
-        IPSX_TRY(ipsx_conv2d_affine(&t->stem, patches + p0 * patch_elems, nullptr, buf[0], n, t->h, t->w, 1, stream));
-        IPSX_TRY(ipsx_maxpool_3x3s2(buf[0], buf[1], n, c, h, w, stream));
+        // stem reads the NCHW patches and writes channels-last; everything after it is channels-last
+        IPSX_TRY(conv2d_affine_impl(&t->stem, patches + p0 * patch_elems, nullptr, buf[0], n, t->h, t->w, 1, 1, stream));
+        IPSX_TRY(ipsx_maxpool_3x3s2_nhwc(buf[0], buf[1], n, c, h, w, stream));
         h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
         int cur = 1;                                   // buf[cur] holds the block input
         for (int b = 0; b < t->n_block; ++b) {
@@ -115,24 +120,24 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
             for (int j = 0; j < B.n_conv - 1; ++j) {   // conv -> BN -> ReLU
                 const ipsx_conv& cv = B.conv[j];
                 const int di = (si == fr[0]) ? fr[1] : fr[0];
-                IPSX_TRY(ipsx_conv2d_affine(&cv, src, nullptr, buf[di], n, ch, cw, 1, stream));
+                IPSX_TRY(ipsx_conv2d_affine_nhwc(&cv, src, nullptr, buf[di], n, ch, cw, 1, stream));
                 ch = conv_out(ch, cv.kh, cv.stride, cv.pad); cw = conv_out(cw, cv.kw, cv.stride, cv.pad);
                 src = buf[di]; si = di;
             }
             const ipsx_conv& last = B.conv[B.n_conv - 1];
             const float* shortcut = buf[cur];
             if (B.has_down) {                          // 1x1 strided conv + BN on the identity path
-                IPSX_TRY(ipsx_conv2d_affine(&B.down, buf[cur], nullptr, buf[fr[2]], n, h, w, 0, stream));
+                IPSX_TRY(ipsx_conv2d_affine_nhwc(&B.down, buf[cur], nullptr, buf[fr[2]], n, h, w, 0, stream));
                 shortcut = buf[fr[2]];
             }
             const int oi = (si == fr[0]) ? fr[1] : fr[0];
             // last conv -> BN -> += identity -> ReLU
-            IPSX_TRY(ipsx_conv2d_affine(&last, src, shortcut, buf[oi], n, ch, cw, 1, stream));
+            IPSX_TRY(ipsx_conv2d_affine_nhwc(&last, src, shortcut, buf[oi], n, ch, cw, 1, stream));
             h = conv_out(ch, last.kh, last.stride, last.pad); w = conv_out(cw, last.kw, last.stride, last.pad);
             c = last.c_out;
             cur = oi;
         }
-        IPSX_TRY(ipsx_avgpool(buf[cur], emb + (size_t)p0 * g.d_out, n, c, h * w, stream));
+        IPSX_TRY(ipsx_avgpool_nhwc(buf[cur], emb + (size_t)p0 * g.d_out, n, c, h * w, stream));
     }
     return IPSX_OK;
 }

@@ -74,6 +74,10 @@ _EXPORTS = {
     "ipsx_bn_affine": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_affine": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_conv2d_affine_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_maxpool_3x3s2_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_avgpool_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_maxpool_3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_avgpool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_trunk_workspace_bytes": (C.c_size_t, [C.POINTER(Trunk), C.c_int64]),
@@ -272,7 +276,7 @@ def encoder_kernel_name(plan):
     if plan is None or plan._sig is None:
         return None
     if not plan.is_image:
-        return "layernorm_rows_kernel + conv_c8_kernel (projector)"
+        return "layernorm_rows_kernel + conv_nhwc_kernel (projector)"
     return lib().ipsx_trunk_kernel(C.byref(plan.trunk)).decode()
 
 

@@ -84,6 +84,54 @@ def test_conv2d_affine_bit_exact(c_in, c_out, k, stride, pad, h, w, n, res, relu
     assert ulp_diff(got, want) == 0, "max abs diff %g" % np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("c_in,c_out,k,stride,pad,h,w,n,res,relu", [
+    (64, 64, 3, 1, 1, 8, 8, 5, True, True),        # layer1 shape
+    (64, 128, 3, 2, 1, 13, 13, 3, False, True),    # strided, odd map (50-px patches)
+    (64, 128, 1, 2, 0, 25, 25, 2, False, False),   # 1x1 strided projection (traffic layer2 shortcut)
+    (128, 256, 3, 2, 1, 13, 13, 3, False, True),   # wide layer: waves along N
+    (256, 512, 3, 1, 1, 4, 4, 5, True, True),
+    (2048, 512, 1, 1, 0, 1, 1, 300, False, True),  # the projector Linear: rows x 2048 -> 512
+    (32, 32, 3, 1, 1, 5, 7, 4, False, False),      # smallest supported: one n-tile, 4 stages per tap
+])
+def test_conv2d_affine_nhwc_bit_exact(c_in, c_out, k, stride, pad, h, w, n, res, relu):
+    """Channels-last conv (16-byte buffer loads, hardware-zeroed halo) vs the oracle (NCHW)."""
+    x = rnd((n, c_in, h, w), 50)
+    wt = rnd((c_out, c_in, k, k), 51, (2.0 / (c_in * k * k)) ** 0.5)
+    alpha, shift = (1 + 0.2 * rnd((c_out,), 52)), rnd((c_out,), 53, 0.1)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    r = rnd((n, c_out, ho, wo), 54) if res else None
+    cv = orc._Conv(c_in, c_out, k, k, stride, pad, orc._f(wt)[1], orc._f(alpha)[1], orc._f(shift)[1])
+    want = np.empty((n, c_out, ho, wo), dtype=np.float32)
+    orc.lib().orc_conv2d_affine(C.byref(cv), orc._f(x)[1], orc._f(r)[1] if res else None,
+                                want.ctypes.data_as(orc.f32p), C.c_int64(n), h, w, int(relu))
+    packed = hip._pack_conv(dev(wt))
+    a, s = dev(alpha), dev(shift)
+    hcv = hip.Conv(c_in, c_out, k, k, stride, pad, packed.data_ptr(), a.data_ptr(), s.data_ptr())
+    xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    rd = dev(np.ascontiguousarray(r.transpose(0, 2, 3, 1))) if res else None
+    y = torch.full((n, ho, wo, c_out), float("nan"), device=DEV)
+    hip._ck(hip.lib().ipsx_conv2d_affine_nhwc(C.byref(hcv), hip._p(xd), hip._p(rd), hip._p(y), n, h, w, int(relu),
+                                              hip._stream()), "conv nhwc")
+    got = y.cpu().numpy().transpose(0, 3, 1, 2)
+    assert not np.isnan(got).any(), "kernel left outputs unwritten"
+    assert ulp_diff(got, want) == 0, "max abs diff %g" % np.abs(got - want).max()
+
+
+def test_nhwc_pools_bit_exact():
+    c = 64
+    x = rnd((3, c, 13, 13), 60)
+    xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    y = torch.empty((3, 7, 7, c), device=DEV)
+    hip._ck(hip.lib().ipsx_maxpool_3x3s2_nhwc(hip._p(xd), hip._p(y), 3, c, 13, 13, hip._stream()), "maxpool nhwc")
+    ref = torch.nn.functional.max_pool2d(torch.from_numpy(x), 3, 2, 1).numpy()
+    assert np.array_equal(y.cpu().numpy().transpose(0, 3, 1, 2), ref)
+    z = torch.empty((3, c), device=DEV)
+    hip._ck(hip.lib().ipsx_avgpool_nhwc(hip._p(xd), hip._p(z), 3, c, 169, hip._stream()), "avgpool nhwc")
+    want = np.empty((3, c), dtype=np.float32)
+    orc.lib().orc_avgpool(orc._f(x)[1], want.ctypes.data_as(orc.f32p), C.c_int64(3), c, 169)
+    assert ulp_diff(z.cpu().numpy(), want) == 0
+
+
 def test_bn_affine_and_pools_bit_exact():
     c = 64
     bn = torch.nn.BatchNorm2d(c)
@@ -138,7 +186,7 @@ def test_fused_trunk_equals_layered_kernels(monkeypatch):
     assert hip.encoder_kernel_name(plan) == "fused_trunk_kernel"
     monkeypatch.setenv("IPSX_NO_FUSED", "1")
     layered = plan.encode(x)
-    assert hip.encoder_kernel_name(plan).startswith("conv_c8_kernel")
+    assert hip.encoder_kernel_name(plan).startswith("conv_nhwc_kernel")
     monkeypatch.delenv("IPSX_NO_FUSED")
     assert torch.equal(fused, layered)
     want = orc.Oracle(g.net("cpu")).encode(x.cpu().numpy())
