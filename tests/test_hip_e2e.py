@@ -172,3 +172,48 @@ def test_sharded_path_on_gpu_single_rank_rccl():
         assert torch.equal(mp, full_patch) and torch.equal(pos, full_pos)
     finally:
         dist.destroy_process_group()
+
+
+def test_training_step_between_ips_calls():
+    """What training/iterative.py does (reference :135-163): ips() in train mode, forward with autograd on the
+    stock ROCm ops, backward, optimizer.step().  Weights and BatchNorm running statistics have moved, so the
+    next ips() must re-pack them: its selection has to equal the oracle's on the UPDATED weights."""
+    g = Golden("mnist_mini")
+    net = g.net(DEV)
+    net.train()
+    x = g.patches().to(DEV)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0.1)
+    mem_patch, mem_pos = net.ips(x)
+    assert np.array_equal(net.last_mem_idx.cpu().numpy(), g.mem_idx)          # eval statistics inside ips()
+    before = net.encoder[1].running_mean.clone()
+    preds = net(mem_patch, mem_pos)                                            # train mode: batch statistics, dropout
+    assert all(p.requires_grad for p in preds.values())
+    loss = sum((p ** 2).mean() for p in preds.values())
+    opt.zero_grad()
+    loss.backward()
+    assert net.encoder[0].weight.grad is not None and net.transf.crs_attn.q.grad is not None
+    opt.step()
+    assert not torch.equal(before, net.encoder[1].running_mean)                # BN buffers moved in forward
+    net.ips(x)
+    after = net.last_mem_idx.cpu().numpy()
+    cpu = IPSNet(torch.device("cpu"), g.conf)
+    cpu.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    cpu.eval()
+    want = orc.Oracle(cpu).ips(g.patches().numpy(), cpu.pos_enc.numpy())
+    assert np.array_equal(after, want["mem_idx"])
+
+
+def test_resnet50_bottleneck_trunk_bit_exact():
+    """enc_type='resnet50' (reference ips_net.py:22-25): Bottleneck blocks through the channels-last kernels."""
+    conf = synth.traffic_conf(N=12, M=4, I=4, patch=48, enc_type='resnet50', n_res_blocks=2, D=512)
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 3).to(DEV).eval()
+    x = synth.make_patches(conf, 1, seed=4)
+    cpu = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 3).eval()
+    o = orc.Oracle(cpu)
+    want = o.encode(x[0].numpy())
+    with torch.no_grad():
+        got = net._embed(x[0].to(DEV)).cpu().numpy()
+    assert got.shape == (12, 512)
+    assert ulp_diff(got, want) == 0
+    net.ips(x.to(DEV))
+    assert np.array_equal(net.last_mem_idx.cpu().numpy(), o.ips(x.numpy())["mem_idx"])
