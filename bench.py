@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--dedup-blank", action="store_true",
+                    help="secondary measurement: exact blank-patch deduplication in front of the encoder "
+                         "(IPSX_DEDUP_BLANK=1; the encoder then runs on the ~7 %% non-blank patches only, so the "
+                         "roofline object reports launch time but no FLOP rate)")
     ap.add_argument("--config", default="mnist", choices=sorted(FLOP_PER_PATCH),
                     help="mnist = the headline workload (BASELINE configs[1], B=16); the others are secondary "
                          "single-GPU measurements: b1 (same, B=1), native50 (reference-native 900 patches of 50 px, "
@@ -125,6 +129,8 @@ def main():
     from ips_amd.architecture import IPSNet
 
     hip.lib()                                                   # fail loudly if the extension is missing
+    if args.dedup_blank:
+        os.environ["IPSX_DEDUP_BLANK"] = "1"
     per_gpu = PATCHES_PER_GPU
     if args.config != "mnist" and world > 1:
         print("secondary configs are single-GPU measurements", file=sys.stderr)
@@ -221,7 +227,8 @@ def main():
             "config": {"workload": "%s (%d per GPU), B=%d, M=%d, I=%d, n_token=%d, %s, eager"
                                    % (label, per_gpu, args.batch, conf.M, conf.I, conf.n_token,
                                       "use_pos" if conf.use_pos else "no pos-enc"),
-                       "parallelism": "patch-sharded x%d, one all-gather of logits" % world if world > 1 else "single GPU"},
+                       "parallelism": "patch-sharded x%d, one all-gather of logits" % world if world > 1 else "single GPU",
+                       "dedup_blank": bool(args.dedup_blank)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
@@ -230,6 +237,10 @@ def main():
                          "launch_ms": enc_ms / max(len(enc_events), 1),
                          "patches_per_launch": enc_patches / max(len(enc_events), 1)},
         }
+        if args.dedup_blank:        # fewer patches are encoded than scored: an algorithmic FLOP rate would be wrong
+            out["roofline"].update({"achieved": None, "frac": None, "traffic": None,
+                                    "note": "blank-patch dedup: encoder ran on %d of %d patches per launch"
+                                            % (int(net._plan.n_encoded.item()), enc_patches // max(len(enc_events), 1))})
         if world == 1 and args.cpu_seconds > 0 and args.config == "mnist":
             out["cpu_baseline"] = cpu_baseline(conf, args.cpu_seconds)
         print(json.dumps(out), flush=True)

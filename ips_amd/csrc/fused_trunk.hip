@@ -53,6 +53,8 @@ struct FusedArgs {
     const float* patches;
     float* emb;
     long long n;
+    const int* index;        // optional: patch j of this launch is patches[index[j]] (blank-patch dedup)
+    const int* count;        // optional: device-side number of valid entries of index (<= n)
     const float *w_stem, *a_stem, *s_stem;
     const float *w[8], *al[8], *sh[8];       // l1.0.c1 l1.0.c2 l1.1.c1 l1.1.c2 l2.0.c1 l2.0.c2 l2.1.c1 l2.1.c2
     const float *w_down, *a_down, *s_down;
@@ -397,8 +399,11 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31;
     const long long p_first = (long long)blockIdx.x * 4;
+    const long long n_valid = a.count ? (long long)*a.count : a.n;        // compacted launches read their length on device
+    if (p_first >= n_valid) return;                                       // workgroup-uniform
     long long pi = p_first + wave;
-    if (pi >= a.n) pi = a.n - 1;                                          // tail: recompute a valid patch, store nothing
+    if (pi >= n_valid) pi = n_valid - 1;                                  // tail: recompute a valid patch, store nothing
+    if (a.index) pi = a.index[pi];
     float* S = lds + wave * SLAB;
     IPSX_STAMP(0);
 
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
         float sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) sum = sum + s[k * PS2];
-        if (p_first + pl < a.n) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
+        if (p_first + pl < n_valid) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
     }
     IPSX_STAMP(15);
 }
@@ -555,9 +560,10 @@ bool fused_trunk_supported(const ipsx_trunk* t) {
 }
 
 static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, float* emb,
-                        unsigned long long* stamps, hipStream_t s) {
+                        unsigned long long* stamps, hipStream_t s, const int* index = nullptr,
+                        const int* count = nullptr) {
     FusedArgs a;
-    a.patches = patches; a.emb = emb; a.n = n;
+    a.patches = patches; a.emb = emb; a.n = n; a.index = index; a.count = count;
     a.w_stem = t->stem.w_packed; a.a_stem = t->stem.alpha; a.s_stem = t->stem.shift;
     for (int k = 0; k < 4; ++k)
         for (int j = 0; j < 2; ++j) {
@@ -584,6 +590,11 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
 
 int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s) {
     return fused_launch(t, patches, n, emb, nullptr, s);
+}
+
+int fused_trunk_encode_indexed(const ipsx_trunk* t, const float* patches, int64_t n_max, const int* index,
+                               const int* count, float* emb, hipStream_t s) {
+    return fused_launch(t, patches, n_max, emb, nullptr, s, index, count);
 }
 
 }  // namespace ipsx

@@ -30,6 +30,11 @@ def backend():
     return b
 
 
+def dedup_blank():
+    """Opt-in exact blank-patch deduplication in front of the fused encoder (IPSX_DEDUP_BLANK=1)."""
+    return os.environ.get("IPSX_DEDUP_BLANK", "0") == "1"
+
+
 def on_device(x):
     """True when ``x`` (tensor / device / str) is a GPU and the HIP backend is selected."""
     if torch.is_tensor(x):
@@ -84,6 +89,9 @@ _EXPORTS = {
     "ipsx_trunk_kernel": (C.c_char_p, [C.POINTER(Trunk)]),
     "ipsx_trunk_encode": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
+    "ipsx_trunk_dedup_workspace_bytes": (C.c_size_t, [C.POINTER(Trunk), C.c_int64]),
+    "ipsx_trunk_encode_dedup": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p, C.c_void_p]),
     "ipsx_projector": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
@@ -259,6 +267,13 @@ class EncoderPlan:
             self.trunk.h, self.trunk.w = x.shape[2], x.shape[3]
             if x.shape[1] != self.trunk.c_in:
                 raise ValueError("patches have {} channels, encoder expects {}".format(x.shape[1], self.trunk.c_in))
+            if dedup_blank() and lib().ipsx_trunk_kernel(C.byref(self.trunk)) == b"fused_trunk_kernel":
+                nb = lib().ipsx_trunk_dedup_workspace_bytes(C.byref(self.trunk), n)
+                ws = self._workspace(nb, x.device)
+                self.n_encoded = torch.zeros((), dtype=torch.int32, device=x.device)
+                _ck(lib().ipsx_trunk_encode_dedup(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb,
+                                                  _p(self.n_encoded), _stream()), "ipsx_trunk_encode_dedup")
+                return out
             nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), n)
             ws = self._workspace(nb, x.device)
             _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()),

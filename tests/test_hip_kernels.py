@@ -193,6 +193,28 @@ def test_fused_trunk_equals_layered_kernels(monkeypatch):
     assert ulp_diff(fused.cpu().numpy(), want) == 0
 
 
+@pytest.mark.parametrize("blank_frac", [0.93, 0.0, 1.0, 0.5])
+def test_blank_patch_dedup_is_exact(monkeypatch, blank_frac):
+    """IPSX_DEDUP_BLANK=1: encode non-blank patches + one blank, copy - must equal encoding every patch, bit for bit."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    conf = g.conf
+    x = synth.make_patches(conf, 1, seed=77, blank_frac=blank_frac, N=1237)[0]
+    if 0.0 < blank_frac < 1.0:
+        x[5] = -0.0                                   # negative zeros count as blank
+        x[7, 0, 3, 3] = 1e-30                         # a single tiny value does not
+    x = x.to(DEV)
+    plan = hip.EncoderPlan(net.encoder, True)
+    full = plan.encode(x)
+    monkeypatch.setenv("IPSX_DEDUP_BLANK", "1")
+    dd = plan.encode(x)
+    n_enc = int(plan.n_encoded.item())
+    monkeypatch.delenv("IPSX_DEDUP_BLANK")
+    nonblank = int((x.reshape(x.shape[0], -1) != 0).any(1).sum().item())
+    assert n_enc == nonblank + (1 if nonblank < x.shape[0] else 0)
+    assert torch.equal(full, dd)
+
+
 def test_encoder_plan_tracks_weight_updates():
     g = Golden("mnist_mini")
     net = g.net(DEV)
