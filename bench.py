@@ -56,6 +56,9 @@ def parse():
                     help="secondary measurement: exact blank-patch deduplication in front of the encoder "
                          "(IPSX_DEDUP_BLANK=1; the encoder then runs on the ~7 %% non-blank patches only, so the "
                          "roofline object reports launch time but no FLOP rate)")
+    ap.add_argument("--lazy", action="store_true",
+                    help="secondary measurement: lazy loading - the patch tensor starts in pinned HOST memory and "
+                         "is streamed over PCIe inside every step (the PCIe-inclusive rate; never the headline)")
     ap.add_argument("--config", default="mnist", choices=sorted(FLOP_PER_PATCH),
                     help="mnist = the headline workload (BASELINE configs[1], B=16); the others are secondary "
                          "single-GPU measurements: b1 (same, B=1), native50 (reference-native 900 patches of 50 px, "
@@ -154,7 +157,8 @@ def main():
         label = "CAMELYON 65536 x 2048 features per slide, projector, M=I=256"
     n_total = per_gpu * world
     net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
-    x = synth.make_patches(conf, args.batch, seed=21 + rank, N=per_gpu).to(dev)   # resident in HBM
+    x = synth.make_patches(conf, args.batch, seed=21 + rank, N=per_gpu)
+    x = x.pin_memory() if args.lazy else x.to(dev)              # headline: resident in HBM before the timed region
 
     if world == 1:
         def step():
@@ -228,7 +232,7 @@ def main():
                                    % (label, per_gpu, args.batch, conf.M, conf.I, conf.n_token,
                                       "use_pos" if conf.use_pos else "no pos-enc"),
                        "parallelism": "patch-sharded x%d, one all-gather of logits" % world if world > 1 else "single GPU",
-                       "dedup_blank": bool(args.dedup_blank)},
+                       "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",

@@ -189,7 +189,9 @@ class IPSNet(nn.Module):
             else:
                 mem_idx = self._select_aten(patches, pos_enc)
 
-            mem_patch = self._take(patches, mem_idx).to(device)
+            src = self._device_patches if getattr(self, "_device_patches", None) is not None else patches
+            mem_patch = self._take(src, mem_idx).to(device)
+            self._device_patches = None
             mem_pos = self._take(pos_enc, mem_idx) if self.use_pos else None
         finally:
             if was_training:
@@ -215,24 +217,79 @@ class IPSNet(nn.Module):
         return torch.gather(src.expand(idx.shape[0], *src.shape[1:]), 1, view)
 
     def _select_hip(self, patches, pos_enc):
-        """encode-all -> logits -> one scan launch.  Patches may still be on the host."""
+        """encode-all -> logits -> one scan launch.  Patches may still be on the host (lazy loading)."""
         B, N = patches.shape[:2]
         ca = self.transf.crs_attn
         qs = ca.scaled_query()
         wk = hip.pack_linear(ca.k_w.weight)
-        n_ht = ca.H * ca.n_token
-        logits = torch.empty((B, N, n_ht), dtype=torch.float32, device=self.device)
-        lazy = not patches.is_cuda
-        # eager: one encoder pass over all B*N patches.  lazy: the reference's chunking
-        # bounds device memory, so keep it (H2D per chunk, reference :206,223).
-        spans = self._chunks(N) if lazy else [(0, N)]
-        for lo, hi in spans:
-            part = patches[:, lo:hi]
-            part = part.to(self.device, non_blocking=True) if lazy else part
+        logits = torch.empty((B, N, ca.H * ca.n_token), dtype=torch.float32, device=self.device)
+        self._device_patches = None
+        if patches.is_cuda:
+            spans, fetch, prefetch = [(0, N)], lambda k: patches, lambda k: None
+        else:
+            spans, fetch, prefetch = self._lazy_slabs(patches)
+        for k, (lo, hi) in enumerate(spans):
+            part = fetch(k)
             emb = self._embed(part.reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
             hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
+            prefetch(k + 1)          # after the encoder is enqueued: a pageable-memory copy blocks the host, not the GPU
         return hip.scan(logits, self.M, self.I, ca.H, ca.n_token)
+
+    # lazy loading (reference :204-206,223,245-247): the reference moves M / I patches per iteration to
+    # bound device memory.  Here the host tensor is streamed in a few large slabs on a copy stream while the
+    # previous slab is being encoded (PCIe Gen5 moves 4 KiB patches ~5x faster than the fp32 encoder consumes
+    # them, so the transfer hides behind the encoder).  With 288 GB of HBM the slabs are kept (up to
+    # IPSX_LAZY_KEEP_MB, default 16 GiB) so the M winners are gathered on the device; beyond that the final
+    # gather happens on the host exactly as in the reference.
+    _LAZY_SLAB_BYTES = 48 << 20
+
+    def _lazy_slabs(self, patches):
+        import os
+        B, N = patches.shape[:2]
+        row_bytes = patches[0, 0].numel() * patches.element_size()
+        per = max(1, min(N, self._LAZY_SLAB_BYTES // max(1, B * row_bytes)))
+        spans = [(lo, min(lo + per, N)) for lo in range(0, N, per)]
+        keep = patches.numel() * patches.element_size() <= int(os.environ.get("IPSX_LAZY_KEEP_MB", "16384")) << 20
+        dev = self.device
+        if keep:
+            store = torch.empty(patches.shape, dtype=patches.dtype, device=dev)
+            self._device_patches = store
+            dst = lambda k, lo, hi: store[:, lo:hi]
+        else:
+            ring = [torch.empty((B, per) + tuple(patches.shape[2:]), dtype=patches.dtype, device=dev) for _ in range(2)]
+            dst = lambda k, lo, hi: ring[k % 2][:, :hi - lo]
+        copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        ready, freed = {}, {}
+
+        def issue(k):
+            lo, hi = spans[k]
+            with torch.cuda.stream(copy_stream):
+                if not keep and k - 2 in freed:
+                    copy_stream.wait_event(freed[k - 2])          # ring slot must have been consumed
+                d = dst(k, lo, hi)
+                for b in range(B):                                  # per image: contiguous on both sides
+                    d[b].copy_(patches[b, lo:hi], non_blocking=True)
+                ready[k] = torch.cuda.Event()
+                ready[k].record(copy_stream)
+
+        issue(0)
+
+        def fetch(k):
+            main.wait_event(ready[k])
+            part = dst(k, *spans[k])
+            if not keep:
+                part = part.clone()
+                freed[k] = torch.cuda.Event()
+                freed[k].record(main)
+            return part
+
+        def prefetch(k):
+            if k < len(spans):
+                issue(k)                                            # travels while slab k-1 is being encoded
+
+        return spans, fetch, prefetch
 
     def _select_aten(self, patches, pos_enc):
         """The reference's loop on stock ATen ops (CPU plumbing path)."""

@@ -77,6 +77,22 @@ def test_lazy_loading_equals_eager():
     assert np.array_equal(idx_lazy.cpu().numpy(), g.mem_idx)
 
 
+@pytest.mark.parametrize("pinned,keep_mb", [(False, "16384"), (True, "16384"), (True, "0")])
+def test_lazy_slab_pipeline(monkeypatch, pinned, keep_mb):
+    """Lazy loading through several slabs (copy stream + events), pinned or pageable host memory, with the
+    slabs kept on the device (device-side final gather) or recycled (host-side gather, as the reference)."""
+    monkeypatch.setenv("IPSX_LAZY_KEEP_MB", keep_mb)
+    g = Golden("mnist_ragged")
+    net = g.net(DEV)
+    monkeypatch.setattr(type(net), "_LAZY_SLAB_BYTES", 2 * 70 * 4096)        # 70 patches per slab -> 5 slabs
+    x = g.patches()
+    if pinned:
+        x = x.pin_memory()
+    mp, pos = net.ips(x)
+    assert mp.is_cuda and np.array_equal(net.last_mem_idx.cpu().numpy(), g.mem_idx)
+    assert torch.equal(mp.cpu(), torch.stack([x[b][net.last_mem_idx[b].cpu()] for b in range(g.B)]))
+
+
 def test_instance_shuffle_against_oracle():
     """shuffle_style='instance' draws on the device generator; check against the oracle fed the same order."""
     g = Golden("mnist_shuffle_instance")
