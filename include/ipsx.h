@@ -62,6 +62,11 @@ size_t ipsx_packed_conv_weight_elems(int c_out, int c_in, int kh, int kw);
 int ipsx_pack_conv_weight(const float* w_oihw, int c_out, int c_in, int kh, int kw,
                           float* packed, void* stream);
 
+/* bf16 variant for the reduced-precision trunk: [C_out/32][K/16][64 lanes][8 bf16], round to nearest even */
+size_t ipsx_packed_conv_weight_bf16_bytes(int c_out, int c_in, int kh, int kw);
+int ipsx_pack_conv_weight_bf16(const float* w_oihw, int c_out, int c_in, int kh, int kw,
+                               void* packed, void* stream);
+
 /* eval-mode BatchNorm (nn.BatchNorm2d/1d with running stats) -> per-channel affine.
  * lin_bias (or NULL): bias of a Linear feeding the BatchNorm, folded in as
  * shift = fma(lin_bias, alpha, shift)                                        */
@@ -74,6 +79,7 @@ typedef struct ipsx_conv {
     const float* w_packed;        /* ipsx_pack_conv_weight output            */
     const float* alpha;           /* c_out, BatchNorm scale (or NULL = 1)    */
     const float* shift;           /* c_out, BatchNorm shift / bias (or NULL) */
+    const void* w_packed_bf16;    /* ipsx_pack_conv_weight_bf16 output, or NULL (fp32 only)  */
 } ipsx_conv;
 
 /* one residual block: BasicBlock (n_conv = 2) or Bottleneck (n_conv = 3)     */
@@ -91,6 +97,8 @@ typedef struct ipsx_trunk {
     ipsx_conv stem;
     int n_block;
     const ipsx_block* blocks;     /* HOST array of n_block descriptors        */
+    int precision;                /* 0 = fp32 (exact, default); 1 = bf16 operands / fp32 accumulate in the
+                                     residual stages (fused 1x32x32 trunk only; needs w_packed_bf16)   */
 } ipsx_trunk;
 
 /* y = act(affine(conv(x)) [+ residual]); x (n,c_in,h,w), y (n,c_out,ho,wo) NCHW */

@@ -30,6 +30,15 @@ def backend():
     return b
 
 
+def precision():
+    """'fp32' (default: exact, reference parity) or 'bf16' (IPSX_PRECISION=bf16: bf16 operands with fp32
+    accumulation in the residual stages of the fused 1x32x32 trunk; no reference behaviour to match)."""
+    p = os.environ.get("IPSX_PRECISION", "fp32").lower()
+    if p not in ("fp32", "bf16"):
+        raise ValueError("IPSX_PRECISION must be 'fp32' or 'bf16', got {!r}".format(p))
+    return p
+
+
 def dedup_blank():
     """Opt-in exact blank-patch deduplication in front of the fused encoder (IPSX_DEDUP_BLANK=1)."""
     return os.environ.get("IPSX_DEDUP_BLANK", "0") == "1"
@@ -48,7 +57,8 @@ def on_device(x):
 class Conv(C.Structure):
     _fields_ = [("c_in", C.c_int), ("c_out", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
                 ("stride", C.c_int), ("pad", C.c_int),
-                ("w_packed", C.c_void_p), ("alpha", C.c_void_p), ("shift", C.c_void_p)]
+                ("w_packed", C.c_void_p), ("alpha", C.c_void_p), ("shift", C.c_void_p),
+                ("w_packed_bf16", C.c_void_p)]
 
 
 class Block(C.Structure):
@@ -57,7 +67,7 @@ class Block(C.Structure):
 
 class Trunk(C.Structure):
     _fields_ = [("c_in", C.c_int), ("h", C.c_int), ("w", C.c_int), ("stem", Conv),
-                ("n_block", C.c_int), ("blocks", C.POINTER(Block))]
+                ("n_block", C.c_int), ("blocks", C.POINTER(Block)), ("precision", C.c_int)]
 
 
 class Transf(C.Structure):
@@ -76,6 +86,8 @@ _EXPORTS = {
     "ipsx_device_is_gfx950": (C.c_int, [C.c_int]),
     "ipsx_packed_conv_weight_elems": (C.c_size_t, [C.c_int] * 4),
     "ipsx_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_packed_conv_weight_bf16_bytes": (C.c_size_t, [C.c_int] * 4),
+    "ipsx_pack_conv_weight_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_bn_affine": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_affine": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -199,23 +211,31 @@ class EncoderPlan:
         self._ws = None
 
     def _signature(self):
-        sig = []
+        sig = [precision()]
         for t in list(self.encoder.parameters()) + list(self.encoder.buffers()):
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)
 
-    def _conv(self, conv, bn):
+    def _conv(self, conv, bn, bf16=False):
         packed = _pack_conv(conv.weight)
         aff = _bn_affine(bn)
         self._keep += [packed, aff]
+        half = None
+        if bf16:
+            w = _f32(conv.weight.detach())
+            co, ci, kh, kw = w.shape
+            half = torch.empty(lib().ipsx_packed_conv_weight_bf16_bytes(co, ci, kh, kw), dtype=torch.uint8, device=w.device)
+            _ck(lib().ipsx_pack_conv_weight_bf16(_p(w), co, ci, kh, kw, _p(half), _stream()), "ipsx_pack_conv_weight_bf16")
+            self._keep.append(half)
         return Conv(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
-                    conv.stride[0], conv.padding[0], _p(packed), _p(aff[0]), _p(aff[1]))
+                    conv.stride[0], conv.padding[0], _p(packed), _p(aff[0]), _p(aff[1]), _p(half))
 
     def _rebuild(self):
         self._keep = []
         enc = self.encoder
         if self.is_image:
             mods = list(enc.children())
+            bf16 = precision() == "bf16"
             blocks = []
             for stage in mods[4:-1]:
                 for blk in stage.children():
@@ -224,10 +244,10 @@ class EncoderPlan:
                              for i in (1, 2, 3) if hasattr(blk, "conv%d" % i)]
                     b.n_conv = len(pairs)
                     for j, (cv, bn) in enumerate(pairs):
-                        b.conv[j] = self._conv(cv, bn)
+                        b.conv[j] = self._conv(cv, bn, bf16)
                     b.has_down = int(blk.downsample is not None)
                     if b.has_down:
-                        b.down = self._conv(blk.downsample[0], blk.downsample[1])
+                        b.down = self._conv(blk.downsample[0], blk.downsample[1], bf16)
                     blocks.append(b)
             self._blocks = (Block * len(blocks))(*blocks)
             t = Trunk()
@@ -235,6 +255,7 @@ class EncoderPlan:
             t.c_in = mods[0].in_channels
             t.n_block = len(blocks)
             t.blocks = C.cast(self._blocks, C.POINTER(Block))
+            t.precision = 1 if bf16 else 0
             self.trunk = t
             self.d_out = blocks[-1].conv[blocks[-1].n_conv - 1].c_out
         else:

@@ -233,3 +233,24 @@ def test_resnet50_bottleneck_trunk_bit_exact():
     assert ulp_diff(got, want) == 0
     net.ips(x.to(DEV))
     assert np.array_equal(net.last_mem_idx.cpu().numpy(), o.ips(x.numpy())["mem_idx"])
+
+
+def test_bf16_precision_end_to_end(monkeypatch):
+    """ips() + forward with the bf16 trunk: finite, close to the fp32 outputs, selection mostly the same."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    x = g.patches().to(DEV)
+    mp32, pos32 = net.ips(x)
+    idx32 = net.last_mem_idx.clone()
+    with torch.no_grad():
+        p32 = net(mp32, pos32)
+    monkeypatch.setenv("IPSX_PRECISION", "bf16")
+    mp16, pos16 = net.ips(x)
+    idx16 = net.last_mem_idx.clone()
+    with torch.no_grad():
+        p16 = net(mp16, pos16)
+    monkeypatch.delenv("IPSX_PRECISION")
+    common = len(set(idx32[0].tolist()) & set(idx16[0].tolist()))
+    assert common >= 0.85 * g.conf.M, common
+    for k in p32:
+        assert torch.isfinite(p16[k]).all() and float((p16[k] - p32[k]).abs().max()) < 0.1

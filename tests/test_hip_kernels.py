@@ -215,6 +215,47 @@ def test_blank_patch_dedup_is_exact(monkeypatch, blank_frac):
     assert torch.equal(full, dd)
 
 
+def test_bf16_trunk_tracks_fp32_within_tolerance(monkeypatch):
+    """IPSX_PRECISION=bf16 (BASELINE configs[4]): bf16 operands / fp32 accumulate in the residual stages.
+    The reference has no reduced-precision path; the check is against this repo's own fp32 kernel and against a
+    float64 emulation that rounds weights and activations to bf16 at the same places."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    x = g.patches()[0, :203].to(DEV)
+    plan = hip.EncoderPlan(net.encoder, True)
+    ref = plan.encode(x).double()
+    monkeypatch.setenv("IPSX_PRECISION", "bf16")
+    got = plan.encode(x)
+    assert hip.encoder_kernel_name(plan) == "fused_trunk_bf16_kernel"
+    monkeypatch.delenv("IPSX_PRECISION")
+    assert torch.isfinite(got).all()
+    rel = ((got.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-12))
+    assert float(rel.max()) < 3e-2, float(rel.max())
+
+    # emulation: stem in fp32; every block conv sees bf16-rounded input and bf16-rounded weights
+    import torch.nn.functional as F
+    sd = {k: v.detach().double().cpu() for k, v in net.encoder.state_dict().items()}
+    r16 = lambda t: t.float().to(torch.bfloat16).double()
+    def bn(y, p):
+        return (y - sd[p + ".running_mean"][None, :, None, None]) / torch.sqrt(sd[p + ".running_var"] + 1e-5)[None, :, None, None] \
+            * sd[p + ".weight"][None, :, None, None] + sd[p + ".bias"][None, :, None, None]
+    y = F.relu(bn(F.conv2d(x.double().cpu(), sd["0.weight"], None, 2, 3), "1"))
+    y = F.max_pool2d(y, 3, 2, 1)
+    for st, stride in ((4, 1), (5, 2)):
+        for blk in (0, 1):
+            p = "%d.%d" % (st, blk)
+            s1 = stride if blk == 0 else 1
+            idt = y
+            z = F.relu(bn(F.conv2d(r16(y), r16(sd[p + ".conv1.weight"]), None, s1, 1), p + ".bn1"))
+            z = bn(F.conv2d(r16(z), r16(sd[p + ".conv2.weight"]), None, 1, 1), p + ".bn2")
+            if p + ".downsample.0.weight" in sd:
+                idt = bn(F.conv2d(r16(y), r16(sd[p + ".downsample.0.weight"]), None, s1, 0), p + ".downsample.1")
+            y = F.relu(z + idt)
+    emu = y.mean(dim=(2, 3))
+    err = (got.double().cpu() - emu).abs().max() / emu.abs().max()
+    assert float(err) < 3e-3, float(err)      # a bf16 rounding flip of one activation is 4e-3 of that activation
+
+
 def test_encoder_plan_tracks_weight_updates():
     g = Golden("mnist_mini")
     net = g.net(DEV)
