@@ -124,6 +124,11 @@ const char* ipsx_trunk_kernel(const ipsx_trunk* t);
 int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n_patch,
                       float* emb, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Encode the patches patches[index[0..n_index)] (int32 indices, device) -> emb (n_index, D): lets a caller
+ * encode a strided subset (e.g. columns lo..hi of a (B, N, ...) tensor) without copying it.  Fused trunk only. */
+int ipsx_trunk_encode_indexed(const ipsx_trunk* t, const float* patches, const int32_t* index,
+                              int64_t n_index, float* emb, void* stream);
+
 /* Same result as ipsx_trunk_encode, with exact blank-patch deduplication (all-zero patches share one
  * embedding in eval mode; ~93 % of Megapixel-MNIST patches): only the non-blank patches and one blank
  * are encoded, everything on the device.  Fused 1x32x32 trunk only.  n_encoded (device int32, or NULL)
@@ -173,6 +178,13 @@ int ipsx_logits(const float* emb, int64_t emb_bstride,
  * then implementation-defined, ips_net.py:199).                               */
 int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
               int64_t* mem_idx, float* mem_score, int32_t* tie_flag, void* stream);
+
+/* Iterations [it_begin, it_end) of the same loop.  it_begin = 0 starts from the first m patches, it_begin > 0
+ * resumes from the state a previous call left in mem_idx; only logits rows below m + it_end*i are read, so a
+ * range can run (on another stream) while later patches are still being encoded.  tie_flag is only ever SET.  */
+int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                    int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                    int32_t* tie_flag, void* stream);
 
 /* Transformer.get_scores on arbitrary embeddings x (b,l,d) -> scores (b,l);
  * attn (b,h,T,l) optionally written too (get_attn).                          */

@@ -220,6 +220,8 @@ class IPSNet(nn.Module):
         """encode-all -> logits -> one scan launch.  Patches may still be on the host (lazy loading)."""
         B, N = patches.shape[:2]
         ca = self.transf.crs_attn
+        if patches.is_cuda and self._can_overlap(patches):
+            return self._select_hip_overlapped(patches, pos_enc)
         qs = ca.scaled_query()
         wk = hip.pack_linear(ca.k_w.weight)
         logits = torch.empty((B, N, ca.H * ca.n_token), dtype=torch.float32, device=self.device)
@@ -235,6 +237,64 @@ class IPSNet(nn.Module):
             hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
             prefetch(k + 1)          # after the encoder is enqueued: a pageable-memory copy blocks the host, not the GPU
         return hip.scan(logits, self.M, self.I, ca.H, ca.n_token)
+
+    # The selection loop is sequential over chunks but only ever needs the logits of the chunks it has
+    # reached, so it runs on a side stream over the part of the image that is already encoded while the
+    # encoder works on the next part (ipsx_scan_range resumes from the memory indices).  Only the last part's
+    # iterations are exposed - this is what keeps the scan off the critical path when the image (and with it
+    # the iteration count) grows across GPUs.  Parts are cut at chunk boundaries and encoded through an index
+    # list, so nothing is copied.  IPSX_OVERLAP_SCAN=0 switches it off.
+    _OVERLAP_PARTS = 4
+
+    def _can_overlap(self, patches):
+        import os
+        if os.environ.get("IPSX_OVERLAP_SCAN", "1") == "0" or hip.dedup_blank() or not self.is_image:
+            return False
+        if self._plan is None:
+            self._plan = hip.EncoderPlan(self.encoder, self.is_image)
+        n_iter = math.ceil((patches.shape[1] - self.M) / self.I)
+        return (not self.encoder.training) and patches.is_contiguous() and n_iter >= 2 * self._OVERLAP_PARTS \
+            and self._plan.fused(patches.shape)
+
+    def _select_hip_overlapped(self, patches, pos_enc):
+        B, N = patches.shape[:2]
+        M, I, dev = self.M, self.I, patches.device
+        ca = self.transf.crs_attn
+        qs = ca.scaled_query()
+        wk = hip.pack_linear(ca.k_w.weight)
+        n_iter = math.ceil((N - M) / I)
+        P = self._OVERLAP_PARTS
+        its = [round(k * n_iter / P) for k in range(P + 1)]
+        edges = [0] + [min(N, M + it * I) for it in its[1:]]
+        edges[-1] = N
+        key = (B, N, tuple(edges), str(dev))
+        if getattr(self, "_part_index_key", None) != key:            # int32 patch indices of every part, cached
+            rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1) * N
+            self._part_index = [(rows + torch.arange(edges[k], edges[k + 1], device=dev, dtype=torch.int32)).reshape(-1)
+                                for k in range(P)]
+            self._part_index_key = key
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
+            self._side_stream = torch.cuda.Stream(device=dev, priority=-1)   # its few workgroups must not queue behind the encoder grid
+        side, main = self._side_stream, torch.cuda.current_stream(dev)
+        flat = patches.reshape(B * N, *patches.shape[2:])
+        logits = torch.empty((B, N, ca.H * ca.n_token), dtype=torch.float32, device=dev)
+        mem_idx = torch.empty((B, M), dtype=torch.int64, device=dev)
+        tie = torch.zeros((B,), dtype=torch.int32, device=dev)
+        for t in (logits, mem_idx, tie):
+            t.record_stream(side)
+        for k in range(P):
+            lo, hi = edges[k], edges[k + 1]
+            emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
+            pos = pos_enc[:, lo:hi] if self.use_pos else None
+            hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(done)
+                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx, tie)
+        main.wait_stream(side)
+        hip.scan.last_tie = tie
+        return mem_idx
 
     # lazy loading (reference :204-206,223,245-247): the reference moves M / I patches per iteration to
     # bound device memory.  Here the host tensor is streamed in a few large slabs on a copy stream while the

@@ -81,6 +81,14 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float4* __restr
 
 using namespace ipsx;
 
+IPSX_API int ipsx_trunk_encode_indexed(const ipsx_trunk* t, const float* patches, const int32_t* index,
+                                       int64_t n_index, float* emb, void* stream) {
+    IPSX_REQUIRE(t && patches && index && emb && n_index >= 0, "trunk_encode_indexed: bad arguments");
+    IPSX_REQUIRE(fused_trunk_supported(t), "trunk_encode_indexed: only the fused 1x32x32 trunk is supported");
+    if (n_index == 0) return IPSX_OK;
+    return fused_trunk_encode_indexed(t, patches, n_index, index, nullptr, emb, as_stream(stream));
+}
+
 IPSX_API size_t ipsx_trunk_dedup_workspace_bytes(const ipsx_trunk* t, int64_t n_patch) {
     if (!t || n_patch <= 0) return 0;
     // nonblank, index, slot (n ints each) + count + the compacted embeddings (n+1 rows of 128 floats)

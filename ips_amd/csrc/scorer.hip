@@ -70,14 +70,26 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
     const float4* wp = reinterpret_cast<const float4*>(a.wkp) + lane;
+    const bool vec = (a.d & 7) == 0;                 // rows are 16-byte aligned and every k-group is complete
     for (int kg = 0; kg < a.kgs; ++kg) {
         float av[4];
+        if (vec) {                                   // one 16-byte load per operand row per k-group
+            const float4 ev = *reinterpret_cast<const float4*>(e + kg * 8);
+            av[0] = ev.x; av[1] = ev.y; av[2] = ev.z; av[3] = ev.w;
+            if (p) {
+                const float4 pv = *reinterpret_cast<const float4*>(p + kg * 8);
+                av[0] = av[0] + pv.x; av[1] = av[1] + pv.y; av[2] = av[2] + pv.z; av[3] = av[3] + pv.w;
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = kg * 8 + j;              // + 4*half is in the base pointers
-            float v = (c + 4 * half < a.d) ? e[c] : 0.0f;
-            if (p) v = v + ((c + 4 * half < a.d) ? p[c] : 0.0f);
-            av[j] = rv ? v : 0.0f;
+            for (int j = 0; j < 4; ++j) av[j] = rv ? av[j] : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = kg * 8 + j;              // + 4*half is in the base pointers
+                float v = (c + 4 * half < a.d) ? e[c] : 0.0f;
+                if (p) v = v + ((c + 4 * half < a.d) ? p[c] : 0.0f);
+                av[j] = rv ? v : 0.0f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
@@ -203,6 +215,7 @@ __device__ __forceinline__ uint64_t* sort_desc(uint64_t* src, uint64_t* tmp, int
 struct ScanArgs {
     const float* lg;       // (b, n, R)
     long long n;
+    long long it0, it1;    // iterations [it0, it1) of the loop; it0 > 0 resumes from mem_idx
     int m, i, h, T, n2, use_lds;
     long long* mem_idx;
     float* mem_score;
@@ -227,11 +240,11 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
 
     int* cand = candA;
     int* cnew = candB;
-    for (int j = tid; j < a.m; j += 256) cand[j] = j;
+    for (int j = tid; j < a.m; j += 256) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
     int tie = 0;
     uint64_t* sorted = keyA;
-    const long long n_iter = (a.n - a.m + a.i - 1) / a.i;
-    for (long long it = 0; it < n_iter; ++it) {
+    const long long n_iter = a.it1 - a.it0;
+    for (long long it = a.it0; it < a.it1; ++it) {
         const long long lo = it * a.i + a.m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = a.m + cnt;
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
         a.mem_idx[(size_t)b * a.m + j] = cand[j];
         if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
     }
-    if (a.tie && tid == 0) a.tie[b] = tie;
+    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
 }
 
 // Resident scan: the logits of the M memory patches stay in LDS from one iteration to the next
@@ -370,13 +383,17 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
     int* cnew = candB;
     float* cl = clA;
     float* clnew = clB;
-    // memory = first m patches: their logits are one contiguous block
-    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = j;
-    for (int e = tid; e < a.m * R; e += SCAN_NT) { const int l = e / R; cl[l * ld + (e - l * R)] = lg[e]; }
-    const long long n_iter = (a.n - a.m + a.i - 1) / a.i;
+    // memory: the first m patches (it0 == 0) or the state a previous range left in mem_idx
+    for (int e = tid; e < a.m * R; e += SCAN_NT) {
+        const int l = e / R;
+        const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
+        cl[l * ld + (e - l * R)] = lg[row * R + (e - l * R)];
+    }
+    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
+    const long long n_iter = a.it1 - a.it0;
     float pf[SCAN_PF];
     {
-        const long long lo = a.m;
+        const long long lo = a.it0 * a.i + a.m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
 #pragma unroll
         for (int k = 0; k < SCAN_PF; ++k) {
@@ -389,7 +406,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
     while (P < 64 && 2 * P * std::min(Lmax, 192) <= SCAN_NT) P <<= 1;
     int tie = 0;
     uint64_t* sorted = keyA;
-    for (long long it = 0; it < n_iter; ++it) {
+    for (long long it = a.it0; it < a.it1; ++it) {
         const long long lo = it * a.i + a.m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = a.m + cnt;
@@ -401,8 +418,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         }
         for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
         {
-            const long long lo2 = lo + a.i;
-            const int cnt2 = (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2));
+            const long long lo2 = lo + a.i;          // the range's last iteration prefetches nothing: those rows may not exist yet
+            const int cnt2 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
 #pragma unroll
             for (int k = 0; k < SCAN_PF; ++k) {
                 const int e = tid + SCAN_NT * k;
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         a.mem_idx[(size_t)b * a.m + j] = cand[j];
         if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
     }
-    if (a.tie && tid == 0) a.tie[b] = tie;
+    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
     if (STAMP && tid == 0)
         for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
 }
@@ -623,10 +640,22 @@ IPSX_API int ipsx_logits(const float* emb, int64_t emb_bstride, const float* pos
 
 IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                        int64_t* mem_idx, float* mem_score, int32_t* tie_flag, void* stream) {
+    IPSX_REQUIRE(n > m && i > 0, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
+    if (tie_flag && hipMemsetAsync(tie_flag, 0, sizeof(int32_t) * (size_t)std::max(b, 0), as_stream(stream)) != hipSuccess)
+        return fail(IPSX_EHIP, "scan: memset failed");
+    return ipsx_scan_range(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, stream);
+}
+
+IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                             int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                             int32_t* tie_flag, void* stream) {
     IPSX_REQUIRE(logits && mem_idx, "scan: null pointer");
     IPSX_REQUIRE(b > 0 && m > 0 && i > 0 && h > 0 && n_token > 0, "scan: bad sizes");
     IPSX_REQUIRE(n > m, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
     IPSX_REQUIRE(n < ((int64_t)1 << 31), "scan: too many patches");
+    IPSX_REQUIRE(it_begin >= 0 && it_begin <= it_end && it_end <= (n - m + i - 1) / i,
+                 "scan: iteration range [%lld, %lld) outside the loop", (long long)it_begin, (long long)it_end);
+    if (it_begin == it_end) return IPSX_OK;
     const int R = h * n_token, Lmax = m + i, n2 = next_pow2(Lmax);
     size_t base = (size_t)n2 * 16 + (size_t)Lmax * 8 + (size_t)R * 8;
     base = (base + 15) & ~(size_t)15;
@@ -634,6 +663,7 @@ IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int 
     IPSX_REQUIRE(base <= kLdsLimit, "scan: M+I = %d candidates do not fit the 160 KiB LDS", Lmax);
     ScanArgs a;
     a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
+    a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
     const size_t resident = base + (size_t)Lmax * R * 4 + 2 * stage;

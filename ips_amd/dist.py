@@ -3,35 +3,84 @@
 The reference is single-device (/root/reference/main.py:19-20); this is the one
 multi-GPU mechanism the hot path admits without changing its result (SURVEY.md
 section 8 e-2): in eval mode the encoder and a patch's attention logits are pure
-per-patch functions, so rank r encodes and scores the contiguous slab
-``[r*n_loc, (r+1)*n_loc)`` of the patch axis, ONE ``all_gather`` moves the logits
-``(B, n_loc, H*T)`` (128 bytes per patch at the MNIST configuration - latency-bound
-on xGMI), and every rank replays the identical scan, so all ranks hold the same
-``mem_idx`` as a single-GPU run, bit for bit.  The M winning patches are then
-assembled with one small ``all_reduce`` of zero-filled owner contributions (exact:
-x + 0 = x).
+per-patch functions, so the patch axis is sharded, the ranks exchange LOGITS
+(H*T floats = 128 bytes per patch at the MNIST configuration - latency-bound on
+xGMI) and every rank replays the identical selection loop, so all ranks hold the
+same ``mem_idx`` as a single-GPU run, bit for bit.
+
+Layout (``partition``): the patch axis is cut into a few PARTS at chunk boundaries of
+the selection loop; every part is split evenly over the ranks.  Per part: each rank
+encodes and scores its piece, ONE ``all_gather_into_tensor`` assembles the part's
+logits, and the loop iterations that part makes possible run on a high-priority side
+stream (``ipsx_scan_range`` resumes from the memory indices) while the encoder is
+already busy with the next part.  Only the last part's iterations are exposed, which
+keeps the sequential loop - whose length grows with the image - off the critical path.
+The M winning patches are then assembled with one small ``all_reduce`` of zero-filled
+owner contributions (exact: x + 0 = x).
 
 On CPU tensors (gloo; the world_size-2 tests) the same partitioning runs with the
-ATen path: embeddings are all-gathered instead of logits and the reference loop
-runs on them.
+ATen path: embeddings are all-gathered instead of logits and the reference loop runs
+on them.
 """
+
+import math
 
 import torch
 import torch.distributed as dist
 
 from . import hip
 
+PARTS = 4
 
-def slab(N, rank, world):
-    """Contiguous slab of the patch axis owned by ``rank``: (lo, hi, n_loc); n_loc is padded."""
-    n_loc = (N + world - 1) // world
-    lo = min(rank * n_loc, N)
-    return lo, min(lo + n_loc, N), n_loc
+
+def partition(N, M, I, world, parts=PARTS):
+    """Cut [0, N) into parts at chunk boundaries and every part into `world` pieces.
+
+    Returns ``(its, edges, piece)``: ``its[k]`` = first loop iteration of part k (``its[-1]`` = n_iter),
+    ``edges[k]`` = first patch of part k, ``piece[k]`` = padded piece length of part k; rank r owns
+    patches ``[edges[k] + r*piece[k], min(edges[k] + (r+1)*piece[k], edges[k+1]))`` of every part k.
+    """
+    n_iter = math.ceil((N - M) / I)
+    P = max(1, min(parts, n_iter))
+    its = [round(k * n_iter / P) for k in range(P + 1)]
+    edges = [0] + [min(N, M + it * I) for it in its[1:]]
+    edges[-1] = N
+    piece = [max(1, math.ceil((edges[k + 1] - edges[k]) / world)) for k in range(P)]
+    return its, edges, piece
+
+
+def local_spans(N, M, I, rank, world, parts=PARTS):
+    """Global [lo, hi) ranges this rank owns, in local order (one per part, possibly empty)."""
+    _, edges, piece = partition(N, M, I, world, parts)
+    out = []
+    for k, q in enumerate(piece):
+        lo = min(edges[k] + rank * q, edges[k + 1])
+        out.append((lo, min(lo + q, edges[k + 1])))
+    return out
+
+
+def local_indices(N, M, I, rank, world, parts=PARTS):
+    """1-D int64 tensor of the global patch indices a rank holds, in local order."""
+    spans = local_spans(N, M, I, rank, world, parts)
+    return torch.cat([torch.arange(lo, hi, dtype=torch.int64) for lo, hi in spans]) if spans else torch.empty(0, dtype=torch.int64)
+
+
+def _owner_maps(N, M, I, world, device, parts=PARTS):
+    """owner[j] = rank holding global patch j, lpos[j] = its position in that rank's local tensor."""
+    owner = torch.empty(N, dtype=torch.int64)
+    lpos = torch.empty(N, dtype=torch.int64)
+    for r in range(world):
+        base = 0
+        for lo, hi in local_spans(N, M, I, r, world, parts):
+            owner[lo:hi] = r
+            lpos[lo:hi] = torch.arange(base, base + hi - lo)
+            base += hi - lo
+    return owner.to(device), lpos.to(device)
 
 
 @torch.no_grad()
 def ips_sharded(net, local_patches, N, group=None):
-    """IPS over ``N`` patches of which this rank holds ``local_patches`` (B, hi-lo, ...).
+    """IPS over ``N`` patches of which this rank holds ``local_patches`` = patches[:, local_indices(...)].
 
     ``net`` is an ``IPSNet`` whose ``conf.N`` (positional table) is the GLOBAL ``N``.
     Shuffling is the caller's business here (shard after shuffling).  Returns
@@ -39,44 +88,96 @@ def ips_sharded(net, local_patches, N, group=None):
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    lo, hi, n_loc = slab(N, rank, world)
-    B = local_patches.shape[0]
-    assert local_patches.shape[1] == hi - lo, "rank %d expects %d patches, got %d" % (rank, hi - lo, local_patches.shape[1])
-    dev = local_patches.device
-    M, D = net.M, net.D
+    M, I, D = net.M, net.I, net.D
     if M >= N:
         raise ValueError("sharded IPS needs N > M")
+    its, edges, piece = partition(N, M, I, world)
+    spans = local_spans(N, M, I, rank, world)
+    n_local = sum(hi - lo for lo, hi in spans)
+    B = local_patches.shape[0]
+    assert local_patches.shape[1] == n_local, "rank %d expects %d patches, got %d" % (rank, n_local, local_patches.shape[1])
+    dev = local_patches.device
     was_training = net.training
     if was_training:
         net.encoder.eval(); net.transf.eval()
     try:
         ca = net.transf.crs_attn
-        pos = net.pos_enc[:, lo:hi] if net.use_pos else None           # (1, n, D) slab of the table
-        emb = net._embed(local_patches.reshape(-1, *local_patches.shape[2:])).view(B, hi - lo, D)
-
-        if hip.on_device(dev):
+        on_gpu = hip.on_device(dev)
+        if on_gpu:
             R = ca.H * ca.n_token
-            mine = torch.zeros((B, n_loc, R), dtype=torch.float32, device=dev)
-            if hi > lo:
-                hip.logits(emb, pos, hip.pack_linear(ca.k_w.weight), ca.scaled_query(), ca.H, ca.D_k,
-                           ca.n_token, out=mine[:, :hi - lo])
-            gathered = torch.empty((world, B, n_loc, R), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(gathered, mine, group=group)   # the one exchange of the scan
-            logits = gathered.permute(1, 0, 2, 3).reshape(B, world * n_loc, R)[:, :N].contiguous()
-            mem_idx = hip.scan(logits, M, net.I, ca.H, ca.n_token)
+            qs, wk = ca.scaled_query(), hip.pack_linear(ca.k_w.weight)
+            logits = torch.empty((B, N, R), dtype=torch.float32, device=dev)
+            mem_idx = torch.empty((B, M), dtype=torch.int64, device=dev)
+            tie = torch.zeros((B,), dtype=torch.int32, device=dev)
+            if getattr(net, "_side_stream", None) is None or net._side_stream.device != dev:
+                net._side_stream = torch.cuda.Stream(device=dev, priority=-1)
+            side, main = net._side_stream, torch.cuda.current_stream(dev)
+            for t in (logits, mem_idx, tie):
+                t.record_stream(side)
         else:
-            mine = torch.zeros((B, n_loc, D), dtype=torch.float32, device=dev)
-            mine[:, :hi - lo] = emb
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine, group=group)
-            all_emb = torch.stack(parts, 1).reshape(B, world * n_loc, D)[:, :N]
+            all_emb = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+
+        indexed = False
+        if on_gpu and net.is_image and not hip.dedup_blank() and local_patches.is_contiguous():
+            if net._plan is None:
+                net._plan = hip.EncoderPlan(net.encoder, net.is_image)
+            indexed = net._plan.fused(local_patches.shape)                 # encode a column range without copying it
+        if indexed:
+            flat = local_patches.reshape(B * n_local, *local_patches.shape[2:])
+            rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1) * n_local
+        base = 0
+        for k, (lo, hi) in enumerate(spans):
+            n_k, q, part_len = hi - lo, piece[k], edges[k + 1] - edges[k]
+            width = R if on_gpu else D
+            mine = torch.zeros((B, q, width), dtype=torch.float32, device=dev)
+            if n_k > 0:
+                if indexed:
+                    cols = torch.arange(base, base + n_k, device=dev, dtype=torch.int32)
+                    emb = net._plan.encode_indexed(flat, (rows + cols).reshape(-1)).view(B, n_k, D)
+                else:
+                    part = local_patches[:, base:base + n_k]
+                    emb = net._embed(part.reshape(-1, *local_patches.shape[2:])).view(B, n_k, D)
+                if on_gpu:
+                    pos = net.pos_enc[:, lo:hi] if net.use_pos else None
+                    hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=mine[:, :n_k])
+                else:
+                    mine[:, :n_k] = emb
+            base += n_k
+            if on_gpu:                                                      # the exchange of this part
+                gathered = torch.empty((world, B, q, width), dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(gathered, mine, group=group)
+            else:                                                           # gloo has no all_gather_into_tensor
+                pieces = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(pieces, mine, group=group)
+                gathered = torch.stack(pieces, 0)
+            full = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
+            if on_gpu:
+                logits[:, edges[k]:edges[k + 1]] = full
+                done = torch.cuda.Event()
+                done.record(main)
+                with torch.cuda.stream(side):                              # loop iterations of this part, off the critical path
+                    side.wait_event(done)
+                    hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx, tie)
+            else:
+                all_emb[:, edges[k]:edges[k + 1]] = full
+        if on_gpu:
+            main.wait_stream(side)
+            hip.scan.last_tie = tie
+        else:
             mem_idx = _scan_aten(net, all_emb)
 
         # assemble the winners: every rank contributes the rows it owns, zeros elsewhere
-        owned = (mem_idx >= lo) & (mem_idx < hi)
-        local_idx = (mem_idx - lo).clamp_(0, max(hi - lo - 1, 0))
-        mem_patch = _take(local_patches, local_idx)
-        mem_patch = mem_patch * owned.view(B, M, *(1,) * (mem_patch.dim() - 2)).to(mem_patch.dtype)
+        key = (N, M, I, world, str(dev))
+        if getattr(net, "_owner_key", None) != key:
+            net._owner_maps, net._owner_key = _owner_maps(N, M, I, world, dev), key
+        owner, lpos = net._owner_maps
+        owned = owner[mem_idx] == rank
+        local_idx = torch.where(owned, lpos[mem_idx], torch.zeros_like(mem_idx)).clamp_(0, max(n_local - 1, 0))
+        if n_local > 0:
+            mem_patch = _take(local_patches, local_idx)
+            mem_patch = mem_patch * owned.view(B, M, *(1,) * (mem_patch.dim() - 2)).to(mem_patch.dtype)
+        else:
+            mem_patch = torch.zeros((B, M) + tuple(local_patches.shape[2:]), dtype=local_patches.dtype, device=dev)
         dist.all_reduce(mem_patch, group=group)
         mem_pos = _take(net.pos_enc, mem_idx) if net.use_pos else None
     finally:

@@ -113,6 +113,9 @@ _EXPORTS = {
                               C.c_void_p, C.c_int64, C.c_void_p]),
     "ipsx_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_scan_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_trunk_encode_indexed": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ipsx_scores_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "ipsx_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -273,12 +276,31 @@ class EncoderPlan:
             self._ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         return self._ws
 
-    def encode(self, x):
-        """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D)."""
+    def _refresh(self):
         sig = self._signature()
         if sig != self._sig:
             self._rebuild()
             self._sig = sig
+
+    def fused(self, x_shape):
+        """True when encode_indexed is available for patches of this (C, h, w)."""
+        if not self.is_image:
+            return False
+        self._refresh()
+        self.trunk.h, self.trunk.w = x_shape[-2], x_shape[-1]
+        return x_shape[-3] == self.trunk.c_in and lib().ipsx_trunk_kernel(C.byref(self.trunk)).startswith(b"fused")
+
+    def encode_indexed(self, flat, index):
+        """flat (P, C, h, w) contiguous on the GPU, index (n,) int32 -> (n, D) embeddings of flat[index]."""
+        self._refresh()
+        out = torch.empty((index.numel(), self.d_out), dtype=torch.float32, device=flat.device)
+        _ck(lib().ipsx_trunk_encode_indexed(C.byref(self.trunk), _p(flat), _p(index), index.numel(), _p(out),
+                                            _stream()), "ipsx_trunk_encode_indexed")
+        return out
+
+    def encode(self, x):
+        """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D)."""
+        self._refresh()
         x = _f32(x)
         n = x.shape[0]
         out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
@@ -361,6 +383,16 @@ def scan(lg, M, I, H, T, want_scores=False):
     _ck(lib().ipsx_scan(_p(lg), B, N, M, I, H, T, _p(mem_idx), _p(sc), _p(tie), _stream()), "ipsx_scan")
     scan.last_tie = tie
     return (mem_idx, sc) if want_scores else mem_idx
+
+
+def scan_range(lg, M, I, H, T, it_begin, it_end, mem_idx, tie):
+    """Iterations [it_begin, it_end) of the loop, state carried in ``mem_idx`` (B, M) int64 / ``tie`` (B,) int32."""
+    B, N = lg.shape[:2]
+    if not lg.is_contiguous():
+        raise ValueError("scan_range needs the full contiguous (B, N, H*T) logits buffer")
+    _ck(lib().ipsx_scan_range(_p(lg), B, N, M, I, H, T, it_begin, it_end, _p(mem_idx), None, _p(tie), _stream()),
+        "ipsx_scan_range")
+    return mem_idx
 
 
 def _scores_impl(x, qs, wk, H, Dk, T, want_attn):

@@ -32,8 +32,8 @@ def _worker(rank, world, port, case, out):
         net = g.net("cpu")
         x = g.patches()
         N = x.shape[1]
-        lo, hi, _ = ipsd.slab(N, rank, world)
-        mem_patch, mem_pos, mem_idx = ipsd.ips_sharded(net, x[:, lo:hi].contiguous(), N)
+        mine = ipsd.local_indices(N, net.M, net.I, rank, world)
+        mem_patch, mem_pos, mem_idx = ipsd.ips_sharded(net, x[:, mine].contiguous(), N)
         ok = np.array_equal(mem_idx.numpy(), g.mem_idx)
         full_patch, full_pos = net.ips(x)
         ok = ok and torch.equal(mem_patch, full_patch)
@@ -52,11 +52,16 @@ def test_sharded_ips_equals_single_process(case):
         assert dict(out) == {0: True, 1: True}
 
 
-def test_slab_partition_covers_everything():
-    for N in (1, 7, 64, 301, 2500, 10000):
+def test_partition_covers_every_patch_once_and_respects_chunk_boundaries():
+    for N, M, I in ((301, 16, 24), (2500, 64, 64), (20000, 64, 64), (40, 16, 64), (1000, 32, 48), (65536, 256, 256)):
         for world in (1, 2, 3, 4, 8):
-            spans = [ipsd.slab(N, r, world) for r in range(world)]
-            assert spans[0][0] == 0 and spans[-1][1] == N
-            for (a, b, n), (c, d, _) in zip(spans, spans[1:]):
-                assert b == c and b - a <= n
-            assert sum(b - a for a, b, _ in spans) == N
+            its, edges, piece = ipsd.partition(N, M, I, world)
+            assert its[0] == 0 and edges[0] == 0 and edges[-1] == N
+            for k in range(1, len(edges) - 1):
+                assert (edges[k] - M) % I == 0 and edges[k] == M + its[k] * I      # parts end where a chunk ends
+            got = torch.cat([ipsd.local_indices(N, M, I, r, world) for r in range(world)])
+            assert sorted(got.tolist()) == list(range(N))
+            # every part's pieces are in rank order: the gathered (rank, piece) layout IS the patch order
+            for k in range(len(piece)):
+                los = [ipsd.local_spans(N, M, I, r, world)[k] for r in range(world)]
+                assert los[0][0] == edges[k] and all(a[1] == b[0] or b[0] == b[1] for a, b in zip(los, los[1:]))

@@ -182,7 +182,8 @@ def test_sharded_path_on_gpu_single_rank_rccl():
         g = Golden("mnist_ragged")
         net = g.net(DEV)
         x = g.patches().to(DEV)
-        mp, pos, idx = ipsd.ips_sharded(net, x, x.shape[1])
+        mine = ipsd.local_indices(x.shape[1], net.M, net.I, 0, 1).to(DEV)
+        mp, pos, idx = ipsd.ips_sharded(net, x[:, mine].contiguous(), x.shape[1])
         full_patch, full_pos = net.ips(x)
         assert torch.equal(idx, net.last_mem_idx) and np.array_equal(idx.cpu().numpy(), g.mem_idx)
         assert torch.equal(mp, full_patch) and torch.equal(pos, full_pos)
@@ -254,3 +255,31 @@ def test_bf16_precision_end_to_end(monkeypatch):
     assert common >= 0.85 * g.conf.M, common
     for k in p32:
         assert torch.isfinite(p16[k]).all() and float((p16[k] - p32[k]).abs().max()) < 0.1
+
+
+def test_scan_overlapped_with_encoder_equals_plain(monkeypatch):
+    """Default path: the image is encoded in 4 parts and the selection loop follows on a side stream
+    (ipsx_scan_range); IPSX_OVERLAP_SCAN=0 is the plain encode-all-then-scan path.  Same result."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    x = torch.cat([g.patches(), synth.make_patches(g.conf, 2, seed=99)], 0).to(DEV)
+    assert net._can_overlap(x)
+    mp_a, pos_a = net.ips(x)
+    idx_a = net.last_mem_idx.clone()
+    monkeypatch.setenv("IPSX_OVERLAP_SCAN", "0")
+    assert not net._can_overlap(x)
+    mp_b, pos_b = net.ips(x)
+    monkeypatch.delenv("IPSX_OVERLAP_SCAN")
+    assert torch.equal(idx_a, net.last_mem_idx) and torch.equal(mp_a, mp_b) and torch.equal(pos_a, pos_b)
+    assert np.array_equal(idx_a[0].cpu().numpy(), g.mem_idx[0])
+
+
+def test_scan_range_resumes_exactly():
+    lg = torch.randn((3, 1000, 32), generator=torch.Generator().manual_seed(5)).mul(3).to(DEV)
+    want = hip.scan(lg, 32, 48, 8, 4)
+    mem = torch.empty((3, 32), dtype=torch.int64, device=DEV)
+    tie = torch.zeros((3,), dtype=torch.int32, device=DEV)
+    n_iter = -(-(1000 - 32) // 48)
+    for a, b in ((0, 1), (1, 7), (7, 8), (8, n_iter)):
+        hip.scan_range(lg, 32, 48, 8, 4, a, b, mem, tie)
+    assert torch.equal(mem, want)
