@@ -226,8 +226,9 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-        if args.config == "mnist" and world == 1 and pmc["kernel"] in hip.encoder_kernel_name(net._plan) \
-                and args.batch * per_gpu == 40000:
+        if args.config == "mnist" and args.precision == "fp32" and not args.dedup_blank \
+                and pmc["kernel"] in hip.encoder_kernel_name(net._plan) \
+                and enc_patches == pmc["patches_per_launch"] * len(enc_events):
             traffic = pmc["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
