@@ -143,13 +143,7 @@ def ips_sharded(net, local_patches, N, group=None):
                 else:
                     mine[:, :n_k] = emb
             base += n_k
-            if on_gpu:                                                      # the exchange of this part
-                gathered = torch.empty((world, B, q, width), dtype=torch.float32, device=dev)
-                dist.all_gather_into_tensor(gathered, mine, group=group)
-            else:                                                           # gloo has no all_gather_into_tensor
-                pieces = [torch.empty_like(mine) for _ in range(world)]
-                dist.all_gather(pieces, mine, group=group)
-                gathered = torch.stack(pieces, 0)
+            gathered = _all_gather(mine, world, group)                      # the exchange of this part
             full = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
             if on_gpu:
                 logits[:, edges[k]:edges[k + 1]] = full
@@ -178,13 +172,35 @@ def ips_sharded(net, local_patches, N, group=None):
             mem_patch = mem_patch * owned.view(B, M, *(1,) * (mem_patch.dim() - 2)).to(mem_patch.dtype)
         else:
             mem_patch = torch.zeros((B, M) + tuple(local_patches.shape[2:]), dtype=local_patches.dtype, device=dev)
-        dist.all_reduce(mem_patch, group=group)
+        mem_patch = _all_reduce(mem_patch, group)
         mem_pos = _take(net.pos_enc, mem_idx) if net.use_pos else None
     finally:
         if was_training:
             net.encoder.train(); net.transf.train()
     net.last_mem_idx = mem_idx
     return mem_patch, mem_pos, mem_idx
+
+
+def _all_gather(mine, world, group):
+    """(world, *mine.shape) from every rank's `mine`.  RCCL moves device buffers directly; any other
+    backend (gloo: the CPU tests, and GPU ranks without RCCL between them) goes through host memory."""
+    if dist.get_backend(group) == "nccl":
+        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        return gathered
+    host = mine.cpu()
+    pieces = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(pieces, host, group=group)
+    return torch.stack(pieces, 0).to(mine.device)
+
+
+def _all_reduce(t, group):
+    if dist.get_backend(group) == "nccl" or not t.is_cuda:
+        dist.all_reduce(t, group=group)
+        return t
+    host = t.cpu()
+    dist.all_reduce(host, group=group)
+    return host.to(t.device)
 
 
 def _take(src, idx):

@@ -191,6 +191,22 @@ def test_sharded_path_on_gpu_single_rank_rccl():
         dist.destroy_process_group()
 
 
+def test_sharded_path_world_size_2_on_one_gpu():
+    """world_size 2 on the GPU path: two child processes share cuda:0 and exchange through gloo/host memory
+    (tools/dist_check.py), so the part-wise indexed encode, the resumable scan on the side stream and the owner
+    all-reduce run with more than one rank; every rank must reproduce the reference fixtures and its own ips()."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(repo, "tools", "dist_check.py"),
+           "--backend", "gloo", "--share-gpu", "--cases", "mnist_ragged,mnist_full,cam_b2"]
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") == 6 and "MISMATCH" not in out.stdout
+
+
 def test_training_step_between_ips_calls():
     """What training/iterative.py does (reference :135-163): ips() in train mode, forward with autograd on the
     stock ROCm ops, backward, optimizer.step().  Weights and BatchNorm running statistics have moved, so the

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""World-size > 1 check of ips_amd.dist.ips_sharded on the GPU path.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \\
+        --master-port 29541 tools/dist_check.py [--backend gloo|nccl] [--share-gpu]
+
+With one GPU per rank use the default (nccl = RCCL).  On a 1-GPU box `--backend gloo --share-gpu`
+puts every rank on cuda:0 and moves the (tiny) messages through host memory, so the sharded HIP path -
+part-wise indexed encode, logits, resumable scan on the side stream, owner all-reduce - still runs
+with world_size > 1.  Every rank compares against the committed reference fixtures and against its
+own single-GPU ips(); exit code 0 = all equal.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ips_amd import dist as ipsd            # noqa: E402
+from tests.util import Golden               # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--backend", default="nccl")
+ap.add_argument("--share-gpu", action="store_true")
+ap.add_argument("--cases", default="mnist_ragged,mnist_full,mnist_native50,cam_b2,cam_small,traffic_tiny")
+args = ap.parse_args()
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", rank)))
+torch.cuda.set_device(dev)
+if args.backend == "nccl":
+    dist.init_process_group("nccl", device_id=dev)
+else:
+    dist.init_process_group(args.backend)
+bad = 0
+try:
+    for case in args.cases.split(","):
+        try:
+            g = Golden(case)
+        except (OSError, KeyError):
+            continue
+        net = g.net(dev)
+        x = g.patches().to(dev)
+        N = x.shape[1]
+        mine = ipsd.local_indices(N, net.M, net.I, rank, world).to(dev)
+        mem_patch, mem_pos, mem_idx = ipsd.ips_sharded(net, x[:, mine].contiguous(), N)
+        full_patch, full_pos = net.ips(x)
+        ok = np.array_equal(mem_idx.cpu().numpy(), g.mem_idx) and torch.equal(mem_idx, net.last_mem_idx)
+        ok = ok and torch.equal(mem_patch, full_patch) and (mem_pos is None or torch.equal(mem_pos, full_pos))
+        print("rank %d/%d %-14s N=%-6d %s" % (rank, world, case, N, "ok" if ok else "MISMATCH"), flush=True)
+        bad += not ok
+    t = torch.tensor([bad], dtype=torch.int64)
+    if args.backend == "nccl":
+        t = t.to(dev)
+    dist.all_reduce(t)
+    bad = int(t.item())
+finally:
+    dist.destroy_process_group()
+sys.exit(1 if bad else 0)
