@@ -107,6 +107,8 @@ class IPSNet(nn.Module):
         # additions that do not change the drop-in surface
         self.last_mem_idx = None      # (B, M) int64 indices chosen by the last ips() call
         self._plan = None             # packed-weight cache of the HIP encoder
+        self._emb_parts = None        # eval-mode embeddings of the last ips() call (see last_mem_emb)
+        self._mem_emb = None
 
     # ---------------------------------------------------------------- small pieces
     def do_shuffle(self, patches, pos_enc):
@@ -170,6 +172,7 @@ class IPSNet(nn.Module):
         M, device, pos_enc = self.M, self.device, self.pos_enc
         B, N = patches.shape[:2]
 
+        self._emb_parts = self._mem_emb = None
         if M >= N:  # nothing to select (:185-188)
             self.last_mem_idx = None
             return patches.to(device), (pos_enc.expand(B, -1, -1) if self.use_pos else None)
@@ -230,12 +233,15 @@ class IPSNet(nn.Module):
             spans, fetch, prefetch = [(0, N)], lambda k: patches, lambda k: None
         else:
             spans, fetch, prefetch = self._lazy_slabs(patches)
+        parts = []
         for k, (lo, hi) in enumerate(spans):
             part = fetch(k)
             emb = self._embed(part.reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
             hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
             prefetch(k + 1)          # after the encoder is enqueued: a pageable-memory copy blocks the host, not the GPU
+            parts.append(emb)
+        self._emb_parts = parts
         return hip.scan(logits, self.M, self.I, ca.H, ca.n_token)
 
     # The selection loop is sequential over chunks but only ever needs the logits of the chunks it has
@@ -282,9 +288,11 @@ class IPSNet(nn.Module):
         tie = torch.zeros((B,), dtype=torch.int32, device=dev)
         for t in (logits, mem_idx, tie):
             t.record_stream(side)
+        self._emb_parts = parts = []
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
             emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
+            parts.append(emb)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
             hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
             done = torch.cuda.Event()
@@ -369,13 +377,32 @@ class IPSNet(nn.Module):
             if self.use_pos:
                 cand_pos = cand_emb + torch.gather(pos_enc, 1, cand_idx.unsqueeze(-1).expand(-1, -1, D))
             mem_emb, mem_idx = self.score_and_select(cand_emb, cand_pos, self.M, cand_idx)
+        self._mem_emb = mem_emb
         return mem_idx
 
+    @property
+    def last_mem_emb(self):
+        """(B, M, D) embeddings (without positional encoding) of the patches the last ``ips()`` selected,
+        as the encoder computed them in eval mode - or ``None`` (shortcut M >= N).  In eval mode
+        ``encoder(mem_patch)`` in ``forward`` recomputes exactly these (reference :273 after :209/:227 with
+        running BatchNorm statistics), so an eval loop can hand them back through ``forward(..., mem_emb=)``
+        and skip the second encoder pass (SURVEY.md section 8 f, N-a).  Gathered on first use."""
+        if self._mem_emb is None and self._emb_parts and self.last_mem_idx is not None:
+            emb = self._emb_parts[0] if len(self._emb_parts) == 1 else torch.cat(self._emb_parts, dim=1)
+            self._mem_emb = self._take(emb, self.last_mem_idx)
+            self._emb_parts = None
+        return self._mem_emb
+
     # ---------------------------------------------------------------- aggregation
-    def forward(self, mem_patch, mem_pos=None):
-        """Embed the M selected patches, aggregate, classify (reference :264-283)."""
+    def forward(self, mem_patch, mem_pos=None, mem_emb=None):
+        """Embed the M selected patches, aggregate, classify (reference :264-283).
+
+        ``mem_emb`` (optional, not in the reference): embeddings of ``mem_patch`` already computed by ``ips()``
+        in eval mode (``last_mem_emb``); used instead of a second encoder pass when the encoder is in eval
+        mode, ignored in train mode where BatchNorm uses batch statistics and the pass carries gradients."""
         B, M = mem_patch.shape[:2]
-        mem_emb = self._embed(mem_patch.reshape(-1, *mem_patch.shape[2:])).view(B, M, -1)
+        if mem_emb is None or self.encoder.training:
+            mem_emb = self._embed(mem_patch.reshape(-1, *mem_patch.shape[2:])).view(B, M, -1)
         if torch.is_tensor(mem_pos):
             mem_emb = mem_emb + mem_pos
         return self.get_preds(self.transf(mem_emb))

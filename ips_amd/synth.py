@@ -124,3 +124,35 @@ def make_patches(conf, B, seed=0, blank_frac=0.93, N=None):
     else:
         x = g.standard_normal((B, N, conf.n_chan_in, h, w), dtype=np.float32)
     return torch.from_numpy(np.ascontiguousarray(x))
+
+
+class ListLoader:
+    """A loader the loops of training/iterative.py can drive: ``len()`` and iteration over dict items."""
+
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        return iter(self.items)
+
+
+def make_loader(conf, n_item, seed=0):
+    """``n_item`` seeded loader items of ``B_seq`` images each: {'input': (B_seq, N, ...), <task>: labels}
+    with labels of the dtype the reference's datasets deliver (int64 class ids, float rows for multi-label)."""
+    items = []
+    for k in range(n_item):
+        g = _rng(seed, "labels%d" % k)
+        item = {'input': make_patches(conf, conf.B_seq, seed=seed * 1000 + k, blank_frac=0.5)}
+        for task in conf.tasks.values():
+            if task['metric'] == 'multilabel_accuracy':
+                lab = torch.from_numpy((g.random((conf.B_seq, conf.n_class)) < 0.3).astype(np.float32))
+            elif task['act_fn'] == 'sigmoid':
+                lab = torch.from_numpy(g.integers(0, 2, (conf.B_seq,)).astype(np.int64))
+            else:
+                lab = torch.from_numpy(g.integers(0, conf.n_class, (conf.B_seq,)).astype(np.int64))
+            item[task['name']] = lab
+        items.append(item)
+    return ListLoader(items)

@@ -1,0 +1,156 @@
+"""The caller loops (ips_amd/training/iterative.py) against fixtures produced by the reference's own
+training/iterative.py (tools/gen_golden_loops.py): same losses, predictions, labels, learning rate and
+trained weights on CPU; on the GPU the evaluation pass goes through the HIP path (with the embeddings of
+the winners reused instead of a second encoder pass) and must agree within the north-star tolerance."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from ips_amd import synth
+from ips_amd.architecture.ips_net import IPSNet
+from ips_amd.training import iterative as loops
+from ips_amd.utils.utils import Logger, adjust_learning_rate
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["loop_mnist_seq", "loop_traffic_short", "loop_cam_seq"]
+
+
+class Recorder:
+    def __init__(self):
+        self.steps = []
+
+    def update(self, losses, preds, labels):
+        self.steps.append((losses, preds, labels))
+
+
+def _setup(case, device):
+    z = np.load(os.path.join(GOLDEN, case + ".npz"), allow_pickle=False)
+    conf = synth.Conf(**json.loads(str(z["conf"])))
+    net = IPSNet(torch.device(device), conf).to(device)
+    synth.fill_weights(net, int(z["weight_seed"]))
+    loader = synth.make_loader(conf, int(z["n_item"]), seed=int(z["data_seed"]))
+    crit = {t['name']: (nn.NLLLoss() if t['act_fn'] == 'softmax' else nn.BCELoss()) for t in conf.tasks.values()}
+    opt = torch.optim.AdamW(net.parameters(), lr=0, weight_decay=conf.wd)
+    torch.manual_seed(int(z["torch_seed"]))
+    return z, conf, net, loader, crit, opt
+
+
+def _check(z, prefix, rec, conf, tol):
+    assert len(rec.steps) == int(z[prefix + "_n_step"])
+    for s, (losses, preds, labels) in enumerate(rec.steps):
+        for task in conf.tasks.values():
+            t = task['name']
+            want_pred = z["%s_%d_pred_%s" % (prefix, s, t)]
+            assert preds[t].shape == want_pred.shape and preds[t].dtype == want_pred.dtype
+            np.testing.assert_allclose(preds[t], want_pred, rtol=0, atol=tol)
+            np.testing.assert_allclose(losses[t], float(z["%s_%d_loss_%s" % (prefix, s, t)]), rtol=tol * 10, atol=tol * 10)
+            want_label = z["%s_%d_label_%s" % (prefix, s, t)]
+            assert labels[t].dtype == want_label.dtype and np.array_equal(labels[t], want_label)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_loops_reproduce_the_reference_on_cpu(case):
+    z, conf, net, loader, crit, opt = _setup(case, "cpu")
+    dev = torch.device("cpu")
+    ev0, tr0, ev, tr1 = Recorder(), Recorder(), Recorder(), Recorder()
+    loops.evaluate(net, crit, loader, dev, ev0, conf)
+    loops.train_one_epoch(net, crit, loader, opt, dev, 0, tr0, conf)
+    assert opt.param_groups[0]['lr'] == pytest.approx(float(z["lr_after_epoch0"]), rel=1e-12)
+    loops.evaluate(net, crit, loader, dev, ev, conf)
+    loops.train_one_epoch(net, crit, loader, opt, dev, 1, tr1, conf)
+    assert opt.param_groups[0]['lr'] == pytest.approx(float(z["lr_after_epoch1"]), rel=1e-12)
+    _check(z, "eval0", ev0, conf, 1e-6)
+    _check(z, "train0", tr0, conf, 1e-6)
+    _check(z, "eval", ev, conf, 1e-5)
+    _check(z, "train1", tr1, conf, 1e-5)
+    sd = net.state_dict()
+    checksum = sum(v.double().abs().sum().item() for k, v in sd.items() if not k.endswith("num_batches_tracked"))
+    assert checksum == pytest.approx(float(z["state_checksum"]), rel=1e-6)
+    np.testing.assert_allclose(sd["transf.crs_attn.q"].numpy(), z["q_after"], rtol=0, atol=1e-5)
+
+
+def test_evaluate_with_and_without_embedding_reuse_agree_on_cpu():
+    z, conf, net, loader, crit, _ = _setup("loop_mnist_seq", "cpu")
+    a, b = Recorder(), Recorder()
+    state = torch.get_rng_state()
+    loops.evaluate(net, crit, loader, torch.device("cpu"), a, conf)
+
+    class NoReuse(type(net)):
+        last_mem_emb = property(lambda self: None)
+    net.__class__ = NoReuse
+    torch.set_rng_state(state)
+    loops.evaluate(net, crit, loader, torch.device("cpu"), b, conf)
+    for (la, pa, _), (lb, pb, _) in zip(a.steps, b.steps):
+        for t in pa:
+            np.testing.assert_allclose(pa[t], pb[t], rtol=0, atol=1e-6)
+
+
+def test_learning_rate_schedule_and_logger():
+    opt = torch.optim.AdamW([nn.Parameter(torch.zeros(1))], lr=0)
+    loader = synth.ListLoader([None] * 10)
+    lrs = []
+    for step in range(1, 51):
+        adjust_learning_rate(1, 5, 1e-3, opt, loader, step)
+        lrs.append(opt.param_groups[0]['lr'])
+    assert lrs[0] == pytest.approx(1e-4) and lrs[8] == pytest.approx(9e-4)       # linear warm-up over 10 steps
+    assert lrs[9] == pytest.approx(1e-3) and lrs[-1] == pytest.approx(1e-6)      # cosine to max_lr / 1000
+    assert all(a >= b for a, b in zip(lrs[9:], lrs[10:]))
+
+    tasks = {'a': {'id': 0, 'name': 'cls', 'act_fn': 'softmax', 'metric': 'accuracy'},
+             'b': {'id': 1, 'name': 'multi', 'act_fn': 'sigmoid', 'metric': 'multilabel_accuracy'},
+             'c': {'id': 2, 'name': 'bin', 'act_fn': 'sigmoid', 'metric': 'auc'}}
+    log = Logger(tasks)
+    log.update({'cls': 1.0, 'multi': 2.0, 'bin': 3.0},
+               {'cls': np.array([[.1, .9], [.8, .2]]), 'multi': np.array([[.9, .1], [.4, .6]]), 'bin': np.array([.9, .2])},
+               {'cls': np.array([1, 1]), 'multi': np.array([[1., 0.], [1., 1.]]), 'bin': np.array([1, 0])})
+    log.update({'cls': 3.0, 'multi': 2.0, 'bin': 1.0},
+               {'cls': np.array([[.3, .7]]), 'multi': np.array([[.2, .7]]), 'bin': np.array([.5])},
+               {'cls': np.array([1]), 'multi': np.array([[0., 1.]]), 'bin': np.array([0])})
+    log.compute_metric()
+    assert log.losses_epoch['cls'] == [2.0] and log.metrics['cls'] == [pytest.approx(2 / 3)]
+    assert log.metrics['multi'] == [pytest.approx(2 / 3)] and log.metrics['bin'] == [1.0]
+    assert log.losses_it['cls'] == [] and log.y_preds['bin'] == []
+    log.print_stats(0, train=False, lr=0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_evaluate_on_the_hip_path_matches_the_reference(case):
+    """evaluate() before any training step: ips() on the HIP path, winners' embeddings reused in forward."""
+    z, conf, net, loader, crit, _ = _setup(case, "cuda:0")
+    rec = Recorder()
+    loops.evaluate(net, crit, loader, torch.device("cuda:0"), rec, conf)
+    _check(z, "eval0", rec, conf, 1e-4)
+
+
+@pytest.mark.gpu
+def test_embedding_reuse_is_bit_identical_on_the_hip_path():
+    z, conf, net, loader, crit, _ = _setup("loop_mnist_seq", "cuda:0")
+    net.eval()
+    x = loader.items[0]['input'].to("cuda:0")
+    with torch.no_grad():
+        torch.manual_seed(3)
+        mem_patch, mem_pos = net.ips(x)
+        emb = net.last_mem_emb
+        assert emb is not None and emb.shape == (x.shape[0], conf.M, conf.D)
+        again = net._embed(mem_patch.reshape(-1, *mem_patch.shape[2:])).view_as(emb)
+        assert torch.equal(emb, again)
+        p0 = net(mem_patch, mem_pos)
+        p1 = net(mem_patch, mem_pos, mem_emb=emb)
+        assert all(torch.equal(p0[k], p1[k]) for k in p0)
+
+
+@pytest.mark.gpu
+def test_training_epoch_runs_on_the_gpu_and_tracks_the_reference():
+    """train_one_epoch on the GPU: ips() on the HIP path, forward/backward on stock ROCm ops.  Dropout masks come
+    from the device generator, so only the first step's loss is comparable, and only loosely."""
+    z, conf, net, loader, crit, opt = _setup("loop_cam_seq", "cuda:0")
+    rec = Recorder()
+    loops.train_one_epoch(net, crit, loader, opt, torch.device("cuda:0"), 0, rec, conf)
+    assert len(rec.steps) == int(z["train0_n_step"])
+    assert all(np.isfinite(v) for losses, _, _ in rec.steps for v in losses.values())

@@ -63,7 +63,7 @@ def import_reference():
     # the reference uses top-level package names (architecture, utils, training)
     for name in list(sys.modules):
         if name.split(".")[0] in ("architecture", "utils", "training") and \
-                not getattr(sys.modules[name], "__file__", "").startswith(REF_ROOT):
+                not (getattr(sys.modules[name], "__file__", None) or REF_ROOT).startswith(REF_ROOT):
             del sys.modules[name]
     sys.path.insert(0, REF_ROOT)
     try:
@@ -73,3 +73,13 @@ def import_reference():
     finally:
         sys.path.remove(REF_ROOT)
     return ips_net, transformer, utils
+
+
+def import_reference_training():
+    """The reference's training/iterative.py (imports its own utils.utils)."""
+    import_reference()
+    sys.path.insert(0, REF_ROOT)
+    try:
+        return importlib.import_module("training.iterative")
+    finally:
+        sys.path.remove(REF_ROOT)
