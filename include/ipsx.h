@@ -136,6 +136,30 @@ int ipsx_trunk_encode_indexed(const ipsx_trunk* t, const float* patches, const i
 size_t ipsx_trunk_dedup_workspace_bytes(const ipsx_trunk* t, int64_t n_patch);
 int ipsx_trunk_encode_dedup(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb,
                             void* workspace, size_t workspace_bytes, int32_t* n_encoded, void* stream);
+/* Same, with the per-patch flags (1 = has a non-zero element) already known, e.g. from
+ * ipsx_patchify_sparse: the pass that reads every patch to find the blank ones is skipped.        */
+int ipsx_trunk_encode_dedup_flagged(const ipsx_trunk* t, const float* patches, int64_t n_patch,
+                                    const int32_t* nonblank, float* emb, void* workspace,
+                                    size_t workspace_bytes, int32_t* n_encoded, void* stream);
+
+/* ---------------------------------------------------------- image -> patches
+ * The step that feeds ips(): replaces, for a whole batch on the device,
+ *   img.unfold(1, ph, sh).unfold(2, pw, sw).permute(1, 2, 0, 3, 4).reshape(-1, C, ph, pw)
+ * of data/megapixel_mnist/mnist_dataset.py:44-51 and data/traffic/traffic_dataset.py:336-343.
+ * img (b,c,h,w) -> patches (b, ny*nx, c, ph, pw), ny = (h-ph)/sh+1, nx = (w-pw)/sw+1, patch order
+ * row-major over (py, px).  ipsx_patchify_count returns ny*nx (0 for an invalid geometry).         */
+int64_t ipsx_patchify_count(int h, int w, int ph, int pw, int sh, int sw);
+int ipsx_patchify(const float* img, int b, int c, int h, int w, int ph, int pw, int sh, int sw,
+                  float* patches, void* stream);
+/* Megapixel-MNIST's on-disk form straight to patches (mnist_dataset.py:34-51): image i owns the
+ * non-zeros [offsets[i], offsets[i+1]) of (index, value); index is the flat position in an (h, w, c)
+ * canvas (the reference's _img_shape), value its pixel.  patches is zeroed and filled; nonblank
+ * (b*ny*nx int32, or NULL) is set to 1 for every patch that received a non-zero value.  Indices
+ * outside the canvas are skipped (the host validates them before upload; numpy would raise).
+ * offsets, index and value are device pointers; nnz = offsets[b].                                  */
+int ipsx_patchify_sparse(const int64_t* index, const float* value, const int64_t* offsets, int64_t nnz,
+                         int b, int c, int h, int w, int ph, int pw, int sh, int sw,
+                         float* patches, int32_t* nonblank, void* stream);
 
 /* Replaces IPSNet.encoder as built by get_projector (ips_net.py:54-60):
  * ReLU(BN1d(Linear(LayerNorm_noaffine(x)))); x (n,f) -> out (n,d).

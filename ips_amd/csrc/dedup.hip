@@ -95,8 +95,8 @@ IPSX_API size_t ipsx_trunk_dedup_workspace_bytes(const ipsx_trunk* t, int64_t n_
     return (size_t)n_patch * 12 + 256 + (size_t)(n_patch + 1) * 128 * sizeof(float) + 256;
 }
 
-IPSX_API int ipsx_trunk_encode_dedup(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb,
-                                     void* workspace, size_t workspace_bytes, int32_t* n_encoded, void* stream) {
+static int encode_dedup(const ipsx_trunk* t, const float* patches, int64_t n_patch, const int32_t* flags, float* emb,
+                        void* workspace, size_t workspace_bytes, int32_t* n_encoded, void* stream) {
     IPSX_REQUIRE(t && patches && emb && n_patch >= 0, "trunk_encode_dedup: bad arguments");
     IPSX_REQUIRE(fused_trunk_supported(t), "trunk_encode_dedup: only the fused 1x32x32 trunk is supported");
     IPSX_REQUIRE(n_patch < ((int64_t)1 << 31), "trunk_encode_dedup: too many patches");
@@ -112,9 +112,12 @@ IPSX_API int ipsx_trunk_encode_dedup(const ipsx_trunk* t, const float* patches, 
     float* emb_u = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) +
                                             (((size_t)n_patch * 12 + 4 + 255) & ~(size_t)255));
     const int elems4 = t->c_in * t->h * t->w / 4;
-    blank_flags_kernel<<<dim3((unsigned)cdiv(n_patch, 4)), dim3(256), 0, s>>>(patches, n_patch, elems4, nonblank);
-    IPSX_TRY(launched("blank_flags"));
-    compact_kernel<<<dim3(1), dim3(1024), 0, s>>>(nonblank, (int)n_patch, index, slot, count);
+    if (!flags) {
+        blank_flags_kernel<<<dim3((unsigned)cdiv(n_patch, 4)), dim3(256), 0, s>>>(patches, n_patch, elems4, nonblank);
+        IPSX_TRY(launched("blank_flags"));
+    }
+    compact_kernel<<<dim3(1), dim3(1024), 0, s>>>(flags ? reinterpret_cast<const int*>(flags) : nonblank, (int)n_patch,
+                                                  index, slot, count);
     IPSX_TRY(launched("compact"));
     IPSX_TRY(fused_trunk_encode_indexed(t, patches, n_patch, index, count, emb_u, s));
     scatter_rows_kernel<<<dim3((unsigned)cdiv(n_patch * 32, 256)), dim3(256), 0, s>>>(
@@ -125,4 +128,16 @@ IPSX_API int ipsx_trunk_encode_dedup(const ipsx_trunk* t, const float* patches, 
             return fail(IPSX_EHIP, "trunk_encode_dedup: count copy failed");
     }
     return IPSX_OK;
+}
+
+IPSX_API int ipsx_trunk_encode_dedup(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb,
+                                     void* workspace, size_t workspace_bytes, int32_t* n_encoded, void* stream) {
+    return encode_dedup(t, patches, n_patch, nullptr, emb, workspace, workspace_bytes, n_encoded, stream);
+}
+
+IPSX_API int ipsx_trunk_encode_dedup_flagged(const ipsx_trunk* t, const float* patches, int64_t n_patch,
+                                             const int32_t* nonblank, float* emb, void* workspace,
+                                             size_t workspace_bytes, int32_t* n_encoded, void* stream) {
+    IPSX_REQUIRE(nonblank, "trunk_encode_dedup_flagged: no flags");
+    return encode_dedup(t, patches, n_patch, nonblank, emb, workspace, workspace_bytes, n_encoded, stream);
 }

@@ -104,6 +104,12 @@ _EXPORTS = {
     "ipsx_trunk_dedup_workspace_bytes": (C.c_size_t, [C.POINTER(Trunk), C.c_int64]),
     "ipsx_trunk_encode_dedup": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ipsx_trunk_encode_dedup_flagged": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ipsx_patchify_count": (C.c_int64, [C.c_int] * 6),
+    "ipsx_patchify": (C.c_int, [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]),
+    "ipsx_patchify_sparse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 8 +
+                             [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_projector": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
@@ -298,8 +304,11 @@ class EncoderPlan:
                                             _stream()), "ipsx_trunk_encode_indexed")
         return out
 
-    def encode(self, x):
-        """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D)."""
+    def encode(self, x, nonblank=None):
+        """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D).
+
+        ``nonblank`` (P int32, 1 = the patch has a non-zero element; e.g. from ``patchify_sparse``) switches on
+        the exact blank-patch dedup without the pass that looks for blank patches."""
         self._refresh()
         x = _f32(x)
         n = x.shape[0]
@@ -310,12 +319,20 @@ class EncoderPlan:
             self.trunk.h, self.trunk.w = x.shape[2], x.shape[3]
             if x.shape[1] != self.trunk.c_in:
                 raise ValueError("patches have {} channels, encoder expects {}".format(x.shape[1], self.trunk.c_in))
-            if dedup_blank() and lib().ipsx_trunk_kernel(C.byref(self.trunk)) == b"fused_trunk_kernel":
+            if (dedup_blank() or nonblank is not None) and \
+                    lib().ipsx_trunk_kernel(C.byref(self.trunk)) == b"fused_trunk_kernel":
                 nb = lib().ipsx_trunk_dedup_workspace_bytes(C.byref(self.trunk), n)
                 ws = self._workspace(nb, x.device)
                 self.n_encoded = torch.zeros((), dtype=torch.int32, device=x.device)
-                _ck(lib().ipsx_trunk_encode_dedup(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb,
-                                                  _p(self.n_encoded), _stream()), "ipsx_trunk_encode_dedup")
+                if nonblank is not None:
+                    if nonblank.dtype != torch.int32 or nonblank.numel() != n or not nonblank.is_contiguous():
+                        raise ValueError("nonblank must be a contiguous int32 tensor with one flag per patch")
+                    _ck(lib().ipsx_trunk_encode_dedup_flagged(C.byref(self.trunk), _p(x), n, _p(nonblank), _p(out), _p(ws),
+                                                              nb, _p(self.n_encoded), _stream()),
+                        "ipsx_trunk_encode_dedup_flagged")
+                else:
+                    _ck(lib().ipsx_trunk_encode_dedup(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb,
+                                                      _p(self.n_encoded), _stream()), "ipsx_trunk_encode_dedup")
                 return out
             nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), n)
             ws = self._workspace(nb, x.device)
@@ -441,6 +458,43 @@ def gather_rows(src, idx):
     _ck(lib().ipsx_gather_rows(_p(src), _p(idx), _p(out), B, N, M, row_bytes, bstride, _stream()),
         "ipsx_gather_rows")
     return out
+
+
+# ------------------------------------------------------------------ image -> patches
+def patchify(img, patch_size, patch_stride):
+    """img (B, C, H, W) float32 on the GPU -> (B, N, C, ph, pw): unfold + permute + reshape of the reference's
+    datasets (data/megapixel_mnist/mnist_dataset.py:44-51, data/traffic/traffic_dataset.py:336-343), batched."""
+    img = _f32(img)
+    B, Cc, H, W = img.shape
+    (ph, pw), (sh, sw) = patch_size, patch_stride
+    n = lib().ipsx_patchify_count(H, W, ph, pw, sh, sw)
+    if n <= 0:
+        raise ValueError("patch {}x{} / stride {}x{} does not fit a {}x{} image".format(ph, pw, sh, sw, H, W))
+    out = torch.empty((B, n, Cc, ph, pw), dtype=torch.float32, device=img.device)
+    _ck(lib().ipsx_patchify(_p(img), B, Cc, H, W, ph, pw, sh, sw, _p(out), _stream()), "ipsx_patchify")
+    return out
+
+
+def patchify_sparse(index, value, offsets, canvas, patch_size, patch_stride, flags=False):
+    """Sparse (H, W, C) canvases -> (B, N, C, ph, pw) patches on the GPU (mnist_dataset.py:34-51).
+
+    ``index`` (nnz int64 flat positions), ``value`` (nnz float32), ``offsets`` (B+1 int64, image i owns
+    [offsets[i], offsets[i+1])) - all on the GPU; ``canvas`` = (H, W, C).  With ``flags`` also returns the
+    per-patch int32 non-blank flags (B*N)."""
+    H, W, Cc = canvas
+    (ph, pw), (sh, sw) = patch_size, patch_stride
+    B = offsets.numel() - 1
+    if index.dtype != torch.int64 or offsets.dtype != torch.int64 or value.dtype != torch.float32:
+        raise TypeError("index / offsets must be int64 and value float32")
+    n = lib().ipsx_patchify_count(H, W, ph, pw, sh, sw)
+    if n <= 0 or B <= 0:
+        raise ValueError("bad geometry")
+    index, value, offsets = index.contiguous(), value.contiguous(), offsets.contiguous()
+    out = torch.empty((B, n, Cc, ph, pw), dtype=torch.float32, device=offsets.device)
+    nb = torch.empty((B * n,), dtype=torch.int32, device=offsets.device) if flags else None
+    _ck(lib().ipsx_patchify_sparse(_p(index), _p(value), _p(offsets), index.numel(), B, Cc, H, W, ph, pw, sh, sw,
+                                   _p(out), _p(nb), _stream()), "ipsx_patchify_sparse")
+    return (out, nb) if flags else out
 
 
 # ------------------------------------------------------------------ aggregation
