@@ -74,12 +74,19 @@ int ipsx_bn_affine(const float* gamma, const float* beta, const float* mean,
                    const float* var, const float* lin_bias, float eps, int c,
                    float* alpha, float* shift, void* stream);
 
+/* split variant for precision 2 ("fp32x3"): every weight as three bf16 terms hi + mid + lo (exact),
+ * [C_out/32][K/16][plane][64 lanes][8 bf16]; three times the bf16 stream                            */
+size_t ipsx_packed_conv_weight_x3_bytes(int c_out, int c_in, int kh, int kw);
+int ipsx_pack_conv_weight_x3(const float* w_oihw, int c_out, int c_in, int kh, int kw,
+                             void* packed, void* stream);
+
 typedef struct ipsx_conv {
     int c_in, c_out, kh, kw, stride, pad;
     const float* w_packed;        /* ipsx_pack_conv_weight output            */
     const float* alpha;           /* c_out, BatchNorm scale (or NULL = 1)    */
     const float* shift;           /* c_out, BatchNorm shift / bias (or NULL) */
-    const void* w_packed_bf16;    /* ipsx_pack_conv_weight_bf16 output, or NULL (fp32 only)  */
+    const void* w_packed_bf16;    /* bf16 operand stream for ipsx_trunk.precision: ipsx_pack_conv_weight_bf16
+                                     (precision 1) or ipsx_pack_conv_weight_x3 (precision 2); NULL = fp32 only */
 } ipsx_conv;
 
 /* one residual block: BasicBlock (n_conv = 2) or Bottleneck (n_conv = 3)     */
@@ -98,7 +105,10 @@ typedef struct ipsx_trunk {
     int n_block;
     const ipsx_block* blocks;     /* HOST array of n_block descriptors        */
     int precision;                /* 0 = fp32 (exact, default); 1 = bf16 operands / fp32 accumulate in the
-                                     residual stages (fused 1x32x32 trunk only; needs w_packed_bf16)   */
+                                     residual stages; 2 = "fp32x3": every fp32 operand split exactly into three
+                                     bf16 terms, the six significant products on the bf16 matrix pipe, fp32
+                                     accumulate - fp32-grade accuracy, not bit-identical to precision 0.
+                                     1 and 2: fused 1x32x32 trunk only, need w_packed_bf16                */
 } ipsx_trunk;
 
 /* y = act(affine(conv(x)) [+ residual]); x (n,c_in,h,w), y (n,c_out,ho,wo) NCHW */

@@ -878,6 +878,8 @@ __global__ void pack_conv_weight_bf16_kernel(const float* __restrict__ w, int c_
     packed[i] = bf16_bits(v);
 }
 
+#include "fused_trunk_x3.h"
+
 static bool is_conv(const ipsx_conv& c, int ci, int co, int k, int s, int p) {
     return c.c_in == ci && c.c_out == co && c.kh == k && c.kw == k && c.stride == s && c.pad == p && c.w_packed &&
            c.alpha && c.shift;
@@ -912,7 +914,7 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
             a.sh[2 * k + j] = t->blocks[k].conv[j].shift;
         }
     a.w_down = t->blocks[2].down.w_packed; a.a_down = t->blocks[2].down.alpha; a.s_down = t->blocks[2].down.shift;
-    bool bf16 = t->precision == 1;
+    bool bf16 = t->precision != 0;
     for (int k = 0; k < 4; ++k)
         for (int j = 0; j < 2; ++j) {
             a.wh[2 * k + j] = t->blocks[k].conv[j].w_packed_bf16;
@@ -920,7 +922,19 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
         }
     a.wh_down = t->blocks[2].down.w_packed_bf16;
     bf16 = bf16 && a.wh_down;
-    if (t->precision == 1 && !bf16) return fail(IPSX_EINVAL, "fused trunk: precision bf16 needs w_packed_bf16 on every block conv");
+    if (t->precision != 0 && !bf16) return fail(IPSX_EINVAL, "fused trunk: precision %d needs w_packed_bf16 on every block conv", t->precision);
+    if (t->precision == 2) {
+        if (stamps) return fail(IPSX_EINVAL, "fused trunk: no stamp build of the fp32x3 kernel");
+        const size_t ldsx = (size_t)4 * SLABX;
+        static bool attr_x3 = false;
+        if (!attr_x3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_x3_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+            attr_x3 = true;
+        }
+        fused_trunk_x3_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), ldsx, s>>>(a);
+        return launched("fused_trunk_x3");
+    }
     if (bf16) {
         if (stamps) return fail(IPSX_EINVAL, "fused trunk: no stamp build of the bf16 kernel");
         const size_t ldsh = (size_t)4 * SLABH;
@@ -965,6 +979,19 @@ IPSX_API int ipsx_pack_conv_weight_bf16(const float* w, int c_out, int c_in, int
     ipsx::pack_conv_weight_bf16_kernel<<<dim3((unsigned)ipsx::cdiv(total, 256)), dim3(256), 0, ipsx::as_stream(stream)>>>(
         w, c_out, c_in, kh, kw, ksteps, total, static_cast<unsigned short*>(packed));
     return ipsx::launched("pack_conv_weight_bf16");
+}
+
+IPSX_API size_t ipsx_packed_conv_weight_x3_bytes(int c_out, int c_in, int kh, int kw) {
+    return 3 * ipsx_packed_conv_weight_bf16_bytes(c_out, c_in, kh, kw);
+}
+
+IPSX_API int ipsx_pack_conv_weight_x3(const float* w, int c_out, int c_in, int kh, int kw, void* packed, void* stream) {
+    IPSX_REQUIRE(w && packed && c_out > 0 && c_in > 0 && kh > 0 && kw > 0, "pack_conv_weight_x3: bad arguments");
+    const size_t total = ipsx_packed_conv_weight_x3_bytes(c_out, c_in, kh, kw) / 2;
+    const int ksteps = (int)ipsx::cdiv((int64_t)kh * kw * c_in, 16);
+    ipsx::pack_conv_weight_x3_kernel<<<dim3((unsigned)ipsx::cdiv(total, 256)), dim3(256), 0, ipsx::as_stream(stream)>>>(
+        w, c_out, c_in, kh, kw, ksteps, total, static_cast<unsigned short*>(packed));
+    return ipsx::launched("pack_conv_weight_x3");
 }
 
 // Diagnostic entry point (not part of include/ipsx.h): the fused trunk with s_memtime stamps,

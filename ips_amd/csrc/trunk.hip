@@ -80,7 +80,8 @@ IPSX_API size_t ipsx_trunk_workspace_bytes(const ipsx_trunk* t, int64_t n_patch)
 }
 
 IPSX_API const char* ipsx_trunk_kernel(const ipsx_trunk* t) {
-    if (t && fused_trunk_supported(t)) return t->precision == 1 ? "fused_trunk_bf16_kernel" : "fused_trunk_kernel";
+    if (t && fused_trunk_supported(t))
+        return t->precision == 2 ? "fused_trunk_x3_kernel" : (t->precision == 1 ? "fused_trunk_bf16_kernel" : "fused_trunk_kernel");
     return "conv_nhwc_kernel (layer by layer)";
 }
 
@@ -89,7 +90,7 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
     TrunkGeom g;
     IPSX_TRY(trunk_geom(t, &g));
     IPSX_REQUIRE(patches && emb && n_patch >= 0, "trunk_encode: bad arguments");
-    IPSX_REQUIRE(t->precision == 0 || fused_trunk_supported(t), "trunk_encode: the bf16 path exists for the fused 1x32x32 trunk only");
+    IPSX_REQUIRE(t->precision == 0 || fused_trunk_supported(t), "trunk_encode: the bf16 / fp32x3 paths exist for the fused 1x32x32 trunk only");
     if (n_patch == 0) return IPSX_OK;
     if (fused_trunk_supported(t)) return fused_trunk_encode(t, patches, n_patch, emb, as_stream(stream));
 

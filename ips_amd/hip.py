@@ -31,11 +31,13 @@ def backend():
 
 
 def precision():
-    """'fp32' (default: exact, reference parity) or 'bf16' (IPSX_PRECISION=bf16: bf16 operands with fp32
-    accumulation in the residual stages of the fused 1x32x32 trunk; no reference behaviour to match)."""
+    """'fp32' (default: exact, reference parity), 'fp32x3' (every fp32 operand of the residual stages split exactly
+    into three bf16 terms, six products on the bf16 matrix pipe, fp32 accumulation: fp32-grade accuracy but not
+    bit-identical to the fp32 kernel) or 'bf16' (bf16 operands with fp32 accumulation; no reference behaviour
+    to match).  The last two exist for the fused 1x32x32 trunk."""
     p = os.environ.get("IPSX_PRECISION", "fp32").lower()
-    if p not in ("fp32", "bf16"):
-        raise ValueError("IPSX_PRECISION must be 'fp32' or 'bf16', got {!r}".format(p))
+    if p not in ("fp32", "fp32x3", "bf16"):
+        raise ValueError("IPSX_PRECISION must be 'fp32', 'fp32x3' or 'bf16', got {!r}".format(p))
     return p
 
 
@@ -88,6 +90,8 @@ _EXPORTS = {
     "ipsx_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_packed_conv_weight_bf16_bytes": (C.c_size_t, [C.c_int] * 4),
     "ipsx_pack_conv_weight_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_packed_conv_weight_x3_bytes": (C.c_size_t, [C.c_int] * 4),
+    "ipsx_pack_conv_weight_x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_bn_affine": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_affine": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -225,16 +229,18 @@ class EncoderPlan:
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)
 
-    def _conv(self, conv, bn, bf16=False):
+    def _conv(self, conv, bn, prec=0):
         packed = _pack_conv(conv.weight)
         aff = _bn_affine(bn)
         self._keep += [packed, aff]
         half = None
-        if bf16:
+        if prec:
             w = _f32(conv.weight.detach())
             co, ci, kh, kw = w.shape
-            half = torch.empty(lib().ipsx_packed_conv_weight_bf16_bytes(co, ci, kh, kw), dtype=torch.uint8, device=w.device)
-            _ck(lib().ipsx_pack_conv_weight_bf16(_p(w), co, ci, kh, kw, _p(half), _stream()), "ipsx_pack_conv_weight_bf16")
+            size, pack = ((lib().ipsx_packed_conv_weight_bf16_bytes, lib().ipsx_pack_conv_weight_bf16) if prec == 1 else
+                          (lib().ipsx_packed_conv_weight_x3_bytes, lib().ipsx_pack_conv_weight_x3))
+            half = torch.empty(size(co, ci, kh, kw), dtype=torch.uint8, device=w.device)
+            _ck(pack(_p(w), co, ci, kh, kw, _p(half), _stream()), "ipsx_pack_conv_weight_bf16/x3")
             self._keep.append(half)
         return Conv(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
                     conv.stride[0], conv.padding[0], _p(packed), _p(aff[0]), _p(aff[1]), _p(half))
@@ -244,7 +250,7 @@ class EncoderPlan:
         enc = self.encoder
         if self.is_image:
             mods = list(enc.children())
-            bf16 = precision() == "bf16"
+            bf16 = {"fp32": 0, "bf16": 1, "fp32x3": 2}[precision()]
             blocks = []
             for stage in mods[4:-1]:
                 for blk in stage.children():
@@ -264,7 +270,7 @@ class EncoderPlan:
             t.c_in = mods[0].in_channels
             t.n_block = len(blocks)
             t.blocks = C.cast(self._blocks, C.POINTER(Block))
-            t.precision = 1 if bf16 else 0
+            t.precision = bf16
             self.trunk = t
             self.d_out = blocks[-1].conv[blocks[-1].n_conv - 1].c_out
         else:

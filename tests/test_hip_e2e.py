@@ -273,6 +273,24 @@ def test_bf16_precision_end_to_end(monkeypatch):
         assert torch.isfinite(p16[k]).all() and float((p16[k] - p32[k]).abs().max()) < 0.1
 
 
+@pytest.mark.parametrize("case", ["mnist_mini", "mnist_ragged", "mnist_tok1", "mnist_full"])
+def test_fp32x3_precision_selects_the_reference_indices(case, monkeypatch):
+    """ips() + forward with the split-bf16 trunk: the reference's indices and its outputs within the north-star
+    tolerance (the boundary gaps of the fixtures are far above fp32 rounding differences)."""
+    g = Golden(case)
+    net = g.net(DEV)
+    x = g.patches().to(DEV)
+    monkeypatch.setenv("IPSX_PRECISION", "fp32x3")
+    mem_patch, mem_pos = net.ips(x)
+    assert hip.encoder_kernel_name(net._plan) == "fused_trunk_x3_kernel"
+    with torch.no_grad():
+        preds = net(mem_patch, mem_pos)
+    monkeypatch.delenv("IPSX_PRECISION")
+    assert np.array_equal(net.last_mem_idx.cpu().numpy(), g.mem_idx)
+    for name, want in g.preds.items():
+        np.testing.assert_allclose(preds[name].cpu().numpy(), want, rtol=0, atol=1e-4)
+
+
 def test_scan_overlapped_with_encoder_equals_plain(monkeypatch):
     """Default path: the image is encoded in 4 parts and the selection loop follows on a side stream
     (ipsx_scan_range); IPSX_OVERLAP_SCAN=0 is the plain encode-all-then-scan path.  Same result."""

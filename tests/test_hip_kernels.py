@@ -256,6 +256,53 @@ def test_bf16_trunk_tracks_fp32_within_tolerance(monkeypatch):
     assert float(err) < 3e-3, float(err)      # a bf16 rounding flip of one activation is 4e-3 of that activation
 
 
+def test_fp32x3_trunk_has_fp32_accuracy(monkeypatch):
+    """IPSX_PRECISION=fp32x3: every fp32 operand of the residual stages as three bf16 terms, six products on the
+    bf16 matrix pipe, fp32 accumulation.  Not bit-identical to the fma chains of the fp32 kernel, but as close to
+    the float64 result of the same network as the exact-fp32 kernel is."""
+    import torch.nn.functional as F
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    x = g.patches()[0, :403].to(DEV)
+    x[7] = 0.0
+    plan = hip.EncoderPlan(net.encoder, True)
+    exact = plan.encode(x).double().cpu()
+    monkeypatch.setenv("IPSX_PRECISION", "fp32x3")
+    got = plan.encode(x)
+    assert hip.encoder_kernel_name(plan) == "fused_trunk_x3_kernel"
+    again = plan.encode(x)
+    monkeypatch.delenv("IPSX_PRECISION")
+    assert torch.equal(got, again) and torch.isfinite(got).all()            # deterministic
+    got = got.double().cpu()
+
+    sd = {k: v.detach().double().cpu() for k, v in net.encoder.state_dict().items()}
+    def bn(y, p):
+        return (y - sd[p + ".running_mean"][None, :, None, None]) / torch.sqrt(sd[p + ".running_var"] + 1e-5)[None, :, None, None] \
+            * sd[p + ".weight"][None, :, None, None] + sd[p + ".bias"][None, :, None, None]
+    y = F.relu(bn(F.conv2d(x.double().cpu(), sd["0.weight"], None, 2, 3), "1"))
+    y = F.max_pool2d(y, 3, 2, 1)
+    for st, stride in ((4, 1), (5, 2)):
+        for blk in (0, 1):
+            p = "%d.%d" % (st, blk)
+            s1 = stride if blk == 0 else 1
+            idt = y
+            z = F.relu(bn(F.conv2d(y, sd[p + ".conv1.weight"], None, s1, 1), p + ".bn1"))
+            z = bn(F.conv2d(z, sd[p + ".conv2.weight"], None, 1, 1), p + ".bn2")
+            if p + ".downsample.0.weight" in sd:
+                idt = bn(F.conv2d(y, sd[p + ".downsample.0.weight"], None, s1, 0), p + ".downsample.1")
+            y = F.relu(z + idt)
+    truth = y.mean(dim=(2, 3))
+    scale = truth.abs().max()
+    err_exact = float((exact - truth).abs().max() / scale)
+    err_x3 = float((got - truth).abs().max() / scale)
+    mean_exact = float((exact - truth).abs().mean() / scale)
+    mean_x3 = float((got - truth).abs().mean() / scale)
+    print("max/mean error vs float64: fp32 kernel %.3e / %.3e, fp32x3 kernel %.3e / %.3e" % (err_exact, mean_exact, err_x3, mean_x3))
+    assert err_x3 < 2e-6 and err_x3 < 3 * err_exact + 1e-7, (err_x3, err_exact)
+    assert mean_x3 < 2 * mean_exact + 1e-8, (mean_x3, mean_exact)
+    assert float((got - exact).abs().max() / scale) < 2e-6
+
+
 def test_encoder_plan_tracks_weight_updates():
     g = Golden("mnist_mini")
     net = g.net(DEV)
