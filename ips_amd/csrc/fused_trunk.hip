@@ -924,15 +924,19 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
     bf16 = bf16 && a.wh_down;
     if (t->precision != 0 && !bf16) return fail(IPSX_EINVAL, "fused trunk: precision %d needs w_packed_bf16 on every block conv", t->precision);
     if (t->precision == 2) {
-        if (stamps) return fail(IPSX_EINVAL, "fused trunk: no stamp build of the fp32x3 kernel");
         const size_t ldsx = (size_t)4 * SLABX;
         static bool attr_x3 = false;
         if (!attr_x3) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_x3_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_x3_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_x3_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
             attr_x3 = true;
         }
-        fused_trunk_x3_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), ldsx, s>>>(a);
+        if (stamps)
+            fused_trunk_x3_kernel<true><<<dim3((unsigned)cdiv(n, 4)), dim3(256), ldsx, s>>>(a, stamps);
+        else
+            fused_trunk_x3_kernel<false><<<dim3((unsigned)cdiv(n, 4)), dim3(256), ldsx, s>>>(a, nullptr);
         return launched("fused_trunk_x3");
     }
     if (bf16) {

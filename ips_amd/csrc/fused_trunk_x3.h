@@ -347,7 +347,8 @@ __device__ __forceinline__ void epilogue_l2x(char* lds, const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256, 1) void fused_trunk_x3_kernel(FusedArgs a) {
+template <bool STAMP>
+__global__ __launch_bounds__(256, 1) void fused_trunk_x3_kernel(FusedArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char ldsx[];           // 4 slabs of SLABX bytes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p_first = (long long)blockIdx.x * 4;
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void fused_trunk_x3_kernel(FusedArgs a) {
     if (a.index) pi = a.index[pi];
     char* Sb = ldsx + wave * SLABX;
     float* S = reinterpret_cast<float*>(Sb);
+    IPSX_STAMP(0);
 
     // ---- fp32 input -> zero-padded 38x38 image; zero pixel row of the 8x8 stage
     {
@@ -377,22 +379,28 @@ __global__ __launch_bounds__(256, 1) void fused_trunk_x3_kernel(FusedArgs a) {
     wave_fence();
 
     f32x16 idn[2][2], acc[2][2];
+    IPSX_STAMP(1);
     stem_pool(a, S, idn, lane);                      // exact fp32 stem + pool (standard layout)
     wave_fence();
     store_stem_x(Sb, idn, lane);
     wave_fence();
     load_l1x(Sb, idn, lane);                         // the identity in the transposed layout (hi + mid + lo is exact)
+    IPSX_STAMP(2);
 
 #pragma unroll 1
     for (int blk = 0; blk < 2; ++blk) {
         conv_l1x(a.wh[2 * blk], Sb, acc, lane);
         wave_fence();
+        IPSX_STAMP(3 + 4 * blk);
         epilogue_l1x<false>(Sb, a.al[2 * blk], a.sh[2 * blk], acc, idn, lane);
         wave_fence();
+        IPSX_STAMP(4 + 4 * blk);
         conv_l1x(a.wh[2 * blk + 1], Sb, acc, lane);
         wave_fence();
+        IPSX_STAMP(5 + 4 * blk);
         epilogue_l1x<true>(Sb, a.al[2 * blk + 1], a.sh[2 * blk + 1], acc, idn, lane);
         __syncthreads();
+        IPSX_STAMP(6 + 4 * blk);
     }
 
     f32x16 t2[2], id2[2];
@@ -411,6 +419,7 @@ __global__ __launch_bounds__(256, 1) void fused_trunk_x3_kernel(FusedArgs a) {
                 for (int j = 0; j < 4; ++j) id2[ct][4 * g + j] = __builtin_fmaf(id2[ct][4 * g + j], Aa[j], Bb[j]);
         }
     }
+    IPSX_STAMP(11);
     __syncthreads();                                  // every wave is done with the 8x8 images
     epilogue_l2x<0>(ldsx, a.al[4], a.sh[4], t2, id2, lane, wave);
     for (int z = lane; z < XR2 / 4; z += 64) reinterpret_cast<unsigned*>(Sb + XZ2 * XR2)[z] = 0u;
@@ -423,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void fused_trunk_x3_kernel(FusedArgs a) {
         else if (cv == 6) epilogue_l2x<0>(ldsx, a.al[cv], a.sh[cv], t2, id2, lane, wave);
         else epilogue_l2x<2>(ldsx, a.al[cv], a.sh[cv], t2, id2, lane, wave);
         __syncthreads();
+        IPSX_STAMP(7 + cv);
     }
     for (int o = threadIdx.x; o < 4 * 128; o += 256) {
         const int pl = o >> 7, n = o & 127;
@@ -432,6 +442,7 @@ __global__ __launch_bounds__(256, 1) void fused_trunk_x3_kernel(FusedArgs a) {
         for (int k = 0; k < 16; ++k) sum = sum + sp[k * PS2];
         if (p_first + pl < n_valid) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
     }
+    IPSX_STAMP(15);
 }
 
 // OIHW fp32 -> three-plane bf16 A-operand stream [C_out/32][K/16][plane][64 lanes][8]: element j of lane l holds

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Diagnostic: per-phase cycle breakdown of fused_trunk_kernel from in-kernel s_memtime stamps.
 
-    python tools/fused_stamps.py [n_patches]
+    python tools/fused_stamps.py [n_patches] [fp32|fp32x3]
 
 Runs the STAMP build (ipsx_dbg_fused_trunk_stamps) on synthetic patches and prints, per phase,
 the median wave-cycles and the matrix-pipe cycles the phase's MFMAs need alone (64 cycles each).
@@ -18,6 +18,8 @@ from ips_amd import hip, synth
 from ips_amd.architecture import IPSNet
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+os.environ["IPSX_PRECISION"] = prec
 dev = torch.device("cuda:0")
 conf = synth.mnist_conf(N=2500)
 net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
@@ -40,9 +42,11 @@ s = st.cpu().numpy().astype(np.int64)
 names = ["load", "stem+pool", "l1.0.c1", "l1.0.c1 epi", "l1.0.c2", "l1.0.c2 epi", "l1.1.c1", "l1.1.c1 epi",
          "l1.1.c2", "l1.1.c2 epi", "l2.0.c1+down", "l2.0 epi+c2", "l2.1.c1", "l2.1.c2", "avgpool"]
 mfma = [0, 400, 1152, 0, 1152, 0, 1152, 0, 1152, 0, 640, 1152, 1152, 1152, 0]
+if prec == "fp32x3":      # bf16 MFMAs of 32 cycles, 6 per 8 fp32 MFMAs of 64 -> in units of 64 cycles: x 6/16; the stem stays fp32
+    mfma = [m if k == 1 else m * 6 / 16 for k, m in enumerate(mfma)]
 # stamps: 0 start,1 loaded,2 stem,3 c1,4 epi,5 c2,6 epi(+barrier),7..10 block 1,11 l2.0 c1+down,12 cv5,13 cv6,14 cv7,15 end
 life = s[:, 15] - s[:, 0]
-print("waves %d  median life %d cycles  (ideal alone: %d MFMA x 64 = %d)" % (len(s), np.median(life), sum(mfma), sum(mfma) * 64))
+print("waves %d  median life %d cycles  (matrix-pipe cycles alone: %d)" % (len(s), np.median(life), sum(mfma) * 64))
 for k in range(15):
     d = s[:, k + 1] - s[:, k]
     print("%-14s median %8d  p10 %8d  p90 %8d   mfma-alone %7d  ratio %.2f" % (
@@ -50,4 +54,4 @@ for k in range(15):
         (np.median(d) / (mfma[k] * 64)) if mfma[k] else float("nan")))
 span = s[:, 15].max() - s[:, 0].min()
 print("kernel span %d cycles; sum of MFMA cycles per SIMD %d -> pipe utilisation %.3f" % (
-    span, len(s) * sum(mfma) * 64 // 1024, len(s) * sum(mfma) * 64 / 1024 / span))
+    span, int(len(s) * sum(mfma) * 64 / 1024), len(s) * sum(mfma) * 64 / 1024 / span))
