@@ -201,6 +201,15 @@ int ipsx_logits(const float* emb, int64_t emb_bstride,
                 int b, int64_t n, int d, int h, int dk, int n_token,
                 float* logits, int64_t logits_bstride, void* stream);
 
+/* Order of equal scores in the top-M steps of ipsx_scan / ipsx_scan_range / ipsx_topm (process-wide).
+ * 1 (default) = the reference's: torch.topk on CPU returns what libstdc++'s nth_element + sort (or
+ * partial_sort when 64*M <= L) leave behind (ATen/native/TopKImpl.h:45-68, reference call site
+ * ips_net.py:148); those routines are replayed on the device whenever two of the first M+1 ranked
+ * scores are equal, so the selected indices match the reference's CPU path under ties as well.
+ * 0 = canonical: score descending, earlier candidate position first (no sequential step).
+ * Returns the previous mode; any other argument only queries.                                       */
+int ipsx_set_tie_order(int mode);
+
 /* The chunk loop of IPSNet.ips (ips_net.py:213-241) on cached logits
  * (b, n, h*T): memory = first m patches; for every chunk of `i` further
  * patches: candidates = memory ++ chunk, per-(h,t) softmax over candidates,

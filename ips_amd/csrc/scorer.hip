@@ -23,6 +23,7 @@
 
 #include "ipsx_common.h"
 #include "ipsx_math.h"
+#include "ipsx_stdorder.h"
 
 namespace ipsx {
 
@@ -212,7 +213,44 @@ __device__ __forceinline__ uint64_t* sort_desc(uint64_t* src, uint64_t* tmp, int
     return src;
 }
 
+// ---- exact score ties (ipsx_stdorder.h).  `sorted` = keys in canonical order (score desc, earlier
+// position first).  When two of the first m+1 ranked scores are equal the reference returns whatever libstdc++'s
+// nth_element / sort / partial_sort leave behind, and that order feeds the next iteration; with tie order 1
+// ("torch", the default) one lane replays those routines on the candidate array and rewrites sorted[0..m).
+static int g_tie_order = 1;
+constexpr int STK_BYTES = 3 * stdorder::STACK_RANGES * 4;
+
+// every wave evaluates this on the same data: the result is uniform over the workgroup without a barrier
+__device__ __forceinline__ bool ranked_ties(const uint64_t* sorted, int L, int m, int lane) {
+    const int n = m < L - 1 ? m : L - 1;
+    bool any = false;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool e = j < n && (sorted[j] >> 32) == (sorted[j + 1] >> 32);
+        any = any || (__ballot(e) != 0ull);
+    }
+    return any;
+}
+
+// sorted and other are the two key arrays (>= L entries each); all threads of the workgroup call this together
+template <int NT>
+__device__ __forceinline__ void torch_tie_order(uint64_t* sorted, uint64_t* other, int L, int m, int* stk, int tid) {
+    stdorder::E* q = reinterpret_cast<stdorder::E*>(other);
+    for (int j = tid; j < L; j += NT) {
+        const uint64_t k = sorted[j];
+        const int p = (int)key_pos(k);
+        q[p].v = key_score(k);
+        q[p].i = p;
+    }
+    __syncthreads();
+    if (tid == 0) stdorder::torch_topk(q, L, m, stk);
+    __syncthreads();
+    for (int j = tid; j < m; j += NT) sorted[j] = rank_key(q[j].v, (uint32_t)q[j].i);
+    __syncthreads();
+}
+
 struct ScanArgs {
+    int tie_order, stk_off;
     const float* lg;       // (b, n, R)
     long long n;
     long long it0, it1;    // iterations [it0, it1) of the loop; it0 > 0 resumes from mem_idx
@@ -264,8 +302,10 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
         for (int l = tid; l < a.n2; l += 256)
             keyA[l] = l < L ? rank_key(cand_score(v, l, a.h, a.T, rmax, rden, nullptr, L), (uint32_t)l) : 0ull;
         sorted = sort_desc(keyA, keyB, L, a.n2);
-        for (int j = tid; j < a.m; j += 256) cnew[j] = cand[key_pos(sorted[j])];
         if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
+        if (a.tie_order == 1 && ranked_ties(sorted, L, a.m, tid & 63))
+            torch_tie_order<256>(sorted, sorted == keyA ? keyB : keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off), tid);
+        for (int j = tid; j < a.m; j += 256) cnew[j] = cand[key_pos(sorted[j])];
         __syncthreads();
         int* t = cand; cand = cnew; cnew = t;
     }
@@ -517,6 +557,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
             SCAN_STAMP(3);
             sorted = sort_desc(keyA, keyB, L, a.n2);
         }
+        if (a.tie_order == 1 && ranked_ties(sorted, L, a.m, lane))
+            torch_tie_order<SCAN_NT>(sorted, sorted == keyA ? keyB : keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off), tid);
         SCAN_STAMP(4);
         // new memory: indices and logit rows of the winners, into the other buffers
         for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
@@ -524,7 +566,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
             const int j = e / R, r = e - j * R;
             clnew[j * ld + r] = cl[key_pos(sorted[j]) * ld + r];
         }
-        if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
+        if (tid == 0 && L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m])) tie = 1;   // (NaN never equal: harmless)
         { int* t = cand; cand = cnew; cnew = t; }
         { float* t = cl; cl = clnew; clnew = t; }
         SCAN_STAMP(5);
@@ -574,6 +616,7 @@ __global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
 }
 
 struct TopmArgs {
+    int tie_order, stk_off;
     const float* scores;
     int L, m, n2;
     long long* top;
@@ -588,9 +631,11 @@ __global__ __launch_bounds__(256) void topm_kernel(TopmArgs a) {
     for (int l = tid; l < a.n2; l += 256)
         keyA[l] = l < a.L ? rank_key(a.scores[(size_t)b * a.L + l], (uint32_t)l) : 0ull;
     uint64_t* sorted = sort_desc(keyA, keyB, a.L, a.n2);
-    for (int j = tid; j < a.m; j += 256) a.top[(size_t)b * a.m + j] = key_pos(sorted[j]);
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) ? 1 : 0;
+    if (a.tie_order == 1 && ranked_ties(sorted, a.L, a.m, tid & 63))
+        torch_tie_order<256>(sorted, sorted == keyA ? keyB : keyA, a.L, a.m, reinterpret_cast<int*>(smem + a.stk_off), tid);
+    for (int j = tid; j < a.m; j += 256) a.top[(size_t)b * a.m + j] = key_pos(sorted[j]);
 }
 
 static unsigned long long* g_scan_stamps = nullptr;   // diagnostic only (ipsx_dbg_scan_stamps)
@@ -660,16 +705,18 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
     size_t base = (size_t)n2 * 16 + (size_t)Lmax * 8 + (size_t)R * 8;
     base = (base + 15) & ~(size_t)15;
     const size_t stage = (size_t)Lmax * (R + 1) * 4;
-    IPSX_REQUIRE(base <= kLdsLimit, "scan: M+I = %d candidates do not fit the 160 KiB LDS", Lmax);
+    IPSX_REQUIRE(base + STK_BYTES <= kLdsLimit, "scan: M+I = %d candidates do not fit the 160 KiB LDS", Lmax);
     ScanArgs a;
     a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
     a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
-    const size_t resident = base + (size_t)Lmax * R * 4 + 2 * stage;
+    a.tie_order = g_tie_order;
+    const size_t resident = base + (size_t)Lmax * R * 4 + 2 * stage + STK_BYTES;
     const bool runs_fit = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)Lmax * R * 4;   // run scratch aliases the weight buffer
     if (resident <= kLdsLimit && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && runs_fit) {
         a.use_lds = 1;
+        a.stk_off = (int)(resident - STK_BYTES);
         if (resident > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
@@ -682,8 +729,9 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
         }
         return launched("scan");
     }
-    a.use_lds = base + stage <= kLdsLimit;
-    const size_t lds = base + (a.use_lds ? stage : 0);
+    a.use_lds = base + stage + STK_BYTES <= kLdsLimit;
+    const size_t lds = base + (a.use_lds ? stage : 0) + STK_BYTES;
+    a.stk_off = (int)(lds - STK_BYTES);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     scan_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
@@ -723,12 +771,19 @@ IPSX_API int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_id
     TopmArgs a;
     a.scores = scores; a.L = l; a.m = m; a.n2 = next_pow2(l);
     a.top = reinterpret_cast<long long*>(top_idx); a.tie = tie_flag;
-    const size_t lds = (size_t)a.n2 * 16;
+    const size_t lds = (size_t)a.n2 * 16 + STK_BYTES;
+    a.tie_order = g_tie_order; a.stk_off = (int)(lds - STK_BYTES);
     IPSX_REQUIRE(lds <= kLdsLimit, "topm: %d candidates do not fit the 160 KiB LDS", l);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     topm_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
     return launched("topm");
+}
+
+IPSX_API int ipsx_set_tie_order(int mode) {
+    const int prev = ipsx::g_tie_order;
+    if (mode == 0 || mode == 1) ipsx::g_tie_order = mode;
+    return prev;
 }
 
 // Diagnostic entry point (not part of include/ipsx.h): when set to a device buffer of b*8 uint64, the next

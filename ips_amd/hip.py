@@ -41,6 +41,21 @@ def precision():
     return p
 
 
+def tie_order():
+    """'torch' (default): equal scores come out in the order torch.topk returns on CPU (the reference's), replayed on
+    the device only when ties occur; 'canonical' (IPSX_TIE_ORDER=canonical): earlier candidate position first."""
+    t = os.environ.get("IPSX_TIE_ORDER", "torch").lower()
+    if t not in ("torch", "canonical"):
+        raise ValueError("IPSX_TIE_ORDER must be 'torch' or 'canonical', got {!r}".format(t))
+    return t
+
+
+def set_tie_order(mode):
+    """Switch the tie order at run time ('torch' | 'canonical'); returns the previous one."""
+    prev = lib().ipsx_set_tie_order({"torch": 1, "canonical": 0}[mode])
+    return "torch" if prev == 1 else "canonical"
+
+
 def dedup_blank():
     """Opt-in exact blank-patch deduplication in front of the fused encoder (IPSX_DEDUP_BLANK=1)."""
     return os.environ.get("IPSX_DEDUP_BLANK", "0") == "1"
@@ -121,6 +136,7 @@ _EXPORTS = {
     "ipsx_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                               C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_int64, C.c_void_p]),
+    "ipsx_set_tie_order": (C.c_int, [C.c_int]),
     "ipsx_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_scan_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
@@ -165,6 +181,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.ipsx_version() // 100 != 1:
             raise RuntimeError("libipsx.so ABI version {} != 1.x".format(L.ipsx_version()))
+        L.ipsx_set_tie_order({"torch": 1, "canonical": 0}[tie_order()])
         _LIB = L
     return _LIB
 

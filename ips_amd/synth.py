@@ -102,7 +102,7 @@ def fill_weights(net, seed=0, q_gain=8.0):
     return net
 
 
-def make_patches(conf, B, seed=0, blank_frac=0.93, N=None):
+def make_patches(conf, B, seed=0, blank_frac=None, N=None):
     """Synthetic ``(B, N, ...)`` patch tensor of the shape ``ips()`` sees (CPU, float32).
 
     Images: Megapixel-MNIST-like sparsity - a patch is all-zero with probability
@@ -112,6 +112,8 @@ def make_patches(conf, B, seed=0, blank_frac=0.93, N=None):
     post-ReLU ResNet-50 features (data/camelyon/camelyon_dataset.py:137-140).
     """
     N = conf.N if N is None else N
+    if blank_frac is None:
+        blank_frac = getattr(conf, "blank_frac", 0.93)          # a fixture may pin its own sparsity in the conf
     g = _rng(seed, "patches")
     if not conf.is_image:
         x = np.maximum(g.standard_normal((B, N, conf.n_chan_in), dtype=np.float32), 0)

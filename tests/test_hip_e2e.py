@@ -43,6 +43,28 @@ def test_ips_and_forward_match_reference_fixture(case):
         assert np.abs(preds[k].cpu().numpy() - v).max() < PRED_TOL, k
 
 
+@pytest.mark.parametrize("case", ["mnist_ties", "mnist_ties_wide"])
+def test_tie_fixtures_need_the_torch_order(case):
+    """The tie fixtures (identical blank patches, no positional encoding) are reproduced by the default tie order
+    (previous test); the canonical order selects other - equally scored - patches and raises the tie flag."""
+    g = Golden(case)
+    net = g.net(DEV)
+    x = g.patches().to(DEV)
+    assert g.min_rel_gap == 0.0
+    hip.set_tie_order("canonical")
+    try:
+        net.ips(x)
+        canonical = net.last_mem_idx.cpu().numpy()
+        assert int(hip.scan.last_tie.sum().item()) > 0
+    finally:
+        hip.set_tie_order("torch")
+    net.ips(x)
+    assert np.array_equal(net.last_mem_idx.cpu().numpy(), g.mem_idx)
+    assert not np.array_equal(canonical, g.mem_idx)
+    o = orc.Oracle(g.net("cpu"))
+    assert np.array_equal(o.ips(g.patches().numpy(), None, aten_ties=True)["mem_idx"], g.mem_idx)
+
+
 @pytest.mark.parametrize("case", ["mnist_mini", "mnist_ragged", "mnist_onechunk", "mnist_tok1", "cam_b2",
                                   "traffic_tiny", "mnist_full"])
 def test_ips_and_forward_bit_exact_vs_oracle(case):

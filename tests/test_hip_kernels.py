@@ -357,11 +357,39 @@ def test_topm_matches_oracle_and_torch(L, M):
     for b in range(2):
         assert np.array_equal(top[b], orc.topm(s[b], M)[0])
         assert np.array_equal(top[b], torch.topk(torch.from_numpy(s[b]), M)[1].numpy())
-    # exact ties: canonical rule = earlier position first
+    # exact ties, canonical rule = earlier position first
     t = np.zeros((1, L), dtype=np.float32)
     t[0, ::3] = 1.0
-    top = hip.topm(dev(t), M).cpu().numpy()[0]
+    assert hip.set_tie_order("canonical") == "torch"          # the default is the reference's order
+    try:
+        top = hip.topm(dev(t), M).cpu().numpy()[0]
+    finally:
+        hip.set_tie_order("torch")
     assert np.array_equal(top, orc.topm(t[0], M)[0])
+
+
+@pytest.mark.parametrize("L,M", [(128, 64), (48, 16), (512, 256), (600, 100), (2000, 64), (7, 7), (1116, 16), (130, 2),
+                                 (300, 299), (1024, 1000)])
+def test_topm_under_ties_returns_torch_cpu_order(L, M):
+    """Equal scores: torch.topk on CPU returns what libstdc++'s nth_element + sort / partial_sort leave behind
+    (SURVEY H2); the kernels replay those routines (csrc/ipsx_stdorder.h).  Checked against torch itself (the host
+    of the GPU box runs the same ATen CPU code as the reference) and against the oracle's restatement."""
+    g = np.random.default_rng(L * 7 + M)
+    rows = []
+    for distinct in (1, 2, 3, 7, 40):                         # from "everything equal" to "a few repeated values"
+        rows.append(g.integers(0, distinct, L).astype(np.float32) * 0.125)
+    r = g.permutation(L).astype(np.float32)
+    r[g.integers(0, L, L // 3)] = r[0]                        # mostly distinct, one value repeated
+    rows.append(r)
+    n = g.standard_normal(L).astype(np.float32).round(1)
+    n[g.integers(0, L, 5)] = np.nan                           # NaNs rank first and tie with each other
+    rows.append(n)
+    s = np.stack(rows)
+    top = hip.topm(dev(s), M).cpu().numpy()
+    for b in range(len(s)):
+        want = torch.topk(torch.from_numpy(s[b]), M)[1].numpy()
+        assert np.array_equal(top[b], want), (b, top[b][:12], want[:12])
+        assert np.array_equal(top[b], orc.topm(s[b], M, aten_ties=True)[0])
 
 
 @pytest.mark.parametrize("N,M,I,H,T", [(300, 16, 16, 8, 4), (301, 16, 24, 8, 4), (40, 16, 64, 8, 4),

@@ -26,10 +26,11 @@ def test_oracle_reproduces_reference(case):
         pos = net.pos_enc.numpy()
         if g.perm is not None:
             pos = np.stack([pos[0][g.perm[b]] for b in range(g.B)])
-    out = orc.ips(x, pos)
+    ties = g.min_rel_gap == 0.0               # fixtures with exact score ties at the top-M boundary
+    out = orc.ips(x, pos, aten_ties=ties)     # ... are pinned with torch.topk's CPU order restated (orc_topm_aten)
     # indices: every iteration, same order
     assert np.array_equal(out["trace_idx"], g.trace_idx), "selected indices differ from the reference"
-    assert out["tie"].sum() == 0
+    assert ties or out["tie"].sum() == 0
     # scores the selection was based on
     assert max_rel(out["trace_score"], g.trace_score) < VALUE_TOL
     # encoder values

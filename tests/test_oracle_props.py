@@ -70,3 +70,15 @@ def test_scores_rows_sum_to_one():
     assert np.allclose(attn.sum(-1), 1.0, atol=1e-5)
     ref = g.net("cpu").transf.get_scores(torch.from_numpy(x)[None])[0].detach().numpy()
     assert np.abs(ref - sc).max() < 1e-6
+
+
+def test_device_tie_order_restatement_equals_libstdcxx():
+    """csrc/ipsx_stdorder.h (nth_element / sort / partial_sort as the kernels replay them under score ties), compiled
+    for the host, against std:: called the way ATen's CPU top-k calls it - tie-heavy random inputs, NaNs, the
+    depth-limit (heap) fallbacks."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "check_stdorder"])
+    out = subprocess.run([os.path.join(root, "oracle", "check_stdorder"), "40000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatching cases 0" in out.stdout, out.stdout + out.stderr

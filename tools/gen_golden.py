@@ -48,6 +48,10 @@ CASES = {
     "traffic_full": (synth.traffic_conf(N=192, M=16, I=32, patch=100), 1, 10, 12, 0),
     "cam_small": (synth.camelyon_conf(N=4096, M=256, I=256), 1, 11, 13, 0),
     "cam_b2": (synth.camelyon_conf(N=1000, M=32, I=48), 2, 12, 14, 0),
+    # no positional encoding + 93 % identical (blank) patches: exact score ties straddle the top-M boundary in
+    # every iteration, so the indices are whatever torch.topk's CPU implementation returns under ties
+    "mnist_ties": (synth.mnist_conf(N=300, M=16, I=16, use_pos=False), 2, 13, 15, 0),
+    "mnist_ties_wide": (synth.mnist_conf(N=1200, M=8, I=1000, use_pos=False, blank_frac=0.995), 1, 14, 16, 0),   # k*64 <= n: partial_sort branch
 }
 
 
