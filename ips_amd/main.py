@@ -51,6 +51,7 @@ def build_conf(args):
         c["n_epoch_warmup"] = min(c["n_epoch_warmup"], max(1, args.epochs // 10))
     if args.lazy:
         c["eager"] = False
+    c["hip_graph"] = bool(args.hip_graph)
     return Struct(**c)
 
 
@@ -73,6 +74,7 @@ def main(argv=None):
     ap.add_argument("--workers", type=int)
     ap.add_argument("--seed", type=int)
     ap.add_argument("--sparse", action="store_true", help="loader delivers non-zero pixels; patches are built on the GPU")
+    ap.add_argument("--hip-graph", action="store_true", help="replay forward+backward+AdamW of a step as one HIP graph")
     ap.add_argument("--lazy", action="store_true", help="lazy loading: patches stay on the host (eager: False)")
     ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     args = ap.parse_args(argv)
@@ -108,7 +110,7 @@ def main(argv=None):
         train_one_epoch(net, criterions, train_loader, optimizer, device, epoch, log_train, conf)
         t1 = time.time()
         log_train.compute_metric()
-        log_train.print_stats(epoch, train=True, lr=optimizer.param_groups[0]['lr'],
+        log_train.print_stats(epoch, train=True, lr=float(optimizer.param_groups[0]['lr']),
                               images_per_s="{:.1f}".format(len(train_loader.dataset) / (t1 - t0)))
         evaluate(net, criterions, test_loader, device, log_test, conf)
         log_test.compute_metric()

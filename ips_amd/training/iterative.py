@@ -107,6 +107,12 @@ def train_one_epoch(net, criterions, data_loader, optimizer, device, epoch, log_
     start_new_batch = True
     times = []
     track = bool(getattr(conf, 'track_efficiency', False))
+    graphed = None
+    if getattr(conf, 'hip_graph', False) and torch.device(device).type == 'cuda':     # addition: see training/graphed.py
+        from .graphed import GraphedStep
+        graphed = getattr(net, '_graphed_step', None)
+        if graphed is None or graphed.optimizer is not optimizer:
+            graphed = net._graphed_step = GraphedStep(net, criterions, optimizer, conf)
 
     for data_it, data in enumerate(data_loader, start=epoch * len(data_loader)):
         image_patches = _patches_of(data, device, conf)
@@ -130,10 +136,13 @@ def train_one_epoch(net, criterions, data_loader, optimizer, device, epoch, log_
             mem_patch, mem_pos_enc, labels = shrink_batch(mem_patch, mem_pos_enc, labels, n_prep, conf)
 
         adjust_learning_rate(conf.n_epoch_warmup, conf.n_epoch, conf.lr, optimizer, data_loader, data_it + 1)
-        optimizer.zero_grad()
-        loss, (task_losses, task_preds, task_labels) = compute_loss(net, mem_patch, mem_pos_enc, criterions, labels, conf)
-        loss.backward()
-        optimizer.step()
+        if graphed is not None:          # zero_grad, forward, losses, backward, optimizer.step replayed as one HIP graph
+            loss, (task_losses, task_preds, task_labels) = graphed(mem_patch, mem_pos_enc, labels)
+        else:
+            optimizer.zero_grad()
+            loss, (task_losses, task_preds, task_labels) = compute_loss(net, mem_patch, mem_pos_enc, criterions, labels, conf)
+            loss.backward()
+            optimizer.step()
 
         if track:
             end_event.record()

@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Where a training step's time goes (reference training/iterative.py:105-189 at config/mnist_config.yml sizes,
+32-px patches): ips() under no-grad on the HIP path vs forward + backward + AdamW on stock ROCm ops, eager and
+captured in a HIP graph (ips_amd/training/graphed.py).
+
+    python tools/train_step_breakdown.py [--batch 16] [--steps 20]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+from torch import nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ips_amd import synth
+from ips_amd.architecture import IPSNet
+from ips_amd.training import iterative as loops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--graph", action="store_true")
+args = ap.parse_args()
+
+dev = torch.device("cuda:0")
+conf = synth.mnist_conf(N=2500, M=64, I=64, B=args.batch, B_seq=args.batch, n_epoch=10, n_epoch_warmup=1, lr=1e-3, wd=0.1)
+net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev)
+x = synth.make_patches(conf, args.batch, seed=3).to(dev)
+labels = {t['name']: (torch.randint(0, 10, (args.batch,), device=dev) if t['act_fn'] == 'softmax'
+                      else (torch.rand(args.batch, 10, device=dev) < 0.3).float()) for t in conf.tasks.values()}
+crit = {t['name']: (nn.NLLLoss() if t['act_fn'] == 'softmax' else nn.BCELoss()) for t in conf.tasks.values()}
+opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=conf.wd)
+net.train()
+
+
+def timed(fn, n):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+state = {}
+
+
+def do_ips():
+    state["mp"], state["pos"] = net.ips(x)
+
+
+def do_step():
+    opt.zero_grad()
+    preds = net(state["mp"], state["pos"])
+    loss = 0
+    for t in conf.tasks.values():
+        p = preds[t['name']].squeeze(-1)
+        loss = loss + (crit[t['name']](torch.log(p + conf.eps), labels[t['name']]) if t['act_fn'] == 'softmax'
+                       else crit[t['name']](p.view(-1), labels[t['name']].view(-1)))
+    (loss / len(conf.tasks)).backward()
+    opt.step()
+
+
+t_ips = timed(do_ips, args.steps)
+if args.graph:                      # a GraphedStep wants a fresh optimizer: measure it in a run of its own
+    t_step = float("nan")
+else:
+    t_step = timed(do_step, args.steps)
+print("ips() %.2f ms   forward+backward+AdamW (eager, stock ROCm ops) %.2f ms   -> %.1f images/s" % (
+    t_ips, t_step, args.batch / (1e-3 * (t_ips + t_step))))
+if args.graph:
+    from ips_amd.training.graphed import GraphedStep
+    gs = GraphedStep(net, crit, opt, conf)
+    t_g = timed(lambda: gs(state["mp"], state["pos"], labels), args.steps)
+    print("forward+backward+AdamW as one HIP graph %.2f ms   -> %.1f images/s" % (t_g, args.batch / (1e-3 * (t_ips + t_g))))
