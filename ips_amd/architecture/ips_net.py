@@ -269,8 +269,9 @@ class IPSNet(nn.Module):
         qs = ca.scaled_query()
         wk = hip.pack_linear(ca.k_w.weight)
         n_iter = math.ceil((N - M) / I)
-        P = self._OVERLAP_PARTS
-        its = [round(k * n_iter / P) for k in range(P + 1)]
+        from ..dist import part_iterations                          # parts shrink towards the end: only the last scan is exposed
+        its = part_iterations(n_iter, self._OVERLAP_PARTS)
+        P = len(its) - 1
         edges = [0] + [min(N, M + it * I) for it in its[1:]]
         edges[-1] = N
         key = (B, N, tuple(edges), str(dev))

@@ -31,6 +31,23 @@ import torch.distributed as dist
 from . import hip
 
 PARTS = 4
+# Cumulative share of the loop iterations per part.  The encoder works through the parts in order while the scan of
+# the previous part runs beside it; what stays exposed is the scan of the LAST part, so the parts shrink towards the
+# end (the encoder's workgroup rounds add up the same way whatever the cut).
+PART_SHARES = (0.5, 0.8, 0.95, 1.0)
+
+
+def part_iterations(n_iter, parts=PARTS):
+    """First iteration of every part (strictly increasing where possible), plus n_iter at the end."""
+    P = max(1, min(parts, n_iter))
+    shares = PART_SHARES if P == len(PART_SHARES) else [(k + 1) / P for k in range(P)]
+    its = [0]
+    for k in range(P):
+        lo = its[-1] + 1                                  # every part gets at least one iteration
+        hi = n_iter - (P - 1 - k)
+        its.append(min(max(round(shares[k] * n_iter), lo), hi))
+    its[-1] = n_iter
+    return its
 
 
 def partition(N, M, I, world, parts=PARTS):
@@ -41,8 +58,8 @@ def partition(N, M, I, world, parts=PARTS):
     patches ``[edges[k] + r*piece[k], min(edges[k] + (r+1)*piece[k], edges[k+1]))`` of every part k.
     """
     n_iter = math.ceil((N - M) / I)
-    P = max(1, min(parts, n_iter))
-    its = [round(k * n_iter / P) for k in range(P + 1)]
+    its = part_iterations(n_iter, parts)
+    P = len(its) - 1
     edges = [0] + [min(N, M + it * I) for it in its[1:]]
     edges[-1] = N
     piece = [max(1, math.ceil((edges[k + 1] - edges[k]) / world)) for k in range(P)]
