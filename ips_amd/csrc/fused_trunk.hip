@@ -244,6 +244,32 @@ __device__ __forceinline__ void l1_mma(const L1Stage& st, const float4 (&b)[2], 
     }
 }
 
+// IPSX_SPREAD = 1 (default): the loads of the next stage are spread between the 16 MFMAs of this one with
+// sched_group_barrier instead of standing in front of them (IPSX_SPREAD = 0).  Measured on the headline workload
+// (ms per step): in front 11.59; early (2 MFMA between loads, then 8) 11.59; even (4,1,4,1,...) 11.27; the patterns
+// below - 3 (8x8 stage) / 2 (4x4 stage) MFMA between loads, 4 MFMA at the end - 11.12.  The MFMA order, i.e. the
+// arithmetic, is the same in every variant.
+#ifndef IPSX_SPREAD
+#define IPSX_SPREAD 1
+#endif
+#if IPSX_SPREAD
+#define SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SG_LDS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define SG_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+#define L1_PRE()
+#define L1_POST() \
+    SG_MFMA(3); SG_LDS(1); SG_MFMA(3); SG_VMEM(1); SG_MFMA(3); SG_LDS(1); SG_MFMA(3); SG_VMEM(1); SG_MFMA(4); SB();
+#define L2_PRE()
+#define L2_POST()                                                                                         \
+    SG_MFMA(2); SG_LDS(1); SG_MFMA(2); SG_LDS(1); SG_MFMA(2); SG_VMEM(1); SG_MFMA(2); SG_LDS(1); SG_MFMA(2); \
+    SG_LDS(1); SG_MFMA(2); SG_VMEM(1); SG_MFMA(4); SB();
+#else
+#define L1_PRE() SB()
+#define L1_POST() SB()
+#define L2_PRE() SB()
+#define L2_POST() SB()
+#endif
+
 __device__ __forceinline__ void conv_l1(const float* __restrict__ wp, const float* S, f32x16 (&acc)[2][2], int lane) {
     const int i = lane & 31, half = lane >> 5;
     const char* w = reinterpret_cast<const char*>(wp);
@@ -262,14 +288,14 @@ __device__ __forceinline__ void conv_l1(const float* __restrict__ wp, const floa
     for (int tap = 0; tap < 9; ++tap) {
         const L1Tap nxt = l1_tap(tap < 8 ? tap + 1 : 8, S, i, half);
         const int g = tap * 8;
-        l1_load<1>(sb, cur); l1_loadb(b2, w, lo, g + 2); SB(); l1_mma(sa, b0, acc); SB();
-        l1_load<2>(sa, cur); l1_loadb(b3, w, lo, g + 3); SB(); l1_mma(sb, b1, acc); SB();
-        l1_load<3>(sb, cur); l1_loadb(b0, w, lo, g + 4); SB(); l1_mma(sa, b2, acc); SB();
-        l1_load<4>(sa, cur); l1_loadb(b1, w, lo, g + 5); SB(); l1_mma(sb, b3, acc); SB();
-        l1_load<5>(sb, cur); l1_loadb(b2, w, lo, g + 6); SB(); l1_mma(sa, b0, acc); SB();
-        l1_load<6>(sa, cur); l1_loadb(b3, w, lo, g + 7); SB(); l1_mma(sb, b1, acc); SB();
-        l1_load<7>(sb, cur); l1_loadb(b0, w, lo, g + 8); SB(); l1_mma(sa, b2, acc); SB();
-        l1_load<0>(sa, nxt); l1_loadb(b1, w, lo, g + 9); SB(); l1_mma(sb, b3, acc); SB();
+        l1_load<1>(sb, cur); l1_loadb(b2, w, lo, g + 2); L1_PRE(); l1_mma(sa, b0, acc); L1_POST();
+        l1_load<2>(sa, cur); l1_loadb(b3, w, lo, g + 3); L1_PRE(); l1_mma(sb, b1, acc); L1_POST();
+        l1_load<3>(sb, cur); l1_loadb(b0, w, lo, g + 4); L1_PRE(); l1_mma(sa, b2, acc); L1_POST();
+        l1_load<4>(sa, cur); l1_loadb(b1, w, lo, g + 5); L1_PRE(); l1_mma(sb, b3, acc); L1_POST();
+        l1_load<5>(sb, cur); l1_loadb(b2, w, lo, g + 6); L1_PRE(); l1_mma(sa, b0, acc); L1_POST();
+        l1_load<6>(sa, cur); l1_loadb(b3, w, lo, g + 7); L1_PRE(); l1_mma(sb, b1, acc); L1_POST();
+        l1_load<7>(sb, cur); l1_loadb(b0, w, lo, g + 8); L1_PRE(); l1_mma(sa, b2, acc); L1_POST();
+        l1_load<0>(sa, nxt); l1_loadb(b1, w, lo, g + 9); L1_PRE(); l1_mma(sb, b3, acc); L1_POST();
         cur = nxt;
     }
 }
@@ -351,19 +377,19 @@ __device__ __forceinline__ void conv_l2(const float* __restrict__ wp, const floa
         const L2Tap nxt = l2_tap<WIN, PS, ZP, STRIDE, KS>(tap < TAPS - 1 ? tap + 1 : TAPS - 1, S0, oy, ox);
         const int g = tap * PER_TAP;
         if (PER_TAP == 8) {
-            l2_load<1>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 2); SB(); l2_mma(sa, b0, acc); SB();
-            l2_load<2>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 3); SB(); l2_mma(sb, b1, acc); SB();
-            l2_load<3>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 4); SB(); l2_mma(sa, b2, acc); SB();
-            l2_load<4>(sa, cur); l2_loadb<G2>(b1, w, lo, g + 5); SB(); l2_mma(sb, b3, acc); SB();
-            l2_load<5>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 6); SB(); l2_mma(sa, b0, acc); SB();
-            l2_load<6>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 7); SB(); l2_mma(sb, b1, acc); SB();
-            l2_load<7>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 8); SB(); l2_mma(sa, b2, acc); SB();
-            l2_load<0>(sa, nxt); l2_loadb<G2>(b1, w, lo, g + 9); SB(); l2_mma(sb, b3, acc); SB();
+            l2_load<1>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 2); L2_PRE(); l2_mma(sa, b0, acc); L2_POST();
+            l2_load<2>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 3); L2_PRE(); l2_mma(sb, b1, acc); L2_POST();
+            l2_load<3>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 4); L2_PRE(); l2_mma(sa, b2, acc); L2_POST();
+            l2_load<4>(sa, cur); l2_loadb<G2>(b1, w, lo, g + 5); L2_PRE(); l2_mma(sb, b3, acc); L2_POST();
+            l2_load<5>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 6); L2_PRE(); l2_mma(sa, b0, acc); L2_POST();
+            l2_load<6>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 7); L2_PRE(); l2_mma(sb, b1, acc); L2_POST();
+            l2_load<7>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 8); L2_PRE(); l2_mma(sa, b2, acc); L2_POST();
+            l2_load<0>(sa, nxt); l2_loadb<G2>(b1, w, lo, g + 9); L2_PRE(); l2_mma(sb, b3, acc); L2_POST();
         } else {
-            l2_load<1>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 2); SB(); l2_mma(sa, b0, acc); SB();
-            l2_load<2>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 3); SB(); l2_mma(sb, b1, acc); SB();
-            l2_load<3>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 4); SB(); l2_mma(sa, b2, acc); SB();
-            l2_load<0>(sa, nxt); l2_loadb<G2>(b1, w, lo, g + 5); SB(); l2_mma(sb, b3, acc); SB();
+            l2_load<1>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 2); L2_PRE(); l2_mma(sa, b0, acc); L2_POST();
+            l2_load<2>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 3); L2_PRE(); l2_mma(sb, b1, acc); L2_POST();
+            l2_load<3>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 4); L2_PRE(); l2_mma(sa, b2, acc); L2_POST();
+            l2_load<0>(sa, nxt); l2_loadb<G2>(b1, w, lo, g + 5); L2_PRE(); l2_mma(sb, b3, acc); L2_POST();
         }
         cur = nxt;
     }
