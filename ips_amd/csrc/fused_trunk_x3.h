@@ -18,7 +18,7 @@
 //   weights     [row tile][K/16][plane][64 lanes][8 bf16]  (ipsx_pack_conv_weight_x3), 4.0 MB for the trunk
 //   stage       one K-step of 16 in the 8x8 stage: 6 ds_read_b128 + 6 global_load_dwordx4 + 24 MFMA, the loads of
 //               the next stage spread between the MFMAs with sched_group_barrier (tools/ubench/x3_stage.hip:
-//               844 cycles per stage against 768 of pure matrix-pipe time; 901 with the loads in front)
+//               833-843 cycles per stage against 768 of pure matrix-pipe time depending on the pattern; 901 with the loads in front)
 // 112 KB of LDS per workgroup: one workgroup (one wave per SIMD) per CU.
 
 constexpr int XP1 = 144, XR1 = 3 * XP1, XZ1 = 64;     // 8x8 stage: plane bytes, row bytes, zero row
@@ -174,9 +174,10 @@ __device__ __forceinline__ void x1_mma(const XOp1& w, const XOp1& x, f32x16 (&ac
     _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                   \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);               \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               \
-    }
+    }                                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 #define X1_STAGE(XC, LOADN, WC, WF) \
     LOADN; x1_loadw(WF, w, lo, g + 2); x1_mma(WC, XC, acc); X1_GROUPS(); SB(); ++g;
 
@@ -266,9 +267,10 @@ __device__ __forceinline__ void x2_mma(const XW2<SK>& b, const XOp2<SK>& st, f32
     _Pragma("unroll") for (int q_ = 0; q_ < 3 * SK; ++q_) {              \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);               \
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               \
-    }
+    }                                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * SK, 0);
 #define X2_STAGE(XC, LOADN, WC, WF) \
     LOADN; x2_loadw<SK, G>(WF, w, lo, g + 2); x2_mma<SK>(WC, XC, acc); X2_GROUPS(); SB(); ++g;
 

@@ -48,13 +48,25 @@ __device__ __forceinline__ void x_mma(const XOp& w, const XOp& x, f32x16 (&acc)[
             for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = MFMA16(w.p[rt][PA[q]], x.p[ct][PB[q]], acc[rt][ct]);
 }
 // 24 MFMAs with the 12 loads of the next stage spread between them: 2 MFMA, 1 DS read, 2 MFMA, 1 VMEM read, ...
-#define GROUPS()                                                                     \
-    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                           \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                           \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
-    }
+#define SGM(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SGD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define SGV(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+#if VARIANT == 0
+#define GROUPS() _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { SGM(2); SGD(1); SGM(2); SGV(1); }
+#elif VARIANT == 1      // loads every 1.5 MFMA, 6 MFMA at the end
+#define GROUPS() _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { SGM(2); SGD(1); SGM(1); SGV(1); } SGM(6);
+#elif VARIANT == 2      // 4 MFMA at the end
+#define GROUPS() _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { SGM(2); SGD(1); SGM(2); SGV(1); } SGM(1); SGD(1); SGM(1); SGV(1); SGM(1); SGD(1); SGM(1); SGV(1); SGM(4);
+#elif VARIANT == 3      // LDS reads first half, global loads second half
+#define GROUPS() _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { SGM(2); SGD(1); } _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { SGM(2); SGV(1); }
+#elif VARIANT == 4      // global first, LDS second
+#define GROUPS() _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { SGM(2); SGV(1); } _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { SGM(2); SGD(1); }
+#elif VARIANT == 5      // 2 MFMA lead-in, then even, 2 at the end
+#define GROUPS() SGM(2); _Pragma("unroll") for (int q_ = 0; q_ < 5; ++q_) { SGD(1); SGM(2); SGV(1); SGM(2); } SGD(1); SGM(1); SGV(1); SGM(1);
+#endif
 template <int MODE>
 __device__ __forceinline__ void conv_l1x(const void* wp, const char* S, f32x16 (&acc)[2][2], int lane) {
     const int i = lane & 31, half = lane >> 5;
