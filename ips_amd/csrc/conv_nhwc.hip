@@ -122,13 +122,16 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
     int gp = 0, pt = 0, pc = 0;
     unsigned pv0 = nhwc_voff(a, p0, 0, half), pv1 = nhwc_voff(a, p1, 0, half);
     NhwcStage s0, s1, s2, s3;
-#define NHWC_LOAD(S)                                                        \
+#define NHWC_ISSUE(S)                                                       \
     do {                                                                    \
         const unsigned ca = (unsigned)pc * 32u, cb = (unsigned)gp * 1024u;  \
         S.a0 = bufload(rx, pv0, ca);                                        \
         S.a1 = bufload(rx, pv1, ca);                                        \
         S.b0 = bufload(rw, lb, wb0 + cb);                                   \
         S.b1 = bufload(rw, lb, wb1 + cb);                                   \
+    } while (0)
+#define NHWC_ADVANCE()                                                      \
+    do {                                                                    \
         if (gp + 1 < total) {                                               \
             ++gp;                                                           \
             if (++pc == a.spt) {                                            \
@@ -138,16 +141,29 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
             }                                                               \
         }                                                                   \
     } while (0)
-    NHWC_LOAD(s0);
-    NHWC_LOAD(s1);
+// the 4 loads of the stage two ahead are spread between the 16 MFMAs of this one (same finding as in
+// fused_trunk.hip: 3 MFMA between loads, 4 at the end); the stream state advances after the stage so that loads
+// and MFMAs share a basic block
+#define NHWC_STAGE(SL, SM)                                                                  \
+    NHWC_ISSUE(SL); nhwc_mma(SM, acc);                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); SB();                                \
+    NHWC_ADVANCE();
+    NHWC_ISSUE(s0); NHWC_ADVANCE();
+    NHWC_ISSUE(s1); NHWC_ADVANCE();
 #pragma unroll 1
     for (int g = 0; g < total; g += 4) {       // total is a multiple of 4 (C_in % 32 == 0)
-        NHWC_LOAD(s2); SB(); nhwc_mma(s0, acc); SB();
-        NHWC_LOAD(s3); SB(); nhwc_mma(s1, acc); SB();
-        NHWC_LOAD(s0); SB(); nhwc_mma(s2, acc); SB();
-        NHWC_LOAD(s1); SB(); nhwc_mma(s3, acc); SB();
+        NHWC_STAGE(s2, s0)
+        NHWC_STAGE(s3, s1)
+        NHWC_STAGE(s0, s2)
+        NHWC_STAGE(s1, s3)
     }
-#undef NHWC_LOAD
+#undef NHWC_STAGE
+#undef NHWC_ADVANCE
+#undef NHWC_ISSUE
 
     // epilogue: BatchNorm affine, residual, ReLU; lanes of a store are 32 consecutive channels
     const int i = lane & 31;
