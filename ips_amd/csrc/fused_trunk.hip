@@ -565,346 +565,13 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
     IPSX_STAMP(15);
 }
 
-// =====================================================================================
-// bf16 body (BASELINE configs[4]; the reference has no reduced-precision path, so this one is
-// tolerance-tested against the fp32 kernel above, not against the reference).
-// The stem stays fp32 (its input is the fp32 image and it is 4 % of the work); the eight 3x3 / 1x1
-// convolutions of the residual stages run on v_mfma_f32_32x32x16_bf16: operands (activations in LDS,
-// pre-packed weights) are bf16, accumulation, BatchNorm, residual and ReLU are fp32, the identity
-// lives in fp32 registers.  Same structure as the fp32 kernel, K-step 16 instead of 2:
-//   LDS image  [pix][C bf16 + 8 pad] (row = 144 B / 272 B): a lane half reads its 8 consecutive k of
-//              a K-step with one ds_read_b128; zero pixel row for the halo
-//   weights    [n-tile][K/16][64 lanes][8 bf16]: 16 B per lane per K-step, L2 resident (1.35 MB)
+// ---- bf16 matrix pipe: the split trunks (fp32x3 and plain bf16) share one template
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
-
-constexpr int HB1 = 144, HZ1 = 64;            // 8x8 stage: row bytes, zero row
-constexpr int HB2 = 272, HZ2 = 16;            // 4x4 stage
-constexpr int SLABH = (HZ1 + 1) * HB1;        // 9,360 B per patch (>= 38*38*4, >= 17*272, >= 16*132*4)
-
 __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
-__device__ __forceinline__ void store_l1h(char* S, const f32x16 (&v)[2][2], int lane) {
-    const int i = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pix = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                *reinterpret_cast<unsigned short*>(S + pix * HB1 + 2 * (nt * 32 + i)) = bf16_bits(v[mt][nt][r]);
-            }
-}
-
-struct H1Tap { const char* s0; const char* s1; };
-struct H1Stage { uint4 a0, a1; };
-
-__device__ __forceinline__ H1Tap l1h_tap(int tap, const char* S, int i, int half) {
-    const int t3 = tap / 3;
-    const int dy = t3 - 1, dx = tap - 3 * t3 - 1;
-    const int x = i & 7, y0 = i >> 3;
-    const bool okx = (unsigned)(x + dx) < 8u;
-    const bool ok0 = okx && (unsigned)(y0 + dy) < 8u;
-    const bool ok1 = okx && (unsigned)(y0 + 4 + dy) < 8u;
-    const int p0 = i + dy * 8 + dx;
-    H1Tap d;
-    d.s0 = S + (ok0 ? p0 : HZ1) * HB1 + 16 * half;
-    d.s1 = S + (ok1 ? p0 + 32 : HZ1) * HB1 + 16 * half;
-    return d;
-}
-
-template <int KS>
-__device__ __forceinline__ void l1h_load(H1Stage& st, const H1Tap& d) {
-    st.a0 = *reinterpret_cast<const uint4*>(d.s0 + KS * 32);
-    st.a1 = *reinterpret_cast<const uint4*>(d.s1 + KS * 32);
-}
-
-__device__ __forceinline__ void l1h_loadb(uint4 (&b)[2], const char* wb, unsigned loff, int g) {
-    g = g < 36 ? g : 35;
-    const char* p = wb + (size_t)g * 1024;
-    b[0] = *reinterpret_cast<const uint4*>(p + loff);
-    b[1] = *reinterpret_cast<const uint4*>(p + 36 * 1024 + loff);
-}
-
-__device__ __forceinline__ void l1h_mma(const H1Stage& st, const uint4 (&b)[2], f32x16 (&acc)[2][2]) {
-    acc[0][0] = MFMA16(st.a0, b[0], acc[0][0]);
-    acc[0][1] = MFMA16(st.a0, b[1], acc[0][1]);
-    acc[1][0] = MFMA16(st.a1, b[0], acc[1][0]);
-    acc[1][1] = MFMA16(st.a1, b[1], acc[1][1]);
-}
-
-__device__ __forceinline__ void conv_l1h(const void* __restrict__ wp, const char* S, f32x16 (&acc)[2][2], int lane) {
-    const int i = lane & 31, half = lane >> 5;
-    const char* w = reinterpret_cast<const char*>(wp);
-    const unsigned lo = lane * 16;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) zero(acc[mt][nt]);
-    H1Tap cur = l1h_tap(0, S, i, half);
-    H1Stage sa, sb;
-    uint4 b0[2], b1[2], b2[2], b3[2];
-    l1h_loadb(b0, w, lo, 0);
-    l1h_loadb(b1, w, lo, 1);
-    l1h_load<0>(sa, cur);
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        const H1Tap nxt = l1h_tap(tap < 8 ? tap + 1 : 8, S, i, half);
-        const int g = tap * 4;
-        l1h_load<1>(sb, cur); l1h_loadb(b2, w, lo, g + 2); SB(); l1h_mma(sa, b0, acc); SB();
-        l1h_load<2>(sa, cur); l1h_loadb(b3, w, lo, g + 3); SB(); l1h_mma(sb, b1, acc); SB();
-        l1h_load<3>(sb, cur); l1h_loadb(b0, w, lo, g + 4); SB(); l1h_mma(sa, b2, acc); SB();
-        l1h_load<0>(sa, nxt); l1h_loadb(b1, w, lo, g + 5); SB(); l1h_mma(sb, b3, acc); SB();
-        cur = nxt;
-    }
-}
-
-// 4x4 stage: tile mt = patches 2mt, 2mt+1; wave owns n-tile `wave`.  SK K-steps per stage so that a
-// tap is always 4 stages (SK = 1 for 64 input channels, 2 for 128).
-struct H2Tap { const char* s0; const char* s1; };
-template <int SK> struct H2Stage { uint4 a[2][SK]; };
-
-template <int WIN, int HB, int ZP, int STRIDE, int KS>
-__device__ __forceinline__ H2Tap l2h_tap(int tap, const char* S0, int oy, int ox) {
-    constexpr int PAD = KS / 2;
-    const int ky = tap / KS, kx = tap - ky * KS;
-    const int iy = oy * STRIDE + ky - PAD, ix = ox * STRIDE + kx - PAD;
-    const bool ok = (unsigned)iy < (unsigned)WIN && (unsigned)ix < (unsigned)WIN;
-    H2Tap d;
-    d.s0 = S0 + (ok ? iy * WIN + ix : ZP) * HB;
-    d.s1 = d.s0 + 2 * SLABH;
-    return d;
-}
-
-template <int SK, int CS>
-__device__ __forceinline__ void l2h_load(H2Stage<SK>& st, const H2Tap& d) {
-#pragma unroll
-    for (int q = 0; q < SK; ++q) {
-        st.a[0][q] = *reinterpret_cast<const uint4*>(d.s0 + (CS * SK + q) * 32);
-        st.a[1][q] = *reinterpret_cast<const uint4*>(d.s1 + (CS * SK + q) * 32);
-    }
-}
-
-template <int SK, int G>
-__device__ __forceinline__ void l2h_loadb(uint4 (&b)[SK], const char* wb, unsigned loff, int g) {
-    g = g < G ? g : G - 1;
-    const char* p = wb + (size_t)g * SK * 1024;
-#pragma unroll
-    for (int q = 0; q < SK; ++q) b[q] = *reinterpret_cast<const uint4*>(p + q * 1024 + loff);
-}
-
-template <int SK>
-__device__ __forceinline__ void l2h_mma(const H2Stage<SK>& st, const uint4 (&b)[SK], f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int q = 0; q < SK; ++q) {
-        acc[0] = MFMA16(st.a[0][q], b[q], acc[0]);
-        acc[1] = MFMA16(st.a[1][q], b[q], acc[1]);
-    }
-}
-
-template <int CIN, int WIN, int HB, int ZP, int STRIDE, int KS>
-__device__ __forceinline__ void conv_l2h(const void* __restrict__ wp, const char* lds, f32x16 (&acc)[2], int lane,
-                                         int wave) {
-    constexpr int SK = CIN / 64, TAPS = KS * KS, KSTEPS = TAPS * CIN / 16, G = KSTEPS / SK;   // G = 4 * TAPS stages
-    const int i = lane & 31, half = lane >> 5;
-    const int pix = i & 15, oy = pix >> 2, ox = pix & 3;
-    const char* S0 = lds + (i >> 4) * SLABH + 16 * half;
-    const char* w = reinterpret_cast<const char*>(wp) + (size_t)__builtin_amdgcn_readfirstlane(wave) * KSTEPS * 1024;
-    const unsigned lo = lane * 16;
-    zero(acc[0]); zero(acc[1]);
-    H2Tap cur = l2h_tap<WIN, HB, ZP, STRIDE, KS>(0, S0, oy, ox);
-    H2Stage<SK> sa, sb;
-    uint4 b0[SK], b1[SK], b2[SK], b3[SK];
-    l2h_loadb<SK, G>(b0, w, lo, 0);
-    l2h_loadb<SK, G>(b1, w, lo, 1);
-    l2h_load<SK, 0>(sa, cur);
-#pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const H2Tap nxt = l2h_tap<WIN, HB, ZP, STRIDE, KS>(tap < TAPS - 1 ? tap + 1 : TAPS - 1, S0, oy, ox);
-        const int g = tap * 4;
-        l2h_load<SK, 1>(sb, cur); l2h_loadb<SK, G>(b2, w, lo, g + 2); SB(); l2h_mma<SK>(sa, b0, acc); SB();
-        l2h_load<SK, 2>(sa, cur); l2h_loadb<SK, G>(b3, w, lo, g + 3); SB(); l2h_mma<SK>(sb, b1, acc); SB();
-        l2h_load<SK, 3>(sb, cur); l2h_loadb<SK, G>(b0, w, lo, g + 4); SB(); l2h_mma<SK>(sa, b2, acc); SB();
-        l2h_load<SK, 0>(sa, nxt); l2h_loadb<SK, G>(b1, w, lo, g + 5); SB(); l2h_mma<SK>(sb, b3, acc); SB();
-        cur = nxt;
-    }
-}
-
-__device__ __forceinline__ void store_l2h(char* lds, const f32x16 (&v)[2], int lane, int wave) {
-    const int i = lane & 31, half = lane >> 5;
-    const int n = 32 * wave + i;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pl = 2 * mt + (r >> 3), pix = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-            *reinterpret_cast<unsigned short*>(lds + pl * SLABH + pix * HB2 + 2 * n) = bf16_bits(v[mt][r]);
-        }
-}
-
-__global__ __launch_bounds__(256, 2) void fused_trunk_bf16_kernel(FusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char ldsb[];           // 4 slabs of SLABH bytes
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31;
-    const long long p_first = (long long)blockIdx.x * 4;
-    const long long n_valid = a.count ? (long long)*a.count : a.n;
-    if (p_first >= n_valid) return;
-    long long pi = p_first + wave;
-    if (pi >= n_valid) pi = n_valid - 1;
-    if (a.index) pi = a.index[pi];
-    char* Sb = ldsb + wave * SLABH;
-    float* S = reinterpret_cast<float*>(Sb);
-
-    // ---- fp32 input -> zero-padded 38x38 image; zero pixel row of the bf16 8x8 stage
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
-        float4 px[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) px[k] = src[k * 64 + lane];
-        for (int z = lane; z < (PW * PW + 3) / 4; z += 64) reinterpret_cast<float4*>(S)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = lane; z < HB1 / 4; z += 64) reinterpret_cast<unsigned*>(Sb + HZ1 * HB1)[z] = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = (k * 64 + lane) * 4, y = e >> 5, x = e & 31;
-            float* d = S + (y + 3) * PW + x + 3;
-            d[0] = px[k].x; d[1] = px[k].y; d[2] = px[k].z; d[3] = px[k].w;
-        }
-    }
-    wave_fence();
-
-    f32x16 idn[2][2], acc[2][2];
-    stem_pool(a, S, idn, lane);                      // fp32 stem + pool, identity in fp32 registers
-    wave_fence();
-    store_l1h(Sb, idn, lane);
-    wave_fence();
-
-#pragma unroll 1
-    for (int blk = 0; blk < 2; ++blk) {
-        conv_l1h(a.wh[2 * blk], Sb, acc, lane);
-        {
-            const float* al = a.al[2 * blk];
-            const float* sh = a.sh[2 * blk];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float A = al[nt * 32 + i], B = sh[nt * 32 + i];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = __builtin_fmaf(acc[mt][nt][r], A, B);
-                        acc[mt][nt][r] = v > 0.0f ? v : 0.0f;
-                    }
-            }
-        }
-        wave_fence();
-        store_l1h(Sb, acc, lane);
-        wave_fence();
-        conv_l1h(a.wh[2 * blk + 1], Sb, acc, lane);
-        {
-            const float* al = a.al[2 * blk + 1];
-            const float* sh = a.sh[2 * blk + 1];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float A = al[nt * 32 + i], B = sh[nt * 32 + i];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = __builtin_fmaf(acc[mt][nt][r], A, B);
-                        v = v + idn[mt][nt][r];
-                        idn[mt][nt][r] = v > 0.0f ? v : 0.0f;
-                    }
-            }
-        }
-        wave_fence();
-        store_l1h(Sb, idn, lane);
-        __syncthreads();
-    }
-
-    f32x16 t2[2], id2[2];
-    const int n2 = 32 * wave + i;
-    conv_l2h<64, 8, HB1, HZ1, 2, 3>(a.wh[4], ldsb, t2, lane, wave);
-    conv_l2h<64, 8, HB1, HZ1, 2, 1>(a.wh_down, ldsb, id2, lane, wave);
-    {
-        const float A = a.al[4][n2], B = a.sh[4][n2], Ad = a.a_down[n2], Bd = a.s_down[n2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = __builtin_fmaf(t2[mt][r], A, B);
-                t2[mt][r] = v > 0.0f ? v : 0.0f;
-                id2[mt][r] = __builtin_fmaf(id2[mt][r], Ad, Bd);
-            }
-    }
-    __syncthreads();
-    store_l2h(ldsb, t2, lane, wave);
-    for (int z = lane; z < HB2 / 4; z += 64) reinterpret_cast<unsigned*>(ldsb + wave * SLABH + HZ2 * HB2)[z] = 0u;
-    __syncthreads();
-#pragma unroll 1
-    for (int cv = 5; cv < 8; ++cv) {
-        conv_l2h<128, 4, HB2, HZ2, 1, 3>(a.wh[cv], ldsb, t2, lane, wave);
-        const float A = a.al[cv][n2], B = a.sh[cv][n2];
-        const bool plain = (cv == 6);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = __builtin_fmaf(t2[mt][r], A, B);
-                if (!plain) v = v + id2[mt][r];
-                v = v > 0.0f ? v : 0.0f;
-                t2[mt][r] = v;
-                if (!plain) id2[mt][r] = v;
-            }
-        __syncthreads();
-        if (cv < 7) {
-            store_l2h(ldsb, t2, lane, wave);
-        } else {                                        // last activation stays fp32 for the average pool
-            const int half = lane >> 5;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pl = 2 * mt + (r >> 3), pix = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-                    reinterpret_cast<float*>(ldsb + pl * SLABH)[pix * PS2 + n2] = t2[mt][r];
-                }
-        }
-        __syncthreads();
-    }
-    for (int o = threadIdx.x; o < 4 * 128; o += 256) {
-        const int pl = o >> 7, n = o & 127;
-        const float* sp = reinterpret_cast<const float*>(ldsb + pl * SLABH) + n;
-        float sum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) sum = sum + sp[k * PS2];
-        if (p_first + pl < n_valid) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
-    }
-}
-
-// OIHW fp32 -> bf16 B-operand stream [C_out/32][K/16][64 lanes][8]: element j of lane l holds
-// k = 16*step + 8*(l>>5) + j (tap-major k), output channel 32*tile + (l&31); round to nearest even.
-__global__ void pack_conv_weight_bf16_kernel(const float* __restrict__ w, int c_out, int c_in, int kh, int kw,
-                                             int ksteps, size_t total, unsigned short* __restrict__ packed) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int j = (int)(i & 7);
-    const int lane = (int)((i >> 3) & 63);
-    const size_t g = i >> 9;
-    const int ks = (int)(g % ksteps);
-    const int nt = (int)(g / ksteps);
-    const int n = nt * 32 + (lane & 31);
-    const int k = ks * 16 + 8 * (lane >> 5) + j;
-    const int K = kh * kw * c_in;
-    float v = 0.0f;
-    if (n < c_out && k < K) {
-        const int tap = k / c_in, c = k - tap * c_in;
-        v = w[((size_t)n * c_in + c) * kh * kw + tap];
-    }
-    packed[i] = bf16_bits(v);
-}
-
-#include "fused_trunk_x3.h"
+#include "fused_trunk_split.h"
 
 static bool is_conv(const ipsx_conv& c, int ci, int co, int k, int s, int p) {
     return c.c_in == ci && c.c_out == co && c.kh == k && c.kw == k && c.stride == s && c.pad == p && c.w_packed &&
@@ -949,27 +616,23 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
     a.wh_down = t->blocks[2].down.w_packed_bf16;
     bf16 = bf16 && a.wh_down;
     if (t->precision != 0 && !bf16) return fail(IPSX_EINVAL, "fused trunk: precision %d needs w_packed_bf16 on every block conv", t->precision);
-    if (t->precision == 2) {
-        const size_t ldsx = (size_t)4 * SLABX;
-        static bool attr_x3 = false;
-        if (!attr_x3) {
+    if (t->precision == 2 || t->precision == 1) {      // the split trunks on the bf16 matrix pipe (fused_trunk_split.h)
+        const bool x3 = t->precision == 2;
+        const size_t ldsx = (size_t)4 * (x3 ? XL<3>::SLAB : XL<1>::SLAB);
+        static bool attr_split = false;
+        if (!attr_split) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_x3_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XL<3>::SLAB);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_x3_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-            attr_x3 = true;
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XL<3>::SLAB);
+            attr_split = true;
         }
-        if (stamps)
-            fused_trunk_x3_kernel<true><<<dim3((unsigned)cdiv(n, 4)), dim3(256), ldsx, s>>>(a, stamps);
-        else
-            fused_trunk_x3_kernel<false><<<dim3((unsigned)cdiv(n, 4)), dim3(256), ldsx, s>>>(a, nullptr);
-        return launched("fused_trunk_x3");
-    }
-    if (bf16) {
-        if (stamps) return fail(IPSX_EINVAL, "fused trunk: no stamp build of the bf16 kernel");
-        const size_t ldsh = (size_t)4 * SLABH;
-        fused_trunk_bf16_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), ldsh, s>>>(a);
-        return launched("fused_trunk_bf16");
+        const dim3 grid((unsigned)cdiv(n, 4)), block(256);
+        if (x3 && stamps) fused_trunk_x3_kernel<true><<<grid, block, ldsx, s>>>(a, stamps);
+        else if (x3) fused_trunk_x3_kernel<false><<<grid, block, ldsx, s>>>(a, nullptr);
+        else if (stamps) fused_trunk_bf16_kernel<true><<<grid, block, ldsx, s>>>(a, stamps);
+        else fused_trunk_bf16_kernel<false><<<grid, block, ldsx, s>>>(a, nullptr);
+        return launched(x3 ? "fused_trunk_x3" : "fused_trunk_bf16");
     }
     const size_t lds = (size_t)4 * SLAB * sizeof(float);
     static bool attr_set = false;
@@ -1006,7 +669,7 @@ IPSX_API int ipsx_pack_conv_weight_bf16(const float* w, int c_out, int c_in, int
     IPSX_REQUIRE(w && packed && c_out > 0 && c_in > 0 && kh > 0 && kw > 0, "pack_conv_weight_bf16: bad arguments");
     const size_t total = ipsx_packed_conv_weight_bf16_bytes(c_out, c_in, kh, kw) / 2;
     const int ksteps = (int)ipsx::cdiv((int64_t)kh * kw * c_in, 16);
-    ipsx::pack_conv_weight_bf16_kernel<<<dim3((unsigned)ipsx::cdiv(total, 256)), dim3(256), 0, ipsx::as_stream(stream)>>>(
+    ipsx::pack_conv_weight_split_kernel<1><<<dim3((unsigned)ipsx::cdiv(total, 256)), dim3(256), 0, ipsx::as_stream(stream)>>>(
         w, c_out, c_in, kh, kw, ksteps, total, static_cast<unsigned short*>(packed));
     return ipsx::launched("pack_conv_weight_bf16");
 }
@@ -1019,7 +682,7 @@ IPSX_API int ipsx_pack_conv_weight_x3(const float* w, int c_out, int c_in, int k
     IPSX_REQUIRE(w && packed && c_out > 0 && c_in > 0 && kh > 0 && kw > 0, "pack_conv_weight_x3: bad arguments");
     const size_t total = ipsx_packed_conv_weight_x3_bytes(c_out, c_in, kh, kw) / 2;
     const int ksteps = (int)ipsx::cdiv((int64_t)kh * kw * c_in, 16);
-    ipsx::pack_conv_weight_x3_kernel<<<dim3((unsigned)ipsx::cdiv(total, 256)), dim3(256), 0, ipsx::as_stream(stream)>>>(
+    ipsx::pack_conv_weight_split_kernel<3><<<dim3((unsigned)ipsx::cdiv(total, 256)), dim3(256), 0, ipsx::as_stream(stream)>>>(
         w, c_out, c_in, kh, kw, ksteps, total, static_cast<unsigned short*>(packed));
     return ipsx::launched("pack_conv_weight_x3");
 }
