@@ -136,7 +136,7 @@ def measure_fp32x3(net, x, args):
     return {"value": x.shape[0] * x.shape[1] * args.steps / dt, "unit": "patches/s", "ms_per_step": 1e3 * dt / args.steps,
             "same_indices_as_f32": same,
             "what": "IPSX_PRECISION=fp32x3: fp32 operands as 3 exact bf16 terms, 6 bf16 MFMA products, f32 accumulate; "
-                    "max error vs float64 6.1e-7 (exact-fp32 kernel: 3.7e-7), tests/test_hip_kernels.py"}
+                    "max error vs float64 6.3e-7 (exact-fp32 kernel: 3.7e-7), tests/test_hip_kernels.py"}
 
 
 def main():
@@ -271,8 +271,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "fp32x3": "f32 as 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate (stem f32)",
-                      "bf16": "bf16 operands / f32 accumulate (stem f32)"}[args.precision],
+            "dtype": {"fp32": "f32", "fp32x3": "f32 as 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate",
+                      "bf16": "bf16 operands / f32 accumulate"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "%s (%d per GPU), B=%d, M=%d, I=%d, n_token=%d, %s, eager"
                                    % (label, per_gpu, args.batch, conf.M, conf.I, conf.n_token,

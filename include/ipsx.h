@@ -80,6 +80,12 @@ size_t ipsx_packed_conv_weight_x3_bytes(int c_out, int c_in, int kh, int kw);
 int ipsx_pack_conv_weight_x3(const float* w_oihw, int c_out, int c_in, int kh, int kw,
                              void* packed, void* stream);
 
+/* stem of the split trunks (precision 1: planes = 1, precision 2: planes = 3): the (c_out, 1, 7, 7) weights as the
+ * B-operand stream of a contraction whose K is laid out as k = 8 ky + kx (zero weights for ky = 7 and kx = 7),
+ * [C_out/32][4][plane][64 lanes][8 bf16]; goes into the stem's ipsx_conv.w_packed_bf16                       */
+size_t ipsx_packed_stem_weight_split_bytes(int c_out, int planes);
+int ipsx_pack_stem_weight_split(const float* w_oihw, int c_out, int planes, void* packed, void* stream);
+
 typedef struct ipsx_conv {
     int c_in, c_out, kh, kw, stride, pad;
     const float* w_packed;        /* ipsx_pack_conv_weight output            */

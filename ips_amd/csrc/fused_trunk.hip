@@ -58,10 +58,20 @@ struct FusedArgs {
     const float *w_stem, *a_stem, *s_stem;
     const float *w[8], *al[8], *sh[8];       // l1.0.c1 l1.0.c2 l1.1.c1 l1.1.c2 l2.0.c1 l2.0.c2 l2.1.c1 l2.1.c2
     const float *w_down, *a_down, *s_down;
-    const void *wh[8], *wh_down;             // bf16 weight streams of the same convolutions (precision 1)
+    const void *wh[8], *wh_down, *wh_stem;   // bf16 operand streams of the same convolutions (precision 1 and 2)
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// bf16 matrix pipe, used by the split trunks (fused_trunk_split.h) and their stem
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+// plane pairs of the split product in issue order; 3 planes: (w.lo, x.hi) (w.hi, x.lo) (w.mid, x.mid) (w.mid, x.hi)
+// (w.hi, x.mid) (w.hi, x.hi) - the six significant ones, small terms first; 1 plane: the single bf16 product
+__device__ __forceinline__ constexpr int pair_w(int pl, int q) { return pl == 3 ? (q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0) : 0; }
+__device__ __forceinline__ constexpr int pair_x(int pl, int q) { return pl == 3 ? (q == 1 ? 2 : (q == 2 || q == 4) ? 1 : 0) : 0; }
 
 // Ordering point for a slab that only ONE wavefront touches (stem and 8x8 stage: wave = patch).
 // DS operations of a wavefront are executed in issue order, so a later ds_read of another lane
@@ -78,21 +88,45 @@ __device__ __forceinline__ void zero(f32x16& v) {
 // S: this wave's slab holding the ZERO-PADDED input as P[38][38] (image at rows/cols 3..34), so
 // every tap address is base + immediate and needs no halo mask.  On return idn[mt][nt] holds
 // the pooled 8x8x64 activation in MFMA C layout (lane = channel, rows = pixels).
+//
+// PL = 0: the exact path - fp32 image, v_mfma_f32_32x32x2_f32 in the contract's k order.
+// PL = 1 / 3 (split trunks): the padded image is PL bf16 planes of [38][SPW] elements and the contraction runs on
+// v_mfma_f32_32x32x16_bf16 with K laid out as k = 8 ky + kx (kx = 7 and ky = 7 carry zero weights): a lane half's
+// 8 k of a K-step are then 8 CONSECUTIVE pixels of one image row - four 4-byte LDS reads - instead of 25 scalar taps,
+// and the 49-tap contraction costs 4 K-steps x NP products x 32 cycles per tile against 25 x 64.
 constexpr int PW = 38;               // padded input width
+constexpr int SPW = 40;              // row pitch (elements) of the bf16 planes of the padded input
+constexpr int SPLANE = PW * SPW * 2; // bytes per plane
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-__device__ __forceinline__ void stem_pool(const FusedArgs& a, const float* S, f32x16 (&idn)[2][2], int lane) {
+template <int PL>
+__device__ __forceinline__ void stem_pool(const FusedArgs& a, const void* Sv, f32x16 (&idn)[2][2], int lane) {
+    constexpr int PLN = PL > 0 ? PL : 1, NP = PL == 3 ? 6 : 1;
+    const float* S = reinterpret_cast<const float*>(Sv);
+    const char* Sp = reinterpret_cast<const char*>(Sv);
     const int i = lane & 31, half = lane >> 5;
     const int ox = i & 15;
-    const float4* wp0 = reinterpret_cast<const float4*>(a.w_stem) + lane;      // n-tile 0, 7 k-groups
-    const float4* wp1 = wp0 + 7 * 64;
-    float bw0[28], bw1[28];                                                    // weights of the 28 k-steps
+    float bw0[28], bw1[28];                                                    // PL = 0: weights of the 28 k-steps
+    uint4 wq[2][4][PLN];                                                       // PL > 0: [n-tile][K-step][plane]
+    if constexpr (PL == 0) {
+        const float4* wp0 = reinterpret_cast<const float4*>(a.w_stem) + lane;  // n-tile 0, 7 k-groups
+        const float4* wp1 = wp0 + 7 * 64;
 #pragma unroll
-    for (int kg = 0; kg < 7; ++kg) {
-        const float4 v0 = wp0[kg * 64], v1 = wp1[kg * 64];
-        bw0[4 * kg] = v0.x; bw0[4 * kg + 1] = v0.y; bw0[4 * kg + 2] = v0.z; bw0[4 * kg + 3] = v0.w;
-        bw1[4 * kg] = v1.x; bw1[4 * kg + 1] = v1.y; bw1[4 * kg + 2] = v1.z; bw1[4 * kg + 3] = v1.w;
+        for (int kg = 0; kg < 7; ++kg) {
+            const float4 v0 = wp0[kg * 64], v1 = wp1[kg * 64];
+            bw0[4 * kg] = v0.x; bw0[4 * kg + 1] = v0.y; bw0[4 * kg + 2] = v0.z; bw0[4 * kg + 3] = v0.w;
+            bw1[4 * kg] = v1.x; bw1[4 * kg + 1] = v1.y; bw1[4 * kg + 2] = v1.z; bw1[4 * kg + 3] = v1.w;
+        }
+    } else {
+        const char* wb = reinterpret_cast<const char*>(a.wh_stem) + lane * 16;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < PLN; ++pl)
+                    wq[nt][ks][pl] = *reinterpret_cast<const uint4*>(wb + ((nt * 4 + ks) * PLN + pl) * 1024);
     }
     const float al0 = a.a_stem[i], sh0 = a.s_stem[i], al1 = a.a_stem[32 + i], sh1 = a.s_stem[32 + i];
 
@@ -109,23 +143,44 @@ __device__ __forceinline__ void stem_pool(const FusedArgs& a, const float* S, f3
         // k = 8kg + 4*half + j -> tap (k/7, k%7): the upper half's tap is 4 columns right of the
         // lower half's, or, when that leaves the 7-wide row (kx0 >= 3), 3 columns left one row down.
         const int oy = 2 * t + (i >> 4);
-        const float* base = S + (2 * oy) * PW + 2 * ox;
-        const float* baseN = base + half * 4;
-        const float* baseW = base + half * (PW - 3);
-        float av[25];
-#pragma unroll
-        for (int st = 0; st < 25; ++st) {                  // steps 0..23: k-groups 0..5; step 24: k = 48 (+ padding)
-            const int k0 = 8 * (st >> 2) + (st & 3), ky0 = k0 / 7, kx0 = k0 % 7;
-            av[st] = (kx0 <= 2) ? baseN[ky0 * PW + kx0] : baseW[ky0 * PW + kx0];
-        }
-        av[24] = half ? 0.0f : av[24];                     // k = 52 does not exist (zero weight): feed a clean 0
-        __builtin_amdgcn_sched_barrier(0);                 // all 25 LDS reads in flight before the MFMAs
         f32x16 acc0, acc1;
-        zero(acc0); zero(acc1);
+        if constexpr (PL == 0) {
+            const float* base = S + (2 * oy) * PW + 2 * ox;
+            const float* baseN = base + half * 4;
+            const float* baseW = base + half * (PW - 3);
+            float av[25];
 #pragma unroll
-        for (int st = 0; st < 25; ++st) {
-            acc0 = MFMA(av[st], bw0[st], acc0);
-            acc1 = MFMA(av[st], bw1[st], acc1);
+            for (int st = 0; st < 25; ++st) {              // steps 0..23: k-groups 0..5; step 24: k = 48 (+ padding)
+                const int k0 = 8 * (st >> 2) + (st & 3), ky0 = k0 / 7, kx0 = k0 % 7;
+                av[st] = (kx0 <= 2) ? baseN[ky0 * PW + kx0] : baseW[ky0 * PW + kx0];
+            }
+            av[24] = half ? 0.0f : av[24];                 // k = 52 does not exist (zero weight): feed a clean 0
+            __builtin_amdgcn_sched_barrier(0);             // all 25 LDS reads in flight before the MFMAs
+            zero(acc0); zero(acc1);
+#pragma unroll
+            for (int st = 0; st < 25; ++st) {
+                acc0 = MFMA(av[st], bw0[st], acc0);
+                acc1 = MFMA(av[st], bw1[st], acc1);
+            }
+        } else {
+            // K-step ks, half h: image row 2 oy + 2 ks + h, columns 2 ox .. 2 ox + 7 (4-byte aligned)
+            uint4 aq[4][PLN];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < PLN; ++pl) {
+                    const unsigned* p = reinterpret_cast<const unsigned*>(Sp + pl * SPLANE + ((2 * oy + 2 * ks + half) * SPW + 2 * ox) * 2);
+                    aq[ks][pl] = make_uint4(p[0], p[1], p[2], p[3]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            zero(acc0); zero(acc1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    acc0 = MFMA16(aq[ks][pair_x(PL, q)], wq[0][ks][pair_w(PL, q)], acc0);
+                    acc1 = MFMA16(aq[ks][pair_x(PL, q)], wq[1][ks][pair_w(PL, q)], acc1);
+                }
         }
         // BN + ReLU; column maxima over stem rows {2t-1, 2t, 2t+1} for the 8 columns this lane holds:
         // C reg r -> tile row r>>3, column (r&3) + 8*((r>>2)&1) + 4*half.
@@ -454,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
     // ---- stem + pool: result in registers = identity of block 1
     f32x16 idn[2][2], acc[2][2];
     IPSX_STAMP(1);
-    stem_pool(a, S, idn, lane);
+    stem_pool<0>(a, S, idn, lane);
     IPSX_STAMP(2);
     wave_fence();                                                      // the input is dead
     store_l1(S, idn, lane);
@@ -565,12 +620,6 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
     IPSX_STAMP(15);
 }
 
-// ---- bf16 matrix pipe: the split trunks (fp32x3 and plain bf16) share one template
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define MFMA16(a, b, c) \
-    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
-__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
-
 #include "fused_trunk_split.h"
 
 static bool is_conv(const ipsx_conv& c, int ci, int co, int k, int s, int p) {
@@ -614,8 +663,9 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
             bf16 = bf16 && a.wh[2 * k + j];
         }
     a.wh_down = t->blocks[2].down.w_packed_bf16;
-    bf16 = bf16 && a.wh_down;
-    if (t->precision != 0 && !bf16) return fail(IPSX_EINVAL, "fused trunk: precision %d needs w_packed_bf16 on every block conv", t->precision);
+    a.wh_stem = t->stem.w_packed_bf16;
+    bf16 = bf16 && a.wh_down && a.wh_stem;
+    if (t->precision != 0 && !bf16) return fail(IPSX_EINVAL, "fused trunk: precision %d needs w_packed_bf16 on the stem (ipsx_pack_stem_weight_split) and every block conv", t->precision);
     if (t->precision == 2 || t->precision == 1) {      // the split trunks on the bf16 matrix pipe (fused_trunk_split.h)
         const bool x3 = t->precision == 2;
         const size_t ldsx = (size_t)4 * (x3 ? XL<3>::SLAB : XL<1>::SLAB);
@@ -685,6 +735,21 @@ IPSX_API int ipsx_pack_conv_weight_x3(const float* w, int c_out, int c_in, int k
     ipsx::pack_conv_weight_split_kernel<3><<<dim3((unsigned)ipsx::cdiv(total, 256)), dim3(256), 0, ipsx::as_stream(stream)>>>(
         w, c_out, c_in, kh, kw, ksteps, total, static_cast<unsigned short*>(packed));
     return ipsx::launched("pack_conv_weight_x3");
+}
+
+IPSX_API size_t ipsx_packed_stem_weight_split_bytes(int c_out, int planes) {
+    return (planes == 1 || planes == 3) ? (size_t)ipsx::cdiv(c_out, 32) * 4 * planes * 1024 : 0;
+}
+
+IPSX_API int ipsx_pack_stem_weight_split(const float* w, int c_out, int planes, void* packed, void* stream) {
+    IPSX_REQUIRE(w && packed && c_out > 0 && (planes == 1 || planes == 3), "pack_stem_weight_split: bad arguments");
+    const size_t total = ipsx_packed_stem_weight_split_bytes(c_out, planes) / 2;
+    const dim3 grid((unsigned)ipsx::cdiv(total, 256)), block(256);
+    if (planes == 3)
+        ipsx::pack_stem_weight_split_kernel<3><<<grid, block, 0, ipsx::as_stream(stream)>>>(w, c_out, total, static_cast<unsigned short*>(packed));
+    else
+        ipsx::pack_stem_weight_split_kernel<1><<<grid, block, 0, ipsx::as_stream(stream)>>>(w, c_out, total, static_cast<unsigned short*>(packed));
+    return ipsx::launched("pack_stem_weight_split");
 }
 
 // Diagnostic entry point (not part of include/ipsx.h): the fused trunk with s_memtime stamps,

@@ -13,8 +13,9 @@
 //     reference has no reduced-precision path; this one is tolerance-tested against the fp32 kernel and a float64
 //     emulation that rounds at the same places.
 //
-// Structure = the fp32 kernel's (wave = patch in the 8x8 stage, 4 waves x 4 patches in the 4x4 stage, stem in exact
-// fp32, identity and BatchNorm / residual / ReLU in fp32 registers), with the contraction TRANSPOSED: weights are the
+// Structure = the fp32 kernel's (wave = patch in the 8x8 stage, 4 waves x 4 patches in the 4x4 stage; the stem runs on
+// the same pipe with a row-padded K, see stem_pool; identity and BatchNorm / residual / ReLU in fp32 registers), with
+// the contraction of the residual stages TRANSPOSED: weights are the
 // A operand (rows = output channels), activations the B operand (columns = pixels).  A lane then owns one pixel and 4
 // CONSECUTIVE channels per register quad, so the epilogue packs 4 bf16 per plane and stores 8 bytes at a time.
 //   LDS image   [pixel][plane][C bf16 + 8 pad]   8x8: PL x 144 B per pixel row, 4x4: PL x 272 B; one zero row (halo)
@@ -31,13 +32,9 @@ template <int PL> struct XL {
     static constexpr int R1 = PL * XP1, R2 = PL * XP2;            // bytes per pixel row
     static constexpr int SLAB = (XZ1 + 1) * R1;                   // 28,080 B (PL = 3) / 9,360 B (PL = 1) per patch
     static constexpr int NP = PL == 3 ? 6 : 1;                    // bf16 products per fp32 product
-    static_assert(SLAB >= PW * PW * 4 && SLAB >= (XZ2 + 1) * R2 && SLAB >= 16 * PS2 * 4 && SLAB >= 32 * PS1 * 4 &&
+    static_assert(SLAB >= PL * SPLANE && SLAB >= (XZ2 + 1) * R2 && SLAB >= 16 * PS2 * 4 && SLAB >= 32 * PS1 * 4 &&
                   SLAB % 16 == 0, "slab");
 };
-
-// plane pairs in issue order: PL = 3 -> (w.lo, x.hi) (w.hi, x.lo) (w.mid, x.mid) (w.mid, x.hi) (w.hi, x.mid) (w.hi, x.hi)
-__device__ __forceinline__ constexpr int pair_w(int pl, int q) { return pl == 3 ? (q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0) : 0; }
-__device__ __forceinline__ constexpr int pair_x(int pl, int q) { return pl == 3 ? (q == 1 ? 2 : (q == 2 || q == 4) ? 1 : 0) : 0; }
 
 __device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
@@ -356,25 +353,40 @@ __device__ __forceinline__ void fused_trunk_split_body(const FusedArgs& a, unsig
     float* S = reinterpret_cast<float*>(Sb);
     IPSX_STAMP(0);
 
-    // ---- fp32 input -> zero-padded 38x38 image
+    // ---- fp32 input -> PL bf16 planes of the zero-padded 38 x 38 image (row pitch SPW)
     {
         const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
         float4 px[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) px[k] = src[k * 64 + lane];
-        for (int z = lane; z < (PW * PW + 3) / 4; z += 64) reinterpret_cast<float4*>(S)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = lane; z < PL * SPLANE / 16; z += 64) reinterpret_cast<uint4*>(Sb)[z] = make_uint4(0u, 0u, 0u, 0u);
+        wave_fence();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int e = (k * 64 + lane) * 4, y = e >> 5, x = e & 31;
-            float* d = S + (y + 3) * PW + x + 3;
-            d[0] = px[k].x; d[1] = px[k].y; d[2] = px[k].z; d[3] = px[k].w;
+            const int e = (k * 64 + lane) * 4, y = e >> 5, x = e & 31;     // 4 pixels of row y starting at x (x % 4 == 0)
+            const float v[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+            unsigned short pl_bits[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned short h = bf16_bits(v[j]);
+                const float r1 = v[j] - __uint_as_float((unsigned)h << 16);
+                const unsigned short m = bf16_bits(r1);
+                pl_bits[0][j] = h; pl_bits[1][j] = m; pl_bits[2][j] = bf16_bits(r1 - __uint_as_float((unsigned)m << 16));
+            }
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) {                             // columns x+3 (odd), x+4..x+5 (aligned pair), x+6
+                char* d = Sb + pl * SPLANE + ((y + 3) * SPW + x + 3) * 2;
+                *reinterpret_cast<unsigned short*>(d) = pl_bits[pl][0];
+                *reinterpret_cast<unsigned*>(d + 2) = (unsigned)pl_bits[pl][1] | ((unsigned)pl_bits[pl][2] << 16);
+                *reinterpret_cast<unsigned short*>(d + 6) = pl_bits[pl][3];
+            }
         }
     }
     wave_fence();
 
     f32x16 idn[2][2], acc[2][2];
     IPSX_STAMP(1);
-    stem_pool(a, S, idn, lane);                      // exact fp32 stem + pool (standard layout)
+    stem_pool<PL>(a, Sb, idn, lane);                 // stem on the bf16 pipe + pool on the accumulators (standard layout)
     wave_fence();                                    // the input image is dead
     transpose_stem(S, idn, acc, lane);               // the identity: one pixel and 4 consecutive channels per lane quad
 #pragma unroll
@@ -479,6 +491,28 @@ __global__ void pack_conv_weight_split_kernel(const float* __restrict__ w, int c
         const int tap = k / c_in, c = k - tap * c_in;
         v = w[((size_t)n * c_in + c) * kh * kw + tap];
     }
+    const unsigned short h = bf16_bits(v);
+    const float r1 = v - __uint_as_float((unsigned)h << 16);
+    const unsigned short m = bf16_bits(r1);
+    const unsigned short l = bf16_bits(r1 - __uint_as_float((unsigned)m << 16));
+    packed[idx] = pl == 0 ? h : (pl == 1 ? m : l);
+}
+
+// Stem weights (C_out, 1, 7, 7) fp32 -> B-operand stream of the split stem [C_out/32][4 K-steps][plane][64 lanes][8]:
+// element j of lane l holds term `plane` of w[32 tile + (l&31)][ky = 2 step + (l>>5)][kx = j], zero for ky = 7 or kx = 7.
+template <int PL>
+__global__ void pack_stem_weight_split_kernel(const float* __restrict__ w, int c_out, size_t total,
+                                              unsigned short* __restrict__ packed) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7);
+    const int lane = (int)((idx >> 3) & 63);
+    const size_t gp = idx >> 9;
+    const int pl = (int)(gp % PL);
+    const size_t g = gp / PL;
+    const int ks = (int)(g & 3), nt = (int)(g >> 2);
+    const int n = nt * 32 + (lane & 31), ky = 2 * ks + (lane >> 5), kx = j;
+    const float v = (n < c_out && ky < 7 && kx < 7) ? w[(size_t)n * 49 + ky * 7 + kx] : 0.0f;
     const unsigned short h = bf16_bits(v);
     const float r1 = v - __uint_as_float((unsigned)h << 16);
     const unsigned short m = bf16_bits(r1);

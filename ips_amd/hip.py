@@ -107,6 +107,8 @@ _EXPORTS = {
     "ipsx_pack_conv_weight_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_packed_conv_weight_x3_bytes": (C.c_size_t, [C.c_int] * 4),
     "ipsx_pack_conv_weight_x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_packed_stem_weight_split_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ipsx_pack_stem_weight_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_bn_affine": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_affine": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -246,12 +248,19 @@ class EncoderPlan:
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)
 
-    def _conv(self, conv, bn, prec=0):
+    def _conv(self, conv, bn, prec=0, stem=False):
         packed = _pack_conv(conv.weight)
         aff = _bn_affine(bn)
         self._keep += [packed, aff]
         half = None
-        if prec:
+        if prec and stem:
+            if tuple(conv.weight.shape[1:]) == (1, 7, 7):     # the split trunks exist for the 1x32x32 stem only
+                w = _f32(conv.weight.detach())
+                planes = 1 if prec == 1 else 3
+                half = torch.empty(lib().ipsx_packed_stem_weight_split_bytes(w.shape[0], planes), dtype=torch.uint8, device=w.device)
+                _ck(lib().ipsx_pack_stem_weight_split(_p(w), w.shape[0], planes, _p(half), _stream()), "ipsx_pack_stem_weight_split")
+                self._keep.append(half)
+        elif prec:
             w = _f32(conv.weight.detach())
             co, ci, kh, kw = w.shape
             size, pack = ((lib().ipsx_packed_conv_weight_bf16_bytes, lib().ipsx_pack_conv_weight_bf16) if prec == 1 else
@@ -283,7 +292,7 @@ class EncoderPlan:
                     blocks.append(b)
             self._blocks = (Block * len(blocks))(*blocks)
             t = Trunk()
-            t.stem = self._conv(mods[0], mods[1])
+            t.stem = self._conv(mods[0], mods[1], bf16, stem=True)
             t.c_in = mods[0].in_channels
             t.n_block = len(blocks)
             t.blocks = C.cast(self._blocks, C.POINTER(Block))

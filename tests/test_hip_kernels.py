@@ -232,14 +232,14 @@ def test_bf16_trunk_tracks_fp32_within_tolerance(monkeypatch):
     rel = ((got.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-12))
     assert float(rel.max()) < 3e-2, float(rel.max())
 
-    # emulation: stem in fp32; every block conv sees bf16-rounded input and bf16-rounded weights
+    # emulation: every conv (stem included) sees bf16-rounded input and bf16-rounded weights
     import torch.nn.functional as F
     sd = {k: v.detach().double().cpu() for k, v in net.encoder.state_dict().items()}
     r16 = lambda t: t.float().to(torch.bfloat16).double()
     def bn(y, p):
         return (y - sd[p + ".running_mean"][None, :, None, None]) / torch.sqrt(sd[p + ".running_var"] + 1e-5)[None, :, None, None] \
             * sd[p + ".weight"][None, :, None, None] + sd[p + ".bias"][None, :, None, None]
-    y = F.relu(bn(F.conv2d(x.double().cpu(), sd["0.weight"], None, 2, 3), "1"))
+    y = F.relu(bn(F.conv2d(r16(x.double().cpu()), r16(sd["0.weight"]), None, 2, 3), "1"))
     y = F.max_pool2d(y, 3, 2, 1)
     for st, stride in ((4, 1), (5, 2)):
         for blk in (0, 1):
