@@ -287,7 +287,7 @@ def main():
                          "launch_ms": enc_ms / max(len(enc_events), 1),
                          "patches_per_launch": enc_patches / max(len(enc_events), 1)},
         }
-        if args.precision == "bf16":    # priced against the dense bf16 MFMA peak; the fp32 stem is 4 % of the FLOP
+        if args.precision == "bf16":    # priced against the dense bf16 MFMA peak
             out["roofline"]["peak"] = 2500.0
             out["roofline"]["frac"] = achieved / 2500.0
         if args.precision == "fp32x3":  # six bf16 products per fp32 product: the bf16 peak / 6 bounds the algorithmic rate
