@@ -220,6 +220,70 @@ def _all_reduce(t, group):
     return host.to(t.device)
 
 
+def slab_span(N, rank, world):
+    """[lo, hi) of the contiguous slab a rank holds in the tournament scheme."""
+    per = -(-N // world)
+    return min(rank * per, N), min((rank + 1) * per, N)
+
+
+@torch.no_grad()
+def ips_tournament(net, local_patches, N, group=None):
+    """The north star's literal multi-GPU scheme, opt-in: rank r runs the WHOLE selection loop
+    on its own contiguous slab ``patches[:, slab_span(N, r, world)]`` (local memory of M), ONE all-gather moves the M
+    winning embeddings and their global indices of every rank ((B, M, D) floats + (B, M) int64: 33 KB per image at the
+    MNIST sizes), and every rank runs one final top-M step over the world*M candidates (rank order).
+
+    This is a tournament, NOT the reference's selection: per-head softmax denominators depend on the candidate set, so
+    slab winners are not the global winners in general.  It is checked against its own CPU restatement
+    (``oracle.Oracle.tournament``); the result-identical scheme - and the one bench.py measures - is ``ips_sharded``.
+    Returns ``(mem_patch, mem_pos, mem_idx)`` identical on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    M, D = net.M, net.D
+    lo, hi = slab_span(N, rank, world)
+    B, n_local = local_patches.shape[:2]
+    assert n_local == hi - lo, "rank %d expects %d patches, got %d" % (rank, hi - lo, n_local)
+    dev = local_patches.device
+    was_training = net.training
+    if was_training:
+        net.encoder.eval(); net.transf.eval()
+    try:
+        pos = net.pos_enc[:, lo:hi].expand(B, -1, -1) if net.use_pos else None
+        k = min(M, n_local)                                      # a slab no larger than the memory keeps everything
+        if n_local > M:
+            net._emb_parts = net._mem_emb = None
+            loc = net._select_hip(local_patches, pos) if hip.on_device(dev) else net._select_aten(local_patches, pos)
+            net.last_mem_idx = loc
+            emb = net.last_mem_emb                               # (B, M, D) embeddings of the slab's winners
+        else:
+            loc = torch.arange(n_local, dtype=torch.int64, device=dev).unsqueeze(0).expand(B, -1)
+            emb = net._embed(local_patches.reshape(-1, *local_patches.shape[2:])).view(B, n_local, D)
+        mine_emb = torch.zeros((B, M, D), dtype=torch.float32, device=dev)
+        mine_idx = torch.full((B, M), -1, dtype=torch.int64, device=dev)
+        mine_emb[:, :k] = emb
+        mine_idx[:, :k] = loc + lo
+        all_emb = _all_gather(mine_emb, world, group).permute(1, 0, 2, 3).reshape(B, world * M, D)
+        all_idx = _all_gather(mine_idx, world, group).permute(1, 0, 2).reshape(B, world * M)
+        valid = all_idx[0] >= 0                                   # slab sizes are the same for every image
+        cand_emb, cand_idx = all_emb[:, valid].contiguous(), all_idx[:, valid].contiguous()
+        cand_pos = None
+        if net.use_pos:
+            cand_pos = cand_emb + torch.gather(net.pos_enc.expand(B, -1, -1), 1, cand_idx.unsqueeze(-1).expand(-1, -1, D))
+        _, mem_idx = net.score_and_select(cand_emb, cand_pos, M, cand_idx)
+
+        owned = (mem_idx >= lo) & (mem_idx < hi)
+        local_idx = torch.where(owned, mem_idx - lo, torch.zeros_like(mem_idx)).clamp_(0, max(n_local - 1, 0))
+        mem_patch = _take(local_patches, local_idx)
+        mem_patch = mem_patch * owned.view(B, M, *(1,) * (mem_patch.dim() - 2)).to(mem_patch.dtype)
+        mem_patch = _all_reduce(mem_patch, group)
+        mem_pos = _take(net.pos_enc, mem_idx) if net.use_pos else None
+    finally:
+        if was_training:
+            net.encoder.train(); net.transf.train()
+    net.last_mem_idx = mem_idx
+    net._emb_parts = net._mem_emb = None
+    return mem_patch, mem_pos, mem_idx
+
+
 def _take(src, idx):
     if hip.on_device(src):
         return hip.gather_rows(src, idx)

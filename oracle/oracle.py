@@ -252,6 +252,34 @@ class Oracle:
         out["mem_pos"] = np.stack([pos[b][idx[b]] for b in range(B)]) if self.use_pos else None
         return out
 
+    def tournament(self, patches, pos_enc, world):
+        """The north star's literal multi-GPU scheme, restated: the patch axis is cut into
+        `world` contiguous slabs, every slab runs the full selection loop on its own (local memory of M), and one final
+        top-M step over the world*M slab winners (slab order, each slab's winners in its final order) picks the
+        result.  NOT the single-device selection (softmax denominators differ per slab) - this is the checker of
+        ips_amd.dist.ips_tournament only.  Returns mem_idx (B, M) global indices."""
+        patches = np.ascontiguousarray(patches, dtype=np.float32)
+        B, N = patches.shape[:2]
+        M = self.M
+        emb = self.encode(patches.reshape(B * N, *patches.shape[2:])).reshape(B, N, self.D)
+        pos = np.broadcast_to(np.asarray(pos_enc, dtype=np.float32), (B, N, self.D)) if self.use_pos else None
+        per = -(-N // world)
+        cand = []
+        for r in range(world):
+            lo, hi = min(r * per, N), min((r + 1) * per, N)
+            if hi - lo <= M:                                   # a slab no larger than the memory keeps everything
+                cand.append(np.broadcast_to(np.arange(lo, hi, dtype=np.int64), (B, hi - lo)))
+                continue
+            loc = self.scan(emb[:, lo:hi], pos[:, lo:hi] if pos is not None else None)["mem_idx"]
+            cand.append(loc + lo)
+        cand = np.concatenate(cand, axis=1)                    # (B, <= world*M)
+        out = np.empty((B, M), dtype=np.int64)
+        for b in range(B):
+            x = emb[b][cand[b]] + (pos[b][cand[b]] if pos is not None else 0)
+            top, _ = topm(self.scores(x), M)
+            out[b] = cand[b][top]
+        return out
+
     def aggregate(self, x):
         """Transformer.forward: x (B,M,D) -> (B,T,D)"""
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -43,6 +43,38 @@ def _worker(rank, world, port, case, out):
         dist.destroy_process_group()
 
 
+def _tournament_worker(rank, world, port, case, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import Oracle
+        g = Golden(case)
+        net = g.net("cpu")
+        x = g.patches()
+        N = x.shape[1]
+        lo, hi = ipsd.slab_span(N, rank, world)
+        mem_patch, mem_pos, mem_idx = ipsd.ips_tournament(net, x[:, lo:hi].contiguous(), N)
+        want = Oracle(net).tournament(x.numpy(), net.pos_enc.numpy() if g.conf.use_pos else None, world)
+        ok = np.array_equal(mem_idx.numpy(), want)
+        ok = ok and torch.equal(mem_patch, torch.stack([x[b][mem_idx[b]] for b in range(x.shape[0])]))
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("mnist_ragged", 2), ("cam_b2", 3)])
+def test_tournament_mode_equals_its_restatement(case, world):
+    """SURVEY 8 e-3, the north star's literal scheme (opt-in): every rank selects on its own slab, one all-gather of
+    the M winners' embeddings, one final top-M step - checked against oracle.Oracle.tournament (it is NOT the
+    reference's selection, which ips_sharded reproduces)."""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_tournament_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
+        assert dict(out) == {r: True for r in range(world)}
+
+
 @pytest.mark.parametrize("case", ["mnist_ragged", "cam_b2"])   # N = 301 (odd, padded slab) and features
 def test_sharded_ips_equals_single_process(case):
     world = 2

@@ -227,6 +227,12 @@ def test_sharded_path_world_size_2_on_one_gpu():
     out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count(" ok") == 6 and "MISMATCH" not in out.stdout
+    # the opt-in tournament scheme against its CPU restatement, same transport
+    cmd = cmd[:cmd.index("--cases")] + ["--tournament", "--cases", "mnist_ragged,mnist_full,cam_b2"]
+    cmd[cmd.index("29547")] = "29548"
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("tournament ok") == 6 and "MISMATCH" not in out.stdout
 
 
 def test_training_step_between_ips_calls():

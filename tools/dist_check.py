@@ -25,6 +25,7 @@ from tests.util import Golden               # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--backend", default="nccl")
 ap.add_argument("--share-gpu", action="store_true")
+ap.add_argument("--tournament", action="store_true", help="check ips_tournament against oracle.Oracle.tournament instead")
 ap.add_argument("--cases", default="mnist_ragged,mnist_full,mnist_native50,cam_b2,cam_small,traffic_tiny")
 args = ap.parse_args()
 
@@ -45,6 +46,17 @@ try:
         net = g.net(dev)
         x = g.patches().to(dev)
         N = x.shape[1]
+        if args.tournament:
+            from oracle.oracle import Oracle
+            lo, hi = ipsd.slab_span(N, rank, world)
+            mem_patch, mem_pos, mem_idx = ipsd.ips_tournament(net, x[:, lo:hi].contiguous(), N)
+            cpu = g.net("cpu")
+            want = Oracle(cpu).tournament(g.patches().numpy(), cpu.pos_enc.numpy() if g.conf.use_pos else None, world)
+            ok = np.array_equal(mem_idx.cpu().numpy(), want)
+            ok = ok and torch.equal(mem_patch, torch.stack([x[b][mem_idx[b]] for b in range(x.shape[0])]))
+            print("rank %d/%d %-14s N=%-6d tournament %s" % (rank, world, case, N, "ok" if ok else "MISMATCH"), flush=True)
+            bad += not ok
+            continue
         mine = ipsd.local_indices(N, net.M, net.I, rank, world).to(dev)
         mem_patch, mem_pos, mem_idx = ipsd.ips_sharded(net, x[:, mine].contiguous(), N)
         full_patch, full_pos = net.ips(x)
