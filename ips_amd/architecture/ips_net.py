@@ -248,19 +248,18 @@ class IPSNet(nn.Module):
     # reached, so it runs on a side stream over the part of the image that is already encoded while the
     # encoder works on the next part (ipsx_scan_range resumes from the memory indices).  Only the last part's
     # iterations are exposed - this is what keeps the scan off the critical path when the image (and with it
-    # the iteration count) grows across GPUs.  Parts are cut at chunk boundaries and encoded through an index
-    # list, so nothing is copied.  IPSX_OVERLAP_SCAN=0 switches it off.
+    # the iteration count) grows across GPUs.  Parts are cut at chunk boundaries; the fused trunk encodes a part
+    # through an index list (nothing is copied), every other encoder through a slice of the patch axis.  With
+    # feature inputs (projector) the loop is the long pole instead, and the parts GROW so that it starts at once
+    # (dist.PART_SHARES_LOOP_BOUND).  IPSX_OVERLAP_SCAN=0 switches it off.
     _OVERLAP_PARTS = 4
 
     def _can_overlap(self, patches):
         import os
-        if os.environ.get("IPSX_OVERLAP_SCAN", "1") == "0" or hip.dedup_blank() or not self.is_image:
+        if os.environ.get("IPSX_OVERLAP_SCAN", "1") == "0" or hip.dedup_blank():
             return False
-        if self._plan is None:
-            self._plan = hip.EncoderPlan(self.encoder, self.is_image)
         n_iter = math.ceil((patches.shape[1] - self.M) / self.I)
-        return (not self.encoder.training) and patches.is_contiguous() and n_iter >= 2 * self._OVERLAP_PARTS \
-            and self._plan.fused(patches.shape)
+        return (not self.encoder.training) and n_iter >= 2 * self._OVERLAP_PARTS
 
     def _select_hip_overlapped(self, patches, pos_enc):
         B, N = patches.shape[:2]
@@ -269,13 +268,17 @@ class IPSNet(nn.Module):
         qs = ca.scaled_query()
         wk = hip.pack_linear(ca.k_w.weight)
         n_iter = math.ceil((N - M) / I)
-        from ..dist import part_iterations                          # parts shrink towards the end: only the last scan is exposed
-        its = part_iterations(n_iter, self._OVERLAP_PARTS)
+        from ..dist import PART_SHARES_LOOP_BOUND, part_iterations
+        if self._plan is None:
+            self._plan = hip.EncoderPlan(self.encoder, self.is_image)
+        indexed = self.is_image and patches.is_contiguous() and self._plan.fused(patches.shape)
+        # image encoders: parts shrink towards the end (only the last scan is exposed); projector: they grow
+        its = part_iterations(n_iter, self._OVERLAP_PARTS, None if self.is_image else PART_SHARES_LOOP_BOUND)
         P = len(its) - 1
         edges = [0] + [min(N, M + it * I) for it in its[1:]]
         edges[-1] = N
         key = (B, N, tuple(edges), str(dev))
-        if getattr(self, "_part_index_key", None) != key:            # int32 patch indices of every part, cached
+        if indexed and getattr(self, "_part_index_key", None) != key:  # int32 patch indices of every part, cached
             rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1) * N
             self._part_index = [(rows + torch.arange(edges[k], edges[k + 1], device=dev, dtype=torch.int32)).reshape(-1)
                                 for k in range(P)]
@@ -283,7 +286,7 @@ class IPSNet(nn.Module):
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
             self._side_stream = torch.cuda.Stream(device=dev, priority=-1)   # its few workgroups must not queue behind the encoder grid
         side, main = self._side_stream, torch.cuda.current_stream(dev)
-        flat = patches.reshape(B * N, *patches.shape[2:])
+        flat = patches.reshape(B * N, *patches.shape[2:]) if indexed else None
         logits = torch.empty((B, N, ca.H * ca.n_token), dtype=torch.float32, device=dev)
         mem_idx = torch.empty((B, M), dtype=torch.int64, device=dev)
         tie = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -292,7 +295,10 @@ class IPSNet(nn.Module):
         self._emb_parts = parts = []
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
-            emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
+            if indexed:
+                emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
+            else:
+                emb = self._embed(patches[:, lo:hi].reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             parts.append(emb)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
             hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])

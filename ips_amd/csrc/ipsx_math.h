@@ -20,11 +20,12 @@ __device__ __forceinline__ uint32_t as_u32(float f) { return __float_as_uint(f);
 // exp(): Cody-Waite reduction by ln2 = C1 + C2, degree-5 Horner polynomial,
 // exponent rebuilt from bits (two-step scaling in the subnormal range).
 __device__ __forceinline__ float det_expf(float x) {
-    if (x != x) return x;
-    if (x > 88.72f) return __builtin_huge_valf();
-    if (x < -104.0f) return 0.0f;
-    float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693359375f, x);
+    // branch-free form of the oracle's det_expf (same operations on the lanes that take its main path, selects for
+    // the special cases): divergent early returns would serialise a wavefront whose lanes mix ranges
+    const bool is_nan = x != x, big = x > 88.72f, small = x < -104.0f;
+    const float xc = (is_nan || big || small) ? 0.0f : x;
+    float n = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, xc);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
@@ -35,16 +36,15 @@ __device__ __forceinline__ float det_expf(float x) {
     float r2 = r * r;
     float y = __builtin_fmaf(p, r2, r);
     y = y + 1.0f;
-    int ni = (int)n;
-    if (ni < -126) {
-        y = y * as_float((uint32_t)(ni + 127 + 64) << 23);
-        return y * 5.42101086242752217e-20f;  // 2^-64
-    }
-    if (ni > 127) {
-        y = y * as_float((uint32_t)(ni + 126) << 23);
-        return y * 2.0f;
-    }
-    return y * as_float((uint32_t)(ni + 127) << 23);
+    const int ni = (int)n;
+    // y * 2^ni, in two exact power-of-two steps where 2^ni itself is not a normal float
+    const bool sub = ni < -126, top = ni > 127;
+    const int e1 = sub ? ni + 127 + 64 : (top ? ni + 126 : ni + 127);
+    const float s2 = sub ? 5.42101086242752217e-20f /* 2^-64 */ : (top ? 2.0f : 1.0f);
+    float res = (y * as_float((uint32_t)e1 << 23)) * s2;
+    res = small ? 0.0f : res;
+    res = big ? __builtin_huge_valf() : res;
+    return is_nan ? x : res;
 }
 
 // xor-butterfly sum over the 64 lanes, offsets 32,16,...,1: every lane ends with

@@ -349,17 +349,79 @@ __device__ __forceinline__ void rank_scatter(const uint64_t* src, uint64_t* dst,
 //      larger keys there, found by a branch-free binary search (7 LDS reads per run, the
 //      searches of all runs in flight together).
 // src/dst hold L keys (dst gets them sorted); runs is scratch for 64 * ceil(L/64) keys.
-__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint64_t other = __shfl_xor(key, j, 64);
-            const bool take_max = ((lane & k) == 0) == ((lane & j) == 0);
-            const bool gt = key > other;
-            key = (take_max == gt) ? key : other;
-        }
+// partner's key for the exchange with lane ^ J.  Strides 1, 2, 4 and 8 stay inside a row of 16 lanes and use DPP
+// (register-to-register, no LDS crossbar): quad permutes, a row shift pair, a row rotate; 16 and 32 go through
+// ds_bpermute (__shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+template <int J>
+__device__ __forceinline__ uint64_t xor_partner(uint64_t key, int lane) {
+    if (J == 1) return dpp64<0xB1>(key);                         // quad_perm [1,0,3,2]
+    if (J == 2) return dpp64<0x4E>(key);                         // quad_perm [2,3,0,1]
+    if (J == 4) {                                                // row_shl:4 (lane i <- i+4) / row_shr:4 (lane i <- i-4)
+        const uint64_t up = dpp64<0x104>(key), down = dpp64<0x114>(key);
+        return (lane & 4) ? down : up;
     }
+    if (J == 8) return dpp64<0x128>(key);                        // row_ror:8 inside the row of 16
+    return __shfl_xor(key, J, 64);
+}
+
+template <int J>
+__device__ __forceinline__ float xor_partner_f32(float v, int lane) {
+    const int x = __float_as_int(v);
+    if (J == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));
+    if (J == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));
+    if (J == 4) {
+        const int up = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0xF, true);
+        const int down = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+        return __int_as_float((lane & 4) ? down : up);
+    }
+    if (J == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true));
+    return __shfl_xor(v, J, 64);
+}
+
+// the wavefront reductions of the contract (xor butterfly, offsets 32 ... 1) on two values at once; the four short
+// strides stay in the row of 16 lanes (DPP), only 32 and 16 cross it
+__device__ __forceinline__ void wave_max2(float& a, float& b, int lane) {
+    a = nanmax(a, xor_partner_f32<32>(a, lane)); b = nanmax(b, xor_partner_f32<32>(b, lane));
+    a = nanmax(a, xor_partner_f32<16>(a, lane)); b = nanmax(b, xor_partner_f32<16>(b, lane));
+    a = nanmax(a, xor_partner_f32<8>(a, lane)); b = nanmax(b, xor_partner_f32<8>(b, lane));
+    a = nanmax(a, xor_partner_f32<4>(a, lane)); b = nanmax(b, xor_partner_f32<4>(b, lane));
+    a = nanmax(a, xor_partner_f32<2>(a, lane)); b = nanmax(b, xor_partner_f32<2>(b, lane));
+    a = nanmax(a, xor_partner_f32<1>(a, lane)); b = nanmax(b, xor_partner_f32<1>(b, lane));
+}
+
+__device__ __forceinline__ void wave_sum2(float& a, float& b, int lane) {
+    a = a + xor_partner_f32<32>(a, lane); b = b + xor_partner_f32<32>(b, lane);
+    a = a + xor_partner_f32<16>(a, lane); b = b + xor_partner_f32<16>(b, lane);
+    a = a + xor_partner_f32<8>(a, lane); b = b + xor_partner_f32<8>(b, lane);
+    a = a + xor_partner_f32<4>(a, lane); b = b + xor_partner_f32<4>(b, lane);
+    a = a + xor_partner_f32<2>(a, lane); b = b + xor_partner_f32<2>(b, lane);
+    a = a + xor_partner_f32<1>(a, lane); b = b + xor_partner_f32<1>(b, lane);
+}
+
+template <int K, int J>
+__device__ __forceinline__ uint64_t cmpx(uint64_t key, int lane) {
+    const uint64_t other = xor_partner<J>(key, lane);
+    const bool take_max = ((lane & K) == 0) == ((lane & J) == 0);
+    const bool gt = key > other;
+    return (take_max == gt) ? key : other;
+}
+
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
+    key = cmpx<2, 1>(key, lane);
+    key = cmpx<4, 2>(key, lane); key = cmpx<4, 1>(key, lane);
+    key = cmpx<8, 4>(key, lane); key = cmpx<8, 2>(key, lane); key = cmpx<8, 1>(key, lane);
+    key = cmpx<16, 8>(key, lane); key = cmpx<16, 4>(key, lane); key = cmpx<16, 2>(key, lane); key = cmpx<16, 1>(key, lane);
+    key = cmpx<32, 16>(key, lane); key = cmpx<32, 8>(key, lane); key = cmpx<32, 4>(key, lane); key = cmpx<32, 2>(key, lane);
+    key = cmpx<32, 1>(key, lane);
+    key = cmpx<64, 32>(key, lane); key = cmpx<64, 16>(key, lane); key = cmpx<64, 8>(key, lane); key = cmpx<64, 4>(key, lane);
+    key = cmpx<64, 2>(key, lane); key = cmpx<64, 1>(key, lane);
     return key;
 }
 
@@ -374,19 +436,32 @@ __device__ __forceinline__ void rank_runs(const uint64_t* src, uint64_t* dst, ui
     }
     __syncthreads();
     if (wave < nruns && mine != 0ull) {
-        int rank = lane;
-        int lo[16];
+        // rank = number of larger keys over ALL runs (in the own run that is the lane index: keys are unique), found
+        // by branch-free binary searches, 8 runs at a time with their LDS reads in flight together - no per-run
+        // control flow, which would serialise the 7 dependent reads of every search
+        int rank = 0;
+        for (int r0 = 0; r0 < nruns; r0 += 8) {
+            int lo[8];
+            const uint64_t* base[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lo[r] = 0;
+            for (int j = 0; j < 8; ++j) {
+                lo[j] = 0;
+                base[j] = runs + (r0 + j < nruns ? r0 + j : nruns - 1) * 64;      // clamped: a duplicate search, not counted
+            }
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
+            for (int step = 32; step >= 1; step >>= 1) {
+                uint64_t probe[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (r < nruns && r != wave) lo[r] += (runs[r * 64 + lo[r] + step - 1] > mine) ? step : 0;
+                for (int j = 0; j < 8; ++j) probe[j] = base[j][lo[j] + step - 1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lo[j] += (probe[j] > mine) ? step : 0;
+            }
+            uint64_t last[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) last[j] = base[j][lo[j]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rank += (r0 + j < nruns) ? lo[j] + ((last[j] > mine) ? 1 : 0) : 0;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (r < nruns && r != wave) rank += lo[r] + ((runs[r * 64 + lo[r]] > mine) ? 1 : 0);
         dst[rank] = mine;
     }
 }
@@ -444,6 +519,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
     // lanes per candidate for the counting rank (uniform)
     int P = 1;
     while (P < 64 && 2 * P * std::min(Lmax, 192) <= SCAN_NT) P <<= 1;
+    // element e = tid + SCAN_NT * k of an (rows, R) array is (row, column) = (e / R, e % R): the split of tid is made
+    // once, and a step of SCAN_NT elements advances it by (dq, dr) - no integer division inside the loop
+    const int dq = SCAN_NT / R, dr = SCAN_NT - dq * R;
+    const int row0 = tid / R, col0 = tid - row0 * R;
+    const int log2T = __ffs(a.T) - 1;                  // used only when T is a power of two
+#define SCAN_ADVANCE(l, r) do { l += dq; r += dr; if (r >= R) { r -= R; ++l; } } while (0)
     int tie = 0;
     uint64_t* sorted = keyA;
     for (long long it = a.it0; it < a.it1; ++it) {
@@ -451,10 +532,14 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = a.m + cnt;
         // chunk registers -> candidate rows m.., next chunk -> registers
+        {
+            int l = row0, r = col0;
 #pragma unroll
-        for (int k = 0; k < SCAN_PF; ++k) {
-            const int e = tid + SCAN_NT * k;
-            if (e < cnt * R) { const int l = e / R; cl[(a.m + l) * ld + (e - l * R)] = pf[k]; }
+            for (int k = 0; k < SCAN_PF; ++k) {
+                const int e = tid + SCAN_NT * k;
+                if (e < cnt * R) cl[(a.m + l) * ld + r] = pf[k];
+                SCAN_ADVANCE(l, r);
+            }
         }
         for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
         {
@@ -477,21 +562,23 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
                 m0 = nanmax(m0, cl[i * ld + r0]);
                 if (has1) m1 = nanmax(m1, cl[i * ld + r1]);
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                m0 = nanmax(m0, __shfl_xor(m0, off, 64));
-                m1 = nanmax(m1, __shfl_xor(m1, off, 64));
-            }
+            wave_max2(m0, m1, lane);
+            // lane j sums its strided elements in ascending order (the contract); four exponentials are computed at a
+            // time so their dependent chains overlap - out-of-range slots add an exact + 0.0
             float s0 = 0.0f, s1 = 0.0f;
-            for (int i = lane; i < L; i += 64) {
-                s0 = s0 + det_expf(cl[i * ld + r0] - m0);
-                if (has1) s1 = s1 + det_expf(cl[i * ld + r1] - m1);
-            }
+            for (int i0 = lane; i0 < L; i0 += 256) {
+                float e0[4], e1[4];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                s0 = s0 + __shfl_xor(s0, off, 64);
-                s1 = s1 + __shfl_xor(s1, off, 64);
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 64 * u;
+                    const bool ok = i < L;
+                    e0[u] = ok ? det_expf(cl[(ok ? i : 0) * ld + r0] - m0) : 0.0f;
+                    e1[u] = (ok && has1) ? det_expf(cl[(ok ? i : 0) * ld + r1] - m1) : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s0 = s0 + e0[u]; s1 = s1 + e1[u]; }
             }
+            wave_sum2(s0, s1, lane);
             if (lane == 0) {
                 rmax[r0] = m0; rden[r0] = s0;
                 if (has1) { rmax[r1] = m1; rden[r1] = s1; }
@@ -500,9 +587,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         __syncthreads();
         SCAN_STAMP(1);
         // attention weight of every (candidate, head, token)
-        for (int e = tid; e < L * R; e += SCAN_NT) {
-            const int l = e / R, r = e - l * R;
-            abuf[e] = det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
+        {
+            int l = row0, r = col0;
+            for (int e = tid; e < L * R; e += SCAN_NT) {
+                abuf[e] = det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
+                SCAN_ADVANCE(l, r);
+            }
         }
         __syncthreads();
         SCAN_STAMP(2);
@@ -511,7 +601,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         // chain); the T lanes of a candidate are adjacent, so the token sum is a few lane reads.
         if ((a.T & (a.T - 1)) == 0 && a.T <= 64 && a.h <= 16) {
             for (int e0 = 0; e0 < a.n2 * a.T; e0 += SCAN_NT) {
-                const int e = e0 + tid, l = e / a.T, t = e - l * a.T;
+                const int e = e0 + tid, l = e >> log2T, t = e - (l << log2T);
                 float q = 0.0f;
                 if (l < L) {
                     float v[16];
@@ -562,9 +652,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         SCAN_STAMP(4);
         // new memory: indices and logit rows of the winners, into the other buffers
         for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
-        for (int e = tid; e < a.m * R; e += SCAN_NT) {
-            const int j = e / R, r = e - j * R;
-            clnew[j * ld + r] = cl[key_pos(sorted[j]) * ld + r];
+        {
+            int j = row0, r = col0;
+            for (int e = tid; e < a.m * R; e += SCAN_NT) {
+                clnew[j * ld + r] = cl[key_pos(sorted[j]) * ld + r];
+                SCAN_ADVANCE(j, r);
+            }
         }
         if (tid == 0 && L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m])) tie = 1;   // (NaN never equal: harmless)
         { int* t = cand; cand = cnew; cnew = t; }

@@ -37,10 +37,17 @@ PARTS = 4
 PART_SHARES = (0.5, 0.8, 0.95, 1.0)
 
 
-def part_iterations(n_iter, parts=PARTS):
+# When the loop, not the encoder, is the long pole (feature inputs: a projector row costs less than its share of a
+# loop iteration) the order flips: a small first part lets the loop start at once, and every later part is ready
+# before the loop reaches it as long as the parts grow by less than the encoder-to-loop speed ratio.
+PART_SHARES_LOOP_BOUND = (0.1, 0.28, 0.6, 1.0)
+
+
+def part_iterations(n_iter, parts=PARTS, shares=None):
     """First iteration of every part (strictly increasing where possible), plus n_iter at the end."""
     P = max(1, min(parts, n_iter))
-    shares = PART_SHARES if P == len(PART_SHARES) else [(k + 1) / P for k in range(P)]
+    shares = shares if shares is not None else PART_SHARES
+    shares = shares if P == len(shares) else [(k + 1) / P for k in range(P)]
     its = [0]
     for k in range(P):
         lo = its[-1] + 1                                  # every part gets at least one iteration
