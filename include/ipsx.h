@@ -195,16 +195,22 @@ int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps
 int ipsx_query_proj(const float* q, const float* wq, float temperature,
                     int n_token, int d, int hdk, float* qs, void* stream);
 
-/* per-patch attention logits, computed ONCE per patch:
- *   x = emb[r] (+ pos[r]);  k = wk . x;  logits[r][h*T+t] = qs[t][h,:] . k[h,:]
- * emb/pos/logits are (b, n, *) with explicit batch strides in ELEMENTS so that a
- * column slice of a larger (b, N, *) buffer can be passed; pos_bstride = 0
- * broadcasts one (n, d) table over the batch; pos may be NULL (use_pos false).
- * wk_packed = ipsx_pack_conv_weight of k_w.weight viewed as (H*Dk, D, 1, 1).    */
+/* Attention logits before the softmax (transformer.py:77,31: matmul(q / temperature, k_w(x)^T)):
+ *   logit[n][h*T + t] = sum_j qs[t][h,j] * sum_c W_k[h*dk + j][c] * x[n][c],   x = emb (+ pos)
+ * evaluated with the query folded into the key weights (the two sums commute; this order is the arithmetic
+ * contract, restated by the oracle):  v = ipsx_fold_query(qs, wk_packed)  once per call, then
+ * logit[n][r] = sum_c x[n][c] * v[r][c]  on the matrix cores - H*T*D multiply-adds per patch instead of
+ * H*Dk*D, so the kernel is bound by reading the embeddings.
+ * emb (b,n,d) with batch stride emb_bstride (floats); pos (b|1,n,d) or NULL, pos_bstride = 0 broadcasts one
+ * (n,d) table over the batch; wk_packed = ipsx_pack_conv_weight of k_w.weight viewed as (H*Dk, D, 1, 1);
+ * v_packed: ipsx_folded_query_elems(h, n_token, d) floats; r = h * n_token; logits (b,n,r).            */
+size_t ipsx_folded_query_elems(int h, int n_token, int d);
+int ipsx_fold_query(const float* qs, const float* wk_packed, int h, int dk, int n_token, int d,
+                    float* v_packed, void* stream);
 int ipsx_logits(const float* emb, int64_t emb_bstride,
                 const float* pos, int64_t pos_bstride,
-                const float* wk_packed, const float* qs,
-                int b, int64_t n, int d, int h, int dk, int n_token,
+                const float* v_packed,
+                int b, int64_t n, int d, int r,
                 float* logits, int64_t logits_bstride, void* stream);
 
 /* Order of equal scores in the top-M steps of ipsx_scan / ipsx_scan_range / ipsx_topm (process-wide).
@@ -241,7 +247,7 @@ int ipsx_scores(const float* x, const float* wk_packed, const float* qs,
                 int b, int l, int d, int h, int dk, int n_token,
                 float* scores, float* attn, void* workspace, size_t workspace_bytes,
                 void* stream);
-size_t ipsx_scores_workspace_bytes(int b, int l, int h, int n_token);
+size_t ipsx_scores_workspace_bytes(int b, int l, int d, int h, int n_token);
 
 /* torch.topk(scores, m, dim=-1)[1] (ips_net.py:148): (b,l) -> (b,m) int64 */
 int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_idx,

@@ -225,8 +225,7 @@ class IPSNet(nn.Module):
         ca = self.transf.crs_attn
         if patches.is_cuda and self._can_overlap(patches):
             return self._select_hip_overlapped(patches, pos_enc)
-        qs = ca.scaled_query()
-        wk = hip.pack_linear(ca.k_w.weight)
+        vq, R = ca.folded_query(), ca.H * ca.n_token
         logits = torch.empty((B, N, ca.H * ca.n_token), dtype=torch.float32, device=self.device)
         self._device_patches = None
         if patches.is_cuda:
@@ -238,7 +237,7 @@ class IPSNet(nn.Module):
             part = fetch(k)
             emb = self._embed(part.reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
-            hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
+            hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
             prefetch(k + 1)          # after the encoder is enqueued: a pageable-memory copy blocks the host, not the GPU
             parts.append(emb)
         self._emb_parts = parts
@@ -267,8 +266,7 @@ class IPSNet(nn.Module):
         B, N = patches.shape[:2]
         M, I, dev = self.M, self.I, patches.device
         ca = self.transf.crs_attn
-        qs = ca.scaled_query()
-        wk = hip.pack_linear(ca.k_w.weight)
+        vq, R = ca.folded_query(), ca.H * ca.n_token
         n_iter = math.ceil((N - M) / I)
         from ..dist import PART_SHARES_LOOP_BOUND, part_iterations
         if self._plan is None:
@@ -303,7 +301,7 @@ class IPSNet(nn.Module):
                 emb = self._embed(patches[:, lo:hi].reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             parts.append(emb)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
-            hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=logits[:, lo:hi])
+            hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
             done = torch.cuda.Event()
             done.record(main)
             with torch.cuda.stream(side):

@@ -102,6 +102,10 @@ class MultiHeadCrossAttention(nn.Module):
         """
         return hip.query_proj(self.q[0], self.q_w.weight, self.attention.temperature)
 
+    def folded_query(self):
+        """The scaled query folded into the key weights: packed (H*n_token, D) operand of ``hip.logits``."""
+        return hip.fold_query(self.scaled_query(), self.k_w.weight, self.H, self.D_k, self.n_token)
+
     def get_attn(self, x):
         """Attention map ``(B, H, n_token, L)`` of the queries over ``x`` (B, L, D)."""
         if _use_hip(x, self.q, self.q_w.weight, self.k_w.weight) and not self._drops():

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ emb,
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct AggLayout {
-    size_t qs, wkp, wvp, lg, v, ctx, total;
+    size_t qs, wkp, vq, wvp, lg, v, ctx, total;
 };
 
 static AggLayout agg_layout(const ipsx_transf* t, int b, int m) {
@@ -193,6 +193,7 @@ static AggLayout agg_layout(const ipsx_transf* t, int b, int m) {
     size_t off = 0;
     L.qs = off;  off += align256((size_t)t->n_token * hdk * 4);
     L.wkp = off; off += align256(ipsx_packed_conv_weight_elems(hdk, t->d, 1, 1) * 4);
+    L.vq = off;  off += align256(ipsx_folded_query_elems(t->h, t->n_token, t->d) * 4);
     L.wvp = off; off += align256(ipsx_packed_conv_weight_elems(hdv, t->d, 1, 1) * 4);
     L.lg = off;  off += align256((size_t)b * m * R * 4);
     L.v = off;   off += align256((size_t)b * m * hdv * 4);
@@ -236,6 +237,7 @@ IPSX_API int ipsx_aggregate(const ipsx_transf* t, const float* x, int b, int m, 
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     float* qs = reinterpret_cast<float*>(ws + L.qs);
     float* wkp = reinterpret_cast<float*>(ws + L.wkp);
+    float* vq = reinterpret_cast<float*>(ws + L.vq);
     float* wvp = reinterpret_cast<float*>(ws + L.wvp);
     float* lg = reinterpret_cast<float*>(ws + L.lg);
     float* v = reinterpret_cast<float*>(ws + L.v);
@@ -246,8 +248,8 @@ IPSX_API int ipsx_aggregate(const ipsx_transf* t, const float* x, int b, int m, 
     IPSX_TRY(ipsx_query_proj(t->q, t->wq, t->temperature, t->n_token, t->d, hdk, qs, stream));
     IPSX_TRY(ipsx_pack_conv_weight(t->wk, hdk, t->d, 1, 1, wkp, stream));
     IPSX_TRY(ipsx_pack_conv_weight(t->wv, hdv, t->d, 1, 1, wvp, stream));
-    IPSX_TRY(ipsx_logits(x, (int64_t)m * t->d, nullptr, 0, wkp, qs, b, m, t->d, t->h, t->dk, t->n_token, lg,
-                         (int64_t)m * R, stream));
+    IPSX_TRY(ipsx_fold_query(qs, wkp, t->h, t->dk, t->n_token, t->d, vq, stream));
+    IPSX_TRY(ipsx_logits(x, (int64_t)m * t->d, nullptr, 0, vq, b, m, t->d, R, lg, (int64_t)m * R, stream));
     ipsx_conv vproj;
     vproj.c_in = t->d; vproj.c_out = hdv; vproj.kh = vproj.kw = 1; vproj.stride = 1; vproj.pad = 0;
     vproj.w_packed = wvp; vproj.alpha = nullptr; vproj.shift = nullptr;

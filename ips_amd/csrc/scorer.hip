@@ -41,36 +41,61 @@ __global__ void query_proj_kernel(const float* __restrict__ q, const float* __re
 }
 
 // ------------------------------------------------------------------ logits
+// logit[n][h*T + t] = sum_j qs[t][h,j] * sum_c W_k[h*dk + j][c] * x[n][c],  x = emb (+ pos).  The reference evaluates
+// the inner sum first (a D x H*Dk projection per patch, transformer.py:77); the two sums commute, and here the query
+// is folded into the key weights once per call:  V[h*T + t][c] = sum_j qs[t][h,j] W_k[h*dk + j][c]  (fold_query_kernel,
+// j ascending), after which a patch costs H*T*D multiply-adds instead of H*Dk*D (+ H*T*Dk) and the kernel is bound by
+// reading the embeddings.  The oracle restates exactly this order (orc_fold_query + orc_logits).
+//
+// wkp: k_w.weight packed as a 1x1 conv ([C_out/32][K/8][64 lanes][4]); vp: V in the same packing (C_out = H*T).
+__global__ void fold_query_kernel(const float* __restrict__ qs, const float* __restrict__ wkp, int h, int dk, int T, int d,
+                                  int kgs, int r_pad, float* __restrict__ vp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // over r_pad x (kgs * 8)
+    const int dpad = kgs * 8;
+    if (idx >= r_pad * dpad) return;
+    const int r = idx / dpad, c = idx - r * dpad;
+    const int R = h * T, hdk = h * dk;
+    float acc = 0.0f;
+    if (r < R && c < d) {
+        const int hh = r / T, t = r - hh * T;
+        const int kg = c >> 3, sub = c & 7;
+        for (int j = 0; j < dk; ++j) {
+            const int o = hh * dk + j;
+            const float w = wkp[(((size_t)(o >> 5) * kgs + kg) * 64 + (o & 31) + 32 * (sub >> 2)) * 4 + (sub & 3)];
+            acc = __builtin_fmaf(qs[(size_t)t * hdk + o], w, acc);
+        }
+    }
+    vp[(((size_t)(r >> 5) * kgs + (c >> 3)) * 64 + (r & 31) + 32 * ((c & 7) >> 2)) * 4 + (c & 3)] = acc;
+}
+
 struct LogitsArgs {
     const float* emb; long long emb_bs;
     const float* pos; long long pos_bs;
-    const float* wkp;            // k_w.weight packed as a 1x1 conv (ipsx_pack_conv_weight)
-    const float* qs;             // (T, H*Dk)
+    const float* vp;             // folded query, packed (fold_query_kernel)
     long long n;
-    int d, h, dk, T, kgs;
+    int d, R, kgs;
     float* out; long long out_bs;
 };
 
-// One workgroup = 32 rows x all H*Dk columns.  Wave w owns n-tiles w, w+4, ... (NTW of them).
-template <int NTW>
+// One wavefront = 32 patches x all H*T logits (NT tiles of 32 columns); 4 wavefronts per workgroup.
+template <int NT>
 __global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float kbuf[];   // [32][hdk + 1]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-    const int hdk = a.h * a.dk, ntiles = (hdk + 31) >> 5, ld = hdk + 1;
-    const long long r0 = (long long)blockIdx.x * 32;
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (r0 >= a.n) return;                                           // wave-uniform
     const int bi = blockIdx.y;
     const long long row = r0 + (lane & 31);
     const bool rv = row < a.n;
     const float* e = a.emb + (size_t)bi * a.emb_bs + (size_t)(rv ? row : 0) * a.d + 4 * half;
     const float* p = a.pos ? a.pos + (size_t)bi * a.pos_bs + (size_t)(rv ? row : 0) * a.d + 4 * half : nullptr;
 
-    f32x16 acc[NTW];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const float4* wp = reinterpret_cast<const float4*>(a.wkp) + lane;
+    const float4* vq = reinterpret_cast<const float4*>(a.vp) + lane;
     const bool vec = (a.d & 7) == 0;                 // rows are 16-byte aligned and every k-group is complete
     for (int kg = 0; kg < a.kgs; ++kg) {
         float av[4];
@@ -93,43 +118,26 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            const int nt = wave + 4 * i;
-            if (nt < ntiles) {                      // wave-uniform
-                const float4 b = wp[((size_t)nt * a.kgs + kg) * 64];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], b.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], b.w, acc[i], 0, 0, 0);
-            }
+        for (int i = 0; i < NT; ++i) {
+            const float4 b = vq[((size_t)i * a.kgs + kg) * 64];
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], b.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], b.w, acc[i], 0, 0, 0);
         }
     }
-    // K tile -> LDS (row = pixel row of the C layout, column = output feature)
+    // C layout: lane = column (logit index), registers = rows (patches)
+    float* out = a.out + (size_t)bi * a.out_bs;
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = wave + 4 * i;
-        if (nt < ntiles) {
-            const int o = nt * 32 + (lane & 31);
-            if (o < hdk) {
+    for (int i = 0; i < NT; ++i) {
+        const int o = i * 32 + (lane & 31);
+        if (o < a.R) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    kbuf[rr * ld + o] = acc[i][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const long long rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (rr < a.n) out[(size_t)rr * a.R + o] = acc[i][r];
             }
         }
-    }
-    __syncthreads();
-    const int R = a.h * a.T;
-    for (int idx = threadIdx.x; idx < 32 * R; idx += 256) {
-        const int rr = idx / R, r = idx - rr * R;
-        const int hh = r / a.T, t = r - hh * a.T;
-        if (r0 + rr >= a.n) continue;
-        const float* kq = a.qs + (size_t)t * hdk + hh * a.dk;
-        const float* kk = kbuf + rr * ld + hh * a.dk;
-        float s = 0.0f;
-        for (int j = 0; j < a.dk; ++j) s = __builtin_fmaf(kq[j], kk[j], s);
-        a.out[(size_t)bi * a.out_bs + (size_t)(r0 + rr) * R + r] = s;
     }
 }
 
@@ -737,16 +745,13 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static const size_t kLdsLimit = 160 * 1024;
 
 static int launch_logits(const LogitsArgs& a, int b, hipStream_t s) {
-    const int hdk = a.h * a.dk;
-    const int ntiles = (hdk + 31) / 32;
-    const size_t lds = (size_t)32 * (hdk + 1) * sizeof(float);
-    IPSX_REQUIRE(ntiles <= 16, "logits: H*Dk = %d > 512 not supported", hdk);
-    dim3 grid((unsigned)cdiv(a.n, 32), (unsigned)b);
-    const int ntw = (ntiles + 3) / 4;
-    if (ntw == 1) logits_kernel<1><<<grid, dim3(256), lds, s>>>(a);
-    else if (ntw == 2) logits_kernel<2><<<grid, dim3(256), lds, s>>>(a);
-    else if (ntw == 3) logits_kernel<3><<<grid, dim3(256), lds, s>>>(a);
-    else logits_kernel<4><<<grid, dim3(256), lds, s>>>(a);
+    const int nt = (a.R + 31) / 32;
+    IPSX_REQUIRE(nt <= 8, "logits: H * n_token = %d > 256 not supported", a.R);
+    dim3 grid((unsigned)cdiv(a.n, 128), (unsigned)b);
+    if (nt == 1) logits_kernel<1><<<grid, dim3(256), 0, s>>>(a);
+    else if (nt == 2) logits_kernel<2><<<grid, dim3(256), 0, s>>>(a);
+    else if (nt <= 4) logits_kernel<4><<<grid, dim3(256), 0, s>>>(a);
+    else logits_kernel<8><<<grid, dim3(256), 0, s>>>(a);
     return launched("logits");
 }
 
@@ -762,15 +767,31 @@ IPSX_API int ipsx_query_proj(const float* q, const float* wq, float temperature,
     return launched("query_proj");
 }
 
+IPSX_API size_t ipsx_folded_query_elems(int h, int n_token, int d) {
+    if (h <= 0 || n_token <= 0 || d <= 0) return 0;
+    const int nt = (h * n_token + 31) / 32;
+    return ipsx_packed_conv_weight_elems((nt <= 2 ? nt : (nt <= 4 ? 4 : 8)) * 32, d, 1, 1);     // whole tiles of the kernel variant
+}
+
+IPSX_API int ipsx_fold_query(const float* qs, const float* wk_packed, int h, int dk, int n_token, int d,
+                             float* v_packed, void* stream) {
+    IPSX_REQUIRE(qs && wk_packed && v_packed && h > 0 && dk > 0 && n_token > 0 && d > 0, "fold_query: bad arguments");
+    const int kgs = (int)cdiv(d, 8);
+    const int r_pad = (int)(ipsx_folded_query_elems(h, n_token, d) / ((size_t)kgs * 8));
+    fold_query_kernel<<<dim3((unsigned)cdiv((int64_t)r_pad * kgs * 8, 256)), dim3(256), 0, as_stream(stream)>>>(
+        qs, wk_packed, h, dk, n_token, d, kgs, r_pad, v_packed);
+    return launched("fold_query");
+}
+
 IPSX_API int ipsx_logits(const float* emb, int64_t emb_bstride, const float* pos, int64_t pos_bstride,
-                         const float* wk_packed, const float* qs, int b, int64_t n, int d, int h, int dk,
-                         int n_token, float* logits, int64_t logits_bstride, void* stream) {
-    IPSX_REQUIRE(emb && wk_packed && qs && logits, "logits: null pointer");
-    IPSX_REQUIRE(b > 0 && n >= 0 && d > 0 && h > 0 && dk > 0 && n_token > 0, "logits: bad sizes");
+                         const float* v_packed, int b, int64_t n, int d, int r, float* logits,
+                         int64_t logits_bstride, void* stream) {
+    IPSX_REQUIRE(emb && v_packed && logits, "logits: null pointer");
+    IPSX_REQUIRE(b > 0 && n >= 0 && d > 0 && r > 0, "logits: bad sizes");
     if (n == 0) return IPSX_OK;
     LogitsArgs a;
     a.emb = emb; a.emb_bs = emb_bstride; a.pos = pos; a.pos_bs = pos_bstride;
-    a.wkp = wk_packed; a.qs = qs; a.n = n; a.d = d; a.h = h; a.dk = dk; a.T = n_token;
+    a.vp = v_packed; a.n = n; a.d = d; a.R = r;
     a.kgs = (int)cdiv(d, 8);
     a.out = logits; a.out_bs = logits_bstride;
     return launch_logits(a, b, as_stream(stream));
@@ -831,8 +852,8 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
     return launched("scan");
 }
 
-IPSX_API size_t ipsx_scores_workspace_bytes(int b, int l, int h, int n_token) {
-    return (size_t)b * l * h * n_token * sizeof(float);
+IPSX_API size_t ipsx_scores_workspace_bytes(int b, int l, int d, int h, int n_token) {
+    return (((size_t)b * l * h * n_token * sizeof(float) + 255) & ~(size_t)255) + ipsx_folded_query_elems(h, n_token, d) * sizeof(float);
 }
 
 IPSX_API int ipsx_scores(const float* x, const float* wk_packed, const float* qs, int b, int l, int d, int h,
@@ -840,13 +861,14 @@ IPSX_API int ipsx_scores(const float* x, const float* wk_packed, const float* qs
                          size_t workspace_bytes, void* stream) {
     IPSX_REQUIRE(x && wk_packed && qs && scores, "scores: null pointer");
     IPSX_REQUIRE(b > 0 && l > 0 && d > 0 && h > 0 && dk > 0 && n_token > 0, "scores: bad sizes");
-    const size_t need = ipsx_scores_workspace_bytes(b, l, h, n_token);
+    const size_t need = ipsx_scores_workspace_bytes(b, l, d, h, n_token);
     if (!workspace || workspace_bytes < need)
         return fail(IPSX_EWORKSPACE, "scores: workspace %zu B < %zu B", workspace_bytes, need);
     const int R = h * n_token;
     float* lg = static_cast<float*>(workspace);
-    IPSX_TRY(ipsx_logits(x, (int64_t)l * d, nullptr, 0, wk_packed, qs, b, l, d, h, dk, n_token, lg,
-                         (int64_t)l * R, stream));
+    float* vp = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + (((size_t)b * l * R * sizeof(float) + 255) & ~(size_t)255));
+    IPSX_TRY(ipsx_fold_query(qs, wk_packed, h, dk, n_token, d, vp, stream));
+    IPSX_TRY(ipsx_logits(x, (int64_t)l * d, nullptr, 0, vp, b, l, d, R, lg, (int64_t)l * R, stream));
     ScoresArgs a;
     const size_t base = (size_t)R * 8, stage = (size_t)l * (R + 1) * 4;
     a.lg = lg; a.L = l; a.h = h; a.T = n_token; a.use_lds = base + stage <= kLdsLimit;

@@ -129,7 +129,7 @@ def ips_sharded(net, local_patches, N, group=None):
         on_gpu = hip.on_device(dev)
         if on_gpu:
             R = ca.H * ca.n_token
-            qs, wk = ca.scaled_query(), hip.pack_linear(ca.k_w.weight)
+            vq = ca.folded_query()
             logits = torch.empty((B, N, R), dtype=torch.float32, device=dev)
             mem_idx = torch.empty((B, M), dtype=torch.int64, device=dev)
             tie = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -163,7 +163,7 @@ def ips_sharded(net, local_patches, N, group=None):
                     emb = net._embed(part.reshape(-1, *local_patches.shape[2:])).view(B, n_k, D)
                 if on_gpu:
                     pos = net.pos_enc[:, lo:hi] if net.use_pos else None
-                    hip.logits(emb, pos, wk, qs, ca.H, ca.D_k, ca.n_token, out=mine[:, :n_k])
+                    hip.logits(emb, pos, vq, R, out=mine[:, :n_k])
                 else:
                     mine[:, :n_k] = emb
             base += n_k

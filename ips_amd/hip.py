@@ -135,8 +135,10 @@ _EXPORTS = {
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
-    "ipsx_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                              C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+    "ipsx_folded_query_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ipsx_fold_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                              C.c_int, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p, C.c_int64, C.c_void_p]),
     "ipsx_set_tie_order": (C.c_int, [C.c_int]),
     "ipsx_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -144,7 +146,7 @@ _EXPORTS = {
     "ipsx_scan_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_trunk_encode_indexed": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "ipsx_scores_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "ipsx_scores_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ipsx_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_topm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -403,22 +405,31 @@ def pack_linear(weight):
     return _pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1))
 
 
-def logits(emb, pos, wk_packed, qs, H, Dk, T, out=None):
-    """Per-patch attention logits (B, n, H*T); ``out`` may be a column slice of (B, N, H*T)."""
+def fold_query(qs, wk_weight, H, Dk, T):
+    """Scaled query (T, H*Dk) folded into the key weights k_w.weight (H*Dk, D) -> packed (H*T, D) operand of
+    ``logits`` (ipsx_fold_query): logit = x . V[h*T + t],  V[h*T + t] = sum_j qs[t][h, j] k_w[h*Dk + j]."""
+    D = wk_weight.shape[1]
+    out = torch.empty(lib().ipsx_folded_query_elems(H, T, D), dtype=torch.float32, device=qs.device)
+    _ck(lib().ipsx_fold_query(_p(_f32(qs)), _p(pack_linear(wk_weight)), H, Dk, T, D, _p(out), _stream()), "ipsx_fold_query")
+    return out
+
+
+def logits(emb, pos, vq, R, out=None):
+    """Per-patch attention logits (B, n, R = H*T) from the folded query ``vq``; ``out`` may be a column slice of
+    (B, N, R)."""
     B, n, D = emb.shape
     emb = _f32(emb)
-    wk = wk_packed
     if out is None:
-        out = torch.empty((B, n, H * T), dtype=torch.float32, device=emb.device)
-    if out.stride(2) != 1 or out.stride(1) != H * T:
+        out = torch.empty((B, n, R), dtype=torch.float32, device=emb.device)
+    if out.stride(2) != 1 or out.stride(1) != R:
         raise ValueError("logits output must be row-contiguous")
     pos_bs = 0
     if pos is not None:
         if pos.stride(2) != 1 or pos.stride(1) != D:
             pos = pos.contiguous()
         pos_bs = pos.stride(0) if pos.shape[0] > 1 else 0
-    _ck(lib().ipsx_logits(_p(emb), n * D, _p(pos), pos_bs, _p(wk), _p(qs), B, n, D, H, Dk, T,
-                          _p(out), out.stride(0), _stream()), "ipsx_logits")
+    _ck(lib().ipsx_logits(_p(emb), n * D, _p(pos), pos_bs, _p(vq), B, n, D, R, _p(out), out.stride(0), _stream()),
+        "ipsx_logits")
     return out
 
 
@@ -449,7 +460,7 @@ def _scores_impl(x, qs, wk, H, Dk, T, want_attn):
     B, L, D = x.shape
     sc = torch.empty((B, L), dtype=torch.float32, device=x.device)
     attn = torch.empty((B, H, T, L), dtype=torch.float32, device=x.device) if want_attn else None
-    nb = lib().ipsx_scores_workspace_bytes(B, L, H, T)
+    nb = lib().ipsx_scores_workspace_bytes(B, L, D, H, T)
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
     wkp = pack_linear(wk)
     _ck(lib().ipsx_scores(_p(x), _p(wkp), _p(qs), B, L, D, H, Dk, T, _p(sc), _p(attn),

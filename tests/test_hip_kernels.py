@@ -330,14 +330,14 @@ def test_logits_scores_attn_bit_exact(case):
     qs = ca.scaled_query()
     assert ulp_diff(qs.cpu().numpy(), o.qs) == 0
     pos = rnd((B, L, D), 22)
-    wkp = hip._pack_conv(ca.k_w.weight.detach().reshape(ca.H * ca.D_k, D, 1, 1))
-    got = hip.logits(dev(x), dev(pos), wkp, qs, ca.H, ca.D_k, ca.n_token).cpu().numpy()
+    vq, R = ca.folded_query(), ca.H * ca.n_token                      # the query folded into the key weights
+    got = hip.logits(dev(x), dev(pos), vq, R).cpu().numpy()
     for b in range(B):
         assert ulp_diff(got[b], o.logits(x[b], pos[b])) == 0
     # broadcast positional table (batch stride 0) and no table at all
-    got = hip.logits(dev(x), dev(pos[:1]), wkp, qs, ca.H, ca.D_k, ca.n_token).cpu().numpy()
+    got = hip.logits(dev(x), dev(pos[:1]), vq, R).cpu().numpy()
     assert ulp_diff(got[1], o.logits(x[1], pos[0])) == 0
-    got = hip.logits(dev(x), None, wkp, qs, ca.H, ca.D_k, ca.n_token).cpu().numpy()
+    got = hip.logits(dev(x), None, vq, R).cpu().numpy()
     assert ulp_diff(got[1], o.logits(x[1])) == 0
     # Transformer.get_scores / get_attn through the module API
     with torch.no_grad():
