@@ -249,7 +249,7 @@ class IPSNet(nn.Module):
     # iterations are exposed - this is what keeps the scan off the critical path when the image (and with it
     # the iteration count) grows across GPUs.  Parts are cut at chunk boundaries; the fused trunk encodes a part
     # through an index list (nothing is copied), every other encoder through a slice of the patch axis.  With
-    # feature inputs (projector) the loop is the long pole instead, and the parts GROW so that it starts at once
+    # feature inputs (projector) the loop is the long pole instead, and the parts GROW so that it starts early
     # (dist.PART_SHARES_LOOP_BOUND).  IPSX_OVERLAP_SCAN=0 switches it off.
     _OVERLAP_PARTS = 4
 
@@ -272,8 +272,12 @@ class IPSNet(nn.Module):
         if self._plan is None:
             self._plan = hip.EncoderPlan(self.encoder, self.is_image)
         indexed = self.is_image and patches.is_contiguous() and self._plan.fused(patches.shape)
-        # image encoders: parts shrink towards the end (only the last scan is exposed); projector: they grow
-        its = part_iterations(n_iter, self._OVERLAP_PARTS, None if self.is_image else PART_SHARES_LOOP_BOUND)
+        # image encoders: parts shrinking towards the end (only the last scan is exposed); projector: the loop is the
+        # long pole, so a small first part lets it start early and the later ones are ready before it reaches them
+        if self.is_image:
+            its = part_iterations(n_iter, self._OVERLAP_PARTS)
+        else:
+            its = part_iterations(n_iter, len(PART_SHARES_LOOP_BOUND), PART_SHARES_LOOP_BOUND)
         P = len(its) - 1
         edges = [0] + [min(N, M + it * I) for it in its[1:]]
         edges[-1] = N

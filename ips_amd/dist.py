@@ -38,9 +38,10 @@ PART_SHARES = (0.5, 0.8, 0.95, 1.0)
 
 
 # When the loop, not the encoder, is the long pole (feature inputs: a projector row costs less than its share of a
-# loop iteration) the order flips: a small first part lets the loop start at once, and every later part is ready
-# before the loop reaches it as long as the parts grow by less than the encoder-to-loop speed ratio.
-PART_SHARES_LOOP_BOUND = (0.1, 0.28, 0.6, 1.0)
+# loop iteration) the order flips: a small first part lets the loop start early, and every later part is ready
+# before the loop reaches it.  Measured at the CAMELYON shape (ms per slide): one part 4.18, two halves 3.51, four
+# equal 3.15, (0.1, 0.28, 0.6, 1) 3.09, these 3.02, eight equal 3.23 (launch and restart overheads take over).
+PART_SHARES_LOOP_BOUND = (0.15, 0.4, 0.7, 1.0)
 
 
 def part_iterations(n_iter, parts=PARTS, shares=None):
