@@ -594,27 +594,22 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         }
         __syncthreads();
         SCAN_STAMP(1);
-        // attention weight of every (candidate, head, token)
-        {
-            int l = row0, r = col0;
-            for (int e = tid; e < L * R; e += SCAN_NT) {
-                abuf[e] = det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
-                SCAN_ADVANCE(l, r);
-            }
-        }
-        __syncthreads();
-        SCAN_STAMP(2);
-        // score = mean over tokens of (mean over heads), ascending sums; ranking key.
-        // One lane per (candidate, token) sums the heads (independent LDS reads, then the ascending
-        // chain); the T lanes of a candidate are adjacent, so the token sum is a few lane reads.
-        if ((a.T & (a.T - 1)) == 0 && a.T <= 64 && a.h <= 16) {
+        // score = mean over tokens of (mean over heads) of the attention weights exp(x - max) / sum, ascending sums;
+        // ranking key.  One lane per (candidate, token) evaluates its H weights and sums them (the ascending chain);
+        // the T lanes of a candidate are adjacent, so the token sum is a few lane reads.
+        const bool lane_per_token = (a.T & (a.T - 1)) == 0 && a.T <= 64 && a.h <= 16;
+        if (lane_per_token) {
+            SCAN_STAMP(2);
             for (int e0 = 0; e0 < a.n2 * a.T; e0 += SCAN_NT) {
                 const int e = e0 + tid, l = e >> log2T, t = e - (l << log2T);
                 float q = 0.0f;
                 if (l < L) {
                     float v[16];
 #pragma unroll
-                    for (int hh = 0; hh < 16; ++hh) v[hh] = hh < a.h ? abuf[l * R + hh * a.T + t] : 0.0f;
+                    for (int hh = 0; hh < 16; ++hh) {
+                        const int r = hh * a.T + t;
+                        v[hh] = hh < a.h ? det_expf(cl[l * ld + r] - rmax[r]) / rden[r] : 0.0f;
+                    }
                     float sh = 0.0f;
 #pragma unroll
                     for (int hh = 0; hh < 16; ++hh) if (hh < a.h) sh = sh + v[hh];
@@ -625,6 +620,16 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
                 if (t == 0 && l < a.n2) keyA[l] = l < L ? rank_key(st / (float)a.T, (uint32_t)l) : 0ull;
             }
         } else {
+            // general shapes: attention weight of every (candidate, head, token) first, then one lane per candidate
+            {
+                int l = row0, r = col0;
+                for (int e = tid; e < L * R; e += SCAN_NT) {
+                    abuf[e] = det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
+                    SCAN_ADVANCE(l, r);
+                }
+            }
+            __syncthreads();
+            SCAN_STAMP(2);
             for (int l = tid; l < a.n2; l += SCAN_NT) {
                 uint64_t key = 0ull;
                 if (l < L) {
