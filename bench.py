@@ -157,11 +157,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    # IPSX_BENCH_SHARE_GPU=1 (testing aid for 1-GPU boxes): every rank uses cuda:0 and the process group is gloo, so
+    # the N > 1 code path of this script can be exercised without N GPUs; RCCL needs one GPU per rank
+    share = os.environ.get("IPSX_BENCH_SHARE_GPU") == "1"
+    local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ips_amd import hip, synth
     from ips_amd import dist as ipsd
@@ -245,7 +252,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
