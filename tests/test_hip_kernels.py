@@ -414,6 +414,53 @@ def test_scan_matches_oracle(N, M, I, H, T):
         assert ulp_diff(sc[b], last) == 0
 
 
+def _oracle_scan_from_logits(lg, M, I, H, T, aten_ties):
+    N = lg.shape[0]
+    L = orc.lib()
+    cur = np.arange(M, dtype=np.int64)
+    for lo in range(M, N, I):
+        cand = np.concatenate([cur, np.arange(lo, min(lo + I, N), dtype=np.int64)])
+        s = np.empty(len(cand), dtype=np.float32)
+        L.orc_scores_from_logits(orc._f(lg[cand])[1], len(cand), H, T, s.ctypes.data_as(orc.f32p), None)
+        cur = cand[orc.topm(s, M, aten_ties=aten_ties)[0]]
+    return cur
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_scan_random_shapes_with_ties_matches_oracle(seed):
+    """Random loop shapes (ragged chunks, odd head / token counts -> the general score path, candidate sets beyond
+    1024 -> the bitonic ranking) on QUANTISED logits, so that equal scores occur in most iterations: the default
+    tie order must follow torch.topk's CPU order (oracle: orc_topm_aten), the canonical one the position rule; a
+    scan cut into resumed ranges must give the same answer."""
+    g = np.random.default_rng(1000 + seed)
+    H = int(g.choice([1, 2, 3, 8]))
+    T = int(g.choice([1, 2, 3, 4]))
+    M = int(g.choice([4, 16, 33, 64, 200]))
+    I = int(g.choice([5, 16, 64, 100, 900]))
+    N = M + int(g.integers(1, 6)) * I + int(g.integers(0, I))
+    B, R = 2, H * T
+    levels = int(g.choice([2, 3, 5, 1000]))
+    lg = (g.integers(0, levels, (B, N, R)).astype(np.float32) - 1.0) * np.float32(0.75)
+    if levels <= 5:
+        lg[:, :, 1:] = lg[:, :, :1]                       # every row the same across (h, t): whole candidates tie
+    for mode, aten in (("torch", True), ("canonical", False)):
+        hip.set_tie_order(mode)
+        try:
+            mem = hip.scan(dev(lg), M, I, H, T).cpu().numpy()
+            n_iter = -(-(N - M) // I)
+            cut = max(1, n_iter // 2)
+            idx = torch.empty((B, M), dtype=torch.int64, device=DEV)
+            tie = torch.zeros((B,), dtype=torch.int32, device=DEV)
+            hip.scan_range(dev(lg), M, I, H, T, 0, cut, idx, tie)
+            hip.scan_range(dev(lg), M, I, H, T, cut, n_iter, idx, tie)
+        finally:
+            hip.set_tie_order("torch")
+        for b in range(B):
+            want = _oracle_scan_from_logits(lg[b], M, I, H, T, aten)
+            assert np.array_equal(mem[b], want), (mode, H, T, M, I, N, levels)
+        assert np.array_equal(idx.cpu().numpy(), mem)
+
+
 def test_gather_rows():
     B, N, M = 3, 50, 7
     src = rnd((B, N, 1, 32, 32), 30)
