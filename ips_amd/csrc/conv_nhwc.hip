@@ -13,7 +13,7 @@
 //     4 loads + 16 MFMAs and no address arithmetic on the vector pipe;
 //   * halo (padding) lanes carry an out-of-range offset: the buffer's hardware bounds check
 //     returns zeros - no select, no zero page;
-//   * 4-slot register ring, operands requested two stages (2 x 1024 matrix-pipe cycles) ahead.
+//   * 4-slot register ring, operands requested three stages (3 x 1024 matrix-pipe cycles) ahead.
 // Wave tile 64(M) x 64(N) = 2x2 accumulators; the 4 waves of a workgroup are arranged WM x WN
 // (along N for wide layers so the activation rows are fetched once per workgroup).
 //
@@ -152,14 +152,16 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); SB();                                \
     NHWC_ADVANCE();
+    // operands are requested THREE stages ahead (ring of 4: the slot being refilled is the one consumed a stage ago)
     NHWC_ISSUE(s0); NHWC_ADVANCE();
     NHWC_ISSUE(s1); NHWC_ADVANCE();
+    NHWC_ISSUE(s2); NHWC_ADVANCE();
 #pragma unroll 1
     for (int g = 0; g < total; g += 4) {       // total is a multiple of 4 (C_in % 32 == 0)
-        NHWC_STAGE(s2, s0)
-        NHWC_STAGE(s3, s1)
-        NHWC_STAGE(s0, s2)
-        NHWC_STAGE(s1, s3)
+        NHWC_STAGE(s3, s0)
+        NHWC_STAGE(s0, s1)
+        NHWC_STAGE(s1, s2)
+        NHWC_STAGE(s2, s3)
     }
 #undef NHWC_STAGE
 #undef NHWC_ADVANCE
