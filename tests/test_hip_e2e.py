@@ -189,6 +189,45 @@ def test_full_size_properties_b16():
     assert np.array_equal(netg.last_mem_idx[0].cpu().numpy(), g.mem_idx[0])
 
 
+def test_configs2_size_properties(monkeypatch):
+    """BASELINE configs[2] size on one GPU (3000 x 3000 image = 10,000 patches of 32 px, 156 iterations): the
+    overlapped path equals the plain one and the reference-structured chunk loop, kept patches are unique, and the
+    memory comes out ordered by the scores of the last iteration."""
+    conf = synth.mnist_conf(N=10000, M=64, I=64)
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 11).to(DEV).eval()
+    x = synth.make_patches(conf, 2, seed=5).to(DEV)
+    assert net._can_overlap(x)
+    net.ips(x)
+    idx = net.last_mem_idx.clone()
+    monkeypatch.setenv("IPSX_OVERLAP_SCAN", "0")
+    net.ips(x)
+    monkeypatch.delenv("IPSX_OVERLAP_SCAN")
+    assert torch.equal(idx, net.last_mem_idx)
+    assert all(len(set(r)) == 64 for r in idx.cpu().numpy())
+    # the reference's structure: score_and_select per chunk on embeddings (ipsx_scores + ipsx_topm)
+    with torch.no_grad():
+        B, N, M, I, D = 2, 10000, 64, 64, conf.D
+        emb = net._embed(x.reshape(-1, 1, 32, 32)).view(B, N, D)
+        pos = net.pos_enc.expand(B, -1, -1)
+        order = torch.arange(N, device=DEV).unsqueeze(0).expand(B, -1)
+        mem_emb, mem_idx = emb[:, :M], order[:, :M]
+        for lo in range(M, N, I):
+            hi = min(lo + I, N)
+            ce = torch.cat((mem_emb, emb[:, lo:hi]), 1)
+            ci = torch.cat((mem_idx, order[:, lo:hi]), 1)
+            cp = ce + torch.gather(pos, 1, ci.unsqueeze(-1).expand(-1, -1, D))
+            mem_emb, mem_idx = net.score_and_select(ce, cp, M, ci)
+            last_scores = net.transf.get_scores(cp)
+            last_ci = ci
+        assert torch.equal(mem_idx, idx)
+        # ordered by the last iteration's scores, and nothing left out scores higher than the last kept one
+        for b in range(B):
+            sc = {int(i): float(v) for i, v in zip(last_ci[b].tolist(), last_scores[b].tolist())}
+            kept = [sc[int(i)] for i in idx[b].tolist()]
+            assert all(a >= c for a, c in zip(kept, kept[1:]))
+            assert max(v for i, v in sc.items() if i not in set(idx[b].tolist())) <= kept[-1]
+
+
 def test_sharded_path_on_gpu_single_rank_rccl():
     """ips_amd.dist.ips_sharded over an RCCL (nccl) group of one rank: exercises the GPU branch
     (logits into a padded slab, all_gather_into_tensor, scan, owner all_reduce) and must equal ips()."""
