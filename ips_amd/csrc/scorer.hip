@@ -484,6 +484,22 @@ __device__ __forceinline__ void rank_runs(const uint64_t* src, uint64_t* dst, ui
         }                                                                          \
     } while (0)
 
+// sum over the heads of one (candidate, token): attention weights exp(x - max) / sum, added in ascending head order (the
+// contract); HMAX bounds the unrolled slots
+template <int HMAX>
+__device__ __forceinline__ float head_sum(const float* erow, const float* rden, int h, int T) {
+    float v[HMAX];
+#pragma unroll
+    for (int hh = 0; hh < HMAX; ++hh) {
+        const int r = (hh < h ? hh : 0) * T;
+        v[hh] = erow[r] / rden[r];                      // erow: exp(x - max) left by the statistics pass
+    }
+    float sh = 0.0f;
+#pragma unroll
+    for (int hh = 0; hh < HMAX; ++hh) if (hh < h) sh = sh + v[hh];
+    return sh;
+}
+
 template <bool STAMP>
 __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -495,8 +511,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
     int* candB = candA + Lmax;
     float* rmax = reinterpret_cast<float*>(candB + Lmax);
     float* rden = rmax + R;
-    float* abuf = rden + R;                       // Lmax * R attention weights of the candidates
-    float* clA = abuf + (size_t)Lmax * R;
+    float* abuf = rden + R;                       // Lmax x (R + 1): exp(x - max) of the candidates; later the run scratch
+    float* clA = abuf + (size_t)Lmax * ld;
     float* clB = clA + (size_t)Lmax * ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
@@ -585,6 +601,16 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { s0 = s0 + e0[u]; s1 = s1 + e1[u]; }
+                // kept for the score phase, so exp(x - max) is not evaluated twice (row stride R + 1: the 64 lanes of a
+                // row hit different banks; slots beyond L are never read)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 64 * u;
+                    if (i < Lmax) {
+                        abuf[i * ld + r0] = e0[u];
+                        if (has1) abuf[i * ld + r1] = e1[u];
+                    }
+                }
             }
             wave_sum2(s0, s1, lane);
             if (lane == 0) {
@@ -604,15 +630,11 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
                 const int e = e0 + tid, l = e >> log2T, t = e - (l << log2T);
                 float q = 0.0f;
                 if (l < L) {
-                    float v[16];
-#pragma unroll
-                    for (int hh = 0; hh < 16; ++hh) {
-                        const int r = hh * a.T + t;
-                        v[hh] = hh < a.h ? det_expf(cl[l * ld + r] - rmax[r]) / rden[r] : 0.0f;
-                    }
-                    float sh = 0.0f;
-#pragma unroll
-                    for (int hh = 0; hh < 16; ++hh) if (hh < a.h) sh = sh + v[hh];
+                    const float* erow = abuf + l * ld + t;
+                    float sh;
+                    if (a.h <= 4) sh = head_sum<4>(erow, rden + t, a.h, a.T);        // workgroup-uniform choice: no work for
+                    else if (a.h <= 8) sh = head_sum<8>(erow, rden + t, a.h, a.T);   // head slots that do not exist
+                    else sh = head_sum<16>(erow, rden + t, a.h, a.T);
                     q = sh / (float)a.h;
                 }
                 float st = 0.0f;
@@ -624,7 +646,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
             {
                 int l = row0, r = col0;
                 for (int e = tid; e < L * R; e += SCAN_NT) {
-                    abuf[e] = det_expf(cl[l * ld + r] - rmax[r]) / rden[r];
+                    abuf[l * ld + r] = abuf[l * ld + r] / rden[r];      // abuf holds exp(x - max) from the statistics pass
                     SCAN_ADVANCE(l, r);
                 }
             }
@@ -636,7 +658,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
                     float st = 0.0f;
                     for (int t = 0; t < a.T; ++t) {
                         float sh = 0.0f;
-                        for (int hh = 0; hh < a.h; ++hh) sh = sh + abuf[l * R + hh * a.T + t];
+                        for (int hh = 0; hh < a.h; ++hh) sh = sh + abuf[l * ld + hh * a.T + t];
                         st = st + sh / (float)a.h;
                     }
                     key = rank_key(st / (float)a.T, (uint32_t)l);
@@ -831,7 +853,7 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
     a.tie_order = g_tie_order;
-    const size_t resident = base + (size_t)Lmax * R * 4 + 2 * stage + STK_BYTES;
+    const size_t resident = base + 3 * stage + STK_BYTES;          // exp buffer + two candidate buffers, (R + 1)-strided
     const bool runs_fit = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)Lmax * R * 4;   // run scratch aliases the weight buffer
     if (resident <= kLdsLimit && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && runs_fit) {
         a.use_lds = 1;
