@@ -103,8 +103,16 @@ class MultiHeadCrossAttention(nn.Module):
         return hip.query_proj(self.q[0], self.q_w.weight, self.attention.temperature)
 
     def folded_query(self):
-        """The scaled query folded into the key weights: packed (H*n_token, D) operand of ``hip.logits``."""
-        return hip.fold_query(self.scaled_query(), self.k_w.weight, self.H, self.D_k, self.n_token)
+        """The scaled query folded into the key weights: packed (H*n_token, D) operand of ``hip.logits``.
+
+        Depends on the three parameters only, so it is kept until one of them changes (in-place updates bump
+        ``_version``; ``.to()`` / ``load_state_dict`` change the storage) - an evaluation loop folds once."""
+        key = tuple((t.data_ptr(), t._version, t.device) for t in (self.q, self.q_w.weight, self.k_w.weight))
+        cached = getattr(self, "_folded", None)
+        if cached is None or cached[0] != key:
+            cached = (key, hip.fold_query(self.scaled_query(), self.k_w.weight, self.H, self.D_k, self.n_token))
+            self._folded = cached
+        return cached[1]
 
     def get_attn(self, x):
         """Attention map ``(B, H, n_token, L)`` of the queries over ``x`` (B, L, D)."""
