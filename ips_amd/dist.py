@@ -10,10 +10,10 @@ same ``mem_idx`` as a single-GPU run, bit for bit.
 
 Layout (``partition``): the patch axis is cut into a few PARTS at chunk boundaries of
 the selection loop; every part is split evenly over the ranks.  Per part: each rank
-encodes and scores its piece, ONE ``all_gather_into_tensor`` assembles the part's
-logits, and the loop iterations that part makes possible run on a high-priority side
-stream (``ipsx_scan_range`` resumes from the memory indices) while the encoder is
-already busy with the next part.  Only the last part's iterations are exposed, which
+encodes and scores its piece; ONE ``all_gather_into_tensor`` assembles the part's
+logits and the loop iterations that part makes possible follow it, both on a
+high-priority side stream (``ipsx_scan_range`` resumes from the memory indices), while
+the encoder is already busy with the next part on the main stream.  Only the last part's iterations are exposed, which
 keeps the sequential loop - whose length grows with the image - off the critical path.
 The M winning patches are then assembled with one small ``all_reduce`` of zero-filled
 owner contributions (exact: x + 0 = x).
@@ -168,17 +168,20 @@ def ips_sharded(net, local_patches, N, group=None):
                 else:
                     mine[:, :n_k] = emb
             base += n_k
-            gathered = _all_gather(mine, world, group)                      # the exchange of this part
-            full = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
             if on_gpu:
-                logits[:, edges[k]:edges[k + 1]] = full
+                # the exchange of this part and its loop iterations run on the side stream: the main stream goes
+                # straight on to encoding the next part (neither the gather nor the scan is on its critical path)
                 done = torch.cuda.Event()
                 done.record(main)
-                with torch.cuda.stream(side):                              # loop iterations of this part, off the critical path
+                mine.record_stream(side)
+                with torch.cuda.stream(side):
                     side.wait_event(done)
+                    gathered = _all_gather(mine, world, group)
+                    logits[:, edges[k]:edges[k + 1]] = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
                     hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx, tie)
             else:
-                all_emb[:, edges[k]:edges[k + 1]] = full
+                gathered = _all_gather(mine, world, group)                  # the exchange of this part
+                all_emb[:, edges[k]:edges[k + 1]] = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
         if on_gpu:
             main.wait_stream(side)
             hip.scan.last_tie = tie
