@@ -338,6 +338,17 @@ class EncoderPlan:
                                             _stream()), "ipsx_trunk_encode_indexed")
         return out
 
+    def encode_plain(self, x, out=None):
+        """The image trunk on every patch of ``x`` (no dedup)."""
+        x = x if x.is_contiguous() else x.contiguous()
+        n = x.shape[0]
+        if out is None:
+            out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
+        nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), n)
+        ws = self._workspace(nb, x.device)
+        _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()), "ipsx_trunk_encode")
+        return out
+
     def encode(self, x, nonblank=None):
         """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D).
 
@@ -368,10 +379,21 @@ class EncoderPlan:
                     _ck(lib().ipsx_trunk_encode_dedup(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb,
                                                       _p(self.n_encoded), _stream()), "ipsx_trunk_encode_dedup")
                 return out
-            nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), n)
-            ws = self._workspace(nb, x.device)
-            _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()),
-                "ipsx_trunk_encode")
+            if (dedup_blank() or nonblank is not None) and n > 1:
+                # layer-by-layer trunks (other patch sizes / depths): the same exact dedup with the index handling in
+                # torch - the layered launches are sized on the host, so the number of distinct patches is read back
+                # (one synchronisation per call; the fused trunk above needs none)
+                flags = nonblank.bool() if nonblank is not None else (x.flatten(1) != 0).any(1)
+                keep = torch.nonzero(flags).flatten()
+                blank = torch.nonzero(~flags).flatten()
+                if blank.numel() > 1:
+                    sel = torch.cat((keep, blank[:1]))
+                    uniq = self.encode_plain(x[sel])
+                    out[keep] = uniq[:keep.numel()]
+                    out[blank] = uniq[keep.numel():keep.numel() + 1]
+                    self.n_encoded = torch.tensor(sel.numel(), dtype=torch.int32, device=x.device)
+                    return out
+            return self.encode_plain(x, out)
         else:
             nb = n * x.shape[1] * 4
             ws = self._workspace(nb, x.device)

@@ -215,6 +215,31 @@ def test_blank_patch_dedup_is_exact(monkeypatch, blank_frac):
     assert torch.equal(full, dd)
 
 
+def test_blank_patch_dedup_is_exact_on_the_layered_trunk(monkeypatch):
+    """The reference-native 50-px patches (about 85 % blank) go through the layer-by-layer trunk; the dedup there gathers
+    the distinct patches with torch indexing and must still be bit-identical to encoding every patch."""
+    g = Golden("mnist_native50")
+    net = g.net(DEV)
+    x = synth.make_patches(g.conf, 1, seed=5, blank_frac=0.85, N=333)[0].to(DEV)
+    x[3] = -0.0
+    plan = hip.EncoderPlan(net.encoder, True)
+    full = plan.encode(x)
+    assert "layer by layer" in hip.encoder_kernel_name(plan)
+    monkeypatch.setenv("IPSX_DEDUP_BLANK", "1")
+    dd = plan.encode(x)
+    monkeypatch.delenv("IPSX_DEDUP_BLANK")
+    nonblank = int((x.reshape(x.shape[0], -1) != 0).any(1).sum().item())
+    assert int(plan.n_encoded.item()) == nonblank + 1 and nonblank < 100
+    assert torch.equal(full, dd)
+    # all blank / none blank
+    monkeypatch.setenv("IPSX_DEDUP_BLANK", "1")
+    z = torch.zeros_like(x[:7])
+    assert torch.equal(plan.encode(z), full[3:4].expand(7, -1))
+    dense = x[(x.flatten(1) != 0).any(1)][:9]
+    assert torch.equal(plan.encode(dense), plan.encode_plain(dense))
+    monkeypatch.delenv("IPSX_DEDUP_BLANK")
+
+
 def test_bf16_trunk_tracks_fp32_within_tolerance(monkeypatch):
     """IPSX_PRECISION=bf16 (BASELINE configs[4]): bf16 operands / fp32 accumulate in the residual stages.
     The reference has no reduced-precision path; the check is against this repo's own fp32 kernel and against a
