@@ -206,16 +206,30 @@ __global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a) {
     conv_epilogue(a, acc, m_base, n_base, lane);
 }
 
-// Any C_in (the 1- and 3-channel stems): the (tap, channel) of every k is decoded per lane.
+// Any C_in (the 1- and 3-channel stems).  The (channel, ky, kx) of every k is decoded ONCE per workgroup into an LDS
+// table (offset inside the image, tap position), so the inner loop has no integer divisions: per element one table
+// read (the lanes of a half share the address), the bounds test, the gather.
 __global__ __launch_bounds__(256) void conv_any_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int ktab[];     // [kgs*8][2]: {c*hw + ky*w + kx, ky | kx << 8 | valid << 16}
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int hw = a.h * a.w;
+    const int K = a.kh * a.kw * a.c_in;
+    for (int k = threadIdx.x; k < a.kgs * 8; k += 256) {
+        const bool kin = k < K;
+        const int kk = kin ? k : 0;
+        const int tap = kk / a.c_in, c = kk - tap * a.c_in;
+        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+        ktab[2 * k] = c * hw + ky * a.w + kx;
+        ktab[2 * k + 1] = ky | (kx << 8) | ((kin ? 1 : 0) << 16);
+    }
+    __syncthreads();
     const unsigned m_base = blockIdx.x * 256u + wave * 64u;
     if (m_base >= a.m_total) return;
     const int n_base = blockIdx.y * 64;
     const PixelCtx p0 = pixel_ctx(a, m_base + (lane & 31));
     const PixelCtx p1 = pixel_ctx(a, m_base + 32 + (lane & 31));
-    const int hw = a.h * a.w;
-    const int K = a.kh * a.kw * a.c_in;
+    // offset of (channel 0, tap 0) of each pixel's window inside its image; table offsets are added to it
+    const int o0 = p0.iy0 * a.w + p0.ix0, o1 = p1.iy0 * a.w + p1.ix0;
     const float4* wp0 = reinterpret_cast<const float4*>(a.wp) + ((size_t)(blockIdx.y * 2) * a.kgs) * 64 + lane;
     const float4* wp1 = wp0 + (size_t)a.kgs * 64;
     const bool n1 = n_base + 32 < a.c_out;
@@ -234,25 +248,26 @@ __global__ __launch_bounds__(256) void conv_any_kernel(ConvArgs a) {
         wp0 += 64; wp1 += 64;
         const float bb0[4] = {b0.x, b0.y, b0.z, b0.w};
         const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
+        const int4 ta = *reinterpret_cast<const int4*>(ktab + 2 * (kg * 8 + 4 * half));          // entries j = 0, 1
+        const int4 tb = *reinterpret_cast<const int4*>(ktab + 2 * (kg * 8 + 4 * half) + 4);      // entries j = 2, 3
+        const int off[4] = {ta.x, ta.z, tb.x, tb.z}, pk[4] = {ta.y, ta.w, tb.y, tb.w};
+        float a0[4], a1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = kg * 8 + 4 * half + j;
-            const bool kin = k < K;
-            const int kk = kin ? k : 0;
-            const int tap = kk / a.c_in, c = kk - tap * a.c_in;
-            const int ky = tap / a.kw, kx = tap - ky * a.kw;
-            const int iy_0 = p0.iy0 + ky, ix_0 = p0.ix0 + kx;
-            const int iy_1 = p1.iy0 + ky, ix_1 = p1.ix0 + kx;
-            const bool ok0 = kin && p0.valid && (unsigned)iy_0 < (unsigned)a.h && (unsigned)ix_0 < (unsigned)a.w;
-            const bool ok1 = kin && p1.valid && (unsigned)iy_1 < (unsigned)a.h && (unsigned)ix_1 < (unsigned)a.w;
-            float a0 = p0.base[ok0 ? c * hw + iy_0 * a.w + ix_0 : 0];
-            float a1 = p1.base[ok1 ? c * hw + iy_1 * a.w + ix_1 : 0];
-            a0 = ok0 ? a0 : 0.0f;
-            a1 = ok1 ? a1 : 0.0f;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb0[j], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb1[j], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb0[j], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb1[j], acc[1][1], 0, 0, 0);
+            const int ky = pk[j] & 0xFF, kx = (pk[j] >> 8) & 0xFF;
+            const bool kin = (pk[j] >> 16) != 0;
+            const bool ok0 = kin && p0.valid && (unsigned)(p0.iy0 + ky) < (unsigned)a.h && (unsigned)(p0.ix0 + kx) < (unsigned)a.w;
+            const bool ok1 = kin && p1.valid && (unsigned)(p1.iy0 + ky) < (unsigned)a.h && (unsigned)(p1.ix0 + kx) < (unsigned)a.w;
+            const float v0 = p0.base[ok0 ? o0 + off[j] : 0], v1 = p1.base[ok1 ? o1 + off[j] : 0];
+            a0[j] = ok0 ? v0 : 0.0f;
+            a1[j] = ok1 ? v1 : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb1[j], acc[1][1], 0, 0, 0);
         }
     }
     conv_epilogue(a, acc, m_base, n_base, lane);
@@ -360,7 +375,7 @@ int ipsx::conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* r
         if (cv->c_in % 8 == 0)
             conv_c8_kernel<<<grid, dim3(256), 0, as_stream(stream)>>>(a);
         else
-            conv_any_kernel<<<grid, dim3(256), 0, as_stream(stream)>>>(a);
+            conv_any_kernel<<<grid, dim3(256), (size_t)a.kgs * 8 * 2 * sizeof(int), as_stream(stream)>>>(a);
         IPSX_TRY(launched("conv2d_affine"));
     }
     return IPSX_OK;
