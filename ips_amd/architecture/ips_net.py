@@ -258,8 +258,9 @@ class IPSNet(nn.Module):
         if os.environ.get("IPSX_OVERLAP_SCAN", "1") == "0" or hip.dedup_blank():
             return False
         n_iter = math.ceil((patches.shape[1] - self.M) / self.I)
-        if self.is_image and patches.shape[0] * patches.shape[1] < 8192:
-            return False          # a small image batch does not fill the GPU four times over: one encoder launch is faster
+        if self.is_image and patches.shape[0] * patches.shape[1] < 32768 and n_iter < 100:
+            return False          # a small batch does not fill the GPU four times over and its loop is short: one
+                                  # encoder launch + one scan is faster (tools/sweep.py)
         return (not self.encoder.training) and n_iter >= 2 * self._OVERLAP_PARTS
 
     def _select_hip_overlapped(self, patches, pos_enc):

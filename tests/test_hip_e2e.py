@@ -363,8 +363,8 @@ def test_scan_overlapped_with_encoder_equals_plain(monkeypatch):
     (ipsx_scan_range); IPSX_OVERLAP_SCAN=0 is the plain encode-all-then-scan path.  Same result."""
     g = Golden("mnist_full")
     net = g.net(DEV)
-    x = torch.cat([g.patches(), synth.make_patches(g.conf, 3, seed=99)], 0).to(DEV)     # 10,000 patches: overlapped
-    assert net._can_overlap(x) and not net._can_overlap(x[:1])
+    x = torch.cat([g.patches(), synth.make_patches(g.conf, 13, seed=99)], 0).to(DEV)    # 35,000 patches: overlapped
+    assert net._can_overlap(x) and not net._can_overlap(x[:4])
     mp_a, pos_a = net.ips(x)
     idx_a = net.last_mem_idx.clone()
     monkeypatch.setenv("IPSX_OVERLAP_SCAN", "0")
