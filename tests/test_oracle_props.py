@@ -82,3 +82,16 @@ def test_device_tie_order_restatement_equals_libstdcxx():
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "check_stdorder"])
     out = subprocess.run([os.path.join(root, "oracle", "check_stdorder"), "40000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "mismatching cases 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_device_tie_order_restatement_is_clean_under_sanitizers():
+    """The same restatement under AddressSanitizer + UBSan (host build): no out-of-bounds access in the hole-sifting
+    heap routines, the unguarded partition / insertion loops or the explicit stack."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "check_stdorder_asan"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([os.path.join(root, "oracle", "check_stdorder_asan"), "6000"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0 and "mismatching cases 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
