@@ -86,6 +86,48 @@ def test_ips_and_forward_bit_exact_vs_oracle(case):
         assert ulp_diff(preds[k].cpu().numpy(), wp[k]) == 0, k
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations_bit_exact_vs_oracle(seed):
+    """Random small configurations: ragged last chunk, I > N - M, the M >= N shortcut, B > 1, 1 / 2 / 4
+    query tokens, with and without positional encoding, image and feature inputs, blank patches with ties - ips() and
+    the eval forward against the oracle, bit for bit (the oracle replays torch's tie order like the device does)."""
+    g = np.random.default_rng(500 + seed)
+    feat = bool(seed % 5 == 4)
+    T = int(g.choice([1, 2, 4]))
+    tasks = {"task%d" % t: {"id": t, "name": "t%d" % t, "act_fn": "softmax" if t % 2 == 0 else "sigmoid",
+                            "metric": "accuracy" if t % 2 == 0 else "multilabel_accuracy"} for t in range(T)}
+    M = int(g.choice([4, 8, 16, 24]))
+    I = int(g.choice([3, 8, 16, 40]))
+    N = int(g.choice([M - 1, M, M + 1, M + I - 1, M + 2 * I + 3, 5 * I + M])) if seed % 3 else int(M + g.integers(1, 60))
+    N = max(N, 2)
+    use_pos = bool(g.integers(0, 2)) and N % 1 == 0
+    B = int(g.choice([1, 2, 3]))
+    if feat:
+        conf = synth.camelyon_conf(N=N, M=M, I=I, n_chan_in=64, D=32, D_k=8, D_v=8, H=4, D_inner=64, n_token=T,
+                                   tasks=tasks, use_pos=use_pos, n_class=3)
+    else:
+        conf = synth.mnist_conf(N=N, M=M, I=I, n_token=T, tasks=tasks, use_pos=use_pos, n_class=3,
+                                blank_frac=float(g.choice([0.0, 0.5, 0.93])))
+    cpu = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 40 + seed).eval()
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 40 + seed).to(DEV).eval()
+    x = synth.make_patches(conf, B, seed=70 + seed)
+    o = orc.Oracle(cpu)
+    mem_patch, mem_pos = net.ips(x.to(DEV))
+    if M >= N:                                                      # shortcut: everything is kept, in order
+        assert torch.equal(mem_patch.cpu(), x) and net.last_mem_idx is None
+        want_patch, want_pos = x.numpy(), (np.broadcast_to(cpu.pos_enc.numpy(), (B, N, conf.D)) if use_pos else None)
+    else:
+        want = o.ips(x.numpy(), cpu.pos_enc.numpy() if use_pos else None, aten_ties=True)
+        assert np.array_equal(net.last_mem_idx.cpu().numpy(), want["mem_idx"]), (N, M, I, T, use_pos, B, feat)
+        assert np.array_equal(mem_patch.cpu().numpy(), want["mem_patch"])
+        want_patch, want_pos = want["mem_patch"], want["mem_pos"]
+    with torch.no_grad():
+        preds = net(mem_patch, mem_pos)
+    wp = o.forward(want_patch, want_pos)
+    for k in wp:
+        assert ulp_diff(preds[k].cpu().numpy(), wp[k]) == 0, k
+
+
 def test_lazy_loading_equals_eager():
     """patches left on the host (reference ips_net.py:204-206,223,245-247)."""
     g = Golden("mnist_ragged")
