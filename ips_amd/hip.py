@@ -365,7 +365,7 @@ class EncoderPlan:
             if x.shape[1] != self.trunk.c_in:
                 raise ValueError("patches have {} channels, encoder expects {}".format(x.shape[1], self.trunk.c_in))
             if (dedup_blank() or nonblank is not None) and \
-                    lib().ipsx_trunk_kernel(C.byref(self.trunk)) == b"fused_trunk_kernel":
+                    lib().ipsx_trunk_kernel(C.byref(self.trunk)).startswith(b"fused_trunk"):      # any precision
                 nb = lib().ipsx_trunk_dedup_workspace_bytes(C.byref(self.trunk), n)
                 ws = self._workspace(nb, x.device)
                 self.n_encoded = torch.zeros((), dtype=torch.int32, device=x.device)
