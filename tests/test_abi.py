@@ -43,3 +43,38 @@ def test_hip_backend_refuses_to_run_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(hip, "_LIB", None)
     with pytest.raises(RuntimeError, match="no fallback"):
         hip.lib()
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """include/ipsx.h through a C compiler (gcc -std=c11 -pedantic), linked against libipsx.so: what a cgo / JNI / FFI
+    binding of the reference's host language would do.  Only host-side entry points are called (no GPU here)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "ipsx.h"
+int main(void) {
+    ipsx_conv cv; ipsx_trunk tr; ipsx_transf tf;
+    (void)cv; (void)tr; (void)tf;
+    if (ipsx_version() / 100 != 1) return 1;
+    if (ipsx_packed_conv_weight_elems(64, 64, 3, 3) != (size_t)2 * 72 * 64 * 4) return 2;
+    if (ipsx_patchify_count(1500, 1500, 32, 32, 32, 32) != 46 * 46) return 3;
+    if (ipsx_patchify_count(10, 10, 32, 32, 32, 32) != 0) return 4;
+    if (ipsx_folded_query_elems(8, 4, 128) != (size_t)1 * 16 * 64 * 4) return 5;
+    if (ipsx_packed_stem_weight_split_bytes(64, 3) != (size_t)2 * 4 * 3 * 1024) return 6;
+    if (ipsx_set_tie_order(-1) != 1) return 7;                /* query: the default is the reference's order */
+    printf("abi ok %d\n", ipsx_version());
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(hip.library_path())
+    cmd = ["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-lipsx", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("abi ok"), (out.returncode, out.stdout, out.stderr)
