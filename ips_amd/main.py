@@ -94,8 +94,7 @@ def main(argv=None):
     sparse = args.sparse and device.type == "cuda" and conf.eager
     kw = dict(num_workers=conf.n_worker, persistent_workers=conf.n_worker > 0,
               collate_fn=mm.collate_sparse if sparse else None)
-    if not sparse:
-        kw["pin_memory"] = bool(conf.pin_memory) and device.type == "cuda"
+    kw["pin_memory"] = bool(conf.pin_memory) and device.type == "cuda"     # SparseImages has pin_memory() too
     train_loader = DataLoader(mm.MegapixelMNIST(conf, train=True, sparse=sparse), batch_size=conf.B_seq, shuffle=True, **kw)
     test_loader = DataLoader(mm.MegapixelMNIST(conf, train=False, sparse=sparse), batch_size=conf.B_seq, shuffle=False, **kw)
 
