@@ -60,9 +60,11 @@ static int trunk_geom(const ipsx_trunk* t, TrunkGeom* g) {
     return IPSX_OK;
 }
 
-// patches per chunk: 4 activation buffers of chunk*max_elems floats, <= ~2 GiB in all
+// patches per chunk: 4 activation buffers of chunk*max_elems floats, <= 24 GiB in all.  Sized for 288 GB of HBM: the
+// deep layers of a trunk have few output pixels per patch, and a chunk has to be large for THEM to fill 256 CUs
+// (traffic signs, 512 channels at 4x4: 768 patches are 384 workgroups - fewer than the GPU runs at once)
 static int64_t trunk_chunk(const TrunkGeom& g, int64_t n) {
-    const size_t budget = (size_t)2 << 30;
+    const size_t budget = (size_t)24 << 30;
     int64_t cap = (int64_t)(budget / (4 * g.max_elems * sizeof(float)));
     cap = std::max<int64_t>(cap, 1);
     return std::min<int64_t>(n, cap);
