@@ -33,7 +33,7 @@ from torch import nn
 
 from .. import hip
 from ..shuffle import shuffle_batch, shuffle_instance
-from .resnet import resnet18_trunk, resnet50_trunk
+from .resnet import load_torchvision_checkpoint, resnet18_trunk, resnet50_trunk
 from .transformer import Transformer, pos_enc_1d
 
 
@@ -43,16 +43,22 @@ class IPSNet(nn.Module):
     # ---------------------------------------------------------------- construction
     def get_conv_patch_enc(self, enc_type, pretrained, n_chan_in, n_res_blocks):
         """ResNet stem + 2 or 4 residual stages + global average pool (reference :17-52)."""
-        if pretrained:
-            raise RuntimeError(
-                "pretrained=True needs torchvision's ImageNet checkpoint, which this offline "
-                "image cannot fetch; load it yourself with net.encoder.load_state_dict(...)")
         if enc_type == 'resnet18':
             trunk = resnet18_trunk()
         elif enc_type == 'resnet50':
             trunk = resnet50_trunk()
         else:
             raise ValueError("unknown enc_type {!r}".format(enc_type))
+        if pretrained:
+            # the reference lets torchvision download IMAGENET1K_V1 (:19-27); this framework targets machines
+            # without network access, so the same file is read from a local path instead
+            import os
+            path = os.environ.get("IPSX_PRETRAINED_" + enc_type.upper()) or os.environ.get("IPSX_PRETRAINED")
+            if not path:
+                raise RuntimeError(
+                    "pretrained=True: point IPSX_PRETRAINED_{} (or IPSX_PRETRAINED) at a local torchvision {} "
+                    "state-dict file (IMAGENET1K_V1 .pth); this image cannot download it".format(enc_type.upper(), enc_type))
+            load_torchvision_checkpoint(trunk, path)
         if n_chan_in == 1:
             # the reference swaps the 3-channel stem for a fresh 1-channel one (:29-31)
             trunk.conv1 = nn.Conv2d(n_chan_in, 64, kernel_size=7, stride=2, padding=3, bias=False)
@@ -339,8 +345,16 @@ class IPSNet(nn.Module):
         else:
             ring = [torch.empty((B, per) + tuple(patches.shape[2:]), dtype=patches.dtype, device=dev) for _ in range(2)]
             dst = lambda k, lo, hi: ring[k % 2][:, :hi - lo]
-        copy_stream = torch.cuda.Stream(device=dev)
+        copy_stream = getattr(self, "_copy_stream", None)
+        if copy_stream is None or copy_stream.device != torch.device(dev):
+            copy_stream = self._copy_stream = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
+        # `store` / `ring` come from the main stream's allocator pool: a block freed in Python a moment ago may still be
+        # read by kernels queued on the main stream (the previous step's backward / optimizer), so the copy stream must
+        # not write it before the main stream got that far - and the allocator must know the copy stream uses it
+        copy_stream.wait_stream(main)
+        for buf in ([store] if keep else ring):
+            buf.record_stream(copy_stream)
         ready, freed = {}, {}
 
         def issue(k):

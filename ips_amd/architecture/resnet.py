@@ -85,6 +85,11 @@ class ResNetTrunk(nn.Module):
         self.layer3 = self._stage(block, 256, depths[2], 2)
         self.layer4 = self._stage(block, 512, depths[3], 2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        # torchvision's ResNet builds its 1000-way classifier here; the reference drops it (ips_net.py:35-50) but its
+        # initialisation has consumed torch's global RNG by then, and the transformer / heads built afterwards draw
+        # from the stream that follows.  Same draws, then discard - so a seeded construction gives the reference's
+        # initial transf.* / output_layers.* weights.
+        nn.Linear(512 * block.expansion, 1000)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -117,3 +122,24 @@ def resnet18_trunk(n_chan_in=3):
 
 def resnet50_trunk(n_chan_in=3):
     return ResNetTrunk(Bottleneck, (3, 4, 6, 3), n_chan_in)
+
+
+def load_torchvision_checkpoint(trunk, path):
+    """Load a torchvision ``resnet18`` / ``resnet50`` state-dict file (the ``IMAGENET1K_V1`` ``.pth`` the reference
+    gets from ``weights=...``, /root/reference/architecture/ips_net.py:19-27) into ``trunk``.  The file's keys are
+    torchvision's (``conv1.weight``, ``layer1.0.bn1.running_mean``, ..., ``fc.weight``); the classifier (``fc.*``)
+    is dropped as the reference drops it, everything else must match key for key and shape for shape."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd and not any(k.startswith("conv1") for k in sd):
+        sd = sd["state_dict"]
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+    own = trunk.state_dict()
+    missing = sorted(set(own) - set(sd))
+    extra = sorted(set(sd) - set(own))
+    wrong = sorted(k for k in set(own) & set(sd) if tuple(own[k].shape) != tuple(sd[k].shape))
+    if missing or extra or wrong:
+        raise RuntimeError("{}: not a torchvision checkpoint of this trunk (missing {}, unexpected {}, shape mismatch {})"
+                           .format(path, missing[:4], extra[:4], wrong[:4]))
+    trunk.load_state_dict(sd, strict=True)
+    return trunk

@@ -107,7 +107,8 @@ class MultiHeadCrossAttention(nn.Module):
 
         Depends on the three parameters only, so it is kept until one of them changes (in-place updates bump
         ``_version``; ``.to()`` / ``load_state_dict`` change the storage) - an evaluation loop folds once."""
-        key = tuple((t.data_ptr(), t._version, t.device) for t in (self.q, self.q_w.weight, self.k_w.weight))
+        key = (hip.weights_generation(),) + tuple((t.data_ptr(), t._version, t.device)
+                                                  for t in (self.q, self.q_w.weight, self.k_w.weight))
         cached = getattr(self, "_folded", None)
         if cached is None or cached[0] != key:
             cached = (key, hip.fold_query(self.scaled_query(), self.k_w.weight, self.H, self.D_k, self.n_token))

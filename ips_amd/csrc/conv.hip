@@ -151,62 +151,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
     }
 }
 
-// C_in % 8 == 0: every packed k-group (8 consecutive k) lies inside one tap.
-__global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-    const unsigned m_base = blockIdx.x * 256u + wave * 64u;
-    if (m_base >= a.m_total) return;                      // wave-uniform
-    const int n_base = blockIdx.y * 64;
-    const PixelCtx p0 = pixel_ctx(a, m_base + (lane & 31));
-    const PixelCtx p1 = pixel_ctx(a, m_base + 32 + (lane & 31));
-    const int hw = a.h * a.w;
-    const int cgs = a.c_in >> 3;
-    const float4* wp0 = reinterpret_cast<const float4*>(a.wp) + ((size_t)(blockIdx.y * 2) * a.kgs) * 64 + lane;
-    const float4* wp1 = wp0 + (size_t)a.kgs * 64;
-    const bool n1 = n_base + 32 < a.c_out;                // second n-tile exists (uniform)
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    for (int ky = 0; ky < a.kh; ++ky) {
-        for (int kx = 0; kx < a.kw; ++kx) {
-            const int iy_0 = p0.iy0 + ky, ix_0 = p0.ix0 + kx;
-            const int iy_1 = p1.iy0 + ky, ix_1 = p1.ix0 + kx;
-            const bool ok0 = p0.valid && (unsigned)iy_0 < (unsigned)a.h && (unsigned)ix_0 < (unsigned)a.w;
-            const bool ok1 = p1.valid && (unsigned)iy_1 < (unsigned)a.h && (unsigned)ix_1 < (unsigned)a.w;
-            // padded taps load element 0 of the patch (always mapped) and are zeroed below
-            const float* s0 = p0.base + (ok0 ? iy_0 * a.w + ix_0 : 0) + 4 * half * hw;
-            const float* s1 = p1.base + (ok1 ? iy_1 * a.w + ix_1 : 0) + 4 * half * hw;
-#pragma unroll 2
-            for (int cg = 0; cg < cgs; ++cg) {
-                const float4 b0 = *wp0;
-                const float4 b1 = n1 ? *wp1 : make_float4(0.f, 0.f, 0.f, 0.f);
-                wp0 += 64; wp1 += 64;
-                const float bb0[4] = {b0.x, b0.y, b0.z, b0.w};
-                const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int coff = (cg * 8 + j) * hw;          // channel cg*8 + 4*half + j
-                    float a0 = s0[coff], a1 = s1[coff];
-                    a0 = ok0 ? a0 : 0.0f;
-                    a1 = ok1 ? a1 : 0.0f;
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb0[j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb1[j], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb0[j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb1[j], acc[1][1], 0, 0, 0);
-                }
-            }
-        }
-    }
-    conv_epilogue(a, acc, m_base, n_base, lane);
-}
-
-// Any C_in (the 1- and 3-channel stems).  The (channel, ky, kx) of every k is decoded ONCE per workgroup into an LDS
+// Any C_in (the 1- and 3-channel stems, and the public NCHW entry point).  The (channel, ky, kx) of every k is decoded ONCE per workgroup into an LDS
 // table (offset inside the image, tap position), so the inner loop has no integer divisions: per element one table
 // read (the lanes of a half share the address), the bounds test, the gather.
 __global__ __launch_bounds__(256) void conv_any_kernel(ConvArgs a) {
@@ -372,10 +317,9 @@ int ipsx::conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* r
         a.kgs = (int)cdiv((int64_t)cv->kh * cv->kw * cv->c_in, 8);
         a.out_nhwc = out_nhwc;
         dim3 grid((unsigned)cdiv(a.m_total, 256), (unsigned)cdiv(cv->c_out, 64));
-        if (cv->c_in % 8 == 0)
-            conv_c8_kernel<<<grid, dim3(256), 0, as_stream(stream)>>>(a);
-        else
-            conv_any_kernel<<<grid, dim3(256), (size_t)a.kgs * 8 * 2 * sizeof(int), as_stream(stream)>>>(a);
+        const size_t table = (size_t)a.kgs * 8 * 2 * sizeof(int);
+        IPSX_REQUIRE(table <= 64 * 1024, "conv2d_affine: K = %d does not fit the k table", a.kgs * 8);
+        conv_any_kernel<<<grid, dim3(256), table, as_stream(stream)>>>(a);
         IPSX_TRY(launched("conv2d_affine"));
     }
     return IPSX_OK;

@@ -17,7 +17,7 @@
 // contain equal neighbours (otherwise the answer is the strict descending order every algorithm agrees on).
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define IPSX_HD __host__ __device__ __forceinline__
 #else
 #define IPSX_HD inline

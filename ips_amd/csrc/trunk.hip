@@ -7,6 +7,7 @@
 // caller's stream, in chunks of patches so the activation workspace stays bounded.
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "ipsx_common.h"
 
@@ -63,11 +64,28 @@ static int trunk_geom(const ipsx_trunk* t, TrunkGeom* g) {
 // patches per chunk: 4 activation buffers of chunk*max_elems floats, <= 24 GiB in all.  Sized for 288 GB of HBM: the
 // deep layers of a trunk have few output pixels per patch, and a chunk has to be large for THEM to fill 256 CUs
 // (traffic signs, 512 channels at 4x4: 768 patches are 384 workgroups - fewer than the GPU runs at once)
-static int64_t trunk_chunk(const TrunkGeom& g, int64_t n) {
-    const size_t budget = (size_t)24 << 30;
-    int64_t cap = (int64_t)(budget / (4 * g.max_elems * sizeof(float)));
-    cap = std::max<int64_t>(cap, 1);
+// The budget is the smallest of: IPSX_TRUNK_WORKSPACE_MB (default 24576), 40 % of the device memory that is free right
+// now (other processes / the training step's activations live there too).  ipsx_trunk_encode itself sizes its chunks
+// from the workspace it is GIVEN, so a caller may hand over less than ipsx_trunk_workspace_bytes proposes.
+static size_t trunk_budget() {
+    size_t budget = (size_t)24 << 30;
+    if (const char* e = getenv("IPSX_TRUNK_WORKSPACE_MB")) {
+        const long long mb = atoll(e);
+        if (mb > 0) budget = (size_t)mb << 20;
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min(budget, free_b / 10 * 4);
+    else (void)hipGetLastError();
+    return budget;
+}
+
+static int64_t chunk_for(const TrunkGeom& g, int64_t n, size_t bytes) {
+    int64_t cap = (int64_t)(bytes / (4 * g.max_elems * sizeof(float)));
     return std::min<int64_t>(n, cap);
+}
+
+static int64_t trunk_chunk(const TrunkGeom& g, int64_t n) {
+    return std::max<int64_t>(chunk_for(g, n, trunk_budget()), 1);
 }
 
 }  // namespace ipsx
@@ -96,11 +114,11 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
     if (n_patch == 0) return IPSX_OK;
     if (fused_trunk_supported(t)) return fused_trunk_encode(t, patches, n_patch, emb, as_stream(stream));
 
-    const int64_t chunk = trunk_chunk(g, n_patch);
+    const int64_t chunk = workspace ? chunk_for(g, n_patch, workspace_bytes) : 0;      // chunks fit what the caller gave
+    if (chunk < 1)
+        return fail(IPSX_EWORKSPACE, "trunk_encode: workspace %zu B < %zu B (one patch)", workspace_bytes,
+                    g.max_elems * sizeof(float) * 4);
     const size_t buf_elems = (size_t)chunk * g.max_elems;
-    if (!workspace || workspace_bytes < buf_elems * sizeof(float) * 4)
-        return fail(IPSX_EWORKSPACE, "trunk_encode: workspace %zu B < %zu B", workspace_bytes,
-                    buf_elems * sizeof(float) * 4);
     float* buf[4];
     for (int i = 0; i < 4; ++i) buf[i] = static_cast<float*>(workspace) + i * buf_elems;
     const size_t patch_elems = (size_t)t->c_in * t->h * t->w;

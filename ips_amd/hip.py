@@ -61,6 +61,23 @@ def dedup_blank():
     return os.environ.get("IPSX_DEDUP_BLANK", "0") == "1"
 
 
+# Graph replays (training/graphed.py) update parameters and BatchNorm statistics without bumping tensor._version or
+# changing storage pointers, so every cache keyed on (data_ptr, _version) also carries this counter; whoever mutates
+# weights behind autograd's back calls weights_changed().
+_WEIGHTS_GENERATION = 0
+
+
+def weights_generation():
+    return _WEIGHTS_GENERATION
+
+
+def weights_changed():
+    """Invalidate every packed-weight cache (EncoderPlan, folded query): call after a HIP-graph replay or any other
+    update of parameters / buffers that bypasses ``_version``."""
+    global _WEIGHTS_GENERATION
+    _WEIGHTS_GENERATION += 1
+
+
 def on_device(x):
     """True when ``x`` (tensor / device / str) is a GPU and the HIP backend is selected."""
     if torch.is_tensor(x):
@@ -245,7 +262,7 @@ class EncoderPlan:
         self._ws = None
 
     def _signature(self):
-        sig = [precision()]
+        sig = [precision(), weights_generation()]
         for t in list(self.encoder.parameters()) + list(self.encoder.buffers()):
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)
@@ -312,7 +329,11 @@ class EncoderPlan:
             self.d_out = w.shape[0]
 
     def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+        # grown on demand; given back when a much smaller request follows (one large evaluation call must not pin
+        # tens of GiB for the rest of a training run)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device or \
+                (self._ws.numel() > (256 << 20) and nbytes < self._ws.numel() // 4):
+            self._ws = None
             self._ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         return self._ws
 

@@ -19,6 +19,7 @@ import copy
 
 import torch
 
+from .. import hip
 from .iterative import compute_loss
 
 
@@ -40,11 +41,17 @@ class GraphedStep:
         return loss, info
 
     def _make_capturable(self):
-        group = self.optimizer.param_groups[0]
-        group['capturable'] = True
-        lr = group['lr']
-        self._lr_tensor = lr if torch.is_tensor(lr) else torch.tensor(float(lr), dtype=torch.float32, device=self.net.device)
-        group['lr'] = self._lr_tensor
+        """Every param group: ``capturable`` AdamW with the learning rate in a device tensor (one per group)."""
+        self._lr_tensors = []
+        for group in self.optimizer.param_groups:
+            group['capturable'] = True
+            lr = group['lr']
+            t = lr if torch.is_tensor(lr) else torch.tensor(float(lr), dtype=torch.float32, device=self.net.device)
+            group['lr'] = t
+            self._lr_tensors.append(t)
+        for p, st in self.optimizer.state.items():               # eager steps keep `step` on the host; capturable needs it
+            if torch.is_tensor(st.get('step')) and st['step'].device != p.device:       # next to the parameter
+                st['step'] = st['step'].to(device=p.device, dtype=torch.float32)
 
     def _capture(self, mem_patch, mem_pos_enc, labels):
         dev = mem_patch.device
@@ -58,6 +65,9 @@ class GraphedStep:
 
         # snapshot everything the warm-up steps will move
         snap_model = copy.deepcopy(self.net.state_dict())
+        had_state = any(len(st) for st in self.optimizer.state.values())
+        snap_opt = {id(p): {k: (v.clone() if torch.is_tensor(v) else copy.deepcopy(v)) for k, v in st.items()}
+                    for p, st in self.optimizer.state.items()}
         rng = torch.cuda.get_rng_state(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -91,13 +101,20 @@ class GraphedStep:
                                     [p.float().reshape(-1) for p in shown])
         self._shown_shapes = [tuple(p.shape) for p in shown]
 
-        # undo the warm-up: weights, BatchNorm statistics, optimizer moments and step counters, RNG
+        # undo the warm-up: weights, BatchNorm statistics, optimizer moments and step counters, RNG.  The optimizer's
+        # state tensors are graph inputs, so they are restored IN PLACE: to the snapshot when the optimizer had already
+        # taken steps (a re-capture after the batch geometry changed), to zero when the warm-up created them.
         self.net.load_state_dict(snap_model)
-        for state in self.optimizer.state.values():
+        for p, state in self.optimizer.state.items():
+            before = snap_opt.get(id(p), {}) if had_state else {}
             for k, v in state.items():
                 if torch.is_tensor(v):
-                    v.zero_()
+                    if k in before and torch.is_tensor(before[k]):
+                        v.copy_(before[k])
+                    else:
+                        v.zero_()
         torch.cuda.set_rng_state(rng, dev)
+        hip.weights_changed()
 
     # ------------------------------------------------------------------ the step
     def __call__(self, mem_patch, mem_pos_enc, labels):
@@ -107,8 +124,6 @@ class GraphedStep:
             return self._eager(mem_patch, mem_pos_enc, labels)
         key = (tuple(mem_patch.shape), torch.is_tensor(mem_pos_enc), tuple(sorted(labels)))
         if self.graph is None or key != self._key:
-            if self.graph is None and any(len(s) for s in self.optimizer.state.values()):
-                raise RuntimeError("GraphedStep must be created before the optimizer has taken eager steps")
             self._capture(mem_patch, mem_pos_enc, labels)
             self._key = key
         self._sync_lr()
@@ -118,6 +133,9 @@ class GraphedStep:
         for k, v in labels.items():
             self.s_labels[k].copy_(v)
         self.graph.replay()
+        # the replay moved every parameter and the BatchNorm running statistics without bumping their _version
+        # counters: the packed-weight caches of the HIP path (EncoderPlan, folded query) must not survive it
+        hip.weights_changed()
 
         flat = self.s_flat.cpu().numpy()
         tasks = list(conf.tasks.values())
@@ -136,8 +154,8 @@ class GraphedStep:
     def _sync_lr(self):
         """``adjust_learning_rate`` assigns a Python float to param_groups[0]['lr'] (reference utils/utils.py:31); the
         captured AdamW reads a device tensor: move the value over and put the tensor back."""
-        group = self.optimizer.param_groups[0]
-        if getattr(self, "_lr_tensor", None) is None or group['lr'] is self._lr_tensor:
-            return
-        self._lr_tensor.fill_(float(group['lr']))
-        group['lr'] = self._lr_tensor
+        for group, t in zip(self.optimizer.param_groups, getattr(self, "_lr_tensors", [])):
+            if group['lr'] is t:
+                continue
+            t.fill_(float(group['lr']))
+            group['lr'] = t

@@ -192,3 +192,42 @@ def test_hip_graph_step_equals_the_eager_step():
             assert torch.allclose(sa[k], sb[k], rtol=0, atol=6e-3), k       # 4 AdamW steps of lr <= 1e-3 each
         else:
             assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.gpu
+def test_graph_replays_do_not_leave_stale_packed_weights():
+    """A HIP-graph replay moves parameters and BatchNorm statistics without bumping ``_version`` or changing storage:
+    the caches of the HIP path (EncoderPlan's packed weights, the folded query) are keyed on exactly those, so
+    GraphedStep must invalidate them (hip.weights_changed).  Three consecutive full-batch graph steps; after each one
+    ``ips()`` with the net's caches must equal ``ips()`` of a fresh net loaded with the current weights - embeddings,
+    logits operand and selected indices."""
+    from ips_amd import hip
+    from ips_amd.training.graphed import GraphedStep
+    dev = torch.device("cuda:0")
+    conf = synth.mnist_conf(N=200, M=16, I=16, B=4, B_seq=4, attn_dropout=0.0, dropout=0.0)
+    conf.wd = 0.1
+    net = synth.fill_weights(IPSNet(dev, conf), 3).to(dev)
+    crit = {t['name']: (nn.NLLLoss() if t['act_fn'] == 'softmax' else nn.BCELoss()) for t in conf.tasks.values()}
+    opt = torch.optim.AdamW(net.parameters(), lr=0.05, weight_decay=conf.wd)       # large steps: stale weights would show
+    step = GraphedStep(net, crit, opt, conf)
+    item = synth.make_loader(conf, 1, seed=5).items[0]
+    x = item['input'].to(dev)
+    labels = {t['name']: item[t['name']].to(dev) for t in conf.tasks.values()}
+    net.train()
+    first_idx = None
+    for k in range(3):
+        mem_patch, mem_pos = net.ips(x)
+        if first_idx is None:
+            first_idx = net.last_mem_idx.clone()
+        emb_cached = net.last_mem_emb.clone()
+        idx_cached = net.last_mem_idx.clone()
+        fresh = IPSNet(dev, conf).to(dev)
+        fresh.load_state_dict(net.state_dict())
+        fresh.train()
+        fresh.ips(x)
+        assert torch.equal(idx_cached, fresh.last_mem_idx), "step %d: stale weights selected other patches" % k
+        assert torch.equal(emb_cached, fresh.last_mem_emb), "step %d: stale packed weights" % k
+        assert torch.equal(net.transf.crs_attn.folded_query(), fresh.transf.crs_attn.folded_query()), k
+        step(mem_patch, mem_pos, labels)
+    net.ips(x)
+    assert not torch.equal(net.last_mem_emb, emb_cached)          # the steps did move the encoder
