@@ -7,25 +7,33 @@
 
 One "step" = one ``IPSNet.ips(patches)`` call (no-grad, eval, eager loading: the patch
 tensor is resident in HBM when the timed region starts): embed every patch, score,
-run the whole selection loop, gather the M winners.  Workload at N = 1: BASELINE.json
-configs[1], Megapixel-MNIST 1500 (2500 patches of 1x32x32 per image, M = I = 64, 4
-query tokens, positional encoding on) at the reference's batch size B = 16
-(config/mnist_config.yml B_seq).  At N > 1 the patch axis is sharded (ips_amd/dist.py):
-every GPU holds 2500 patches of each of the 16 images (weak scaling: the image grows
-with the node, N = 4 is the 3000x3000 / 10000-patch case of configs[2]); value counts
-the patches all ranks scored.
+run the whole selection loop, gather the M winners.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus
+Workloads (``ips_amd.synth.BENCH_WORKLOADS``; weights seed 7, patches seed 21):
+  N = 1   BASELINE.json configs[1]: Megapixel-MNIST 1500 - 2500 patches of 1x32x32 per image,
+          M = I = 64, 4 query tokens, positional encoding on, at the reference's batch size
+          B = 16 (config/mnist_config.yml B_seq).
+  N > 1   BASELINE.json configs[2]: Megapixel-MNIST 3000 - 10,000 patches per image, B = 16, the patch
+          axis sharded over the N ranks (ips_amd/dist.py; strong scaling: the job is the same at
+          every N).  ``--scaling weak`` instead gives every GPU 2500 patches of each image (the
+          image grows with the node).  value counts the patches all ranks scored.
+
+Every line carries
+  parity        ``net.last_mem_idx`` after the timed loop against the REFERENCE's selection on the same
+                inputs (tests/golden/bench_<workload>.npz, recorded by running the imported reference in the
+                build container, tools/gen_golden_bench.py) - on every rank;
   roofline      encoder launch(es) timed with HIP events on the launch stream inside the
                 timed region; achieved = algorithmic FLOP (37,257,216 per 32-px patch,
                 SURVEY.md 8 d-4) / that time, against the 157.3 TFLOP/s fp32 MFMA peak;
   cpu_baseline  oracle/ips_torch.py (the reference's ATen CPU path restated) on this host's
-                cores, on a bounded sample of the same workload.
+                cores, on a bounded sample of the same workload (N = 1 only).
 """
 
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,16 +41,24 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
-FLOP_PER_PATCH_MNIST32 = 37_257_216      # encoder MACs*2, SURVEY.md section 8 d-4
-# secondary workloads (--config): algorithmic encoder FLOP per patch, SURVEY.md section 8 d-4
-FLOP_PER_PATCH = {"mnist": 37_257_216, "b1": 37_257_216, "native50": 2 * 52_570_176,
+# algorithmic encoder FLOP per patch, SURVEY.md section 8 d-4
+FLOP_PER_PATCH = {"mnist": 37_257_216, "b1": 37_257_216, "mnist3000": 37_257_216, "native50": 2 * 52_570_176,
                   "traffic": 2 * 441_262_848, "cam": 2 * 1_048_576}
 FP32_MFMA_PEAK_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-PATCHES_PER_GPU = 2500
-BATCH = 16
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+PATCHES_PER_GPU_WEAK = 2500
+LABEL = {
+    "mnist": "Megapixel-MNIST 1500: 2500 patches of 1x32x32 per image (BASELINE configs[1])",
+    "b1": "Megapixel-MNIST 1500: 2500 patches of 1x32x32, ONE image (image 0 of the headline batch)",
+    "mnist3000": "Megapixel-MNIST 3000: 10000 patches of 1x32x32 per image (BASELINE configs[2])",
+    "native50": "Megapixel-MNIST reference-native: 900 patches of 1x50x50 per image, M=I=100",
+    "traffic": "traffic signs: 192 patches of 3x100x100 per image, ResNet-18 x4 stages, M=16, I=32",
+    "cam": "CAMELYON: 65536 x 2048 features per slide, projector, M=I=256 (BASELINE configs[3])",
+}
 
 
 def parse():
@@ -50,7 +66,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--batch", type=int, default=None, help="images per step (default: the workload's, 16 / 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--dedup-blank", action="store_true",
                     help="secondary measurement: exact blank-patch deduplication in front of the encoder "
@@ -62,53 +78,76 @@ def parse():
     ap.add_argument("--lazy", action="store_true",
                     help="secondary measurement: lazy loading - the patch tensor starts in pinned HOST memory and "
                          "is streamed over PCIe inside every step (the PCIe-inclusive rate; never the headline)")
-    ap.add_argument("--config", default="mnist", choices=sorted(FLOP_PER_PATCH),
-                    help="mnist = the headline workload (BASELINE configs[1], B=16); the others are secondary "
-                         "single-GPU measurements: b1 (same, B=1), native50 (reference-native 900 patches of 50 px, "
-                         "M=I=100, B=16), traffic (192 patches of 3x100x100, ResNet-18 x4, M=16, I=32, B=16), "
-                         "cam (65536 x 2048 features, projector, M=I=256, B=1)")
+    ap.add_argument("--config", default=None, choices=sorted(FLOP_PER_PATCH),
+                    help="default: mnist at --gpus 1 (the headline, BASELINE configs[1], B=16), mnist3000 at --gpus N > 1 "
+                         "(configs[2], patch-sharded); the others are secondary single-GPU measurements: b1 (headline "
+                         "image 0 alone), native50, traffic, cam")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1 only. strong (default): configs[2], the same 16 x 10000 patches at every N; weak: 2500 "
+                         "patches of every image per GPU (the image grows with N)")
     return ap.parse_args()
 
 
-def cpu_baseline(conf, budget_s):
-    """The reference's CPU path (ATen restatement) on a bounded sample of the same workload."""
+def cpu_baseline(conf, x, budget_s):
+    """The reference's CPU path (ATen restatement) on a bounded sample of the same workload: whole calls on the
+    headline batch itself, repeated until the budget is used."""
     from ips_amd import synth
     from ips_amd.architecture import IPSNet
     from oracle import ips_torch
 
-    c1 = conf.clone(N=PATCHES_PER_GPU)
-    net = synth.fill_weights(IPSNet(torch.device("cpu"), c1), 7).eval()
+    net = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 7).eval()
     sd = dict(net.state_dict())
-    B = 2
-    x = synth.make_patches(c1, B, seed=21)
-    # The reference loop feeds the encoder 64 patches per image per call: too little work for every
-    # core of a big host (256 threads measured 14 patches/s).  Probe a few thread counts on a 300-patch
-    # prefix and keep the fastest - that is the reference's best case on this host.
+    B, N = x.shape[:2]
+    # The reference loop feeds the encoder I patches per image per call: too little work for every core of a big
+    # host (256 threads measured 14 patches/s).  Probe a few thread counts on a short prefix of the same batch and keep
+    # the fastest - that is the reference's best case on this host.
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    best, probe = None, conf.clone(N=320)
+    n_probe = min(N, conf.M + 4 * conf.I)
+    best, probe = None, conf.clone(N=n_probe)
+    pos = net.pos_enc[:, :n_probe] if conf.use_pos else None
     for thr in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(thr)
-        ips_torch.ips(sd, probe, x[:1, :320], net.pos_enc[:, :320])
+        ips_torch.ips(sd, probe, x[:, :n_probe], pos)
         t0 = time.perf_counter()
-        ips_torch.ips(sd, probe, x[:1, :320], net.pos_enc[:, :320])
+        ips_torch.ips(sd, probe, x[:, :n_probe], pos)
         dt = time.perf_counter() - t0
         if best is None or dt < best[1]:
             best = (thr, dt)
         if dt > 4 * best[1]:
             break
     torch.set_num_threads(best[0])
-    ips_torch.ips(sd, c1, x, net.pos_enc)                      # warm-up (oneDNN primitive cache)
     reps, t0 = 0, time.perf_counter()
     while True:
-        ips_torch.ips(sd, c1, x, net.pos_enc)
+        ips_torch.ips(sd, conf, x, net.pos_enc)
         reps += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or reps >= 50:
             break
-    return {"value": B * PATCHES_PER_GPU * reps / dt, "unit": "patches/s", "cores": torch.get_num_threads(),
+    return {"value": B * N * reps / dt, "unit": "patches/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": "%d x ips() on %d images x %d patches (oracle/ips_torch.py, ATen/oneDNN, %.1f s)"
-                      % (reps, B, PATCHES_PER_GPU, dt)}
+            "sample": "%d x ips() on the headline batch itself, %d images x %d patches (oracle/ips_torch.py, ATen/oneDNN, "
+                      "%.1f s; thread count = fastest of 4..64 on a %d-patch prefix)" % (reps, B, N, dt, n_probe)}
+
+
+def parity(name, mem_idx, images=None):
+    """``mem_idx`` (B, M) against the reference's final selection on the same inputs."""
+    path = os.path.join(REPO, "tests", "golden", "bench_%s.npz" % name)
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    want = z["trace_idx"][:, -1].astype(np.int64)
+    gap = z["rel_gap"]
+    if images is not None:
+        want, gap = want[images], gap[images]
+    got = mem_idx.detach().cpu().numpy()
+    if got.shape != want.shape:
+        return {"fixture": os.path.relpath(path, REPO), "indices_equal": False, "note": "shape %s vs %s" % (got.shape, want.shape)}
+    rows = (got == want).all(1)
+    same_set = float(np.mean([len(set(a) & set(b)) / len(a) for a, b in zip(got.tolist(), want.tolist())]))
+    return {"fixture": os.path.relpath(path, REPO) + " (the reference's CPU run on these inputs, tools/gen_golden_bench.py)",
+            "indices_equal": bool(rows.all()), "images": int(rows.size), "images_equal": int(rows.sum()),
+            "selected_in_common": same_set,
+            "min_rel_gap": float(gap[:, -1].min()), "min_rel_gap_any_iteration": float(gap.min())}
 
 
 _ALSO = {
@@ -119,10 +158,9 @@ _ALSO = {
 }
 
 
-def measure_precision(net, x, args, precision):
+def measure_precision(net, x, args, precision, fixture):
     """The same workload with another trunk arithmetic (opt-in; never the headline `value`), reported next to the
-    exact-fp32 headline together with whether it selected the same patches."""
-    import torch
+    exact-fp32 headline together with its own parity object."""
     for name in ("encode", "encode_indexed"):                   # drop the event-recording wrappers of the headline run
         net._plan.__dict__.pop(name, None)
     net.ips(x)
@@ -138,10 +176,29 @@ def measure_precision(net, x, args, precision):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         same = bool(torch.equal(net.last_mem_idx, ref_idx))
+        par = parity(fixture, net.last_mem_idx)
     finally:
         os.environ["IPSX_PRECISION"] = "fp32"
     return {"value": x.shape[0] * x.shape[1] * args.steps / dt, "unit": "patches/s", "ms_per_step": 1e3 * dt / args.steps,
-            "same_indices_as_f32": same, "what": _ALSO[precision]}
+            "same_indices_as_f32": same, "parity": par, "what": _ALSO[precision]}
+
+
+def pmc_traffic(kernel_name, enc_patches, n_launch):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process; they are
+    collected with separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command
+    (tools/pmc_traffic.py, gfx950 correction applied) and committed under profiles/ together with a hash of the kernel's
+    source: a figure measured on another version of the kernel is reported as null, not silently reused."""
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        src = os.path.join(REPO, "ips_amd", "csrc", pmc["source"])
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        if sha != pmc["source_sha16"]:
+            return None, "profiles/pmc_traffic.json was measured on another version of %s (stale)" % pmc["source"]
+        if pmc["kernel"] in (kernel_name or "") and enc_patches == pmc["patches_per_launch"] * n_launch:
+            return pmc["hbm_bytes_per_launch"], "bytes per launch (PMC, profiles/pmc_traffic.json)"
+        return None, "profiles/pmc_traffic.json holds %s at %d patches per launch" % (pmc["kernel"], pmc["patches_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC record"
 
 
 def main():
@@ -178,42 +235,50 @@ def main():
     if args.dedup_blank:
         os.environ["IPSX_DEDUP_BLANK"] = "1"
     os.environ["IPSX_PRECISION"] = args.precision
-    per_gpu = PATCHES_PER_GPU
-    if args.config != "mnist" and world > 1:
+    name = args.config or ("mnist" if world == 1 else "mnist3000")
+    if world > 1 and name not in ("mnist", "mnist3000"):
         print("secondary configs are single-GPU measurements", file=sys.stderr)
         sys.exit(2)
-    if args.config == "b1":
-        args.batch = 1
-    if args.config in ("mnist", "b1"):
-        conf = synth.mnist_conf(N=per_gpu * world, M=64, I=64)
-        label = "Megapixel-MNIST %d patches of 1x32x32 per image" % (per_gpu * world)
-    elif args.config == "native50":
-        per_gpu = 900
-        conf = synth.mnist_conf(N=900, M=100, I=100, patch=50)
-        label = "Megapixel-MNIST reference-native 900 patches of 1x50x50 per image, M=I=100"
-    elif args.config == "traffic":
-        per_gpu = 192
-        conf = synth.traffic_conf(N=192, M=16, I=32, patch=100)
-        label = "traffic signs 192 patches of 3x100x100 per image, ResNet-18 x4 stages, M=16, I=32"
+    weak = world > 1 and args.scaling == "weak"
+    fixture, images = name, None
+    if name == "b1":
+        conf, B = synth.bench_workload("mnist")
+        fixture, images = "mnist", slice(0, 1)
     else:
-        per_gpu, args.batch = 65536, 1
-        conf = synth.camelyon_conf(N=65536, M=256, I=256)
-        label = "CAMELYON 65536 x 2048 features per slide, projector, M=I=256"
-    n_total = per_gpu * world
+        conf, B = synth.bench_workload(name)
+    if weak:                                                    # the image grows with the node; 4 GPUs = configs[2]
+        conf, B = synth.bench_workload("mnist")
+        conf = conf.clone(N=PATCHES_PER_GPU_WEAK * world)
+        fixture = "mnist3000" if conf.N == 10000 else None
+    batch = 1 if name == "b1" else (args.batch or B)
+    n_total = conf.N
     net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
-    n_mine = per_gpu if world == 1 else int(ipsd.local_indices(n_total, conf.M, conf.I, rank, world).numel())
-    x = synth.make_patches(conf, args.batch, seed=21 + rank, N=n_mine)    # ~per_gpu patches of every image per rank
+    x = synth.make_patches(conf, max(batch, B), seed=21)        # the fixture's batch; --batch may take a prefix of it
+    if name == "b1":
+        x = x[:1]
+    elif batch != x.shape[0]:
+        x, images = x[:batch], slice(0, batch)
+        if batch > B:
+            fixture = None
+    x_host = x
+    if world > 1:
+        mine = ipsd.local_indices(n_total, conf.M, conf.I, rank, world)
+        x = x[:, mine].contiguous()                             # this rank's shard of every image
+    n_mine = x.shape[1]
     x = x.pin_memory() if args.lazy else x.to(dev)              # headline: resident in HBM before the timed region
 
+    timings = [] if world > 1 else None
     if world == 1:
         def step():
             return net.ips(x)
     else:
         def step():
-            return ipsd.ips_sharded(net, x, n_total)
+            return ipsd.ips_sharded(net, x, n_total, timings=timings)
 
     for _ in range(max(args.warmup, 1)):                        # also builds the encoder plan
         step()
+    if timings is not None:
+        timings.clear()
     # time the encoder launches with HIP events on the stream they run on
     enc_events = []
     plan_encode = net._plan.encode
@@ -258,22 +323,34 @@ def main():
 
     enc_ms = sum(a.elapsed_time(b) for a, b, _ in enc_events)
     enc_patches = sum(n for _, _, n in enc_events)
-    achieved = enc_patches * FLOP_PER_PATCH[args.config] / (enc_ms * 1e-3) / 1e12
-    patches_per_step = args.batch * n_total
-    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process;
-    # they are collected with separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this
-    # very command (tools/pmc_traffic.py, gfx950 correction applied) and committed under profiles/.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-        if args.config == "mnist" and args.precision == "fp32" and not args.dedup_blank \
-                and pmc["kernel"] in hip.encoder_kernel_name(net._plan) \
-                and enc_patches == pmc["patches_per_launch"] * len(enc_events):
-            traffic = pmc["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    n_launch = max(len(enc_events), 1)
+    achieved = enc_patches * FLOP_PER_PATCH[name] / (enc_ms * 1e-3) / 1e12
+    phases = ipsd.phase_ms(timings) if timings else None
+    par = parity(fixture, net.last_mem_idx, images) if fixture else None
+
+    # SURVEY d-1 protocol next to the throughput figure: device sync around every call, median
+    lat = []
+    for _ in range(args.steps):
+        fence()
+        c0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - c0))
+    fence()
+
+    if world > 1:                                               # every rank's verdict and phase times travel to rank 0
+        mine_rec = {"rank": rank, "patches_per_image": n_mine, "phases": phases,
+                    "indices_equal": par["indices_equal"] if par else None}
+        recs = [None] * world
+        dist.all_gather_object(recs, mine_rec)
+    kernel_name = hip.encoder_kernel_name(net._plan)
+    traffic, traffic_note = pmc_traffic(kernel_name, enc_patches, len(enc_events))
+    if not (name == "mnist" and args.precision == "fp32" and not args.dedup_blank and world == 1):
+        traffic = None
 
     if rank == 0:
+        patches_per_step = batch * n_total
+        per_patch_bytes = (conf.n_chan_in * (conf.patch_size[0] * conf.patch_size[1] if conf.is_image else 1) + conf.D) * 4
         out = {
             "metric": "patches scored/sec (no-grad IPS loop)",
             "value": patches_per_step * args.steps / elapsed,
@@ -281,40 +358,46 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if (weak or world == 1) else "strong",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "fp32x3": "f32 as 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate",
                       "bf16": "bf16 operands / f32 accumulate"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%s (%d per GPU), B=%d, M=%d, I=%d, n_token=%d, %s, eager"
-                                   % (label, per_gpu, args.batch, conf.M, conf.I, conf.n_token,
-                                      "use_pos" if conf.use_pos else "no pos-enc"),
+            "config": {"workload": "%s, B=%d, M=%d, I=%d, n_token=%d, %s, eager%s"
+                                   % (LABEL[name] if not weak else "Megapixel-MNIST %d patches of 1x32x32 per image (2500 per GPU)" % n_total,
+                                      batch, conf.M, conf.I, conf.n_token,
+                                      "use_pos" if conf.use_pos else "no pos-enc",
+                                      "" if world == 1 else ", %d of the %d patches of every image per GPU" % (n_mine, n_total)),
                        "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, ipsd.PARTS) if world > 1 else "single GPU",
                        "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy)},
+            "ms_per_call_median_synced": statistics.median(lat),
+            "parity": par,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
-                         "algorithmic_bytes": enc_patches / max(len(enc_events), 1) * (conf.n_chan_in * (conf.patch_size[0] * conf.patch_size[1] if conf.is_image else 1) + conf.D) * 4,
-                         "kernel": hip.encoder_kernel_name(net._plan),
-                         "launch_ms": enc_ms / max(len(enc_events), 1),
-                         "patches_per_launch": enc_patches / max(len(enc_events), 1)},
+                         "traffic_unit": traffic_note,
+                         "algorithmic_bytes": enc_patches / n_launch * per_patch_bytes,
+                         "kernel": kernel_name,
+                         "launch_ms": enc_ms / n_launch,
+                         "patches_per_launch": enc_patches / n_launch},
         }
+        if world > 1:
+            out["parity_all_ranks"] = all(r["indices_equal"] for r in recs) if par else None
+            out["per_rank"] = recs
         if args.precision == "bf16":    # priced against the dense bf16 MFMA peak
-            out["roofline"]["peak"] = 2500.0
-            out["roofline"]["frac"] = achieved / 2500.0
+            out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
+            out["roofline"]["frac"] = achieved / BF16_MFMA_PEAK_TFLOPS
         if args.precision == "fp32x3":  # six bf16 products per fp32 product: the bf16 peak / 6 bounds the algorithmic rate
-            out["roofline"]["peak"] = 2500.0 / 6
-            out["roofline"]["frac"] = achieved / (2500.0 / 6)
+            out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS / 6
+            out["roofline"]["frac"] = achieved / (BF16_MFMA_PEAK_TFLOPS / 6)
             out["roofline"]["note"] = "algorithmic fp32 FLOP priced against dense bf16 peak / 6 (6 MFMA products per fp32 product)"
-            out["roofline"]["traffic"] = None
         if args.dedup_blank:        # fewer patches are encoded than scored: an algorithmic FLOP rate would be wrong
             out["roofline"].update({"achieved": None, "frac": None, "traffic": None,
                                     "note": "blank-patch dedup: encoder ran on %d of %d patches per launch"
-                                            % (int(net._plan.n_encoded.item()), enc_patches // max(len(enc_events), 1))})
-        if world == 1 and args.config == "mnist" and args.precision == "fp32" and not (args.dedup_blank or args.lazy):
-            out["also_measured"] = {p: measure_precision(net, x, args, p) for p in ("fp32x3", "bf16")}
-        if world == 1 and args.cpu_seconds > 0 and args.config == "mnist":
-            out["cpu_baseline"] = cpu_baseline(conf, args.cpu_seconds)
+                                            % (int(net._plan.n_encoded.item()), enc_patches // n_launch)})
+        if world == 1 and name == "mnist" and args.precision == "fp32" and not (args.dedup_blank or args.lazy) and batch == B:
+            out["also_measured"] = {p: measure_precision(net, x, args, p, fixture) for p in ("fp32x3", "bf16")}
+        if world == 1 and args.cpu_seconds > 0 and name == "mnist" and batch == B:
+            out["cpu_baseline"] = cpu_baseline(conf, x_host, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

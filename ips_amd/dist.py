@@ -104,12 +104,15 @@ def _owner_maps(N, M, I, world, device, parts=PARTS):
 
 
 @torch.no_grad()
-def ips_sharded(net, local_patches, N, group=None):
+def ips_sharded(net, local_patches, N, group=None, timings=None):
     """IPS over ``N`` patches of which this rank holds ``local_patches`` = patches[:, local_indices(...)].
 
     ``net`` is an ``IPSNet`` whose ``conf.N`` (positional table) is the GLOBAL ``N``.
     Shuffling is the caller's business here (shard after shuffling).  Returns
     ``(mem_patch, mem_pos, mem_idx)`` identical on every rank.
+
+    ``timings`` (GPU path only): a list that receives one dict of HIP events per call - see ``phase_ms`` - so that a
+    run can say where a rank's time went (encoder, exchange, loop, what of the loop stayed exposed).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -150,6 +153,11 @@ def ips_sharded(net, local_patches, N, group=None):
         if indexed:
             flat = local_patches.reshape(B * n_local, *local_patches.shape[2:])
             rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1) * n_local
+        ev = None
+        if timings is not None and on_gpu:
+            mk = lambda: torch.cuda.Event(enable_timing=True)
+            ev = {"start": mk(), "enc": [], "xch": [], "scan": [], "end_select": mk(), "end": mk()}
+            ev["start"].record(main)
         base = 0
         for k, (lo, hi) in enumerate(spans):
             n_k, q, part_len = hi - lo, piece[k], edges[k + 1] - edges[k]
@@ -171,20 +179,32 @@ def ips_sharded(net, local_patches, N, group=None):
             if on_gpu:
                 # the exchange of this part and its loop iterations run on the side stream: the main stream goes
                 # straight on to encoding the next part (neither the gather nor the scan is on its critical path)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=ev is not None)
                 done.record(main)
                 mine.record_stream(side)
                 with torch.cuda.stream(side):
                     side.wait_event(done)
+                    if ev is not None:
+                        ev["enc"].append(done)
+                        x0, x1, s1 = mk(), mk(), mk()
+                        x0.record(side)
                     gathered = _all_gather(mine, world, group)
                     logits[:, edges[k]:edges[k + 1]] = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
+                    if ev is not None:
+                        x1.record(side)
                     hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx, tie)
+                    if ev is not None:
+                        s1.record(side)
+                        ev["xch"].append((x0, x1))
+                        ev["scan"].append((x1, s1))
             else:
                 gathered = _all_gather(mine, world, group)                  # the exchange of this part
                 all_emb[:, edges[k]:edges[k + 1]] = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
         if on_gpu:
             main.wait_stream(side)
             hip.scan.last_tie = tie
+            if ev is not None:
+                ev["end_select"].record(main)
         else:
             mem_idx = _scan_aten(net, all_emb)
 
@@ -202,11 +222,33 @@ def ips_sharded(net, local_patches, N, group=None):
             mem_patch = torch.zeros((B, M) + tuple(local_patches.shape[2:]), dtype=local_patches.dtype, device=dev)
         mem_patch = _all_reduce(mem_patch, group)
         mem_pos = _take(net.pos_enc, mem_idx) if net.use_pos else None
+        if on_gpu and ev is not None:
+            ev["end"].record(main)
+            timings.append(ev)
     finally:
         if was_training:
             net.encoder.train(); net.transf.train()
     net.last_mem_idx = mem_idx
     return mem_patch, mem_pos, mem_idx
+
+
+def phase_ms(timings):
+    """Mean milliseconds per call of the phases of ``ips_sharded`` from the events it recorded (synchronise first):
+    ``encode_ms`` (main stream: encoder + logits of all parts), ``exchange_ms`` (side stream: the all-gathers incl.
+    waiting for the slowest rank), ``scan_ms`` (side stream: all loop iterations), ``exposed_scan_ms`` (what the main
+    stream still waited for after its last part was encoded: exchange + loop of the last part - the serial tail),
+    ``winners_ms`` (gather + all-reduce of the M winning patches), ``total_ms``."""
+    if not timings:
+        return None
+    acc = {"encode_ms": 0.0, "exchange_ms": 0.0, "scan_ms": 0.0, "exposed_scan_ms": 0.0, "winners_ms": 0.0, "total_ms": 0.0}
+    for ev in timings:
+        acc["encode_ms"] += ev["start"].elapsed_time(ev["enc"][-1])
+        acc["exchange_ms"] += sum(a.elapsed_time(b) for a, b in ev["xch"])
+        acc["scan_ms"] += sum(a.elapsed_time(b) for a, b in ev["scan"])
+        acc["exposed_scan_ms"] += ev["enc"][-1].elapsed_time(ev["end_select"])
+        acc["winners_ms"] += ev["end_select"].elapsed_time(ev["end"])
+        acc["total_ms"] += ev["start"].elapsed_time(ev["end"])
+    return {k: v / len(timings) for k, v in acc.items()}
 
 
 def _all_gather(mine, world, group):

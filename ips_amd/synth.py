@@ -65,6 +65,44 @@ def camelyon_conf(N=65536, M=256, I=256, **over):
     return c.clone(**over)
 
 
+# The workloads bench.py times (name -> (configuration, images per step)); tools/gen_golden_bench.py runs the
+# reference on exactly these (weights seed 7, patches seed 21) and tests/golden/bench_<name>.npz holds its selections.
+BENCH_WORKLOADS = {
+    "mnist": lambda: (mnist_conf(N=2500, M=64, I=64), 16),              # BASELINE configs[1] at the reference's B_seq
+    "mnist3000": lambda: (mnist_conf(N=10000, M=64, I=64), 16),         # configs[2]: 3000x3000, 10,000 patches per image
+    "native50": lambda: (mnist_conf(N=900, M=100, I=100, patch=50), 16),
+    "traffic": lambda: (traffic_conf(N=192, M=16, I=32, patch=100), 16),
+    "cam": lambda: (camelyon_conf(N=65536, M=256, I=256), 1),           # configs[3]
+}
+
+
+# Seed sweeps (tools/gen_golden_seeds.py -> tests/golden/seeds_<family>.npz): per family a small configuration run by
+# the reference under >= 20 (weights, inputs) seeds.  Case k: weights seed 100 + k, input seed 200 + k; the learned
+# queries at their DEFAULT scale (q_gain = 1: flat attention, small top-M gaps) for even k and sharpened (q_gain = 8)
+# for odd k; Megapixel-MNIST families alternate stroke-like sparse images (k % 4 < 2) with U[0,1) noise patches.
+SEED_FAMILIES = {
+    "mnist32": lambda: (mnist_conf(N=400, M=16, I=16), 2, 24),
+    "mnist50": lambda: (mnist_conf(N=144, M=12, I=12, patch=50), 1, 20),
+    "traffic": lambda: (traffic_conf(N=24, M=4, I=8, patch=64), 1, 20),
+    "cam": lambda: (camelyon_conf(N=2048, M=64, I=64), 1, 20),
+}
+
+
+def seed_case(family, k):
+    """(conf, B, weight seed, q_gain, patches) of case k of a family."""
+    conf, B, n = SEED_FAMILIES[family]()
+    q_gain = 1.0 if k % 2 == 0 else 8.0
+    if conf.is_image and conf.n_chan_in == 1 and k % 4 < 2:
+        x = make_stroke_patches(conf, B, seed=200 + k)
+    else:
+        x = make_patches(conf, B, seed=200 + k)
+    return conf, B, 100 + k, q_gain, x
+
+
+def bench_workload(name):
+    return BENCH_WORKLOADS[name]()
+
+
 def _rng(seed, name):
     return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
 
@@ -100,6 +138,65 @@ def fill_weights(net, seed=0, q_gain=8.0):
             v = g.standard_normal(shape) * np.sqrt(2.0 / fan_in)
         t.copy_(torch.from_numpy(v.astype(np.float32)))
     return net
+
+
+def _stroke_object(g, size=28):
+    """One digit-like object: a thick, soft-edged polyline through 3-5 random control points of a size x size box,
+    intensities in [0, 1] like an anti-aliased MNIST digit."""
+    n = int(g.integers(3, 6))
+    pts = g.uniform(3, size - 4, (n, 2))
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    d = np.full((size, size), 1e9)
+    for a, b in zip(pts[:-1], pts[1:]):
+        ab = b - a
+        t = np.clip(((yy - a[0]) * ab[0] + (xx - a[1]) * ab[1]) / max(float(ab @ ab), 1e-9), 0, 1)
+        d = np.minimum(d, np.hypot(yy - (a[0] + t * ab[0]), xx - (a[1] + t * ab[1])))
+    return np.clip(1.7 - d / 1.1, 0, 1).astype(np.float32)
+
+
+def _scribble_object(g, size=28):
+    """One noise object of Megapixel-MNIST (data/megapixel_mnist/make_mnist.py:81-106 describes them: two straight
+    lines through a 28 x 28 box, intensities in [0.8, 1])."""
+    img = np.zeros((size, size), dtype=np.float32)
+    for _ in range(2):
+        ang = np.tan(g.random() * np.pi / 2.5)
+        m = min(size - 0.51, (size - 0.51) / max(ang, 1e-6))
+        x = np.linspace(0, m, 2 * size)
+        y = ang * x
+        r, c = np.round(x).astype(int), np.round(y).astype(int)
+        if g.random() < 0.33:
+            c = size - 1 - c
+        img[r, c] = 1.0
+    return img * (g.random((size, size)).astype(np.float32) * 0.2 + 0.8)
+
+
+def make_stroke_patches(conf, B, seed=0, N=None):
+    """Megapixel-MNIST-like images cut into patches: per image a zero canvas of (rows*h) x (cols*w) pixels with 5
+    digit-like stroke objects and noise scribbles (50 per 1500 x 1500 pixels, at least 3) of 28 x 28 pixels at random
+    positions - so objects straddle patch borders, most patches are blank and the others are SPARSE (thin strokes on
+    zero background), unlike ``make_patches``' dense U[0,1) noise.  (B, N, 1, h, w) float32, row-major patch order
+    like the reference's unfold (data/megapixel_mnist/mnist_dataset.py:44-51)."""
+    N = conf.N if N is None else N
+    h, w = conf.patch_size
+    cols = int(np.ceil(np.sqrt(N)))
+    rows = -(-N // cols)
+    H, W = rows * h, cols * w
+    size = min(28, H, W)
+    n_noise = max(3, int(round(50 * H * W / 1500.0 ** 2)))
+    g = _rng(seed, "strokes")
+    out = np.zeros((B, N, 1, h, w), dtype=np.float32)
+    for b in range(B):
+        canvas = np.zeros((H, W), dtype=np.float32)
+        for k in range(n_noise + 5):
+            obj = _scribble_object(g, size) if k < n_noise else _stroke_object(g, size)
+            y, x = int(g.integers(0, H - size + 1)), int(g.integers(0, W - size + 1))
+            if k < n_noise:
+                canvas[y:y + size, x:x + size] = obj                # the reference overwrites, digits last
+            else:
+                canvas[y:y + size, x:x + size] = np.where(obj > 0, obj, canvas[y:y + size, x:x + size])
+        patches = canvas.reshape(rows, h, cols, w).transpose(0, 2, 1, 3).reshape(rows * cols, h, w)
+        out[b, :, 0] = patches[:N]
+    return torch.from_numpy(out)
 
 
 def make_patches(conf, B, seed=0, blank_frac=None, N=None):

@@ -1,0 +1,139 @@
+"""Seed sweeps: >= 20 (weights, inputs) seeds per configuration family, run by the REFERENCE (tools/gen_golden_seeds.py,
+tests/golden/seeds_<family>.npz) - default-scale queries (flat attention, small gaps) and sharpened ones, stroke-like
+sparse Megapixel-MNIST images and noise patches - against the CPU oracle (a subset sized for the CPU suite) and, on the
+GPU, against the HIP path (every case; the fused 32-px family also with the fp32x3 trunk).
+
+Rule per image: walk the iterations.  Same memory, same order: go on.  Same patches in another order: allowed only
+when two neighbouring scores of the reference's sorted top M + 1 are closer than GAP_FLOOR (``order_gap``; 1e-5 is an
+order of magnitude over the reference's batch-size self-noise) - counted, walk goes on (the next iteration
+re-sorts everything).  Other patches: allowed only when the reference's top-M boundary gap (``rel_gap``) is at or
+below GAP_FLOOR - counted as "diverged inside the reference's noise", and the walk stops (later iterations start from
+another memory).  Anything else is a FAILURE.  The counts are printed (-s shows them); the final predictions are
+compared for every image that kept the reference's patches to the end.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ips_amd import synth
+from tests.util import GOLDEN_DIR
+
+GAP_FLOOR = 1e-5
+FAMILIES = sorted(synth.SEED_FAMILIES)
+# what the scalar CPU oracle replays in seconds per case
+ORACLE_CASES = {"mnist32": range(0, 24, 2), "mnist50": range(0, 20, 4), "traffic": range(0, 20, 5), "cam": range(0, 20)}
+
+
+def fixture(family):
+    return np.load(os.path.join(GOLDEN_DIR, "seeds_%s.npz" % family))
+
+
+def walk(trace, want, gap, ogap):
+    """-> [images that kept the reference's patches to the end, images diverged in noise, iterations reordered in noise,
+    iterations compared]; raises on a difference the reference's own gaps do not excuse."""
+    kept = noise = reordered = compared = 0
+    for b in range(want.shape[0]):
+        for it in range(want.shape[1]):
+            compared += 1
+            if np.array_equal(trace[b, it], want[b, it]):
+                continue
+            if np.array_equal(np.sort(trace[b, it]), np.sort(want[b, it])):
+                assert min(ogap[b, it], gap[b, it]) <= GAP_FLOOR, \
+                    "image %d iteration %d: other order although the closest scores are %.2e apart" % (b, it, ogap[b, it])
+                reordered += 1
+                continue
+            assert gap[b, it] <= GAP_FLOOR, "image %d iteration %d: other patches at a boundary gap of %.2e" % (b, it, gap[b, it])
+            noise += 1
+            break
+        else:
+            kept += 1
+    return [kept, noise, reordered, compared]
+
+
+def cpu_net(conf, wseed, q_gain):
+    from ips_amd.architecture import IPSNet
+    return synth.fill_weights(IPSNet(torch.device("cpu"), conf), wseed, q_gain=q_gain).eval()
+
+
+def test_fixtures_cover_what_they_claim():
+    for family in FAMILIES:
+        z = fixture(family)
+        conf, B, n = synth.SEED_FAMILIES[family]()
+        assert int(z["n_case"]) == n >= 20
+        for k in range(n):
+            _, _, _, _, x = synth.seed_case(family, k)
+            assert float(x.double().sum()) == pytest.approx(float(z["c%d_x_sum" % k]), rel=1e-12), (family, k)
+            assert z["c%d_trace_idx" % k].shape[0] == B and z["c%d_trace_idx" % k].shape[2] == conf.M
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_oracle_follows_the_reference_over_seeds(family):
+    from oracle.oracle import Oracle
+    z = fixture(family)
+    tot = [0, 0, 0, 0]
+    for k in ORACLE_CASES[family]:
+        conf, B, wseed, q_gain, x = synth.seed_case(family, k)
+        net = cpu_net(conf, wseed, q_gain)
+        orc = Oracle(net)
+        out = orc.ips(x.numpy(), net.pos_enc.numpy() if conf.use_pos else None, aten_ties=True)
+        want, gap, ogap = z["c%d_trace_idx" % k].astype(np.int64), z["c%d_rel_gap" % k], z["c%d_order_gap" % k]
+        res = walk(out["trace_idx"], want, gap, ogap)
+        tot = [a + b for a, b in zip(tot, res)]
+        if res[1] == 0:
+            preds = orc.forward(out["mem_patch"], out["mem_pos"])
+            for name, v in preds.items():
+                assert np.abs(v - z["c%d_pred_%s" % (k, name)]).max() <= 1e-4, (family, k, name)
+    print("%s oracle: %d images keep the reference's patches to the end, %d diverged at a boundary gap <= %.0e, "
+          "%d of %d iterations in another order (neighbouring scores closer than that)" % (family, tot[0], tot[1], GAP_FLOOR, tot[2], tot[3]))
+
+
+def hip_trace(net, x):
+    """Memory indices after every iteration on the HIP path (encode -> logits once, one ipsx_scan_range per iteration)."""
+    import math
+    from ips_amd import hip
+    B, N = x.shape[:2]
+    ca = net.transf.crs_attn
+    emb = net._embed(x.reshape(-1, *x.shape[2:])).view(B, N, -1)
+    pos = net.pos_enc.expand(B, -1, -1) if net.use_pos else None
+    lg = hip.logits(emb, pos, ca.folded_query(), ca.H * ca.n_token)
+    mem_idx = torch.empty((B, net.M), dtype=torch.int64, device=x.device)
+    tie = torch.zeros((B,), dtype=torch.int32, device=x.device)
+    out = []
+    for it in range(math.ceil((N - net.M) / net.I)):
+        hip.scan_range(lg, net.M, net.I, ca.H, ca.n_token, it, it + 1, mem_idx, tie)
+        out.append(mem_idx.clone())
+    return torch.stack(out, 1).cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,precision", [(f, "fp32") for f in FAMILIES] + [("mnist32", "fp32x3")])
+def test_hip_path_follows_the_reference_over_seeds(family, precision, monkeypatch):
+    from ips_amd.architecture import IPSNet
+    monkeypatch.setenv("IPSX_PRECISION", precision)
+    z = fixture(family)
+    dev = torch.device("cuda:0")
+    _, _, n_case = synth.SEED_FAMILIES[family]()
+    tot = [0, 0, 0, 0]
+    for k in range(n_case):
+        conf, B, wseed, q_gain, x = synth.seed_case(family, k)
+        net = synth.fill_weights(IPSNet(dev, conf), wseed, q_gain=q_gain).to(dev).eval()
+        xd = x.to(dev)
+        want, gap, ogap = z["c%d_trace_idx" % k].astype(np.int64), z["c%d_rel_gap" % k], z["c%d_order_gap" % k]
+        res = walk(hip_trace(net, xd), want, gap, ogap)
+        tot = [a + b for a, b in zip(tot, res)]
+        mem_patch, mem_pos = net.ips(xd)                       # the product call: same final selection as the walk's
+        if res[1] == 0:
+            got = net.last_mem_idx.cpu().numpy()
+            assert np.array_equal(np.sort(got, -1), np.sort(want[:, -1], -1)), (family, k)
+            if res[2] == 0:
+                assert np.array_equal(got, want[:, -1]), (family, k)
+            with torch.no_grad():
+                preds = net(mem_patch, mem_pos)
+            for name, v in preds.items():
+                assert np.abs(v.cpu().numpy() - z["c%d_pred_%s" % (k, name)]).max() <= 1e-4, (family, k, name)
+    print("%s %s: %d images keep the reference's patches to the end, %d diverged at a boundary gap <= %.0e, "
+          "%d of %d iterations in another order (neighbouring scores closer than that)"
+          % (family, precision, tot[0], tot[1], GAP_FLOOR, tot[2], tot[3]))
