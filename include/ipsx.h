@@ -181,9 +181,11 @@ int ipsx_patchify_sparse(const int64_t* index, const float* value, const int64_t
  * ReLU(BN1d(Linear(LayerNorm_noaffine(x)))); x (n,f) -> out (n,d).
  * `lin` is the Linear packed as a 1x1 conv (c_in=f, c_out=d) whose alpha/shift
  * hold the BatchNorm affine with the Linear bias folded into shift
- * (shift' = fma(bias, alpha, shift)).  workspace: n*f floats.                */
+ * (shift' = fma(bias, alpha, shift)).  LayerNorm is applied to the GEMM's A operand in
+ * registers from a (mean, rstd) pass; workspace: ipsx_projector_workspace_bytes(n).                */
 int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps,
                    float* out, void* workspace, size_t workspace_bytes, void* stream);
+size_t ipsx_projector_workspace_bytes(int64_t n);      /* 8 bytes per row: (mean, rstd) */
 
 /* ------------------------------------------------------------------- scorer
  * Replaces MultiHeadCrossAttention.get_attn + ScaledDotProductAttention.

@@ -40,6 +40,38 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     }
 }
 
+// (mean, rstd) of every row - the moments of layernorm_rows_kernel, same arithmetic (64 strided partial sums in
+// ascending order + xor butterfly; centred second moment) - for consumers that normalise on the fly
+// (conv_nhwc_kernel<.., NORM>).  One wavefront per row; a row of up to 64 * RS_MAX floats stays in registers between
+// the two passes (every element is read ONCE, 256 B per wave-instruction), longer rows are re-read.
+constexpr int RS_MAX = 32;
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, long long n, int d, float eps,
+                                                        float2* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* xr = x + (size_t)row * d;
+    float s = 0.0f, q = 0.0f, mean;
+    if (d <= 64 * RS_MAX) {
+        float v[RS_MAX];
+#pragma unroll
+        for (int k = 0; k < RS_MAX; ++k) v[k] = (lane + 64 * k < d) ? xr[lane + 64 * k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < RS_MAX; ++k) if (lane + 64 * k < d) s = s + v[k];
+        mean = wave_butterfly_sum(s) / (float)d;
+#pragma unroll
+        for (int k = 0; k < RS_MAX; ++k)
+            if (lane + 64 * k < d) { const float c = v[k] - mean; const float c2 = c * c; q = q + c2; }
+    } else {
+        for (int i = lane; i < d; i += 64) s = s + xr[i];
+        mean = wave_butterfly_sum(s) / (float)d;
+        for (int i = lane; i < d; i += 64) { const float c = xr[i] - mean; const float c2 = c * c; q = q + c2; }
+    }
+    const float var = wave_butterfly_sum(q) / (float)d;
+    const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+    if (lane == 0) stats[row] = make_float2(mean, rstd);
+}
+
 // LayerNorm of a row held in LDS by ONE wavefront (all 64 lanes call it)
 __device__ __forceinline__ void layernorm_lds_row(const float* xr, int d, float eps, const float* g,
                                                   const float* b, float* yr, int lane) {
@@ -181,6 +213,10 @@ __global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ emb,
     }
 }
 
+// conv_nhwc.hip
+int conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* residual, const float* row_stats, float* y,
+                   int64_t n, int h, int w, int relu, void* stream);
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct AggLayout {
@@ -211,15 +247,18 @@ IPSX_API int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, flo
     IPSX_REQUIRE(lin && x && out && n >= 0, "projector: bad arguments");
     IPSX_REQUIRE(lin->kh == 1 && lin->kw == 1 && lin->stride == 1 && lin->pad == 0, "projector: lin must be 1x1");
     if (n == 0) return IPSX_OK;
-    const size_t need = (size_t)n * lin->c_in * sizeof(float);
+    // LayerNorm is fused into the Linear: a statistics pass leaves (mean, rstd) per row (8 B per row - the only
+    // workspace) and the GEMM normalises its A operand in registers; the normalised rows never exist in memory
+    const size_t need = (size_t)n * 2 * sizeof(float);
     if (!workspace || workspace_bytes < need)
         return fail(IPSX_EWORKSPACE, "projector: workspace %zu B < %zu B", workspace_bytes, need);
-    float* xn = static_cast<float*>(workspace);
-    layernorm_rows_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(
-        x, n, lin->c_in, ln_eps, nullptr, nullptr, xn);
-    IPSX_TRY(launched("projector layernorm"));
-    return ipsx_conv2d_affine_nhwc(lin, xn, nullptr, out, n, 1, 1, 1, stream);
+    float2* stats = static_cast<float2*>(workspace);
+    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, lin->c_in, ln_eps, stats);
+    IPSX_TRY(launched("projector row statistics"));
+    return conv_nhwc_impl(lin, x, nullptr, reinterpret_cast<const float*>(stats), out, n, 1, 1, 1, stream);
 }
+
+IPSX_API size_t ipsx_projector_workspace_bytes(int64_t n) { return n > 0 ? (size_t)n * 2 * sizeof(float) : 0; }
 
 IPSX_API size_t ipsx_aggregate_workspace_bytes(const ipsx_transf* t, int b, int m) {
     if (!t || b <= 0 || m <= 0) return 0;

@@ -46,6 +46,7 @@ struct NhwcArgs {
     int c_in, h, w, c_out, ho, wo, kh, kw, stride, pad, relu;
     int spt;               // stages (k-groups) per tap = c_in / 8
     int kgs;               // packed k-groups per n-tile = kh*kw*c_in / 8
+    const float* stats;    // NORM kernels: (mean, rstd) per input row (1x1 convolutions = Linear layers only)
 };
 
 struct NhwcStage {
@@ -93,7 +94,11 @@ __device__ __forceinline__ unsigned nhwc_voff(const NhwcArgs& a, const NhwcPixel
     return ok ? ((p.img_pix + (unsigned)(iy * a.w + ix)) * (unsigned)a.c_in + 4u * half) * 4u : kOob;
 }
 
-template <int WM, int WN>
+// NORM: the A operand is LayerNorm'ed on its way into the matrix pipe - (x - mean) * rstd with the row moments of
+// row_stats_kernel (aggregate.hip), the very expression layernorm_rows_kernel evaluates, so the normalised row never
+// exists in memory (projector: 8 KB per row written and read back otherwise).  1x1 convolutions only (no padding
+// lanes: a zero from the bounds check must stay a zero).
+template <int WM, int WN, bool NORM>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int wm = __builtin_amdgcn_readfirstlane(wave % WM), wn = __builtin_amdgcn_readfirstlane(wave / WM);
@@ -109,6 +114,12 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
     const unsigned wb0 = (unsigned)nt0 * (unsigned)a.kgs * 1024u;   // byte offset of n-tile nt0's stream
     const unsigned wb1 = n1 ? wb0 + (unsigned)a.kgs * 1024u : wb0;
     const int taps = a.kh * a.kw, total = taps * a.spt;
+    float mean0 = 0.0f, rstd0 = 1.0f, mean1 = 0.0f, rstd1 = 1.0f;
+    if (NORM) {
+        const unsigned r0 = min(m_base + (lane & 31), a.m_total - 1), r1 = min(m_base + 32 + (lane & 31), a.m_total - 1);
+        const float2 st0 = reinterpret_cast<const float2*>(a.stats)[r0], st1 = reinterpret_cast<const float2*>(a.stats)[r1];
+        mean0 = st0.x; rstd0 = st0.y; mean1 = st1.x; rstd1 = st1.y;
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -145,7 +156,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
 // fused_trunk.hip: 3 MFMA between loads, 4 at the end); the stream state advances after the stage so that loads
 // and MFMAs share a basic block
 #define NHWC_STAGE(SL, SM)                                                                  \
-    NHWC_ISSUE(SL); nhwc_mma(SM, acc);                                                      \
+    NHWC_ISSUE(SL);                                                                         \
+    if (NORM) { SM.a0 = (SM.a0 - mean0) * rstd0; SM.a1 = (SM.a1 - mean1) * rstd1; }         \
+    nhwc_mma(SM, acc);                                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
@@ -232,9 +245,22 @@ __global__ void avgpool_nhwc_kernel(const float* __restrict__ x, float* __restri
 
 using namespace ipsx;
 
+namespace ipsx {
+int conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* residual, const float* row_stats, float* y,
+                   int64_t n, int h, int w, int relu, void* stream);
+}
+
 IPSX_API int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* residual, float* y,
                                      int64_t n, int h, int w, int relu, void* stream) {
+    return conv_nhwc_impl(cv, x, residual, nullptr, y, n, h, w, relu, stream);
+}
+
+// row_stats != null: x rows are LayerNorm'ed on the fly ((mean, rstd) per row; 1x1 convolution on 1x1 maps)
+int ipsx::conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* residual, const float* row_stats, float* y,
+                         int64_t n, int h, int w, int relu, void* stream) {
     IPSX_REQUIRE(cv && cv->w_packed && x && y && n >= 0 && h > 0 && w > 0, "conv2d_affine_nhwc: bad arguments");
+    IPSX_REQUIRE(!row_stats || (cv->kh == 1 && cv->kw == 1 && cv->pad == 0 && cv->stride == 1 && h == 1 && w == 1),
+                 "conv2d_affine_nhwc: row statistics go with a Linear layer (1x1 convolution on rows)");
     IPSX_REQUIRE(cv->c_in % 32 == 0, "conv2d_affine_nhwc: C_in = %d is not a multiple of 32", cv->c_in);
     if (n == 0) return IPSX_OK;
     const int ho = conv_out(h, cv->kh, cv->stride, cv->pad), wo = conv_out(w, cv->kw, cv->stride, cv->pad);
@@ -260,14 +286,20 @@ IPSX_API int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const 
         a.c_in = cv->c_in; a.h = h; a.w = w; a.c_out = cv->c_out; a.ho = ho; a.wo = wo;
         a.kh = cv->kh; a.kw = cv->kw; a.stride = cv->stride; a.pad = cv->pad; a.relu = relu;
         a.spt = cv->c_in / 8; a.kgs = kgs;
+        a.stats = row_stats ? row_stats + (size_t)i0 * 2 : nullptr;
         const unsigned mt64 = (unsigned)cdiv(a.m_total, 64), nt64 = (unsigned)cdiv(cv->c_out, 64);
         hipStream_t s = as_stream(stream);
-        if (cv->c_out >= 256)        // wide layer: the 4 waves share the activation rows
-            conv_nhwc_kernel<1, 4><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
+        if (row_stats) {
+            if (cv->c_out >= 256)
+                conv_nhwc_kernel<1, 4, true><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
+            else
+                conv_nhwc_kernel<2, 2, true><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
+        } else if (cv->c_out >= 256)        // wide layer: the 4 waves share the activation rows
+            conv_nhwc_kernel<1, 4, false><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
         else if (cv->c_out > 64)
-            conv_nhwc_kernel<2, 2><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
+            conv_nhwc_kernel<2, 2, false><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
         else
-            conv_nhwc_kernel<4, 1><<<dim3((unsigned)cdiv(mt64, 4), nt64), dim3(256), 0, s>>>(a);
+            conv_nhwc_kernel<4, 1, false><<<dim3((unsigned)cdiv(mt64, 4), nt64), dim3(256), 0, s>>>(a);
         IPSX_TRY(launched("conv2d_affine_nhwc"));
     }
     return IPSX_OK;

@@ -47,6 +47,46 @@ __device__ __forceinline__ float det_expf(float x) {
     return is_nan ? x : res;
 }
 
+// det_expf for arguments that are never positive (a logit minus its row maximum: <= 0, or NaN when the row holds a NaN or
+// an infinity): the same operations as det_expf on every such input - the overflow tests, whose branches cannot be
+// taken, are the only thing left out.
+__device__ __forceinline__ float det_expf_np(float x) {
+    const bool is_nan = x != x, small = x < -104.0f;
+    const float xc = (is_nan || small) ? 0.0f : x;
+    float n = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, xc);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r);
+    y = y + 1.0f;
+    const int ni = (int)n;
+    const bool sub = ni < -126;
+    const int e1 = sub ? ni + 127 + 64 : ni + 127;
+    const float s2 = sub ? 5.42101086242752217e-20f /* 2^-64 */ : 1.0f;
+    float res = (y * as_float((uint32_t)e1 << 23)) * s2;
+    res = small ? 0.0f : res;
+    return is_nan ? x : res;
+}
+
+// order-preserving integer image of a float for max reductions with one v_max_u32 per step: larger float <=> larger
+// key, every NaN -> 0xFFFFFFFF (a NaN wins, as in nanmax); 0 is below every float (the neutral element)
+__device__ __forceinline__ uint32_t max_key(float x) {
+    const uint32_t u = as_u32(x);
+    const uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return x != x ? 0xFFFFFFFFu : k;
+}
+
+__device__ __forceinline__ float max_key_value(uint32_t k) {
+    if (k == 0xFFFFFFFFu) return as_float(0x7FC00000u);
+    return as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
 // xor-butterfly sum over the 64 lanes, offsets 32,16,...,1: every lane ends with
 // the same total (the second half of wave_sum64 of the oracle).
 __device__ __forceinline__ float wave_butterfly_sum(float v) {

@@ -20,6 +20,7 @@
 // once per iteration it takes part in.
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "ipsx_common.h"
 #include "ipsx_math.h"
@@ -442,7 +443,7 @@ __device__ __forceinline__ void rank_runs(const uint64_t* src, uint64_t* dst, ui
         mine = wave_sort_desc(idx < L ? src[idx] : 0ull, lane);     // padding keys (0) sort last
         runs[idx] = mine;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS traffic only
     if (wave < nruns && mine != 0ull) {
         // rank = number of larger keys over ALL runs (in the own run that is the lane index: keys are unique), found
         // by branch-free binary searches, 8 runs at a time with their LDS reads in flight together - no per-run
@@ -470,6 +471,60 @@ __device__ __forceinline__ void rank_runs(const uint64_t* src, uint64_t* dst, ui
 #pragma unroll
             for (int j = 0; j < 8; ++j) rank += (r0 + j < nruns) ? lo[j] + ((last[j] > mine) ? 1 : 0) : 0;
         }
+        dst[rank] = mine;
+    }
+}
+
+// rank_runs for the fast scan: the same ranking (wave-sorted runs of 64, rank = larger keys over all runs), with the
+// searches organised for LATENCY - the loop runs at two waves per SIMD, so a dependent LDS round trip costs more than
+// the instructions around it: a 4-ary search (three probes per round, three rounds + one final probe for 64 keys) of
+// every run, all runs' probes of a round in flight together, and no probes for runs that do not exist.
+template <int NRUN>
+__device__ __forceinline__ int rank_in_runs(const uint64_t* runs, uint64_t mine) {
+    int lo[NRUN];                                    // number of keys of run j known to be larger than `mine`
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) lo[j] = 0;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 2) {     // 64 = 4 * 16 -> 4 * 4 -> 4 * 1
+        uint64_t p1[NRUN], p2[NRUN], p3[NRUN];
+#pragma unroll
+        for (int j = 0; j < NRUN; ++j) {
+            const uint64_t* q = runs + j * 64 + lo[j];
+            p1[j] = q[step - 1]; p2[j] = q[2 * step - 1]; p3[j] = q[3 * step - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < NRUN; ++j)               // descending run: the probes that are larger form a prefix
+            lo[j] += ((p1[j] > mine) ? step : 0) + ((p2[j] > mine) ? step : 0) + ((p3[j] > mine) ? step : 0);
+    }
+    uint64_t last[NRUN];
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) last[j] = runs[j * 64 + lo[j]];
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) rank += lo[j] + ((last[j] > mine) ? 1 : 0);
+    return rank;
+}
+
+__device__ __forceinline__ void rank_runs4(const uint64_t* src, uint64_t* dst, uint64_t* runs, int L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nruns = (L + 63) >> 6;
+    uint64_t mine = 0ull;
+    if (wave < nruns) {
+        const int idx = wave * 64 + lane;
+        mine = wave_sort_desc(idx < L ? src[idx] : 0ull, lane);     // padding keys (0) sort last
+        runs[idx] = mine;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave < nruns && mine != 0ull) {
+        // every run is searched, the own one too (there the result is the lane index: keys are unique)
+        int rank = 0;
+        int r0 = 0;
+        for (; r0 + 8 <= nruns; r0 += 8) rank += rank_in_runs<8>(runs + r0 * 64, mine);
+        const int left = nruns - r0;                 // workgroup-uniform
+        if (left >= 4) { rank += rank_in_runs<4>(runs + r0 * 64, mine); r0 += 4; }
+        if (nruns - r0 == 3) rank += rank_in_runs<3>(runs + r0 * 64, mine);
+        else if (nruns - r0 == 2) rank += rank_in_runs<2>(runs + r0 * 64, mine);
+        else if (nruns - r0 == 1) rank += rank_in_runs<1>(runs + r0 * 64, mine);
         dst[rank] = mine;
     }
 }
@@ -711,6 +766,356 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
         for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast resident scan (R = H*T a power of two <= 64, (M+I)*R <= 1024*EPT, M+I <= 64*LCH): the same loop, same
+// arithmetic.  One image runs on ONE compute unit, 16 waves on 4 SIMDs: an instruction every thread executes costs
+// 16 issue slots, so the loop is bound by instructions per thread and by dependent LDS round trips
+// (tools/scan_stamps.py).  What this organisation does about it:
+//   * one thread per ELEMENT (candidate l, row r) with r fixed per thread (1024 % R == 0), EPT elements per thread: the
+//     row maximum is a v_max_f32 reduction (lane steps R .. 32, then one LDS exchange between the 16 waves) instead of
+//     one wave walking a whole row.  NaNs (a NaN must win, the contract's nanmax) are looked for on the side; an
+//     iteration that sees one takes the exact key-based reduction instead (workgroup-uniform branch);
+//   * exp(x - max) is a function of (x, max) alone, and the maximum of a row rarely moves from one iteration to the
+//     next (it belongs to a patch that stays in the memory): the exponentials of the M memory rows travel with the
+//     winners and only the I new rows are evaluated - unless the row's maximum changed (bitwise), then that row is
+//     recomputed.  det_expf_np leaves out the overflow tests a non-positive argument cannot trigger;
+//   * the contract's row sums (lane j adds elements j, j+64, ... in ascending order, then the xor butterfly) read the
+//     exponentials back row-wise with all LCH reads of a lane in flight together: R short wave jobs;
+//   * the attention weights e / den are formed by all 1024 threads and transposed through LDS for the per-candidate
+//     ascending head / token sums;
+//   * barriers wait for LDS traffic only (lds_barrier): the prefetch of the next chunk stays in flight across them;
+//   * the kernel claims 128 registers per lane: 16 waves x 128 = the whole register file of the compute unit, so no
+//     workgroup of the encoder running beside the loop can be placed on it and compete for its issue slots.
+// LDS: two logit buffers + two exp buffers of (M+I) x (R+1) floats (the spare exp buffer doubles as the weight
+// buffer and as the run scratch of the ranking).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define FAST_STAMP(k)                                                              \
+    do {                                                                           \
+        if (STAMP) {                                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();            \
+            if (tid == 0) { tacc[k] += t_ - tlast; }                               \
+            tlast = t_;                                                            \
+        }                                                                          \
+    } while (0)
+
+// the replay of torch.topk's tie order (rare) lives outside the loop body: inlined, its registers would be the loop's
+__device__ __attribute__((noinline)) void tie_order_slow(uint64_t* sorted, uint64_t* other, int L, int m, int* stk) {
+    torch_tie_order<SCAN_NT>(sorted, other, L, m, stk, threadIdx.x);
+}
+
+template <int R, int T, int EPT, int LCH, bool STAMP>
+__global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    constexpr int H = R / T, ld = R + 1;
+    constexpr int log2R = R == 8 ? 3 : (R == 16 ? 4 : (R == 32 ? 5 : 6));
+    constexpr int log2T = T == 1 ? 0 : (T == 2 ? 1 : (T == 4 ? 2 : 3));
+    static_assert((1 << log2R) == R && (1 << log2T) == T && H * T == R, "scan_fast_kernel: R, T powers of two");
+    const int Lmax = a.m + a.i;
+    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* keyB = keyA + a.n2;
+    int* candA = reinterpret_cast<int*>(keyB + a.n2);
+    int* candB = candA + Lmax;
+    uint32_t* pmax = reinterpret_cast<uint32_t*>(candB + Lmax + ((4 - ((2 * Lmax) & 3)) & 3));   // [R][16], 16-byte aligned
+    uint32_t* wmin = pmax + 16 * R;               // [16] (16-byte aligned): per wave, the lowest score key of its memory rows
+    int* ccount = reinterpret_cast<int*>(wmin + 16);          // [0]: chunk candidates that can still reach the top M;
+                                                              // [1]: lowest memory score key; [2], [3]: tie flag (by parity)
+    int* nanflag = ccount + 4;                    // [2]: a NaN among this iteration's logits (by parity)
+    uint32_t* prevk = reinterpret_cast<uint32_t*>(ccount + 8);     // [2][R]: bits of the row maxima of the previous iteration
+    float* rden = reinterpret_cast<float*>(prevk + 2 * R);
+    float* xA = rden + R;
+    float* xB = xA + (size_t)Lmax * ld;
+    float* eA = xB + (size_t)Lmax * ld;
+    float* eB = eA + (size_t)Lmax * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float* lg = a.lg + (size_t)b * a.n * R;
+    const int r = tid & (R - 1), lrow0 = tid >> log2R;
+    constexpr int lstep = SCAN_NT >> log2R;
+
+    int* cand = candA;
+    int* cnew = candB;
+    float* xc = xA;
+    float* xn = xB;
+    float* ec = eA;
+    float* en = eB;
+    for (int k = 0; k < EPT; ++k) {
+        const int l = lrow0 + k * lstep;
+        if (l < a.m) {
+            const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
+            xc[l * ld + r] = lg[row * R + r];
+        }
+    }
+    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
+    if (tid < 2) { nanflag[tid] = 0; ccount[2 + tid] = 0; }
+    const long long n_iter = a.it1 - a.it0;
+    float pf[SCAN_PF];
+    {
+        const long long lo = a.it0 * a.i + a.m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+#pragma unroll
+        for (int k = 0; k < SCAN_PF; ++k) {
+            const int e = tid + SCAN_NT * k;
+            pf[k] = (n_iter > 0 && e < cnt * R) ? lg[(size_t)lo * R + e] : 0.0f;
+        }
+    }
+    int tie = 0;
+    uint64_t* const sorted = keyB;
+    for (long long it = a.it0; it < a.it1; ++it) {
+        const long long lo = it * a.i + a.m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+        const int L = a.m + cnt;
+        const int par = (int)((it - a.it0) & 1);
+        // P0: chunk registers -> candidate rows m.., next chunk -> registers (it lands during this iteration: no barrier
+        // below waits for it)
+#pragma unroll
+        for (int k = 0; k < SCAN_PF; ++k) {
+            const int e = tid + SCAN_NT * k;
+            if (e < cnt * R) xc[(a.m + (e >> log2R)) * ld + r] = pf[k];
+        }
+        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
+        {
+            const long long lo2 = lo + a.i;          // the range's last iteration prefetches nothing: those rows may not exist yet
+            const int cnt2 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
+#pragma unroll
+            for (int k = 0; k < SCAN_PF; ++k) {
+                const int e = tid + SCAN_NT * k;
+                pf[k] = e < cnt2 * R ? lg[(size_t)lo2 * R + e] : 0.0f;
+            }
+        }
+        lds_barrier();
+        FAST_STAMP(0);
+        // P1: row maxima.  Own elements, then the lanes that hold the same row (offsets R, 2R, .. 32), then the waves.
+        float xv[EPT];
+        float mx = -__builtin_huge_valf();
+        bool seen_nan = false;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int l = lrow0 + k * lstep;
+            xv[k] = l < L ? xc[l * ld + r] : -__builtin_huge_valf();
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            mx = __builtin_fmaxf(mx, xv[k]);
+            seen_nan = seen_nan || (xv[k] != xv[k]);
+        }
+        for (int off = R; off < 64; off <<= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
+        if (lane < R) pmax[lane * 16 + wave] = as_u32(mx);
+        if (__ballot(seen_nan) != 0ull && lane == 0) nanflag[par] = 1;
+        if (tid == 0) {                                        // (all last read several barriers ago)
+            nanflag[par ^ 1] = 0; ccount[0] = 0; ccount[1] = -1; ccount[2 + (par ^ 1)] = 0;
+        }
+        lds_barrier();
+        uint32_t mbits;
+        if (nanflag[par] == 0) {
+            const float4* pm = reinterpret_cast<const float4*>(pmax + r * 16);
+            const float4 p0 = pm[0], p1 = pm[1], p2 = pm[2], p3 = pm[3];
+            const float m01 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(p0.x, p0.y), __builtin_fmaxf(p0.z, p0.w)),
+                                              __builtin_fmaxf(__builtin_fmaxf(p1.x, p1.y), __builtin_fmaxf(p1.z, p1.w)));
+            const float m23 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(p2.x, p2.y), __builtin_fmaxf(p2.z, p2.w)),
+                                              __builtin_fmaxf(__builtin_fmaxf(p3.x, p3.y), __builtin_fmaxf(p3.z, p3.w)));
+            mbits = as_u32(__builtin_fmaxf(m01, m23));
+        } else {
+            // a NaN somewhere: the contract's maximum lets a NaN win (nanmax).  Exact reduction over order-preserving
+            // keys, every thread over the whole row (rare: nobody optimises this path)
+            uint32_t mk = 0u;
+            for (int l = 0; l < L; ++l) mk = max(mk, max_key(xc[l * ld + r]));
+            mbits = as_u32(max_key_value(mk));
+        }
+        const float rowmax = as_float(mbits);
+        // the exponentials of the memory rows are those of the previous iteration while the row's maximum is the same
+        const bool changed = it == a.it0 || prevk[par * R + r] != mbits;
+        if (tid < R) prevk[(par ^ 1) * R + r] = mbits;
+        FAST_STAMP(1);
+        // P2: exp(x - max) where it is new
+        float ev[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int l = lrow0 + k * lstep;
+            ev[k] = 0.0f;
+            if (l < L) {
+                if (changed || l >= a.m) {
+                    ev[k] = det_expf_np(xv[k] - rowmax);
+                    ec[l * ld + r] = ev[k];
+                } else {
+                    ev[k] = ec[l * ld + r];
+                }
+            }
+        }
+        lds_barrier();
+        FAST_STAMP(2);
+        // P3: softmax denominators in the contract's order: lane j adds rows j, j + 64, ... ascending, xor butterfly
+        for (int r0 = wave; r0 < R; r0 += 32) {
+            const int r1 = r0 + 16;
+            const bool has1 = r1 < R;
+            float v0[LCH], v1[LCH];
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) {                    // every read in flight before the first add; slots beyond L
+                const int i = lane + 64 * u;                   // add an exact + 0.0
+                v0[u] = i < L ? ec[i * ld + r0] : 0.0f;
+                v1[u] = (i < L && has1) ? ec[i * ld + r1] : 0.0f;
+            }
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) { s0 = s0 + v0[u]; s1 = s1 + v1[u]; }
+            wave_sum2(s0, s1, lane);
+            if (lane == 0) { rden[r0] = s0; if (has1) rden[r1] = s1; }
+        }
+        lds_barrier();
+        FAST_STAMP(3);
+        // P4: attention weights e / den by every thread, transposed through the spare buffer; then one lane per
+        // (candidate, token) adds its H weights in ascending head order and the T lanes of a candidate their tokens
+        {
+            const float den = rden[r];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int l = lrow0 + k * lstep;
+                if (l < L) en[l * ld + r] = ev[k] / den;
+            }
+        }
+        lds_barrier();
+        // Keys: the M memory keys go to keyA[0, M); a chunk candidate keeps its key in a register until it is known
+        // whether it can still reach the top M (below)
+        constexpr int KT = (LCH * 64 * T + SCAN_NT - 1) / SCAN_NT;
+        uint64_t mykey[KT];
+        uint32_t lowest = 0xFFFFFFFFu;                           // lowest score key among this lane's memory candidates
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int e = kt * SCAN_NT + tid, l = e >> log2T, t = e & (T - 1);
+            mykey[kt] = 0ull;
+            if (e < a.n2 * T) {                                  // (workgroup-uniform up to the last trip)
+                float q = 0.0f;
+                if (l < L) {
+                    const float* wrow = en + l * ld + t;
+                    float wh[H];                                 // all reads in flight together
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh) wh[hh] = wrow[hh * T];
+                    float sh = 0.0f;
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh) sh = sh + wh[hh];
+                    q = sh / (float)H;
+                }
+                float st = q;
+                if (T > 1) {
+                    st = 0.0f;
+#pragma unroll
+                    for (int tt = 0; tt < T; ++tt) st = st + __shfl(q, (lane & ~(T - 1)) + tt, 64);
+                }
+                if (t == 0 && l < L) {
+                    mykey[kt] = rank_key(st / (float)T, (uint32_t)l);
+                    if (l < a.m) {
+                        keyA[l] = mykey[kt];
+                        lowest = min(lowest, (uint32_t)(mykey[kt] >> 32));
+                    }
+                }
+            }
+        }
+        // (64 lanes on one LDS address serialise: the wave reduces first - DPP inside a row of 16, two cross-row steps)
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x124, 0xF, 0xF, false));    // row_ror:4
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x128, 0xF, 0xF, false));    // row_ror:8
+        lowest = min(lowest, (uint32_t)__shfl_xor((int)lowest, 16, 64));
+        lowest = min(lowest, (uint32_t)__shfl_xor((int)lowest, 32, 64));
+        if (lane == 0 && lowest != 0xFFFFFFFFu) atomicMin(reinterpret_cast<unsigned int*>(ccount + 1), lowest);
+        lds_barrier();
+        // A chunk candidate whose score is below the lowest memory score cannot be among the M best of memory + chunk
+        // (the M memory candidates alone beat it), and in a long scan that is almost every one of them: only the others
+        // - equal scores included, so exact ties are all still there - are appended behind the memory keys and ranked.
+        {
+            const uint32_t tau = (uint32_t)ccount[1];             // lowest memory score key (ds_min_u32 above)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int e = kt * SCAN_NT + tid, l = e >> log2T;
+                const bool in = mykey[kt] != 0ull && l >= a.m && (uint32_t)(mykey[kt] >> 32) >= tau;
+                const unsigned long long mask = __ballot(in);
+                if (mask != 0ull) {                              // wave-uniform
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(ccount, __popcll(mask));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (in) keyA[a.m + base + __popcll(mask & ((1ull << lane) - 1ull))] = mykey[kt];
+                }
+            }
+        }
+        lds_barrier();
+        const int Lr = a.m + ccount[0];                          // candidates that take part in the ranking
+        if (STAMP && tid == 0) tacc[7] += (unsigned long long)(Lr - a.m);
+        FAST_STAMP(4);
+        if (Lr <= 192) {                     // counting rank below the crossover of the two rankings (~200 keys)
+            int P = 1;
+            while (P < 64 && 2 * P * Lr <= SCAN_NT) P <<= 1;
+            rank_scatter(keyA, keyB, Lr, P);
+        } else {
+            rank_runs4(keyA, keyB, reinterpret_cast<uint64_t*>(en), Lr);
+        }
+        lds_barrier();
+        // exact ties among the first M + 1 ranked scores?  One pair per thread, any hit raises the flag.
+        {
+            const int npair = a.m < Lr - 1 ? a.m : Lr - 1;
+            bool hit = false;
+            for (int j = tid; j < npair; j += SCAN_NT) hit = hit || (sorted[j] >> 32) == (sorted[j + 1] >> 32);
+            if (__ballot(hit) != 0ull && lane == 0) ccount[2 + par] = 1;
+        }
+        lds_barrier();
+        bool boundary_tie = Lr > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m]);   // (NaN never equal: harmless)
+        if (a.tie_order == 1 && ccount[2 + par] != 0) {
+            // torch.topk's order under ties depends on the WHOLE candidate array, so every chunk key goes back to its
+            // place, all L candidates are ranked and the replay runs on them (rare)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int l = (kt * SCAN_NT + tid) >> log2T;
+                if (mykey[kt] != 0ull && l >= a.m) keyA[l] = mykey[kt];
+            }
+            lds_barrier();
+            if (L <= 192) {
+                int P = 1;
+                while (P < 64 && 2 * P * L <= SCAN_NT) P <<= 1;
+                rank_scatter(keyA, keyB, L, P);
+            } else {
+                rank_runs(keyA, keyB, reinterpret_cast<uint64_t*>(en), L);
+            }
+            lds_barrier();
+            boundary_tie = L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m]);
+            tie_order_slow(keyB, keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off));
+        }
+        FAST_STAMP(5);
+        // P6: new memory: indices, logit rows and exponentials of the winners, into the other buffers
+        for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
+        {
+            int src[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int j = lrow0 + k * lstep;
+                src[k] = j < a.m ? (int)key_pos(sorted[j]) * ld + r : 0;
+            }
+            float gx[EPT], ge[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) { gx[k] = xc[src[k]]; ge[k] = ec[src[k]]; }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int j = lrow0 + k * lstep;
+                if (j < a.m) { xn[j * ld + r] = gx[k]; en[j * ld + r] = ge[k]; }
+            }
+        }
+        if (tid == 0 && boundary_tie) tie = 1;
+        { int* t = cand; cand = cnew; cnew = t; }
+        { float* t = xc; xc = xn; xn = t; }
+        { float* t = ec; ec = en; en = t; }
+        FAST_STAMP(6);
+        // no barrier here: the next iteration's first phase writes rows m.. of the new buffers only, and its barrier
+        // orders everything before the maxima are read
+    }
+    lds_barrier();
+    for (int j = tid; j < a.m; j += SCAN_NT) {
+        a.mem_idx[(size_t)b * a.m + j] = cand[j];
+        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
+    }
+    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
+    if (STAMP && tid == 0)
+        for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
+}
+
 // Transformer.get_scores on the logits (b, L, R) of arbitrary embeddings
 struct ScoresArgs {
     const float* lg;
@@ -851,8 +1256,54 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
     a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
     a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
-    // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
     a.tie_order = g_tie_order;
+    // fast variant (scan_fast_kernel): R a power of two, one thread per element
+    {
+        const bool pow2 = (R & (R - 1)) == 0 && R <= 64;
+        int ept = 1;
+        while ((size_t)ept * SCAN_NT < (size_t)Lmax * R) ept <<= 1;
+        const int pad = (4 - ((2 * Lmax) & 3)) & 3;
+        const size_t fixed = (size_t)n2 * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
+        const size_t fast = ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES;
+        const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= stage;
+        static const bool fast_off = getenv("IPSX_SCAN_FAST") && getenv("IPSX_SCAN_FAST")[0] == '0';
+        if (pow2 && ept <= 8 && Lmax <= SCAN_NT && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && scratch_fits &&
+            fast <= kLdsLimit && !fast_off) {
+            a.use_lds = 1;
+            a.stk_off = (int)(fast - STK_BYTES);
+            unsigned long long* st = g_scan_stamps;
+            const int lch = Lmax <= 128 ? 2 : (Lmax <= 512 ? 8 : 16);
+#define IPSX_LAUNCH_FAST(RR, TT, E, C, S)                                                                           \
+            do {                                                                                                    \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, S>),         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                   \
+                scan_fast_kernel<RR, TT, E, C, S><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st); \
+                return launched("scan");                                                                            \
+            } while (0)
+#define IPSX_LAUNCH_FAST_C(RR, TT, E)                                                                               \
+            do {                                                                                                    \
+                if (lch == 2) IPSX_LAUNCH_FAST(RR, TT, E, 2, false);                                                \
+                else if (lch == 8) IPSX_LAUNCH_FAST(RR, TT, E, 8, false);                                           \
+                else IPSX_LAUNCH_FAST(RR, TT, E, 16, false);                                                        \
+            } while (0)
+#define IPSX_LAUNCH_FAST_E(RR, TT)                                                                                  \
+            do {                                                                                                    \
+                if (ept == 1) IPSX_LAUNCH_FAST_C(RR, TT, 1);                                                        \
+                else if (ept == 2) IPSX_LAUNCH_FAST_C(RR, TT, 2);                                                   \
+                else if (ept == 4) IPSX_LAUNCH_FAST_C(RR, TT, 4);                                                   \
+                else IPSX_LAUNCH_FAST_C(RR, TT, 8);                                                                 \
+            } while (0)
+            // the diagnostic (stamped) build exists for the two benchmark shapes
+            if (st && R == 8 && n_token == 1 && ept == 4 && lch == 8) IPSX_LAUNCH_FAST(8, 1, 4, 8, true);
+            if (st && R == 32 && n_token == 4 && ept == 4 && lch == 2) IPSX_LAUNCH_FAST(32, 4, 4, 2, true);
+            if (R == 8 && n_token == 1) IPSX_LAUNCH_FAST_E(8, 1);
+            if (R == 32 && n_token == 4) IPSX_LAUNCH_FAST_E(32, 4);
+#undef IPSX_LAUNCH_FAST_C
+#undef IPSX_LAUNCH_FAST_E
+#undef IPSX_LAUNCH_FAST
+        }
+    }
+    // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
     const size_t resident = base + 3 * stage + STK_BYTES;          // exp buffer + two candidate buffers, (R + 1)-strided
     const bool runs_fit = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)Lmax * R * 4;   // run scratch aliases the weight buffer
     if (resident <= kLdsLimit && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && runs_fit) {

@@ -150,6 +150,7 @@ _EXPORTS = {
                              [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_projector": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_projector_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
     "ipsx_folded_query_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -416,7 +417,7 @@ class EncoderPlan:
                     return out
             return self.encode_plain(x, out)
         else:
-            nb = n * x.shape[1] * 4
+            nb = lib().ipsx_projector_workspace_bytes(n)
             ws = self._workspace(nb, x.device)
             _ck(lib().ipsx_projector(C.byref(self.lin), _p(x), n, C.c_float(self.ln_eps), _p(out),
                                      _p(ws), nb, _stream()), "ipsx_projector")
@@ -428,7 +429,7 @@ def encoder_kernel_name(plan):
     if plan is None or plan._sig is None:
         return None
     if not plan.is_image:
-        return "layernorm_rows_kernel + conv_nhwc_kernel (projector)"
+        return "row_stats_kernel + conv_nhwc_kernel<NORM> (projector)"
     return lib().ipsx_trunk_kernel(C.byref(plan.trunk)).decode()
 
 

@@ -225,6 +225,39 @@ def make_patches(conf, B, seed=0, blank_frac=None, N=None):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
+def pos_table_record(conf):
+    """What a fixture keeps of the positional table of the machine that generated it.  ``pos_enc_1d`` (reference
+    transformer.py:6-18) runs on the host CPU, and its frequency vector ``exp(-2j ln(1e4) / D)`` differs in the last
+    ulp between CPU models; multiplied by positions up to N that moves table entries by up to ~N * 6e-8 - enough to
+    reorder near-identical blank patches (which differ by their positional encoding ONLY) at N = 10,000.  "Identical
+    inputs" includes this table, so fixtures carry the frequency vector (D/2 floats) and a checksum of the table."""
+    import math
+    freq = torch.exp(torch.arange(0, conf.D, 2, dtype=torch.float) * -(math.log(10000.0) / conf.D))
+    return {"pos_freq": freq.numpy(), "pos_abs_sum": np.float64(pos_table_from(freq, conf.N).double().abs().sum().item())}
+
+
+def pos_table_from(freq, N):
+    """The table of ``pos_enc_1d`` from a given frequency vector: (N, D) float32."""
+    freq = torch.as_tensor(freq, dtype=torch.float32)
+    phase = torch.arange(0, N).unsqueeze(1).float() * freq
+    table = torch.zeros(N, 2 * freq.numel())
+    table[:, 0::2] = torch.sin(phase)
+    table[:, 1::2] = torch.cos(phase)
+    return table
+
+
+def use_fixture_pos_table(net, z):
+    """Give ``net`` the positional table of the machine that recorded fixture ``z`` (see pos_table_record); returns
+    True when this host's own table was already identical to it."""
+    if not net.use_pos or "pos_freq" not in z.files:
+        return True
+    own = net.pos_enc
+    table = pos_table_from(z["pos_freq"], own.shape[1]).unsqueeze(0).to(own.device)
+    same = bool(torch.equal(table, own))
+    net.pos_enc = table
+    return same
+
+
 class ListLoader:
     """A loader the loops of training/iterative.py can drive: ``len()`` and iteration over dict items."""
 

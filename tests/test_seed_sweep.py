@@ -120,6 +120,7 @@ def test_hip_path_follows_the_reference_over_seeds(family, precision, monkeypatc
     for k in range(n_case):
         conf, B, wseed, q_gain, x = synth.seed_case(family, k)
         net = synth.fill_weights(IPSNet(dev, conf), wseed, q_gain=q_gain).to(dev).eval()
+        synth.use_fixture_pos_table(net, z)
         xd = x.to(dev)
         want, gap, ogap = z["c%d_trace_idx" % k].astype(np.int64), z["c%d_rel_gap" % k], z["c%d_order_gap" % k]
         res = walk(hip_trace(net, xd), want, gap, ogap)

@@ -67,6 +67,8 @@ def run(name, ref_ips):
                mem_patch_sum=mem_patch.double().sum(dim=tuple(range(2, mem_patch.dim()))).numpy())
     for k, v in preds.items():
         out["pred_" + k] = v.numpy()
+    if conf.use_pos:
+        out.update(synth.pos_table_record(conf))
     np.savez_compressed(os.path.join(GOLDEN, "bench_" + name + ".npz"), **out)
     g = out["rel_gap"]
     print("{:10s} B={:2d} N={:5d} M={:3d} I={:3d} n_iter={:3d} min gap {:.2e} (final iteration {:.2e}; order: {:.2e} / {:.2e})  {:.1f} s  {:.0f} KB".format(

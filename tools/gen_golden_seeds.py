@@ -63,6 +63,8 @@ def main():
     for family in sys.argv[1:] or list(synth.SEED_FAMILIES):
         conf, B, n = synth.SEED_FAMILIES[family]()
         pack, gmin = {"n_case": n}, []
+        if conf.use_pos:
+            pack.update(synth.pos_table_record(conf))
         for k in range(n):
             for key, v in run_case(ref_ips, family, k).items():
                 pack["c%d_%s" % (k, key)] = v

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Diagnostic: per-phase cycles of scan_resident_kernel (STAMP build), summed over iterations.
-    python tools/scan_stamps.py mnist|cam
+"""Diagnostic: per-phase cycles of the selection-loop kernel (STAMP build), summed over iterations.
+    python tools/scan_stamps.py mnist|cam          # scan_fast_kernel; IPSX_SCAN_FAST=0 in the environment: scan_resident_kernel
+Also times the un-instrumented kernel (HIP events) and checks that both kernels select the same indices.
 """
 import ctypes as C
 import os
@@ -25,8 +26,26 @@ hip.scan(lg, M, I, H, T)
 torch.cuda.synchronize()
 L.ipsx_dbg_scan_stamps(None)
 n_iter = -(-(N - M) // I)
-names = ["stage chunk+barrier", "row stats", "attention weights", "scores+keys", "rank", "gather winners"]
+if os.environ.get("IPSX_SCAN_FAST", "1") == "0":
+    names = ["stage chunk+barrier", "row stats", "attention weights", "scores+keys", "rank", "gather winners"]
+else:
+    names = ["stage chunk+barrier", "row maxima", "exp (new rows)", "row sums", "weights+scores+keys", "rank", "gather winners"]
 s = st.cpu().numpy()[0]
-print("%s: %d iterations, L=%d, R=%d; total %d cycles = %.1f per iteration" % (kind, n_iter, M + I, H * T, s.sum(), s.sum() / n_iter))
+tot = s[:7].sum()
+print("%s: %d iterations, L=%d, R=%d; total %d cycles = %.1f per iteration" % (kind, n_iter, M + I, H * T, tot, tot / n_iter))
 for k, nme in enumerate(names):
     print("  %-22s %9.0f cycles/iter" % (nme, s[k] / n_iter))
+if len(names) == 7:
+    print("  chunk candidates ranked per iteration (score >= the lowest memory score): %.1f of %d" % (s[7] / n_iter, I))
+    s[7] = 0
+
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(3):
+    idx = hip.scan(lg, M, I, H, T)
+a.record()
+for _ in range(10):
+    idx = hip.scan(lg, M, I, H, T)
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 10
+print("  un-instrumented: %.3f ms per launch = %.2f us per iteration" % (ms, 1e3 * ms / n_iter))
