@@ -243,6 +243,21 @@ int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, 
                     int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                     int32_t* tie_flag, void* stream);
 
+/* The whole loop as ONE launch that may start before any logits exist (overlap with the encoder without re-launching
+ * per part): the kernel waits until *ready (device int32, written with ipsx_publish_rows on another stream after the
+ * kernels that produced the rows) says the rows it is about to read are in memory.  The wait is bounded (~5 s); on a
+ * timeout, or when *ready is set negative, the kernel ends and sets bit 0 of *status (results are then invalid; bit 1 =
+ * the kernel is resident).  The
+ * workgroup of an image claims its compute unit exclusively.  Shapes: ipsx_scan_persistent_supported() != 0.     */
+int ipsx_scan_persistent_supported(int m, int i, int h, int n_token);
+int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                         int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
+                         int32_t* status, void* stream);
+int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream);
+/* holds `stream` (one waiting thread, bounded) until the persistent scan that owns `status` is resident: enqueue it on
+ * the producing stream right after launching the scan, so that the producers do not take the compute units first */
+int ipsx_scan_gate(const int32_t* status, void* stream);
+
 /* Transformer.get_scores on arbitrary embeddings x (b,l,d) -> scores (b,l);
  * attn (b,h,T,l) optionally written too (get_attn).                          */
 int ipsx_scores(const float* x, const float* wk_packed, const float* qs,

@@ -304,6 +304,21 @@ class IPSNet(nn.Module):
         for t in (logits, mem_idx, tie):
             t.record_stream(side)
         self._emb_parts = parts = []
+        # Few images (each occupies ONE compute unit in the loop): the loop is launched once, up front, as a persistent
+        # kernel that owns its compute unit and waits for the rows as the encoder publishes them - no re-launch per
+        # part and no encoder workgroups competing for the loop's issue slots (IPSX_SCAN_PERSIST=0 switches it off).
+        import os
+        persistent = (B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8")) and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
+                      and hip.scan_persistent_supported(M, I, ca.H, ca.n_token))
+        if persistent:
+            ready = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self._scan_status = status = torch.zeros((1,), dtype=torch.int32, device=dev)
+            for t in (ready, status):
+                t.record_stream(side)
+            side.wait_stream(main)                     # the buffers above are the main stream's allocations
+            with torch.cuda.stream(side):
+                hip.scan_persistent(logits, M, I, ca.H, ca.n_token, mem_idx, tie, ready, status)
+            hip.scan_gate(status)                      # the encoder must not take the compute units before the loop has its own
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
             if indexed:
@@ -313,6 +328,9 @@ class IPSNet(nn.Module):
             parts.append(emb)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
             hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
+            if persistent:
+                hip.publish_rows(ready, hi)            # after the kernels that wrote rows [0, hi) of every image
+                continue
             done = torch.cuda.Event()
             done.record(main)
             with torch.cuda.stream(side):

@@ -267,6 +267,8 @@ struct ScanArgs {
     long long* mem_idx;
     float* mem_score;
     int* tie;
+    const int* ready;      // persistent launch: number of patches whose logits are in memory (grows while we run)
+    int* status;           // persistent launch: set to 1 when the wait for `ready` timed out
 };
 
 // Generic scan (any M+I that fits the key arrays): candidates' logits are re-staged from global
@@ -804,9 +806,26 @@ __device__ __attribute__((noinline)) void tie_order_slow(uint64_t* sorted, uint6
     torch_tie_order<SCAN_NT>(sorted, other, L, m, stk, threadIdx.x);
 }
 
-template <int R, int T, int EPT, int LCH, bool STAMP>
+// PERSIST: ONE launch for the whole loop, started BEFORE the encoder has produced anything: the kernel waits (bounded)
+// until `*a.ready` says the logits of the rows it is about to read exist, reads them past the vector L1 (agent-scope
+// loads: the producer is another kernel that finished meanwhile), and claims 128 registers per lane - 16 waves x 128 =
+// the whole register file of its compute unit, so no workgroup of the encoder running beside the loop is placed there
+// to compete for issue slots.  (A claim like that only works for a launch onto an idle GPU: later, a compute unit is
+// never empty long enough.)
+template <bool PERSIST>
+__device__ __forceinline__ float scan_load(const float* p) {
+    if (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+template <int R, int T, int EPT, int LCH, bool STAMP, bool PERSIST>
 __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (PERSIST) {
+        asm volatile("v_mov_b32 v127, 0" ::: "v127");
+        // resident: tell the gate on the producing stream (ipsx_scan_gate) that the encoder may start
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     constexpr int H = R / T, ld = R + 1;
     constexpr int log2R = R == 8 ? 3 : (R == 16 ? 4 : (R == 32 ? 5 : 6));
@@ -840,11 +859,36 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
     float* xn = xB;
     float* ec = eA;
     float* en = eB;
+    // persistent launch: rows below ready_known exist.  Wave 0 polls (bounded: ~5 s of the 100 MHz clock), everybody
+    // learns the result through LDS; a negative value (cancelled / timed out) ends the kernel.
+    long long ready_known = 0;
+#define SCAN_WAIT_ROWS(need)                                                                                   \
+    do {                                                                                                       \
+        if (PERSIST && (long long)(need) > ready_known) {                                                      \
+            if (wave == 0) {                                                                                   \
+                const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();                               \
+                int v_ = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+                while (v_ >= 0 && v_ < (need)) {                                                               \
+                    __builtin_amdgcn_s_sleep(16);                                                              \
+                    if (__builtin_amdgcn_s_memrealtime() - t0_ > 500000000ull) { v_ = -1; break; }             \
+                    v_ = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+                }                                                                                              \
+                if (lane == 0) ccount[6] = v_;                                                     \
+            }                                                                                                  \
+            lds_barrier();                                                                                     \
+            ready_known = ccount[6];                                                               \
+            if (ready_known < 0) {                                                                             \
+                if (tid == 0 && b == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                return;                                                                                        \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+    SCAN_WAIT_ROWS(std::min<long long>(a.n, a.it0 * a.i + a.m + a.i));
     for (int k = 0; k < EPT; ++k) {
         const int l = lrow0 + k * lstep;
         if (l < a.m) {
             const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
-            xc[l * ld + r] = lg[row * R + r];
+            xc[l * ld + r] = scan_load<PERSIST>(lg + row * R + r);
         }
     }
     for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
@@ -857,7 +901,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
 #pragma unroll
         for (int k = 0; k < SCAN_PF; ++k) {
             const int e = tid + SCAN_NT * k;
-            pf[k] = (n_iter > 0 && e < cnt * R) ? lg[(size_t)lo * R + e] : 0.0f;
+            pf[k] = (n_iter > 0 && e < cnt * R) ? scan_load<PERSIST>(lg + (size_t)lo * R + e) : 0.0f;
         }
     }
     int tie = 0;
@@ -878,10 +922,11 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         {
             const long long lo2 = lo + a.i;          // the range's last iteration prefetches nothing: those rows may not exist yet
             const int cnt2 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
+            if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
 #pragma unroll
             for (int k = 0; k < SCAN_PF; ++k) {
                 const int e = tid + SCAN_NT * k;
-                pf[k] = e < cnt2 * R ? lg[(size_t)lo2 * R + e] : 0.0f;
+                pf[k] = e < cnt2 * R ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
             }
         }
         lds_barrier();
@@ -1237,9 +1282,64 @@ IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int 
     return ipsx_scan_range(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, stream);
 }
 
+static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                           int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                           int32_t* tie_flag, const int32_t* ready, int32_t* status, void* stream);
+
 IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                              int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                              int32_t* tie_flag, void* stream) {
+    return scan_range_impl(logits, b, n, m, i, h, n_token, it_begin, it_end, mem_idx, mem_score, tie_flag, nullptr, nullptr, stream);
+}
+
+__global__ void publish_rows_kernel(int* ready, int value) {
+    __hip_atomic_store(ready, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+IPSX_API int ipsx_scan_persistent_supported(int m, int i, int h, int n_token) {
+    const int R = h * n_token, Lmax = m + i;
+    if (!((R == 8 && n_token == 1) || (R == 32 && n_token == 4))) return 0;
+    if (Lmax > SCAN_NT || (size_t)Lmax * R > (size_t)SCAN_NT * 8 || (size_t)i * R > (size_t)SCAN_NT * SCAN_PF) return 0;
+    const size_t stage = (size_t)Lmax * (R + 1) * 4;
+    if ((size_t)((Lmax + 63) / 64) * 64 * 8 > stage) return 0;
+    const int pad = (4 - ((2 * Lmax) & 3)) & 3;
+    const size_t fixed = (size_t)next_pow2(Lmax) * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
+    return ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES <= kLdsLimit;
+}
+
+IPSX_API int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                                  int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
+                                  int32_t* status, void* stream) {
+    IPSX_REQUIRE(ready && status, "scan_persistent: needs the progress word and the status word");
+    IPSX_REQUIRE(n > m && i > 0, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
+    IPSX_REQUIRE(ipsx_scan_persistent_supported(m, i, h, n_token), "scan_persistent: shape not covered (use ipsx_scan_range)");
+    return scan_range_impl(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, ready, status, stream);
+}
+
+// one thread that holds its stream until every workgroup of the persistent scan is resident (bounded: ~0.5 s)
+__global__ void scan_gate_kernel(const int* status) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) == 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) break;
+    }
+}
+
+IPSX_API int ipsx_scan_gate(const int32_t* status, void* stream) {
+    IPSX_REQUIRE(status, "scan_gate: null pointer");
+    scan_gate_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(status);
+    return launched("scan_gate");
+}
+
+IPSX_API int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream) {
+    IPSX_REQUIRE(ready, "publish_rows: null pointer");
+    publish_rows_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(ready, value);
+    return launched("publish_rows");
+}
+
+static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                           int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                           int32_t* tie_flag, const int32_t* ready, int32_t* status, void* stream) {
     IPSX_REQUIRE(logits && mem_idx, "scan: null pointer");
     IPSX_REQUIRE(b > 0 && m > 0 && i > 0 && h > 0 && n_token > 0, "scan: bad sizes");
     IPSX_REQUIRE(n > m, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
@@ -1256,6 +1356,7 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
     a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
     a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
+    a.ready = ready; a.status = status;
     a.tie_order = g_tie_order;
     // fast variant (scan_fast_kernel): R a power of two, one thread per element
     {
@@ -1268,16 +1369,22 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
         const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= stage;
         static const bool fast_off = getenv("IPSX_SCAN_FAST") && getenv("IPSX_SCAN_FAST")[0] == '0';
         if (pow2 && ept <= 8 && Lmax <= SCAN_NT && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && scratch_fits &&
-            fast <= kLdsLimit && !fast_off) {
+            fast <= kLdsLimit && (!fast_off || ready)) {
             a.use_lds = 1;
             a.stk_off = (int)(fast - STK_BYTES);
             unsigned long long* st = g_scan_stamps;
             const int lch = Lmax <= 128 ? 2 : (Lmax <= 512 ? 8 : 16);
 #define IPSX_LAUNCH_FAST(RR, TT, E, C, S)                                                                           \
             do {                                                                                                    \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, S>),         \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                   \
-                scan_fast_kernel<RR, TT, E, C, S><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st); \
+                if (a.ready) {                                                                                      \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, false, true>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);               \
+                    scan_fast_kernel<RR, TT, E, C, false, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, nullptr); \
+                } else {                                                                                            \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, S, false>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);               \
+                    scan_fast_kernel<RR, TT, E, C, S, false><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st); \
+                }                                                                                                   \
                 return launched("scan");                                                                            \
             } while (0)
 #define IPSX_LAUNCH_FAST_C(RR, TT, E)                                                                               \
@@ -1303,6 +1410,7 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
 #undef IPSX_LAUNCH_FAST
         }
     }
+    IPSX_REQUIRE(!ready, "scan_persistent: shape not covered");
     // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
     const size_t resident = base + 3 * stage + STK_BYTES;          // exp buffer + two candidate buffers, (R + 1)-strided
     const bool runs_fit = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)Lmax * R * 4;   // run scratch aliases the weight buffer

@@ -163,6 +163,11 @@ _EXPORTS = {
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_scan_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_scan_persistent_supported": (C.c_int, [C.c_int] * 4),
+    "ipsx_scan_persistent": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_publish_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ipsx_scan_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ipsx_trunk_encode_indexed": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ipsx_scores_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ipsx_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
@@ -497,6 +502,30 @@ def scan_range(lg, M, I, H, T, it_begin, it_end, mem_idx, tie):
     _ck(lib().ipsx_scan_range(_p(lg), B, N, M, I, H, T, it_begin, it_end, _p(mem_idx), None, _p(tie), _stream()),
         "ipsx_scan_range")
     return mem_idx
+
+
+def scan_persistent_supported(M, I, H, T):
+    return bool(lib().ipsx_scan_persistent_supported(M, I, H, T))
+
+
+def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status):
+    """The whole loop as one launch on the CURRENT stream that waits for ``ready`` (int32 device scalar, advanced with
+    ``publish_rows`` on the producing stream) before it reads rows; see include/ipsx.h."""
+    B, N = lg.shape[:2]
+    if not lg.is_contiguous():
+        raise ValueError("scan_persistent needs the full contiguous (B, N, H*T) logits buffer")
+    _ck(lib().ipsx_scan_persistent(_p(lg), B, N, M, I, H, T, _p(mem_idx), None, _p(tie), _p(ready), _p(status), _stream()),
+        "ipsx_scan_persistent")
+    return mem_idx
+
+
+def scan_gate(status):
+    """Hold the current stream until the persistent scan owning ``status`` is resident (bounded wait)."""
+    _ck(lib().ipsx_scan_gate(_p(status), _stream()), "ipsx_scan_gate")
+
+
+def publish_rows(ready, n_rows):
+    _ck(lib().ipsx_publish_rows(_p(ready), int(n_rows), _stream()), "ipsx_publish_rows")
 
 
 def _scores_impl(x, qs, wk, H, Dk, T, want_attn):
