@@ -275,18 +275,16 @@ def main():
         def step():
             return ipsd.ips_sharded(net, x, n_total, timings=timings)
 
-    for _ in range(max(args.warmup, 1)):                        # also builds the encoder plan
-        step()
-    if timings is not None:
-        timings.clear()
-    # time the encoder launches with HIP events on the stream they run on
+    step()                                                      # builds the encoder plan
+    # time the encoder launches with HIP events on the stream they run on (installed BEFORE the warm-up so that the
+    # warm-up steps run exactly what the timed steps run, event creation included)
     enc_events = []
     plan_encode = net._plan.encode
 
-    def timed_encode(t):
+    def timed_encode(t, **kw):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        out = plan_encode(t)
+        out = plan_encode(t, **kw)
         b.record()
         enc_events.append((a, b, t.shape[0]))
         return out
@@ -303,6 +301,12 @@ def main():
         return out
 
     net._plan.encode_indexed = timed_encode_indexed
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    enc_events.clear()
+    if timings is not None:
+        timings.clear()
 
     def fence():
         torch.cuda.synchronize()
@@ -314,6 +318,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_enqueue = time.perf_counter() - t0                     # the host's share: how long it took to ENQUEUE the steps
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -371,6 +376,7 @@ def main():
                        "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, ipsd.PARTS) if world > 1 else "single GPU",
                        "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy)},
             "ms_per_call_median_synced": statistics.median(lat),
+            "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "parity": par,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,

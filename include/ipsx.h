@@ -186,6 +186,10 @@ int ipsx_patchify_sparse(const int64_t* index, const float* value, const int64_t
 int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps,
                    float* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t ipsx_projector_workspace_bytes(int64_t n);      /* 8 bytes per row: (mean, rstd) */
+/* the two halves of ipsx_projector, for callers that compute the row statistics (n x 2 floats: mean, rstd) ahead of
+ * the GEMM - e.g. on another stream, beside the GEMM of an earlier slab (the pass is HBM-bound, the GEMM MFMA-bound) */
+int ipsx_projector_stats(const float* x, int64_t n, int f, float ln_eps, float* stats, void* stream);
+int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out, void* stream);
 
 /* ------------------------------------------------------------------- scorer
  * Replaces MultiHeadCrossAttention.get_attn + ScaledDotProductAttention.
@@ -247,8 +251,8 @@ int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, 
  * per part): the kernel waits until *ready (device int32, written with ipsx_publish_rows on another stream after the
  * kernels that produced the rows) says the rows it is about to read are in memory.  The wait is bounded (~5 s); on a
  * timeout, or when *ready is set negative, the kernel ends and sets bit 0 of *status (results are then invalid; bit 1 =
- * the kernel is resident).  The
- * workgroup of an image claims its compute unit exclusively.  Shapes: ipsx_scan_persistent_supported() != 0.     */
+ * the kernel is resident).
+ * Shapes: ipsx_scan_persistent_supported() != 0.     */
 int ipsx_scan_persistent_supported(int m, int i, int h, int n_token);
 int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                          int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,

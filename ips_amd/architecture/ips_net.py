@@ -279,12 +279,26 @@ class IPSNet(nn.Module):
         if self._plan is None:
             self._plan = hip.EncoderPlan(self.encoder, self.is_image)
         indexed = self.is_image and patches.is_contiguous() and self._plan.fused(patches.shape)
-        # image encoders: parts shrinking towards the end (only the last scan is exposed); projector: the loop is the
-        # long pole, so a small first part lets it start early and the later ones are ready before it reaches them
+        import os
+        # image encoders: parts shrinking towards the end (only the last scan is exposed).  Projector: the loop is the
+        # long pole (it consumes rows about as fast as the projector makes them), so the parts are EQUAL and sized to
+        # what fills the GPU exactly once - 256 compute units x 64 rows - because a GEMM launch of 1.2 rounds takes as
+        # long as one of 2.
         if self.is_image:
             its = part_iterations(n_iter, self._OVERLAP_PARTS)
         else:
-            its = part_iterations(n_iter, len(PART_SHARES_LOOP_BOUND), PART_SHARES_LOOP_BOUND)
+            # (persistent loop: every slide's loop owns a compute unit, the projector has the others - and a launch of one
+            #  workgroup too many takes twice as long)
+            cus = 256 - (B if B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8")) else 0)
+            cap = max(I, (cus * 64 // max(B, 1)) // I * I)       # most rows of every image one launch can take, whole chunks
+            n_part = min(16, max(1, math.ceil(N / cap)))
+            its = [0]
+            for k in range(1, n_part):                           # equal parts: edge k at about k * N / n_part rows
+                nxt = max(its[-1] + 1, round((k * N / n_part - M) / I))
+                if nxt >= n_iter:
+                    break
+                its.append(nxt)
+            its.append(n_iter)
         P = len(its) - 1
         edges = [0] + [min(N, M + it * I) for it in its[1:]]
         edges[-1] = N
@@ -298,31 +312,57 @@ class IPSNet(nn.Module):
             self._side_stream = torch.cuda.Stream(device=dev, priority=-1)   # its few workgroups must not queue behind the encoder grid
         side, main = self._side_stream, torch.cuda.current_stream(dev)
         flat = patches.reshape(B * N, *patches.shape[2:]) if indexed else None
-        logits = torch.empty((B, N, ca.H * ca.n_token), dtype=torch.float32, device=dev)
-        mem_idx = torch.empty((B, M), dtype=torch.int64, device=dev)
-        tie = torch.zeros((B,), dtype=torch.int32, device=dev)
-        for t in (logits, mem_idx, tie):
-            t.record_stream(side)
+        # per-call device buffers are kept between calls of the same shape: a buffer that another stream has used cannot be
+        # re-used by the allocator until that stream's work is known to be over, and allocating afresh in every call makes
+        # the host stall in hipMalloc now and then
+        bkey = (B, N, M, R, str(dev))
+        if getattr(self, "_scan_bufs_key", None) != bkey:
+            self._scan_bufs = (torch.empty((B, N, R), dtype=torch.float32, device=dev),
+                               torch.empty((B, M), dtype=torch.int64, device=dev),
+                               torch.zeros((B,), dtype=torch.int32, device=dev),
+                               torch.zeros((2,), dtype=torch.int32, device=dev))
+            self._scan_bufs_key = bkey
+            for t in self._scan_bufs:
+                t.record_stream(side)
+        logits, mem_idx_buf, tie, words = self._scan_bufs
+        tie.zero_()
         self._emb_parts = parts = []
-        # Few images (each occupies ONE compute unit in the loop): the loop is launched once, up front, as a persistent
-        # kernel that owns its compute unit and waits for the rows as the encoder publishes them - no re-launch per
-        # part and no encoder workgroups competing for the loop's issue slots (IPSX_SCAN_PERSIST=0 switches it off).
+        # Feature inputs, few slides (the loop is the long pole and each slide occupies ONE compute unit in it): the loop
+        # is launched once, up front, as a persistent kernel that owns its compute unit and waits for the rows as the
+        # projector publishes them - no re-launch per part, no waiting for a compute unit to drain, no projector
+        # workgroups competing for the loop's issue slots (IPSX_SCAN_PERSIST=0 switches it off).
         import os
-        persistent = (B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8")) and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
+        persistent = (not self.is_image and B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8"))
+                      and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
                       and hip.scan_persistent_supported(M, I, ca.H, ca.n_token))
         if persistent:
-            ready = torch.zeros((1,), dtype=torch.int32, device=dev)
-            self._scan_status = status = torch.zeros((1,), dtype=torch.int32, device=dev)
-            for t in (ready, status):
-                t.record_stream(side)
-            side.wait_stream(main)                     # the buffers above are the main stream's allocations
+            words.zero_()
+            ready, status = words[0:1], words[1:2]
+            self._scan_status = status
+            side.wait_stream(main)                     # the buffers above are the main stream's; previous readers are done
             with torch.cuda.stream(side):
-                hip.scan_persistent(logits, M, I, ca.H, ca.n_token, mem_idx, tie, ready, status)
+                hip.scan_persistent(logits, M, I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status)
             hip.scan_gate(status)                      # the encoder must not take the compute units before the loop has its own
+        else:
+            side.wait_stream(main)
+        stats = None
+        if not self.is_image and patches.is_contiguous() and P > 1 and B == 1:
+            # LayerNorm moments of ALL rows in one HBM-bound pass up front (0.1 ms per 64 Ki rows of 2048 features) instead
+            # of one small pass per part.  (Tried beside the first part's GEMM on a helper stream: its workgroups
+            # are in the way when the GEMM's are placed, some compute units end up with two of them and the launch takes
+            # twice as long.)
+            skey = (B, N, str(dev))
+            if getattr(self, "_stats_key", None) != skey:
+                self._stats_buf = torch.empty((B * N, 2), dtype=torch.float32, device=dev)
+                self._stats_key = skey
+            self._plan._refresh()
+            stats = self._plan.row_stats(patches.reshape(B * N, -1), out=self._stats_buf)
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
             if indexed:
                 emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
+            elif stats is not None:
+                emb = self._plan.encode(patches[0, lo:hi], stats=stats[lo:hi]).view(B, hi - lo, -1)
             else:
                 emb = self._embed(patches[:, lo:hi].reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             parts.append(emb)
@@ -335,7 +375,9 @@ class IPSNet(nn.Module):
             done.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(done)
-                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx, tie)
+                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie)
+        main.wait_stream(side)
+        mem_idx = mem_idx_buf.clone()                  # the buffer is overwritten by the next call
         main.wait_stream(side)
         hip.scan.last_tie = tie
         return mem_idx

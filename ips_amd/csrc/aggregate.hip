@@ -242,20 +242,32 @@ static AggLayout agg_layout(const ipsx_transf* t, int b, int m) {
 
 using namespace ipsx;
 
+IPSX_API int ipsx_projector_stats(const float* x, int64_t n, int f, float ln_eps, float* stats, void* stream) {
+    IPSX_REQUIRE(x && stats && n >= 0 && f > 0, "projector_stats: bad arguments");
+    if (n == 0) return IPSX_OK;
+    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, f, ln_eps, reinterpret_cast<float2*>(stats));
+    return launched("projector row statistics");
+}
+
+IPSX_API int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
+                                  void* stream) {
+    IPSX_REQUIRE(lin && x && out && stats && n >= 0, "projector_apply: bad arguments");
+    IPSX_REQUIRE(lin->kh == 1 && lin->kw == 1 && lin->stride == 1 && lin->pad == 0, "projector: lin must be 1x1");
+    if (n == 0) return IPSX_OK;
+    return conv_nhwc_impl(lin, x, nullptr, stats, out, n, 1, 1, 1, stream);
+}
+
 IPSX_API int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps, float* out,
                             void* workspace, size_t workspace_bytes, void* stream) {
     IPSX_REQUIRE(lin && x && out && n >= 0, "projector: bad arguments");
-    IPSX_REQUIRE(lin->kh == 1 && lin->kw == 1 && lin->stride == 1 && lin->pad == 0, "projector: lin must be 1x1");
     if (n == 0) return IPSX_OK;
     // LayerNorm is fused into the Linear: a statistics pass leaves (mean, rstd) per row (8 B per row - the only
     // workspace) and the GEMM normalises its A operand in registers; the normalised rows never exist in memory
     const size_t need = (size_t)n * 2 * sizeof(float);
     if (!workspace || workspace_bytes < need)
         return fail(IPSX_EWORKSPACE, "projector: workspace %zu B < %zu B", workspace_bytes, need);
-    float2* stats = static_cast<float2*>(workspace);
-    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, lin->c_in, ln_eps, stats);
-    IPSX_TRY(launched("projector row statistics"));
-    return conv_nhwc_impl(lin, x, nullptr, reinterpret_cast<const float*>(stats), out, n, 1, 1, 1, stream);
+    IPSX_TRY(ipsx_projector_stats(x, n, lin->c_in, ln_eps, static_cast<float*>(workspace), stream));
+    return ipsx_projector_apply(lin, x, n, static_cast<const float*>(workspace), out, stream);
 }
 
 IPSX_API size_t ipsx_projector_workspace_bytes(int64_t n) { return n > 0 ? (size_t)n * 2 * sizeof(float) : 0; }

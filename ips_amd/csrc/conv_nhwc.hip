@@ -49,21 +49,23 @@ struct NhwcArgs {
     const float* stats;    // NORM kernels: (mean, rstd) per input row (1x1 convolutions = Linear layers only)
 };
 
+template <int NTW>
 struct NhwcStage {
-    f32x4 a0, a1, b0, b1;
+    f32x4 a0, a1, b[NTW];
 };
 
 __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-__device__ __forceinline__ void nhwc_mma(const NhwcStage& st, f32x16 (&acc)[2][2]) {
+template <int NTW>
+__device__ __forceinline__ void nhwc_mma(const NhwcStage<NTW>& st, f32x16 (&acc)[2][NTW]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        acc[0][0] = MFMA(st.a0[j], st.b0[j], acc[0][0]);
-        acc[0][1] = MFMA(st.a0[j], st.b1[j], acc[0][1]);
-        acc[1][0] = MFMA(st.a1[j], st.b0[j], acc[1][0]);
-        acc[1][1] = MFMA(st.a1[j], st.b1[j], acc[1][1]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[0][t] = MFMA(st.a0[j], st.b[t][j], acc[0][t]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[1][t] = MFMA(st.a1[j], st.b[t][j], acc[1][t]);
     }
 }
 
@@ -98,21 +100,25 @@ __device__ __forceinline__ unsigned nhwc_voff(const NhwcArgs& a, const NhwcPixel
 // row_stats_kernel (aggregate.hip), the very expression layernorm_rows_kernel evaluates, so the normalised row never
 // exists in memory (projector: 8 KB per row written and read back otherwise).  1x1 convolutions only (no padding
 // lanes: a zero from the bounds check must stay a zero).
-template <int WM, int WN, bool NORM>
-__global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
+// NTW: n-tiles (32 output channels each) per wave - 2 (wave tile 64 x 64) or 4 (64 x 128: half the activation loads
+// and half the NORM arithmetic per MFMA, and with 4 waves along N a workgroup covers 512 output channels, so very
+// wide layers read every activation row once); 8 * NTW MFMAs and 2 + NTW loads per stage.
+template <int WM, int WN, bool NORM, int NTW>
+__global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int wm = __builtin_amdgcn_readfirstlane(wave % WM), wn = __builtin_amdgcn_readfirstlane(wave / WM);
     const unsigned m_base = (blockIdx.x * WM + wm) * 64u;
-    const int nt0 = (blockIdx.y * WN + wn) * 2;                     // first of this wave's two n-tiles
+    const int nt0 = (blockIdx.y * WN + wn) * NTW;                   // first of this wave's n-tiles
     if (m_base >= a.m_total || nt0 * 32 >= a.c_out) return;         // wave-uniform
-    const bool n1 = (nt0 + 1) * 32 < a.c_out;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)a.w_bytes, 0x00020000);
     const NhwcPixel p0 = nhwc_pixel(a, m_base + (lane & 31));
     const NhwcPixel p1 = nhwc_pixel(a, m_base + 32 + (lane & 31));
     const unsigned lb = lane * 16u;
-    const unsigned wb0 = (unsigned)nt0 * (unsigned)a.kgs * 1024u;   // byte offset of n-tile nt0's stream
-    const unsigned wb1 = n1 ? wb0 + (unsigned)a.kgs * 1024u : wb0;
+    unsigned wb[NTW];                                               // byte offset of every n-tile's weight stream
+#pragma unroll                                                      // (a tile beyond C_out re-reads the last real one;
+    for (int t = 0; t < NTW; ++t)                                   //  its accumulators are never stored)
+        wb[t] = (unsigned)min(nt0 + t, (a.c_out + 31) / 32 - 1) * (unsigned)a.kgs * 1024u;
     const int taps = a.kh * a.kw, total = taps * a.spt;
     float mean0 = 0.0f, rstd0 = 1.0f, mean1 = 0.0f, rstd1 = 1.0f;
     if (NORM) {
@@ -121,25 +127,24 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
         mean0 = st0.x; rstd0 = st0.y; mean1 = st1.x; rstd1 = st1.y;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NTW];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // prefetch stream state: stage gp = (tap pt, k-group pc); pv0/pv1 = pixel offsets of tap pt
     int gp = 0, pt = 0, pc = 0;
     unsigned pv0 = nhwc_voff(a, p0, 0, half), pv1 = nhwc_voff(a, p1, 0, half);
-    NhwcStage s0, s1, s2, s3;
+    NhwcStage<NTW> s0, s1, s2, s3;       // (s3: ring of 4 only)
 #define NHWC_ISSUE(S)                                                       \
     do {                                                                    \
         const unsigned ca = (unsigned)pc * 32u, cb = (unsigned)gp * 1024u;  \
         S.a0 = bufload(rx, pv0, ca);                                        \
         S.a1 = bufload(rx, pv1, ca);                                        \
-        S.b0 = bufload(rw, lb, wb0 + cb);                                   \
-        S.b1 = bufload(rw, lb, wb1 + cb);                                   \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) S.b[t] = bufload(rw, lb, wb[t] + cb); \
     } while (0)
 #define NHWC_ADVANCE()                                                      \
     do {                                                                    \
@@ -152,38 +157,57 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(NhwcArgs a) {
             }                                                               \
         }                                                                   \
     } while (0)
-// the 4 loads of the stage two ahead are spread between the 16 MFMAs of this one (same finding as in
-// fused_trunk.hip: 3 MFMA between loads, 4 at the end); the stream state advances after the stage so that loads
-// and MFMAs share a basic block
+// the loads of the stage three ahead are spread between the MFMAs of this one (same finding as in fused_trunk.hip:
+// a few MFMAs between two loads); the stream state advances after the stage so that loads and MFMAs share a basic block
+#define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SGB_LOAD() __builtin_amdgcn_sched_group_barrier(0x020, 1, 0)
 #define NHWC_STAGE(SL, SM)                                                                  \
     NHWC_ISSUE(SL);                                                                         \
     if (NORM) { SM.a0 = (SM.a0 - mean0) * rstd0; SM.a1 = (SM.a1 - mean1) * rstd1; }         \
-    nhwc_mma(SM, acc);                                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); SB();                                \
+    nhwc_mma<NTW>(SM, acc);                                                                 \
+    if (NTW == 2) {                                                                         \
+        SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(4); \
+    } else {                                                                                \
+        SGB_MFMA(5); SGB_LOAD(); SGB_MFMA(5); SGB_LOAD(); SGB_MFMA(5); SGB_LOAD();          \
+        SGB_MFMA(5); SGB_LOAD(); SGB_MFMA(5); SGB_LOAD(); SGB_MFMA(5); SGB_LOAD(); SGB_MFMA(2); \
+    }                                                                                       \
+    SB();                                                                                   \
     NHWC_ADVANCE();
-    // operands are requested THREE stages ahead (ring of 4: the slot being refilled is the one consumed a stage ago)
-    NHWC_ISSUE(s0); NHWC_ADVANCE();
-    NHWC_ISSUE(s1); NHWC_ADVANCE();
-    NHWC_ISSUE(s2); NHWC_ADVANCE();
+    if (NTW == 2) {
+        // operands are requested THREE stages ahead (ring of 4: the slot being refilled is the one consumed a stage ago)
+        NHWC_ISSUE(s0); NHWC_ADVANCE();
+        NHWC_ISSUE(s1); NHWC_ADVANCE();
+        NHWC_ISSUE(s2); NHWC_ADVANCE();
 #pragma unroll 1
-    for (int g = 0; g < total; g += 4) {       // total is a multiple of 4 (C_in % 32 == 0)
-        NHWC_STAGE(s3, s0)
-        NHWC_STAGE(s0, s1)
-        NHWC_STAGE(s1, s2)
-        NHWC_STAGE(s2, s3)
+        for (int g = 0; g < total; g += 4) {       // total is a multiple of 4 (C_in % 32 == 0)
+            NHWC_STAGE(s3, s0)
+            NHWC_STAGE(s0, s1)
+            NHWC_STAGE(s1, s2)
+            NHWC_STAGE(s2, s3)
+        }
+    } else {
+        // 64 x 128 wave tile: a stage is 32 MFMAs (2048 matrix-pipe cycles), so TWO stages ahead cover more time than
+        // three did above - and a ring of 3 keeps the kernel at 2 waves per SIMD (128 accumulator registers + 3 x 24
+        // operand registers).  total need not be a multiple of 3: the stages past the end are skipped (uniform branch).
+        NHWC_ISSUE(s0); NHWC_ADVANCE();
+        NHWC_ISSUE(s1); NHWC_ADVANCE();
+#pragma unroll 1
+        for (int g = 0; g < total; g += 3) {
+            NHWC_STAGE(s2, s0)
+            if (g + 1 < total) { NHWC_STAGE(s0, s1) }
+            if (g + 2 < total) { NHWC_STAGE(s1, s2) }
+        }
     }
 #undef NHWC_STAGE
+#undef SGB_MFMA
+#undef SGB_LOAD
 #undef NHWC_ADVANCE
 #undef NHWC_ISSUE
 
     // epilogue: BatchNorm affine, residual, ReLU; lanes of a store are 32 consecutive channels
     const int i = lane & 31;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
         const int n = (nt0 + nt) * 32 + i;
         if (n >= a.c_out) continue;
         const float al = a.alpha ? a.alpha[n] : 1.0f;
@@ -289,17 +313,20 @@ int ipsx::conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* resid
         a.stats = row_stats ? row_stats + (size_t)i0 * 2 : nullptr;
         const unsigned mt64 = (unsigned)cdiv(a.m_total, 64), nt64 = (unsigned)cdiv(cv->c_out, 64);
         hipStream_t s = as_stream(stream);
+        const unsigned nt128 = (unsigned)cdiv(cv->c_out, 128);
         if (row_stats) {
-            if (cv->c_out >= 256)
-                conv_nhwc_kernel<1, 4, true><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
+            if (cv->c_out >= 512)       // Linear layers with LayerNorm in the operand load (projector): wave tile 64 x 128
+                conv_nhwc_kernel<1, 4, true, 4><<<dim3(mt64, (unsigned)cdiv(nt128, 4)), dim3(256), 0, s>>>(a);
+            else if (cv->c_out >= 256)
+                conv_nhwc_kernel<1, 4, true, 2><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
             else
-                conv_nhwc_kernel<2, 2, true><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
+                conv_nhwc_kernel<2, 2, true, 2><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
         } else if (cv->c_out >= 256)        // wide layer: the 4 waves share the activation rows
-            conv_nhwc_kernel<1, 4, false><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
+            conv_nhwc_kernel<1, 4, false, 2><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
         else if (cv->c_out > 64)
-            conv_nhwc_kernel<2, 2, false><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
+            conv_nhwc_kernel<2, 2, false, 2><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
         else
-            conv_nhwc_kernel<4, 1, false><<<dim3((unsigned)cdiv(mt64, 4), nt64), dim3(256), 0, s>>>(a);
+            conv_nhwc_kernel<4, 1, false, 2><<<dim3((unsigned)cdiv(mt64, 4), nt64), dim3(256), 0, s>>>(a);
         IPSX_TRY(launched("conv2d_affine_nhwc"));
     }
     return IPSX_OK;

@@ -807,11 +807,13 @@ __device__ __attribute__((noinline)) void tie_order_slow(uint64_t* sorted, uint6
 }
 
 // PERSIST: ONE launch for the whole loop, started BEFORE the encoder has produced anything: the kernel waits (bounded)
-// until `*a.ready` says the logits of the rows it is about to read exist, reads them past the vector L1 (agent-scope
-// loads: the producer is another kernel that finished meanwhile), and claims 128 registers per lane - 16 waves x 128 =
-// the whole register file of its compute unit, so no workgroup of the encoder running beside the loop is placed there
-// to compete for issue slots.  (A claim like that only works for a launch onto an idle GPU: later, a compute unit is
-// never empty long enough.)
+// until `*a.ready` says the logits of the rows it is about to read exist and reads them past the vector L1 (agent-scope
+// loads: the producer is another kernel that finished meanwhile).  Launched onto an idle GPU (ipsx_scan_gate holds the
+// producers back until it is resident) it never has to wait for a compute unit to drain, which a workgroup of 16 waves
+// does for a long time beside an encoder grid - and it claims 128 registers per lane, i.e. with 16 waves the whole
+// register file of its compute unit, so no producer workgroup is placed beside it: a producer launch must then be sized
+// for the OTHER compute units (one sized for all 256 runs two workgroups on one of them and takes twice as long; a
+// producer workgroup sharing the loop's compute unit is a straggler that costs about as much).
 template <bool PERSIST>
 __device__ __forceinline__ float scan_load(const float* p) {
     if (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -821,7 +823,12 @@ __device__ __forceinline__ float scan_load(const float* p) {
 template <int R, int T, int EPT, int LCH, bool STAMP, bool PERSIST>
 __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // encoder workgroups share this compute unit (their matrix-pipe work coexists with this VALU-bound loop); where the
+    // two compete for issue slots the loop - the serial part of the job - goes first
+    __builtin_amdgcn_s_setprio(3);
     if (PERSIST) {
+        // 128 registers per lane x 16 waves = the whole register file of the compute unit: it is ours alone (callers
+        // size the producers' launches for the remaining compute units)
         asm volatile("v_mov_b32 v127, 0" ::: "v127");
         // resident: tell the gate on the producing stream (ipsx_scan_gate) that the encoder may start
         if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

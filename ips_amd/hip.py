@@ -151,6 +151,8 @@ _EXPORTS = {
     "ipsx_projector": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_projector_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "ipsx_projector_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "ipsx_projector_apply": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
     "ipsx_folded_query_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -376,7 +378,18 @@ class EncoderPlan:
         _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()), "ipsx_trunk_encode")
         return out
 
-    def encode(self, x, nonblank=None):
+    def row_stats(self, x, out=None):
+        """(mean, rstd) of every feature row of ``x`` (P, F) -> (P, 2): the LayerNorm moments the projector's GEMM applies
+        to its operand; for callers that run this HBM-bound pass ahead of / beside the GEMM (``encode(x, stats=...)``)."""
+        self._refresh()
+        x = _f32(x)
+        if out is None:
+            out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+        _ck(lib().ipsx_projector_stats(_p(x), x.shape[0], x.shape[1], C.c_float(self.ln_eps), _p(out), _stream()),
+            "ipsx_projector_stats")
+        return out
+
+    def encode(self, x, nonblank=None, stats=None):
         """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D).
 
         ``nonblank`` (P int32, 1 = the patch has a non-zero element; e.g. from ``patchify_sparse``) switches on
@@ -421,6 +434,10 @@ class EncoderPlan:
                     self.n_encoded = torch.tensor(sel.numel(), dtype=torch.int32, device=x.device)
                     return out
             return self.encode_plain(x, out)
+        elif stats is not None:
+            if stats.shape != (n, 2) or stats.dtype != torch.float32 or not stats.is_contiguous():
+                raise ValueError("stats must be a contiguous (P, 2) float32 tensor")
+            _ck(lib().ipsx_projector_apply(C.byref(self.lin), _p(x), n, _p(stats), _p(out), _stream()), "ipsx_projector_apply")
         else:
             nb = lib().ipsx_projector_workspace_bytes(n)
             ws = self._workspace(nb, x.device)
