@@ -92,6 +92,13 @@ def test_conv2d_affine_bit_exact(c_in, c_out, k, stride, pad, h, w, n, res, relu
     (256, 512, 3, 1, 1, 4, 4, 5, True, True),
     (2048, 512, 1, 1, 0, 1, 1, 300, False, True),  # the projector Linear: rows x 2048 -> 512
     (32, 32, 3, 1, 1, 5, 7, 4, False, False),      # smallest supported: one n-tile, 4 stages per tap
+    # large maps
+    (64, 64, 3, 1, 1, 13, 13, 5, True, True),      # 50-px patches, layer1: whole images per workgroup, odd image count
+    (64, 64, 3, 1, 1, 25, 25, 3, True, True),      # 100-px patches, layer1: strips of rows
+    (64, 128, 3, 2, 1, 25, 25, 3, False, True),    # strided, four n-tiles
+    (128, 128, 3, 1, 1, 13, 13, 4, True, True),    # 128 input channels
+    (64, 64, 3, 1, 1, 10, 12, 3, False, False),    # not square, no BatchNorm tail
+    (64, 64, 3, 2, 1, 26, 22, 2, True, False),     # strided, even map, residual without ReLU
 ])
 def test_conv2d_affine_nhwc_bit_exact(c_in, c_out, k, stride, pad, h, w, n, res, relu):
     """Channels-last conv (16-byte buffer loads, hardware-zeroed halo) vs the oracle (NCHW)."""
@@ -326,6 +333,111 @@ def test_fp32x3_trunk_has_fp32_accuracy(monkeypatch):
     assert err_x3 < 2e-6 and err_x3 < 3 * err_exact + 1e-7, (err_x3, err_exact)
     assert mean_x3 < 2 * mean_exact + 1e-8, (mean_x3, mean_exact)
     assert float((got - exact).abs().max() / scale) < 2e-6
+
+
+def _trunk_f64(sd, x):
+    """float64 evaluation of the 2-stage ResNet-18 trunk (eval BatchNorm) from a state dict: the yardstick."""
+    import torch.nn.functional as F
+    sd = {k: v.detach().double().cpu() for k, v in sd.items()}
+
+    def bn(y, p):
+        return (y - sd[p + ".running_mean"][None, :, None, None]) / torch.sqrt(sd[p + ".running_var"] + 1e-5)[None, :, None, None] \
+            * sd[p + ".weight"][None, :, None, None] + sd[p + ".bias"][None, :, None, None]
+    y = F.relu(bn(F.conv2d(x.double().cpu(), sd["0.weight"], None, 2, 3), "1"))
+    y = F.max_pool2d(y, 3, 2, 1)
+    for st, stride in ((4, 1), (5, 2)):
+        for blk in (0, 1):
+            p = "%d.%d" % (st, blk)
+            s1 = stride if blk == 0 else 1
+            idt = y
+            z = F.relu(bn(F.conv2d(y, sd[p + ".conv1.weight"], None, s1, 1), p + ".bn1"))
+            z = bn(F.conv2d(z, sd[p + ".conv2.weight"], None, 1, 1), p + ".bn2")
+            if p + ".downsample.0.weight" in sd:
+                idt = bn(F.conv2d(y, sd[p + ".downsample.0.weight"], None, s1, 0), p + ".downsample.1")
+            y = F.relu(z + idt)
+    return y.mean(dim=(2, 3))
+
+
+def _pass_through_after(enc, n_block):
+    """Make every residual block after the first ``n_block`` a pass-through (second convolution zero, BatchNorm
+    of the shortcut an exact identity), so the embedding is the spatial mean of what block ``n_block`` produced -
+    a probe of THAT layer's output through arithmetic that adds no error of its own (x * 1 and x + 0 are exact in
+    both the fma-chain and the split-product arithmetic)."""
+    blocks = [enc[4][0], enc[4][1], enc[5][0], enc[5][1]]
+    with torch.no_grad():
+        for b in blocks[n_block:]:
+            b.conv2.weight.zero_()
+            b.bn2.weight.fill_(1.0); b.bn2.bias.zero_(); b.bn2.running_mean.zero_(); b.bn2.running_var.fill_(1.0 - 1e-5)
+            if b.downsample is not None:
+                w = b.downsample[0].weight
+                w.zero_()
+                for c in range(w.shape[1]):
+                    w[c, c, 0, 0] = 1.0
+                bn = b.downsample[1]
+                bn.weight.fill_(1.0); bn.bias.zero_(); bn.running_mean.zero_(); bn.running_var.fill_(1.0 - 1e-5)
+
+
+@pytest.mark.parametrize("probe", [0, 1, 2, 3, 4])
+def test_fp32x3_accuracy_under_adversarial_ranges_layer_by_layer(probe, monkeypatch):
+    """The evidence behind fp32x3's status: not one pooled embedding on benign data, but every stage's
+    output (probed through an exact pass-through tail: 0 = stem + pool, k = after residual block k) on data built to
+    hurt a split-product scheme - weights whose output channels span 2^-6 .. 2^6, BatchNorm scales and variances
+    spanning 2^-5 .. 2^5 / 2^-8 .. 2^8 so that activations of neighbouring channels differ by tens of binades and the
+    spread compounds from layer to layer, inputs spanning 1e-6 .. 1e3 with mixed signs, and a band of patches scaled by
+    1e-20 (activations far below 1, towards the range where the low term of the split meets bf16's underflow; channels
+    whose magnitude ends up below 1e-30 are outside what the scheme promises, DESIGN 6d, and are not judged).
+    Yardstick: float64.  Requirement: per output channel, the error of fp32x3 relative to that channel's magnitude stays
+    within 3x the exact-fp32 kernel's own error (+ 2 ulp) on dense patches - the same accuracy class everywhere, not on
+    average.  Measured limit of that statement (why fp32x3 stays opt-in): on nearly blank patches, where an output is
+    the small remainder of convolution sums and BatchNorm shifts that cancel, the truncated cross terms of the split
+    do not average out the way fma roundings do and its error reaches ~10x the exact kernel's (bounded here at 16x)."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    enc = net.encoder
+    gen = torch.Generator(device="cpu").manual_seed(100 + probe)
+    with torch.no_grad():
+        for name, p in enc.named_parameters():
+            if p.dim() == 4:                                       # output channels over 24 binades
+                sc = torch.exp2(torch.randint(-6, 7, (p.shape[0], 1, 1, 1), generator=gen).float())
+                p.mul_(sc.to(DEV))
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                sc = torch.exp2(torch.randint(-5, 6, (m.num_features,), generator=gen).float()).to(DEV)
+                m.weight.mul_(sc)
+                m.running_var.mul_(torch.exp2(torch.randint(-8, 9, (m.num_features,), generator=gen).float()).to(DEV))
+    _pass_through_after(enc, probe)
+    n = 96
+    x = torch.randn((n, 1, 32, 32), generator=gen) * torch.pow(10.0, torch.rand((n, 1, 32, 32), generator=gen) * 9 - 6)
+    x[64:80] *= 1e-20                                               # activations around 1e-26 .. 1e-17 from the stem on
+    x[80:88] = x[80:88].abs()
+    x[88:] = 0.0
+    x[88:, :, 5:9, 7:12] = 3.0e-5
+    x = x.to(DEV)
+    plan = hip.EncoderPlan(enc, True)
+    exact = plan.encode(x).double().cpu()
+    monkeypatch.setenv("IPSX_PRECISION", "fp32x3")
+    got = plan.encode(x).double().cpu()
+    assert hip.encoder_kernel_name(plan) == "fused_trunk_x3_kernel"
+    monkeypatch.delenv("IPSX_PRECISION")
+    truth = _trunk_f64(enc.state_dict(), x)
+    assert torch.isfinite(truth).all() and torch.isfinite(got).all()
+    # per (patch group, channel) scale: the largest magnitude that channel takes within patches of similar input scale
+    worst = []
+    for lo, hi in ((0, 64), (64, 80), (80, 88), (88, 96)):
+        t = truth[lo:hi]
+        scale = t.abs().amax(dim=0).clamp_min(1e-300)
+        keep = t.abs().amax(dim=0) > 1e-30                          # channels that are alive (and in range) in this group
+        if not bool(keep.any()):
+            continue
+        e_fp32 = ((exact[lo:hi] - t).abs() / scale)[:, keep].max()
+        e_x3 = ((got[lo:hi] - t).abs() / scale)[:, keep].max()
+        worst.append((float(e_fp32), float(e_x3)))
+        # dense patches: 3x; the nearly blank group, whose outputs are what is left after the BatchNorm shifts cancel the
+        # convolution sums (the exact kernel itself is 100x its usual error there): an order of magnitude
+        bound = 3 if lo < 88 else 16
+        assert float(e_x3) <= bound * float(e_fp32) + 2.4e-7, (probe, lo, float(e_x3), float(e_fp32))
+    print("probe %d: max channel-relative error vs float64 per patch group (fp32, fp32x3): %s"
+          % (probe, ", ".join("%.2e / %.2e" % w for w in worst)))
 
 
 def test_encoder_plan_tracks_weight_updates():

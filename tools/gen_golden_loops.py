@@ -35,6 +35,10 @@ CASES = {
     # B_seq = B = 2, N = 12 <= M = 16: ips() shortcut, buffer rows [12, 16) stay zero; 3 items
     "loop_traffic_short": (synth.traffic_conf(N=12, M=16, I=8, patch=32, B=2, B_seq=2, n_res_blocks=2, D=128, D_k=16,
                                               D_v=16, D_inner=256, **_OPT), 3, 22, 32, 6),
+    # no dropout anywhere: every training step is deterministic, so a GPU run can be held to the losses of every step
+    # and to the trained weights (tests/test_loops_golden.py::test_training_on_the_gpu_follows_the_reference)
+    "loop_mnist_nodrop": (synth.mnist_conf(N=64, M=8, I=16, B=4, B_seq=2, shuffle=False, attn_dropout=0.0, dropout=0.0,
+                                           **_OPT), 4, 24, 34, 8),
     # features, sigmoid / auc task, B_seq = 1, 5 items -> 4 + 1
     "loop_cam_seq": (synth.camelyon_conf(N=96, M=16, I=32, B=4, B_seq=1, n_chan_in=256, D=128, D_k=16, D_v=16,
                                          D_inner=256, **_OPT), 5, 23, 33, 7),
