@@ -314,11 +314,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the interpreter's cyclic garbage collector must not pick the timed region for a full collection: with the host
+    # several steps ahead of the GPU, a collection that ends up waiting on the device costs tens of milliseconds once
+    import gc
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
+    per_step = []
+    prof = None
+    if os.environ.get("IPSX_BENCH_DEBUG") == "2":
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         step()
+        per_step.append(time.perf_counter() - h0)
     host_enqueue = time.perf_counter() - t0                     # the host's share: how long it took to ENQUEUE the steps
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
+    if os.environ.get("IPSX_BENCH_DEBUG") and rank == 0:
+        print("host ms per step:", " ".join("%.2f" % (1e3 * v) for v in per_step), file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:

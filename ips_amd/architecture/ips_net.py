@@ -355,6 +355,9 @@ class IPSNet(nn.Module):
             if getattr(self, "_stats_key", None) != skey:
                 self._stats_buf = torch.empty((B * N, 2), dtype=torch.float32, device=dev)
                 self._stats_key = skey
+                # (embeddings of the whole slide too: allocating five 27 MB parts afresh in every call makes the caching
+                #  allocator go back to the driver now and then - tens of milliseconds on the host)
+                self._emb_buf = torch.empty((B, N, self.D), dtype=torch.float32, device=dev)
             self._plan._refresh()
             stats = self._plan.row_stats(patches.reshape(B * N, -1), out=self._stats_buf)
         for k in range(P):
@@ -362,7 +365,7 @@ class IPSNet(nn.Module):
             if indexed:
                 emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
             elif stats is not None:
-                emb = self._plan.encode(patches[0, lo:hi], stats=stats[lo:hi]).view(B, hi - lo, -1)
+                emb = self._plan.encode(patches[0, lo:hi], stats=stats[lo:hi], out=self._emb_buf[0, lo:hi]).view(B, hi - lo, -1)
             else:
                 emb = self._embed(patches[:, lo:hi].reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             parts.append(emb)

@@ -389,7 +389,7 @@ class EncoderPlan:
             "ipsx_projector_stats")
         return out
 
-    def encode(self, x, nonblank=None, stats=None):
+    def encode(self, x, nonblank=None, stats=None, out=None):
         """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D).
 
         ``nonblank`` (P int32, 1 = the patch has a non-zero element; e.g. from ``patchify_sparse``) switches on
@@ -397,7 +397,10 @@ class EncoderPlan:
         self._refresh()
         x = _f32(x)
         n = x.shape[0]
-        out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (n, self.d_out) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (P, D) float32 tensor")
         if n == 0:
             return out
         if self.is_image:
