@@ -368,7 +368,7 @@ def main():
         recs = [None] * world
         dist.all_gather_object(recs, mine_rec)
     kernel_name = hip.encoder_kernel_name(net._plan)
-    traffic, traffic_note = pmc_traffic(kernel_name, enc_patches, len(enc_events))
+    traffic, traffic_note = pmc_traffic(kernel_name, enc_patches, n_launch)
     if not (name == "mnist" and args.precision == "fp32" and not args.dedup_blank and world == 1):
         traffic = None
 
