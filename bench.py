@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32x3", "bf16"],
                     help="fp32 = the headline (reference parity); bf16 = secondary measurement of BASELINE configs[4]: "
                          "bf16 operands / fp32 accumulate in the residual stages (IPSX_PRECISION=bf16)")
+    ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f16"],
+                    help="storage type of the patch tensor (BASELINE configs[4]: half-precision storage; needs "
+                         "--precision bf16 or fp32x3 - the exact trunk reads float32)")
     ap.add_argument("--lazy", action="store_true",
                     help="secondary measurement: lazy loading - the patch tensor starts in pinned HOST memory and "
                          "is streamed over PCIe inside every step (the PCIe-inclusive rate; never the headline)")
@@ -265,6 +268,11 @@ def main():
         mine = ipsd.local_indices(n_total, conf.M, conf.I, rank, world)
         x = x[:, mine].contiguous()                             # this rank's shard of every image
     n_mine = x.shape[1]
+    if args.storage != "f32":
+        if args.precision == "fp32":
+            print("--storage %s needs --precision bf16 or fp32x3" % args.storage, file=sys.stderr)
+            sys.exit(2)
+        x = x.to({"bf16": torch.bfloat16, "f16": torch.float16}[args.storage])
     x = x.pin_memory() if args.lazy else x.to(dev)              # headline: resident in HBM before the timed region
 
     timings = [] if world > 1 else None
@@ -393,7 +401,8 @@ def main():
                                       "use_pos" if conf.use_pos else "no pos-enc",
                                       "" if world == 1 else ", %d of the %d patches of every image per GPU" % (n_mine, n_total)),
                        "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, ipsd.PARTS) if world > 1 else "single GPU",
-                       "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy)},
+                       "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy),
+                       "patch_storage": args.storage},
             "ms_per_call_median_synced": statistics.median(lat),
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "parity": par,

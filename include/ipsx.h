@@ -115,6 +115,9 @@ typedef struct ipsx_trunk {
                                      bf16 terms, the six significant products on the bf16 matrix pipe, fp32
                                      accumulate - fp32-grade accuracy, not bit-identical to precision 0.
                                      1 and 2: fused 1x32x32 trunk only, need w_packed_bf16                */
+    int patch_dtype;              /* storage type of the `patches` argument of the encode calls: 0 = float32
+                                     (default), 1 = bfloat16, 2 = float16 (BASELINE configs[4]: half-precision patch
+                                     storage; precision 1 or 2 only - the exact path reads float32)        */
 } ipsx_trunk;
 
 /* y = act(affine(conv(x)) [+ residual]); x (n,c_in,h,w), y (n,c_out,ho,wo) NCHW */
@@ -218,6 +221,16 @@ int ipsx_logits(const float* emb, int64_t emb_bstride,
                 const float* v_packed,
                 int b, int64_t n, int d, int r,
                 float* logits, int64_t logits_bstride, void* stream);
+
+/* BASELINE configs[4]: the same logits on the bf16 matrix pipe - x = emb (+ pos) rounded to bfloat16, the folded query
+ * rounded to bfloat16 (ipsx_fold_query_bf16: ipsx_folded_query_bf16_bytes(h, n_token, d) bytes, from the float32 folded
+ * query's inputs), float32 accumulation.  No reference behaviour to match: tolerance-tested against ipsx_logits.   */
+size_t ipsx_folded_query_bf16_bytes(int h, int n_token, int d);
+int ipsx_fold_query_bf16(const float* qs, const float* wk_packed, int h, int dk, int n_token, int d,
+                         void* v_packed_bf16, void* stream);
+int ipsx_logits_bf16(const float* emb, int64_t emb_bstride, const float* pos, int64_t pos_bstride,
+                     const void* v_packed_bf16, int b, int64_t n, int d, int r,
+                     float* logits, int64_t logits_bstride, void* stream);
 
 /* Order of equal scores in the top-M steps of ipsx_scan / ipsx_scan_range / ipsx_topm (process-wide).
  * 1 (default) = the reference's: torch.topk on CPU returns what libstdc++'s nth_element + sort (or

@@ -107,11 +107,13 @@ class MultiHeadCrossAttention(nn.Module):
 
         Depends on the three parameters only, so it is kept until one of them changes (in-place updates bump
         ``_version``; ``.to()`` / ``load_state_dict`` change the storage) - an evaluation loop folds once."""
-        key = (hip.weights_generation(),) + tuple((t.data_ptr(), t._version, t.device)
-                                                  for t in (self.q, self.q_w.weight, self.k_w.weight))
+        half = hip.precision() == "bf16"          # BASELINE configs[4]: the logits on the bf16 matrix pipe as well
+        key = (hip.weights_generation(), half) + tuple((t.data_ptr(), t._version, t.device)
+                                                        for t in (self.q, self.q_w.weight, self.k_w.weight))
         cached = getattr(self, "_folded", None)
         if cached is None or cached[0] != key:
-            cached = (key, hip.fold_query(self.scaled_query(), self.k_w.weight, self.H, self.D_k, self.n_token))
+            fold = hip.fold_query_bf16 if half else hip.fold_query
+            cached = (key, fold(self.scaled_query(), self.k_w.weight, self.H, self.D_k, self.n_token))
             self._folded = cached
         return cached[1]
 

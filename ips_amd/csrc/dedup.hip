@@ -130,8 +130,14 @@ static int encode_dedup(const ipsx_trunk* t, const float* patches, int64_t n_pat
     return IPSX_OK;
 }
 
+static int dedup_needs_f32(const ipsx_trunk* t) {
+    IPSX_REQUIRE(t && t->patch_dtype == 0, "trunk_encode_dedup: blank-patch detection reads float32 patches");
+    return IPSX_OK;
+}
+
 IPSX_API int ipsx_trunk_encode_dedup(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb,
                                      void* workspace, size_t workspace_bytes, int32_t* n_encoded, void* stream) {
+    IPSX_TRY(dedup_needs_f32(t));
     return encode_dedup(t, patches, n_patch, nullptr, emb, workspace, workspace_bytes, n_encoded, stream);
 }
 
@@ -139,5 +145,6 @@ IPSX_API int ipsx_trunk_encode_dedup_flagged(const ipsx_trunk* t, const float* p
                                              const int32_t* nonblank, float* emb, void* workspace,
                                              size_t workspace_bytes, int32_t* n_encoded, void* stream) {
     IPSX_REQUIRE(nonblank, "trunk_encode_dedup_flagged: no flags");
+    IPSX_TRY(dedup_needs_f32(t));
     return encode_dedup(t, patches, n_patch, nonblank, emb, workspace, workspace_bytes, n_encoded, stream);
 }

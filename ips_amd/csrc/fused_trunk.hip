@@ -59,6 +59,7 @@ struct FusedArgs {
     const float *w[8], *al[8], *sh[8];       // l1.0.c1 l1.0.c2 l1.1.c1 l1.1.c2 l2.0.c1 l2.0.c2 l2.1.c1 l2.1.c2
     const float *w_down, *a_down, *s_down;
     const void *wh[8], *wh_down, *wh_stem;   // bf16 operand streams of the same convolutions (precision 1 and 2)
+    int in_dtype;            // storage type of `patches`: 0 float32, 1 bfloat16, 2 float16 (split trunks only)
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -648,6 +649,10 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
                         const int* count = nullptr) {
     FusedArgs a;
     a.patches = patches; a.emb = emb; a.n = n; a.index = index; a.count = count;
+    a.in_dtype = t->patch_dtype;
+    if (t->patch_dtype != 0 && !(t->precision == 1 || t->precision == 2))
+        return fail(IPSX_EINVAL, "fused trunk: half-precision patch storage goes with precision 1 (bf16) or 2 (fp32x3)");
+    if (t->patch_dtype < 0 || t->patch_dtype > 2) return fail(IPSX_EINVAL, "fused trunk: patch_dtype %d", t->patch_dtype);
     a.w_stem = t->stem.w_packed; a.a_stem = t->stem.alpha; a.s_stem = t->stem.shift;
     for (int k = 0; k < 4; ++k)
         for (int j = 0; j < 2; ++j) {

@@ -355,10 +355,26 @@ __device__ __forceinline__ void fused_trunk_split_body(const FusedArgs& a, unsig
 
     // ---- fp32 input -> PL bf16 planes of the zero-padded 38 x 38 image (row pitch SPW)
     {
-        const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
         float4 px[4];
+        if (a.in_dtype == 0) {
+            const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) px[k] = src[k * 64 + lane];
+            for (int k = 0; k < 4; ++k) px[k] = src[k * 64 + lane];
+        } else {                                     // half-precision storage: 2 KiB per patch, 8 bytes per lane and load
+            const uint2* src = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.patches) + (size_t)pi * 1024);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 h = src[k * 64 + lane];
+                const unsigned short hs[4] = {(unsigned short)(h.x & 0xFFFFu), (unsigned short)(h.x >> 16),
+                                              (unsigned short)(h.y & 0xFFFFu), (unsigned short)(h.y >> 16)};
+                float f[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    f[j] = a.in_dtype == 1 ? __uint_as_float((unsigned)hs[j] << 16)
+                                           : (float)__builtin_bit_cast(_Float16, hs[j]);
+                px[k] = make_float4(f[0], f[1], f[2], f[3]);
+            }
+        }
         for (int z = lane; z < PL * SPLANE / 16; z += 64) reinterpret_cast<uint4*>(Sb)[z] = make_uint4(0u, 0u, 0u, 0u);
         wave_fence();
 #pragma unroll

@@ -142,6 +142,82 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
     }
 }
 
+// ---- the same logits on the bf16 matrix pipe (BASELINE configs[4]: "MFMA bf16/fp16 QK^T path").  x = emb (+ pos)
+// rounded to bfloat16 in the A-operand load, the folded query rounded to bfloat16 once per call, fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16: lane l holds row / column l & 31 and the 8 consecutive k of half l >> 5).  No reference
+// behaviour exists for reduced precision; checked against logits_kernel with a tolerance.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// vq16: [R/32 tiles][D/16 k-steps][64 lanes][8 bf16]; element (r, c) at tile r>>5, step c>>4, lane (r&31) + 32*((c&15)>>3), j = c&7
+__global__ void fold_query_bf16_kernel(const float* __restrict__ qs, const float* __restrict__ wkp, int h, int dk, int T, int d,
+                                       int kgs, int ksteps, int r_pad, unsigned short* __restrict__ vq16) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // over r_pad x (ksteps * 16)
+    const int dpad = ksteps * 16;
+    if (idx >= r_pad * dpad) return;
+    const int r = idx / dpad, c = idx - r * dpad;
+    const int R = h * T, hdk = h * dk;
+    float acc = 0.0f;
+    if (r < R && c < d) {                                           // the fp32 fold of fold_query_kernel (j ascending)
+        const int hh = r / T, t = r - hh * T;
+        const int kg = c >> 3, sub = c & 7;
+        for (int j = 0; j < dk; ++j) {
+            const int o = hh * dk + j;
+            const float w = wkp[(((size_t)(o >> 5) * kgs + kg) * 64 + (o & 31) + 32 * (sub >> 2)) * 4 + (sub & 3)];
+            acc = __builtin_fmaf(qs[(size_t)t * hdk + o], w, acc);
+        }
+    }
+    const __bf16 hv = (__bf16)acc;
+    vq16[(((size_t)(r >> 5) * ksteps + (c >> 4)) * 64 + (r & 31) + 32 * ((c & 15) >> 3)) * 8 + (c & 7)] =
+        __builtin_bit_cast(unsigned short, hv);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void logits_bf16_kernel(LogitsArgs a, const uint4* __restrict__ vq16, int ksteps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (r0 >= a.n) return;                                           // wave-uniform
+    const int bi = blockIdx.y;
+    const long long row = r0 + (lane & 31);
+    const bool rv = row < a.n;
+    const float* e = a.emb + (size_t)bi * a.emb_bs + (size_t)(rv ? row : 0) * a.d + 8 * half;
+    const float* p = a.pos ? a.pos + (size_t)bi * a.pos_bs + (size_t)(rv ? row : 0) * a.d + 8 * half : nullptr;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ks * 16 + 8 * half + j;
+            float v = (rv && c < a.d) ? e[ks * 16 + j] : 0.0f;
+            if (p) v = v + ((rv && c < a.d) ? p[ks * 16 + j] : 0.0f);
+            xv[j] = v;
+        }
+        bf16x8_t av;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = (__bf16)xv[j];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const uint4 b = vq16[((size_t)i * ksteps + ks) * 64 + lane];
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b), acc[i], 0, 0, 0);
+        }
+    }
+    float* out = a.out + (size_t)bi * a.out_bs;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int o = i * 32 + (lane & 31);
+        if (o < a.R) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (rr < a.n) out[(size_t)rr * a.R + o] = acc[i][r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ scoring of a candidate set
 // Candidate logits either staged in LDS (cl, row stride R+1) or read through `cand`
 // from the global (n, R) table of one image.
@@ -1279,6 +1355,40 @@ IPSX_API int ipsx_logits(const float* emb, int64_t emb_bstride, const float* pos
     a.kgs = (int)cdiv(d, 8);
     a.out = logits; a.out_bs = logits_bstride;
     return launch_logits(a, b, as_stream(stream));
+}
+
+IPSX_API size_t ipsx_folded_query_bf16_bytes(int h, int n_token, int d) {
+    if (h <= 0 || n_token <= 0 || d <= 0) return 0;
+    return (size_t)cdiv(h * n_token, 32) * (size_t)cdiv(d, 16) * 64 * 16;
+}
+
+IPSX_API int ipsx_fold_query_bf16(const float* qs, const float* wk_packed, int h, int dk, int n_token, int d,
+                                  void* v_packed_bf16, void* stream) {
+    IPSX_REQUIRE(qs && wk_packed && v_packed_bf16 && h > 0 && dk > 0 && n_token > 0 && d > 0, "fold_query_bf16: bad arguments");
+    const int R = h * n_token, r_pad = (int)cdiv(R, 32) * 32, ksteps = (int)cdiv(d, 16), kgs = (int)cdiv(d, 8);
+    const int total = r_pad * ksteps * 16;
+    fold_query_bf16_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream)>>>(
+        qs, wk_packed, h, dk, n_token, d, kgs, ksteps, r_pad, static_cast<unsigned short*>(v_packed_bf16));
+    return launched("fold_query_bf16");
+}
+
+IPSX_API int ipsx_logits_bf16(const float* emb, int64_t emb_bstride, const float* pos, int64_t pos_bstride,
+                              const void* v_packed_bf16, int b, int64_t n, int d, int r, float* logits,
+                              int64_t logits_bstride, void* stream) {
+    IPSX_REQUIRE(emb && v_packed_bf16 && logits && b > 0 && n >= 0 && d > 0 && r > 0, "logits_bf16: bad arguments");
+    IPSX_REQUIRE(r <= 128, "logits_bf16: at most 128 logits per patch (got %d)", r);
+    if (n == 0) return IPSX_OK;
+    LogitsArgs a;
+    a.emb = emb; a.emb_bs = emb_bstride; a.pos = pos; a.pos_bs = pos_bstride; a.vp = nullptr; a.n = n; a.d = d; a.R = r;
+    a.kgs = 0; a.out = logits; a.out_bs = logits_bstride;
+    const int ksteps = (int)cdiv(d, 16), nt = (int)cdiv(r, 32);
+    const dim3 grid((unsigned)cdiv(n, 128), (unsigned)b), block(256);
+    const uint4* vq = static_cast<const uint4*>(v_packed_bf16);
+    hipStream_t s = as_stream(stream);
+    if (nt == 1) logits_bf16_kernel<1><<<grid, block, 0, s>>>(a, vq, ksteps);
+    else if (nt == 2) logits_bf16_kernel<2><<<grid, block, 0, s>>>(a, vq, ksteps);
+    else logits_bf16_kernel<4><<<grid, block, 0, s>>>(a, vq, ksteps);
+    return launched("logits_bf16");
 }
 
 IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,

@@ -111,6 +111,8 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
     IPSX_TRY(trunk_geom(t, &g));
     IPSX_REQUIRE(patches && emb && n_patch >= 0, "trunk_encode: bad arguments");
     IPSX_REQUIRE(t->precision == 0 || fused_trunk_supported(t), "trunk_encode: the bf16 / fp32x3 paths exist for the fused 1x32x32 trunk only");
+    IPSX_REQUIRE(t->patch_dtype == 0 || (fused_trunk_supported(t) && t->precision != 0),
+                 "trunk_encode: half-precision patch storage exists for the fused 1x32x32 trunk at precision 1 / 2 only");
     if (n_patch == 0) return IPSX_OK;
     if (fused_trunk_supported(t)) return fused_trunk_encode(t, patches, n_patch, emb, as_stream(stream));
 

@@ -101,7 +101,7 @@ class Block(C.Structure):
 
 class Trunk(C.Structure):
     _fields_ = [("c_in", C.c_int), ("h", C.c_int), ("w", C.c_int), ("stem", Conv),
-                ("n_block", C.c_int), ("blocks", C.POINTER(Block)), ("precision", C.c_int)]
+                ("n_block", C.c_int), ("blocks", C.POINTER(Block)), ("precision", C.c_int), ("patch_dtype", C.c_int)]
 
 
 class Transf(C.Structure):
@@ -160,6 +160,11 @@ _EXPORTS = {
     "ipsx_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                               C.c_int, C.c_int64, C.c_int, C.c_int,
                               C.c_void_p, C.c_int64, C.c_void_p]),
+    "ipsx_folded_query_bf16_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ipsx_fold_query_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_logits_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_int, C.c_int64, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "ipsx_set_tie_order": (C.c_int, [C.c_int]),
     "ipsx_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -231,6 +236,19 @@ def _p(t):
 def _f32(t):
     if t.dtype != torch.float32:
         raise TypeError("expected float32, got {}".format(t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_PATCH_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _patches(t):
+    """Patch tensors may be stored in bfloat16 / float16 (BASELINE configs[4]); only the reduced-precision fused trunks
+    read those (the exact path's contract is float32 in)."""
+    if t.dtype not in _PATCH_DTYPES:
+        raise TypeError("patches must be float32, bfloat16 or float16, got {}".format(t.dtype))
+    if t.dtype != torch.float32 and precision() == "fp32":
+        raise TypeError("{} patch storage needs IPSX_PRECISION=bf16 or fp32x3 (the exact trunk reads float32)".format(t.dtype))
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -324,6 +342,7 @@ class EncoderPlan:
             t.n_block = len(blocks)
             t.blocks = C.cast(self._blocks, C.POINTER(Block))
             t.precision = bf16
+            t.patch_dtype = 0
             self.trunk = t
             self.d_out = blocks[-1].conv[blocks[-1].n_conv - 1].c_out
         else:
@@ -362,20 +381,29 @@ class EncoderPlan:
     def encode_indexed(self, flat, index):
         """flat (P, C, h, w) contiguous on the GPU, index (n,) int32 -> (n, D) embeddings of flat[index]."""
         self._refresh()
+        flat = _patches(flat)
+        self.trunk.patch_dtype = _PATCH_DTYPES[flat.dtype]
         out = torch.empty((index.numel(), self.d_out), dtype=torch.float32, device=flat.device)
-        _ck(lib().ipsx_trunk_encode_indexed(C.byref(self.trunk), _p(flat), _p(index), index.numel(), _p(out),
-                                            _stream()), "ipsx_trunk_encode_indexed")
+        try:
+            _ck(lib().ipsx_trunk_encode_indexed(C.byref(self.trunk), _p(flat), _p(index), index.numel(), _p(out),
+                                                _stream()), "ipsx_trunk_encode_indexed")
+        finally:
+            self.trunk.patch_dtype = 0
         return out
 
     def encode_plain(self, x, out=None):
         """The image trunk on every patch of ``x`` (no dedup)."""
-        x = x if x.is_contiguous() else x.contiguous()
+        x = _patches(x)
         n = x.shape[0]
         if out is None:
             out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
         nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), n)
         ws = self._workspace(nb, x.device)
-        _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()), "ipsx_trunk_encode")
+        self.trunk.patch_dtype = _PATCH_DTYPES[x.dtype]
+        try:
+            _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()), "ipsx_trunk_encode")
+        finally:
+            self.trunk.patch_dtype = 0
         return out
 
     def row_stats(self, x, out=None):
@@ -395,8 +423,10 @@ class EncoderPlan:
         ``nonblank`` (P int32, 1 = the patch has a non-zero element; e.g. from ``patchify_sparse``) switches on
         the exact blank-patch dedup without the pass that looks for blank patches."""
         self._refresh()
-        x = _f32(x)
+        x = _patches(x) if self.is_image else _f32(x)
         n = x.shape[0]
+        if x.dtype != torch.float32 and (dedup_blank() or nonblank is not None):
+            raise TypeError("blank-patch dedup reads float32 patches")
         if out is None:
             out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
         elif tuple(out.shape) != (n, self.d_out) or out.dtype != torch.float32 or not out.is_contiguous():
@@ -483,9 +513,19 @@ def fold_query(qs, wk_weight, H, Dk, T):
     return out
 
 
+def fold_query_bf16(qs, wk_weight, H, Dk, T):
+    """The folded query rounded to bfloat16 in the operand layout of ``ipsx_logits_bf16`` (a uint8 tensor: that dtype is
+    how ``logits`` tells the two apart)."""
+    D = wk_weight.shape[1]
+    out = torch.empty(lib().ipsx_folded_query_bf16_bytes(H, T, D), dtype=torch.uint8, device=qs.device)
+    _ck(lib().ipsx_fold_query_bf16(_p(_f32(qs)), _p(pack_linear(wk_weight)), H, Dk, T, D, _p(out), _stream()),
+        "ipsx_fold_query_bf16")
+    return out
+
+
 def logits(emb, pos, vq, R, out=None):
     """Per-patch attention logits (B, n, R = H*T) from the folded query ``vq``; ``out`` may be a column slice of
-    (B, N, R)."""
+    (B, N, R).  A bfloat16 folded query (``fold_query_bf16``) selects the bf16 matrix pipe."""
     B, n, D = emb.shape
     emb = _f32(emb)
     if out is None:
@@ -497,6 +537,10 @@ def logits(emb, pos, vq, R, out=None):
         if pos.stride(2) != 1 or pos.stride(1) != D:
             pos = pos.contiguous()
         pos_bs = pos.stride(0) if pos.shape[0] > 1 else 0
+    if vq.dtype == torch.uint8:
+        _ck(lib().ipsx_logits_bf16(_p(emb), n * D, _p(pos), pos_bs, _p(vq), B, n, D, R, _p(out), out.stride(0), _stream()),
+            "ipsx_logits_bf16")
+        return out
     _ck(lib().ipsx_logits(_p(emb), n * D, _p(pos), pos_bs, _p(vq), B, n, D, R, _p(out), out.stride(0), _stream()),
         "ipsx_logits")
     return out

@@ -426,3 +426,27 @@ def test_scan_range_resumes_exactly():
     for a, b in ((0, 1), (1, 7), (7, 8), (8, n_iter)):
         hip.scan_range(lg, 32, 48, 8, 4, a, b, mem, tie)
     assert torch.equal(mem, want)
+
+
+@pytest.mark.gpu
+def test_configs4_half_storage_and_bf16_logits_end_to_end(monkeypatch):
+    """BASELINE configs[4] as written: patches stored in float16, bf16 trunk, bf16 logits (IPSX_PRECISION=bf16).  The
+    reference has no reduced-precision behaviour; the selection must stay close to the exact path's (>= 80 % of the
+    patches in common on the 2500-patch fixture) and ips() must hand back the winners in the storage type."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    x = g.patches().to(DEV)
+    net.ips(x)
+    exact = net.last_mem_idx.cpu().numpy()
+    monkeypatch.setenv("IPSX_PRECISION", "bf16")
+    for dtype in (torch.float16, torch.bfloat16):
+        xh = x.to(dtype)
+        mem_patch, mem_pos = net.ips(xh)
+        got = net.last_mem_idx.cpu().numpy()
+        assert mem_patch.dtype == dtype and tuple(mem_patch.shape) == (g.B, g.conf.M, 1, 32, 32)
+        assert torch.equal(mem_patch, xh[0][net.last_mem_idx[0]].unsqueeze(0))
+        common = np.mean([len(set(a) & set(b)) / len(a) for a, b in zip(got.tolist(), exact.tolist())])
+        assert common >= 0.80, common
+        with torch.no_grad():
+            preds = net(mem_patch, mem_pos)
+        assert all(torch.isfinite(v).all() for v in preds.values())

@@ -335,6 +335,57 @@ def test_fp32x3_trunk_has_fp32_accuracy(monkeypatch):
     assert float((got - exact).abs().max() / scale) < 2e-6
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32x3"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_precision_patch_storage(precision, dtype, monkeypatch):
+    """BASELINE configs[4]: patches STORED in bfloat16 / float16 (2 KiB per 32-px patch).  The reduced-precision trunks
+    read them directly; the result must be bit-identical to handing over the same values as float32 (both half formats
+    convert to float exactly), for plain and indexed launches.  The exact trunk refuses half input."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    x = g.patches()[0, :300].to(DEV)
+    xh = x.to(dtype)
+    plan = hip.EncoderPlan(net.encoder, True)
+    with pytest.raises(TypeError):
+        plan.encode(xh)
+    monkeypatch.setenv("IPSX_PRECISION", precision)
+    want = plan.encode(xh.float())
+    got = plan.encode(xh)
+    assert torch.equal(got, want)
+    idx = torch.arange(299, -1, -3, device=DEV, dtype=torch.int32)
+    assert plan.fused(xh.shape)
+    assert torch.equal(plan.encode_indexed(xh, idx), want[idx.long()])
+
+
+def test_bf16_logits_track_fp32_logits(monkeypatch):
+    """BASELINE configs[4]: QK^T on the bf16 matrix pipe (ipsx_logits_bf16: x = emb + pos and the folded query rounded
+    to bfloat16, float32 accumulation) against the float32 logits: within 2 % of the logit scale (two operands of 8
+    significant bits over a D = 128 contraction), and against a float64 evaluation of the bf16-rounded operands: 1e-5."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    ca = net.transf.crs_attn
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    emb = torch.randn((2, 333, ca.q.shape[-1]), generator=gen).to(DEV)
+    pos = net.pos_enc[:, :333]
+    R = ca.H * ca.n_token
+    want = hip.logits(emb, pos, ca.folded_query(), R)
+    monkeypatch.setenv("IPSX_PRECISION", "bf16")
+    vq16 = ca.folded_query()
+    assert vq16.dtype == torch.uint8
+    got = hip.logits(emb, pos, vq16, R)
+    monkeypatch.delenv("IPSX_PRECISION")
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-2 * scale
+    # float64 with operands rounded where the kernel rounds them
+    D, H, T, Dk = emb.shape[-1], ca.H, ca.n_token, ca.D_k
+    qs = hip.query_proj(ca.q[0], ca.q_w.weight, ca.attention.temperature).view(T, H, Dk)
+    V = torch.einsum("thj,hjc->htc", qs.double(), ca.k_w.weight.detach().view(H, Dk, D).double()).reshape(H * T, D)
+    V16 = V.float().to(torch.bfloat16).double()
+    x16 = (emb + pos).to(torch.bfloat16).double()
+    emu = torch.einsum("bnc,rc->bnr", x16, V16)
+    assert float((got.double() - emu).abs().max()) < 1e-3 * scale      # the fp32 fold of V differs from float64 by < 1 bf16 ulp rarely
+
+
 def _trunk_f64(sd, x):
     """float64 evaluation of the 2-stage ResNet-18 trunk (eval BatchNorm) from a state dict: the yardstick."""
     import torch.nn.functional as F
