@@ -977,16 +977,33 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
     for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
     if (tid < 2) { nanflag[tid] = 0; ccount[2 + tid] = 0; }
     const long long n_iter = a.it1 - a.it0;
+    // The chunk of iteration it + 1 is fetched into registers during iteration it - 1 .. it and moved into the spare
+    // buffers, together with its exponentials under the CURRENT row maxima, while the ranking of iteration it runs
+    // (below: "prep").  With more than 128 candidates the ranking occupies waves 0-4 only, so the prefetch registers live
+    // in the threads of waves 5-15 (PF0 = 320 and the number of prefetching threads are multiples of R: a prefetching
+    // thread's elements belong to its own row r).
+    constexpr int PF0 = LCH > 2 ? 320 : 0, PFT = SCAN_NT - PF0;
+    const int pt = tid - PF0;                                  // < 0: this thread prefetches nothing
     float pf[SCAN_PF];
     {
         const long long lo = a.it0 * a.i + a.m;
-        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+        const int cnt = n_iter > 0 ? (int)std::min<long long>(a.i, a.n - lo) : 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PF; ++k) {                    // first chunk: straight into its rows
+            const int e = tid + SCAN_NT * k;
+            if (e < cnt * R) xc[(a.m + (e >> log2R)) * ld + r] = scan_load<PERSIST>(lg + (size_t)lo * R + e);
+        }
+        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
+        const long long lo1 = lo + a.i;
+        const int cnt1 = n_iter > 1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+        if (cnt1 > 0) SCAN_WAIT_ROWS(lo1 + cnt1);
 #pragma unroll
         for (int k = 0; k < SCAN_PF; ++k) {
-            const int e = tid + SCAN_NT * k;
-            pf[k] = (n_iter > 0 && e < cnt * R) ? scan_load<PERSIST>(lg + (size_t)lo * R + e) : 0.0f;
+            const int e = pt + PFT * k;
+            pf[k] = (pt >= 0 && e < cnt1 * R) ? scan_load<PERSIST>(lg + (size_t)lo1 * R + e) : 0.0f;
         }
     }
+    bool spec_valid = false;                                   // the chunk rows of `ec` hold exponentials under prevk's maxima
     int tie = 0;
     uint64_t* const sorted = keyB;
     for (long long it = a.it0; it < a.it1; ++it) {
@@ -994,24 +1011,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = a.m + cnt;
         const int par = (int)((it - a.it0) & 1);
-        // P0: chunk registers -> candidate rows m.., next chunk -> registers (it lands during this iteration: no barrier
-        // below waits for it)
-#pragma unroll
-        for (int k = 0; k < SCAN_PF; ++k) {
-            const int e = tid + SCAN_NT * k;
-            if (e < cnt * R) xc[(a.m + (e >> log2R)) * ld + r] = pf[k];
-        }
-        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
-        {
-            const long long lo2 = lo + a.i;          // the range's last iteration prefetches nothing: those rows may not exist yet
-            const int cnt2 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
-            if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
-#pragma unroll
-            for (int k = 0; k < SCAN_PF; ++k) {
-                const int e = tid + SCAN_NT * k;
-                pf[k] = e < cnt2 * R ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
-            }
-        }
+        // P0: nothing to stage - this iteration's chunk rows (and, speculatively, their exponentials) were written by the
+        // previous iteration's prep (or by the prologue)
         lds_barrier();
         FAST_STAMP(0);
         // P1: row maxima.  Own elements, then the lanes that hold the same row (offsets R, 2R, .. 32), then the waves.
@@ -1056,14 +1057,15 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         const bool changed = it == a.it0 || prevk[par * R + r] != mbits;
         if (tid < R) prevk[(par ^ 1) * R + r] = mbits;
         FAST_STAMP(1);
-        // P2: exp(x - max) where it is new
+        // P2: exp(x - max) where it is new: every row whose maximum moved; the chunk rows only when the prep's speculation
+        // (same maxima as last iteration) does not hold or has not happened (first iteration of a launch)
         float ev[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int l = lrow0 + k * lstep;
             ev[k] = 0.0f;
             if (l < L) {
-                if (changed || l >= a.m) {
+                if (changed || (l >= a.m && !spec_valid)) {
                     ev[k] = det_expf_np(xv[k] - rowmax);
                     ec[l * ld + r] = ev[k];
                 } else {
@@ -1168,6 +1170,33 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         }
         lds_barrier();
         const int Lr = a.m + ccount[0];                          // candidates that take part in the ranking
+        // prep of iteration it + 1 (fills the issue slots the ranking leaves idle): its chunk into rows m.. of the SPARE
+        // buffers (they become the current ones at the end of this iteration; the weights that lived in `en` are dead, the
+        // ranking's scratch sits in its first rows only), with exponentials under this iteration's maxima - right when
+        // the maxima do not move, which the next iteration checks bitwise; then the loads of the chunk after that
+        {
+            const long long lo1 = lo + a.i;
+            const int cnt1 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+#pragma unroll
+            for (int k = 0; k < SCAN_PF; ++k) {
+                const int e = pt + PFT * k;
+                if (pt >= 0 && e < cnt1 * R) {
+                    const int row = a.m + (e >> log2R);
+                    xn[row * ld + r] = pf[k];
+                    en[row * ld + r] = det_expf_np(pf[k] - rowmax);
+                }
+            }
+            for (int j = tid; j < cnt1; j += SCAN_NT) cnew[a.m + j] = (int)(lo1 + j);
+            spec_valid = cnt1 > 0;
+            const long long lo2 = lo1 + a.i;
+            const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
+            if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
+#pragma unroll
+            for (int k = 0; k < SCAN_PF; ++k) {
+                const int e = pt + PFT * k;
+                pf[k] = (pt >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
+            }
+        }
         if (STAMP && tid == 0) tacc[7] += (unsigned long long)(Lr - a.m);
         FAST_STAMP(4);
         if (Lr <= 192) {                     // counting rank below the crossover of the two rankings (~200 keys)
@@ -1416,9 +1445,10 @@ __global__ void publish_rows_kernel(int* ready, int value) {
 IPSX_API int ipsx_scan_persistent_supported(int m, int i, int h, int n_token) {
     const int R = h * n_token, Lmax = m + i;
     if (!((R == 8 && n_token == 1) || (R == 32 && n_token == 4))) return 0;
-    if (Lmax > SCAN_NT || (size_t)Lmax * R > (size_t)SCAN_NT * 8 || (size_t)i * R > (size_t)SCAN_NT * SCAN_PF) return 0;
+    if (Lmax > SCAN_NT || (size_t)Lmax * R > (size_t)SCAN_NT * 8) return 0;
     const size_t stage = (size_t)Lmax * (R + 1) * 4;
-    if ((size_t)((Lmax + 63) / 64) * 64 * 8 > stage) return 0;
+    if ((size_t)((Lmax + 63) / 64) * 64 * 8 > (size_t)m * (R + 1) * 4) return 0;
+    if ((size_t)i * R > (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * SCAN_PF) return 0;
     const int pad = (4 - ((2 * Lmax) & 3)) & 3;
     const size_t fixed = (size_t)next_pow2(Lmax) * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
     return ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES <= kLdsLimit;
@@ -1483,9 +1513,10 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         const int pad = (4 - ((2 * Lmax) & 3)) & 3;
         const size_t fixed = (size_t)n2 * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
         const size_t fast = ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES;
-        const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= stage;
+        const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)m * (R + 1) * 4;     // inside the memory rows
+        const bool pf_fits = (size_t)i * R <= (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * SCAN_PF;
         static const bool fast_off = getenv("IPSX_SCAN_FAST") && getenv("IPSX_SCAN_FAST")[0] == '0';
-        if (pow2 && ept <= 8 && Lmax <= SCAN_NT && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && scratch_fits &&
+        if (pow2 && ept <= 8 && Lmax <= SCAN_NT && pf_fits && scratch_fits &&
             fast <= kLdsLimit && (!fast_off || ready)) {
             a.use_lds = 1;
             a.stk_off = (int)(fast - STK_BYTES);
