@@ -265,9 +265,25 @@ class IPSNet(nn.Module):
             return False
         n_iter = math.ceil((patches.shape[1] - self.M) / self.I)
         if self.is_image and patches.shape[0] * patches.shape[1] < 32768 and n_iter < 100:
-            return False          # a small batch does not fill the GPU four times over and its loop is short: one
-                                  # encoder launch + one scan is faster (tools/sweep.py)
+            # a small batch does not fill the GPU four times over: it is encoded in the whole workgroup rounds it fills
+            # (2048 patches each) plus the remainder, and the loop over the first part runs beside the remainder's
+            # encoding, where most compute units are idle anyway (_small_batch_split); below one round there is
+            # nothing to run beside
+            return (not self.encoder.training) and self._small_batch_split(patches.shape[0], patches.shape[1]) is not None
         return (not self.encoder.training) and n_iter >= 2 * self._OVERLAP_PARTS
+
+    def _small_batch_split(self, B, N):
+        """Iterations after which to cut a small image batch in two: the first part = as many whole rounds of the fused
+        trunk (512 workgroups x 4 patches) as the batch fills, cut at a chunk boundary; None when that leaves nothing on
+        either side."""
+        n_iter = math.ceil((N - self.M) / self.I)
+        rounds = (B * N) // 2048
+        if rounds != 1:        # measured (bench.py --config b1 / --batch 2): +8 % at one round + remainder, -4 % at two
+            return None
+        it = (rounds * 2048 // B - self.M) // self.I           # iterations whose rows lie inside the whole rounds
+        if it < 1 or n_iter - it < 1:
+            return None
+        return it
 
     def _select_hip_overlapped(self, patches, pos_enc):
         B, N = patches.shape[:2]
@@ -284,7 +300,9 @@ class IPSNet(nn.Module):
         # long pole (it consumes rows about as fast as the projector makes them), so the parts are EQUAL and sized to
         # what fills the GPU exactly once - 256 compute units x 64 rows - because a GEMM launch of 1.2 rounds takes as
         # long as one of 2.
-        if self.is_image:
+        if self.is_image and B * N < 32768 and n_iter < 100:
+            its = [0, self._small_batch_split(B, N), n_iter]
+        elif self.is_image:
             its = part_iterations(n_iter, self._OVERLAP_PARTS)
         else:
             # (persistent loop: every slide's loop owns a compute unit, the projector has the others - and a launch of one
