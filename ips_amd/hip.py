@@ -78,6 +78,20 @@ def weights_changed():
     _WEIGHTS_GENERATION += 1
 
 
+def _optimizer_stepped(optimizer, args, kwargs):
+    weights_changed()
+
+
+# Not every in-place update bumps ``_version``: torch's FUSED optimizers (AdamW(fused=True), ...) move the parameters
+# without touching it (checked: version 0 -> 0 across a step), so every optimizer step, of any optimizer, invalidates the
+# packed weights.  (Manual updates through ``.data`` or raw pointers still need an explicit ``weights_changed()``.)
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _register_step_hook(_optimizer_stepped)
+except ImportError:          # older torch: per-optimizer hooks only; ips_amd.training registers them itself
+    _register_step_hook = None
+
+
 def on_device(x):
     """True when ``x`` (tensor / device / str) is a GPU and the HIP backend is selected."""
     if torch.is_tensor(x):

@@ -158,15 +158,22 @@ def test_training_epoch_runs_on_the_gpu_and_tracks_the_reference():
 
 
 @pytest.mark.gpu
-def test_training_on_the_gpu_follows_the_reference():
+@pytest.mark.parametrize("fused", [False, True])
+def test_training_on_the_gpu_follows_the_reference(fused):
     """Two epochs WITHOUT dropout (fixture loop_mnist_nodrop, recorded from the reference's own train_one_epoch /
     evaluate on CPU): ips() runs on the HIP path between optimizer steps (packed weights and BatchNorm statistics are
     refreshed after every step), forward / backward / AdamW on stock ROCm ops.  The first step sees identical weights:
     its losses and predictions match the reference to 1e-4.  Later steps inherit the rounding differences of MIOpen's
     convolutions through AdamW (an update is +-lr whatever the gradient's size, so a gradient that is zero up to rounding
     can move a weight by 2 lr the other way): losses within 2e-3, predictions within 5e-3, trained queries within a few
-    learning rates, and the evaluation pass between the epochs within 5e-3."""
+    learning rates, and the evaluation pass between the epochs within 5e-3.  ``fused``: torch's fused AdamW kernel (what
+    ips_amd/main.py uses on a GPU) - the same update as one kernel over all parameter tensors.  It does NOT bump the
+    parameters' ``_version`` counters, which the packed-weight caches of the HIP path are keyed on: without the optimizer
+    step hook of ips_amd/hip.py, ips() would keep selecting with the weights of step 0 (this test's fourth step was 10 %
+    off the reference before the hook existed)."""
     z, conf, net, loader, crit, opt = _setup("loop_mnist_nodrop", "cuda:0")
+    if fused:          # ips_amd/main.py's choice on a GPU: the same update as one kernel over all parameter tensors
+        opt = torch.optim.AdamW(net.parameters(), lr=0, weight_decay=conf.wd, fused=True)
     dev = torch.device("cuda:0")
     ev0, tr0, ev, tr1 = Recorder(), Recorder(), Recorder(), Recorder()
     loops.evaluate(net, crit, loader, dev, ev0, conf)
@@ -181,13 +188,15 @@ def test_training_on_the_gpu_follows_the_reference():
             for task in conf.tasks.values():
                 t = task['name']
                 want = float(z["%s_%d_loss_%s" % (prefix, s_, t)])
-                assert losses[t] == pytest.approx(want, rel=1e-4 if first else 2e-3, abs=1e-4 if first else 2e-3), (prefix, s_, t)
-                np.testing.assert_allclose(preds[t], z["%s_%d_pred_%s" % (prefix, s_, t)], rtol=0, atol=1e-4 if first else 5e-3)
-    _check(z, "eval", ev, conf, 5e-3)
+                later = 4e-3 if fused else 2e-3
+                assert losses[t] == pytest.approx(want, rel=1e-4 if first else later, abs=1e-4 if first else later), (prefix, s_, t)
+                np.testing.assert_allclose(preds[t], z["%s_%d_pred_%s" % (prefix, s_, t)], rtol=0,
+                                           atol=1e-4 if first else (1e-2 if fused else 5e-3))
+    _check(z, "eval", ev, conf, 1e-2 if fused else 5e-3)
     q = net.state_dict()["transf.crs_attn.q"].cpu().numpy()
     lr_max = float(conf.lr)
     assert np.abs(q - z["q_after"]).max() <= 4 * 2 * lr_max          # 4 steps, at most 2 lr apart each
-    assert np.abs(q - z["q_after"]).mean() <= 0.05 * lr_max          # ... and almost everywhere much closer
+    assert np.abs(q - z["q_after"]).mean() <= (0.1 if fused else 0.05) * lr_max      # ... and almost everywhere much closer
 
 
 @pytest.mark.gpu
@@ -265,3 +274,21 @@ def test_graph_replays_do_not_leave_stale_packed_weights():
         step(mem_patch, mem_pos, labels)
     net.ips(x)
     assert not torch.equal(net.last_mem_emb, emb_cached)          # the steps did move the encoder
+
+
+def test_every_optimizer_step_invalidates_the_packed_weights():
+    """Fused optimizers update parameters without bumping ``_version`` (the key of EncoderPlan / folded-query caches): the
+    global optimizer-step hook of ips_amd/hip.py must advance the weights generation for ANY optimizer."""
+    from ips_amd import hip
+    for kw in (dict(), dict(fused=True), dict(foreach=True)):
+        p = nn.Parameter(torch.randn(7))
+        p.grad = torch.randn(7)
+        opt = torch.optim.AdamW([p], lr=1e-3, **kw)
+        before = hip.weights_generation()
+        opt.step()
+        assert hip.weights_generation() > before, kw
+    p = nn.Parameter(torch.randn(7))
+    p.grad = torch.randn(7)
+    before = hip.weights_generation()
+    torch.optim.SGD([p], lr=0.1).step()
+    assert hip.weights_generation() > before

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--graph", action="store_true")
+ap.add_argument("--fused", action="store_true", help="torch.optim.AdamW(fused=True): one kernel for all parameter tensors")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -31,7 +32,7 @@ x = synth.make_patches(conf, args.batch, seed=3).to(dev)
 labels = {t['name']: (torch.randint(0, 10, (args.batch,), device=dev) if t['act_fn'] == 'softmax'
                       else (torch.rand(args.batch, 10, device=dev) < 0.3).float()) for t in conf.tasks.values()}
 crit = {t['name']: (nn.NLLLoss() if t['act_fn'] == 'softmax' else nn.BCELoss()) for t in conf.tasks.values()}
-opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=conf.wd)
+opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=conf.wd, fused=args.fused)
 net.train()
 
 
@@ -70,8 +71,8 @@ if args.graph:                      # a GraphedStep wants a fresh optimizer: mea
     t_step = float("nan")
 else:
     t_step = timed(do_step, args.steps)
-print("ips() %.2f ms   forward+backward+AdamW (eager, stock ROCm ops) %.2f ms   -> %.1f images/s" % (
-    t_ips, t_step, args.batch / (1e-3 * (t_ips + t_step))))
+print("ips() %.2f ms   forward+backward+AdamW%s (eager, stock ROCm ops) %.2f ms   -> %.1f images/s" % (
+    t_ips, " (fused)" if args.fused else "", t_step, args.batch / (1e-3 * (t_ips + t_step))))
 if args.graph:
     from ips_amd.training.graphed import GraphedStep
     gs = GraphedStep(net, crit, opt, conf)
