@@ -354,6 +354,14 @@ class IPSNet(nn.Module):
                       and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
                       and hip.scan_persistent_supported(M, I, ca.H, ca.n_token))
         if persistent:
+            # a loop that gave up waiting (bounded at ~5 s: e.g. an exception between its launch and the last publish)
+            # leaves garbage: the status word of the previous call is mirrored into pinned host memory, asynchronously,
+            # and looked at here - by now that call has long finished, and no synchronisation is added to the pipeline
+            mirror = getattr(self, "_scan_status_host", None)
+            if mirror is not None and int(mirror.item()) & 1:
+                mirror.zero_()
+                raise RuntimeError("the persistent selection loop of the previous ips() call timed out waiting for rows; "
+                                   "its results were invalid (IPSX_SCAN_PERSIST=0 selects the per-part launches)")
             words.zero_()
             ready, status = words[0:1], words[1:2]
             self._scan_status = status
@@ -398,6 +406,10 @@ class IPSNet(nn.Module):
                 side.wait_event(done)
                 hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie)
         main.wait_stream(side)
+        if persistent:
+            if getattr(self, "_scan_status_host", None) is None:
+                self._scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            self._scan_status_host.copy_(status, non_blocking=True)
         mem_idx = mem_idx_buf.clone()                  # the buffer is overwritten by the next call
         main.wait_stream(side)
         hip.scan.last_tie = tie

@@ -450,3 +450,34 @@ def test_configs4_half_storage_and_bf16_logits_end_to_end(monkeypatch):
         with torch.no_grad():
             preds = net(mem_patch, mem_pos)
         assert all(torch.isfinite(v).all() for v in preds.values())
+
+
+@pytest.mark.gpu
+def test_persistent_loop_equals_per_part_launches_and_reports_a_timeout(monkeypatch):
+    """Feature inputs: the selection loop as ONE persistent launch that follows the projector (ipsx_scan_persistent +
+    gate + published row counts) selects exactly what the per-part launches select; a loop whose rows never arrive ends
+    by itself (bounded wait), sets its status word, and the next ips() call reports it."""
+    conf = synth.camelyon_conf(N=8192, M=64, I=64)
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 5).to(DEV).eval()
+    x = synth.make_patches(conf, 1, seed=9).to(DEV)
+    monkeypatch.setenv("IPSX_SCAN_PERSIST", "0")
+    net.ips(x)
+    want = net.last_mem_idx.clone()
+    monkeypatch.setenv("IPSX_SCAN_PERSIST", "1")
+    for _ in range(3):
+        net.ips(x)
+        assert torch.equal(net.last_mem_idx, want)
+    assert int(net._scan_status.item()) & 1 == 0 and int(net._scan_status.item()) & 2 == 2
+    # a loop nobody feeds: negative progress word = cancelled -> it ends at once with the failure bit set
+    lg = torch.randn((1, 1024, 8), device=DEV)
+    mem = torch.empty((1, 64), dtype=torch.int64, device=DEV)
+    tie = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    words = torch.tensor([-1, 0], dtype=torch.int32, device=DEV)
+    hip.scan_persistent(lg, 64, 64, 8, 1, mem, tie, words[0:1], words[1:2])
+    torch.cuda.synchronize()
+    assert int(words[1].item()) & 1 == 1
+    net._scan_status_host.fill_(1)                      # what the mirror would hold after such a call
+    with pytest.raises(RuntimeError, match="timed out"):
+        net.ips(x)
+    net.ips(x)                                          # ... and the call after that works again
+    assert torch.equal(net.last_mem_idx, want)
