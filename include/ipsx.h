@@ -316,6 +316,25 @@ int ipsx_head(const float* emb, int b, int n_token, int d, int token,
               const float* w, const float* bias, int n_class, int act,
               float* out, void* stream);
 
+/* ------------------------------------------------------- training step (with-grad forward, SURVEY 8 f N-b)
+ * Training-mode BatchNorm2d of the ResNet trunk with its residual add and ReLU, forward and backward, on channels-last
+ * activations x (rows, c), rows = patches * pixels.  Replaces, under net.train() with autograd
+ * (training/iterative.py:158-163 -> ips_net.py:273), the bn / += identity / relu kernels of a torchvision BasicBlock:
+ *   forward : y = [relu]( (x - mean_batch) * invstd_batch * gamma + beta [+ residual] ); running_mean / running_var are
+ *             updated in place with `momentum` (unbiased variance), save_mean / save_invstd (c floats) go to backward;
+ *   backward: g = dy masked by y > 0 (when relu); dbeta = sum g; dgamma = sum g * xhat;
+ *             dx = gamma * invstd * (g - dbeta / rows - xhat * dgamma / rows); dresidual = g (when not NULL).
+ * c / 4 must be a power of two <= 256 (ipsx_bn_train_supported); workspace: ipsx_bn_train_workspace_floats floats.
+ * fp32 results to rounding of torch.nn.functional.batch_norm (another summation order), deterministic.          */
+int ipsx_bn_train_supported(int64_t rows, int c);
+size_t ipsx_bn_train_workspace_floats(int64_t rows, int c);
+int ipsx_bn_train_forward(const float* x, const float* residual, int64_t rows, int c, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          int relu, float* y, float* save_mean, float* save_invstd, float* workspace, void* stream);
+int ipsx_bn_train_backward(const float* dy, const float* y, const float* x, int64_t rows, int c, const float* gamma,
+                           const float* save_mean, const float* save_invstd, int relu, float* dx, float* dresidual,
+                           float* dgamma, float* dbeta, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,6 +163,11 @@ class IPSNet(nn.Module):
             if self._plan is None:
                 self._plan = hip.EncoderPlan(self.encoder, self.is_image)
             return self._plan.encode(x)
+        if hip.on_device(x) and self.encoder.training and self.is_image and torch.is_grad_enabled():
+            # training step (reference training/iterative.py:158-163): same modules, BatchNorm + add + ReLU fused
+            from ..training import fused_encoder
+            if fused_encoder.enabled() and fused_encoder.supported(self.encoder):
+                return fused_encoder.encode(self.encoder, x)
         return self.encoder(x).flatten(1)
 
     # ---------------------------------------------------------------- IPS

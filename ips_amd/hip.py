@@ -201,6 +201,14 @@ _EXPORTS = {
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_bn_train_supported": (C.c_int, [C.c_int64, C.c_int]),
+    "ipsx_bn_train_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int]),
+    "ipsx_bn_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_bn_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -725,3 +733,47 @@ def head(emb, token, linear, act):
     _ck(lib().ipsx_head(_p(emb), B, T, D, token, _p(w), _p(b), w.shape[0],
                         {"softmax": 0, "sigmoid": 1}[act], _p(out), _stream()), "ipsx_head")
     return out
+
+
+# ---------------------------------------------------------------- training step (with-grad forward of the trunk)
+def _rows_cl(t):
+    """(P, C, H, W) channels-last tensor -> (rows, C) of its memory."""
+    if t.dim() != 4 or t.dtype != torch.float32 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("expected a float32 channels-last (P, C, H, W) tensor")
+    return t.shape[0] * t.shape[2] * t.shape[3], t.shape[1]
+
+
+def bn_train_supported(rows, c):
+    return bool(lib().ipsx_bn_train_supported(rows, c))
+
+
+def bn_train_forward(x, residual, gamma, beta, eps, momentum, running_mean, running_var, relu):
+    """Batch-statistics BatchNorm2d (+ residual) (+ ReLU) of a channels-last activation; updates the running
+    statistics in place.  Returns y (channels-last), mean, invstd."""
+    rows, c = _rows_cl(x)
+    if residual is not None and _rows_cl(residual) != (rows, c):
+        raise ValueError("residual shape")
+    y = torch.empty_like(x)                        # (preserves channels-last)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    ws = torch.empty(lib().ipsx_bn_train_workspace_floats(rows, c), dtype=torch.float32, device=x.device)
+    _ck(lib().ipsx_bn_train_forward(_p(x), _p(residual), rows, c, _p(_f32(gamma)), _p(_f32(beta)), eps, momentum,
+                                    _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
+                                    _p(ws), _stream()), "ipsx_bn_train_forward")
+    return y, mean, invstd
+
+
+def bn_train_backward(dy, y, x, gamma, mean, invstd, relu, want_residual):
+    """-> dx, dresidual | None, dgamma, dbeta."""
+    rows, c = _rows_cl(x)
+    if _rows_cl(dy) != (rows, c):
+        raise ValueError("dy shape")
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_residual else None
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = torch.empty(lib().ipsx_bn_train_workspace_floats(rows, c), dtype=torch.float32, device=x.device)
+    _ck(lib().ipsx_bn_train_backward(_p(dy), _p(y), _p(x), rows, c, _p(_f32(gamma)), _p(mean), _p(invstd), int(relu),
+                                     _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), _stream()),
+        "ipsx_bn_train_backward")
+    return dx, dres, dgamma, dbeta

@@ -1,0 +1,114 @@
+"""With-grad, training-mode forward of the ResNet patch encoder with fused BatchNorm kernels (SURVEY 8 f, N-b).
+
+Reference: ``training/iterative.py:158-163`` calls ``net(mem_patch, mem_pos)`` under ``net.train()``;
+``architecture/ips_net.py:273`` sends the ``B * M`` selected patches through the torchvision ResNet trunk with
+BatchNorm in batch-statistics mode.  On stock ROCm ops the step's device time is dominated not by the convolutions
+(MIOpen runs them on Winograd / implicit-GEMM kernels at ~90 TFLOP/s fp32-equivalent) but by what surrounds them:
+per BasicBlock two BatchNorms in each direction, the ``+= identity``, the ReLUs and their ``threshold_backward``s,
+layout transposes around MIOpen's channels-last kernels.  This module keeps the modules, parameters and buffers of
+``IPSNet.encoder`` exactly as they are (state dicts, the optimizer and ``ips()`` see no difference) and evaluates them
+differently:
+
+* activations stay channels-last from the stem to the average pool, so MIOpen's NHWC convolution kernels run without
+  transposes;
+* every ``bn -> relu`` and ``bn -> (+ identity) -> relu`` is ONE autograd node backed by ``libipsx.so``
+  (``ipsx_bn_train_forward`` / ``_backward``: two memory passes each way, csrc/bn_train.hip).
+
+Convolutions (forward, data and weight gradients) and the two poolings remain stock ops.  Results equal the stock
+path to fp32 rounding (another summation order for the batch moments): tests/test_hip_train.py compares loss,
+gradients, running statistics and post-step weights.  ``IPSX_TRAIN_FUSED=0`` switches it off.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip
+from ..architecture.resnet import BasicBlock
+
+_CL = torch.channels_last
+
+
+def enabled():
+    return os.environ.get("IPSX_TRAIN_FUSED", "1") != "0"
+
+
+def _bn_ok(bn):
+    return (isinstance(bn, nn.BatchNorm2d) and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and hip.bn_train_supported(1, bn.num_features))
+
+
+def supported(encoder):
+    """True for the encoders ``IPSNet.get_conv_patch_enc`` builds from BasicBlocks (ResNet-18)."""
+    mods = list(encoder.children())
+    if len(mods) < 6 or not (isinstance(mods[0], nn.Conv2d) and isinstance(mods[2], nn.ReLU)
+                             and isinstance(mods[3], nn.MaxPool2d) and isinstance(mods[-1], nn.AdaptiveAvgPool2d)):
+        return False
+    if not _bn_ok(mods[1]) or mods[0].bias is not None:
+        return False
+    for stage in mods[4:-1]:
+        if not isinstance(stage, nn.Sequential):
+            return False
+        for blk in stage:
+            if not isinstance(blk, BasicBlock) or not (_bn_ok(blk.bn1) and _bn_ok(blk.bn2)):
+                return False
+            if blk.downsample is not None and not (isinstance(blk.downsample[0], nn.Conv2d) and _bn_ok(blk.downsample[1])):
+                return False
+    return True
+
+
+class _BnAct(torch.autograd.Function):
+    """y = [relu](batch_norm_train(x) [+ residual]) on channels-last tensors; running statistics updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bn, relu):
+        x = x.contiguous(memory_format=_CL)
+        if residual is not None:
+            residual = residual.contiguous(memory_format=_CL)
+        y, mean, invstd = hip.bn_train_forward(x, residual, gamma, beta, bn.eps, bn.momentum, bn.running_mean,
+                                               bn.running_var, relu)
+        bn.num_batches_tracked.add_(1)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=_CL)
+        dx, dres, dgamma, dbeta = hip.bn_train_backward(dy, y, x, gamma, mean, invstd, ctx.relu, ctx.has_res)
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    return _BnAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
+
+
+def _conv(conv, x):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def encode(encoder, x, taps=None):
+    """(P, C, h, w) patches -> (P, D) embeddings; same value as ``encoder(x).flatten(1)`` in train mode.
+    ``taps`` (a list, diagnostics): receives every post-ReLU activation (stem, and per block: after bn1, after the block)."""
+    mods = list(encoder.children())
+    conv1, bn1, _, pool = mods[:4]
+    h = _conv(conv1, x.contiguous(memory_format=_CL))
+    h = bn_act(h, bn1, None, True)
+    h = pool(h)
+    if taps is not None:
+        taps.append(h)
+    for stage in mods[4:-1]:
+        for blk in stage:
+            idt = h
+            o = bn_act(_conv(blk.conv1, h), blk.bn1, None, True)
+            if taps is not None:
+                taps.append(o)
+            o = _conv(blk.conv2, o)
+            if blk.downsample is not None:
+                idt = bn_act(_conv(blk.downsample[0], h), blk.downsample[1], None, False)
+            h = bn_act(o, blk.bn2, idt, True)
+            if taps is not None:
+                taps.append(h)
+    return mods[-1](h).flatten(1)

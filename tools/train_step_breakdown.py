@@ -23,6 +23,8 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--graph", action="store_true")
 ap.add_argument("--fused", action="store_true", help="torch.optim.AdamW(fused=True): one kernel for all parameter tensors")
+ap.add_argument("--channels-last", action="store_true", help="encoder weights and activations in torch.channels_last")
+ap.add_argument("--profile", action="store_true", help="per-kernel device time of the steady-state forward+backward+AdamW (torch.profiler)")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -34,6 +36,8 @@ labels = {t['name']: (torch.randint(0, 10, (args.batch,), device=dev) if t['act_
 crit = {t['name']: (nn.NLLLoss() if t['act_fn'] == 'softmax' else nn.BCELoss()) for t in conf.tasks.values()}
 opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=conf.wd, fused=args.fused)
 net.train()
+if args.channels_last:
+    net.encoder.to(memory_format=torch.channels_last)
 
 
 def timed(fn, n):
@@ -73,6 +77,17 @@ else:
     t_step = timed(do_step, args.steps)
 print("ips() %.2f ms   forward+backward+AdamW%s (eager, stock ROCm ops) %.2f ms   -> %.1f images/s" % (
     t_ips, " (fused)" if args.fused else "", t_step, args.batch / (1e-3 * (t_ips + t_step))))
+if args.profile:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(10):
+            do_step()
+        torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+    tot = sum(e.device_time_total for e in rows)
+    print("device time per step %.3f ms over %d kernels" % (tot / 1e4, sum(e.count for e in rows) // 10))
+    for e in rows[:30]:
+        print("  %-90s %4d x %8.1f us  %5.1f%%" % (e.key[:90], e.count // 10, e.device_time_total / e.count, 100 * e.device_time_total / tot))
 if args.graph:
     from ips_amd.training.graphed import GraphedStep
     gs = GraphedStep(net, crit, opt, conf)
