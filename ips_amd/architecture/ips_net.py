@@ -115,6 +115,13 @@ class IPSNet(nn.Module):
         self._plan = None             # packed-weight cache of the HIP encoder
         self._emb_parts = None        # eval-mode embeddings of the last ips() call (see last_mem_emb)
         self._mem_emb = None
+        if self.is_image and hip.on_device(device):
+            # the training step's convolutions run channels-last (training/fused_encoder.py): weights stored that way
+            # from the start (before any optimizer state exists) are not re-laid-out in every step.  Shapes, names and
+            # values are untouched - state dicts interchange with the reference as before.
+            from ..training import fused_encoder
+            if fused_encoder.enabled() and fused_encoder.supported(self.encoder):
+                self.encoder.to(memory_format=torch.channels_last)
 
     # ---------------------------------------------------------------- small pieces
     def do_shuffle(self, patches, pos_enc):

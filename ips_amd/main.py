@@ -76,6 +76,10 @@ def main(argv=None):
     ap.add_argument("--sparse", action="store_true", help="loader delivers non-zero pixels; patches are built on the GPU")
     ap.add_argument("--hip-graph", action="store_true", help="replay forward+backward+AdamW of a step as one HIP graph")
     ap.add_argument("--lazy", action="store_true", help="lazy loading: patches stay on the host (eager: False)")
+    ap.add_argument("--precision", choices=["fp32", "fp32x3", "bf16"],
+                    help="arithmetic of the no-grad selection pass ips() (IPSX_PRECISION): fp32 = the reference's, exact "
+                         "(default); fp32x3 = fp32-grade on the bf16 matrix pipe, ~1.8x faster; bf16. The with-grad forward "
+                         "and backward are fp32 in every case")
     ap.add_argument("--no-fused-adamw", action="store_true", help="torch's default (per-tensor) AdamW instead of the fused kernel")
     ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     args = ap.parse_args(argv)
@@ -88,6 +92,8 @@ def main(argv=None):
         ap.error("--data-dir (or --make-synthetic) is required")
 
     device = torch.device(args.device)
+    if args.precision:
+        os.environ["IPSX_PRECISION"] = args.precision
     conf = build_conf(args)
     torch.manual_seed(conf.seed)
     np.random.seed(conf.seed)

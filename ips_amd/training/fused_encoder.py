@@ -94,7 +94,14 @@ def encode(encoder, x, taps=None):
     ``taps`` (a list, diagnostics): receives every post-ReLU activation (stem, and per block: after bn1, after the block)."""
     mods = list(encoder.children())
     conv1, bn1, _, pool = mods[:4]
-    h = _conv(conv1, x.contiguous(memory_format=_CL))
+    x = x.contiguous()
+    if x.shape[1] == 1:
+        # one input channel: NCHW and NHWC are the same memory, and torch reads the strides as NCHW - spell the
+        # channels-last strides out so that the stem's output is channels-last too (no transposes around it)
+        x = x.as_strided(x.shape, (x.shape[2] * x.shape[3], 1, x.shape[3], 1))
+    else:
+        x = x.contiguous(memory_format=_CL)
+    h = _conv(conv1, x)
     h = bn_act(h, bn1, None, True)
     h = pool(h)
     if taps is not None:
