@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-layer efficiency of conv_nhwc_kernel at the shapes of the layered trunks (channels-last activations).
 
-    python tools/conv_layers.py [n_patches]
+    python tools/conv_layers.py [n_patches] [train]
 """
 import ctypes as C
 import os
@@ -20,6 +20,8 @@ L = hip.lib()
 shapes = [(64, 64, 25, 3, 1), (64, 128, 25, 3, 2), (128, 128, 13, 3, 1), (128, 256, 13, 3, 2), (256, 256, 7, 3, 1),
           (256, 512, 7, 3, 2), (512, 512, 4, 3, 1), (64, 128, 25, 1, 2), (64, 64, 13, 3, 1), (64, 128, 13, 3, 2),
           (128, 128, 7, 3, 1)]
+if len(sys.argv) > 2 and sys.argv[2] == "train":       # the with-grad forward of the MNIST configuration (B * M = 1024 patches of 32 px)
+    shapes = [(64, 64, 8, 3, 1), (64, 128, 8, 3, 2), (128, 128, 4, 3, 1), (64, 128, 8, 1, 2)]
 for ci, co, h, k, st in shapes:
     pad = k // 2
     ho = (h + 2 * pad - k) // st + 1
