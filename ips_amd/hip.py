@@ -754,13 +754,16 @@ def bn_train_forward(x, residual, gamma, beta, eps, momentum, running_mean, runn
     if residual is not None and _rows_cl(residual) != (rows, c):
         raise ValueError("residual shape")
     y = torch.empty_like(x)                        # (preserves channels-last)
-    mean = torch.empty(c, dtype=torch.float32, device=x.device)
-    invstd = torch.empty_like(mean)
-    ws = torch.empty(lib().ipsx_bn_train_workspace_floats(rows, c), dtype=torch.float32, device=x.device)
+    # one allocation: mean | invstd | workspace (at most _BN_MAX_SLABS x 2 x C partial sums - the library checks)
+    buf = torch.empty((2 + 2 * _BN_MAX_SLABS) * c, dtype=torch.float32, device=x.device)
+    mean, invstd, ws = buf[:c], buf[c:2 * c], buf[2 * c:]
     _ck(lib().ipsx_bn_train_forward(_p(x), _p(residual), rows, c, _p(_f32(gamma)), _p(_f32(beta)), eps, momentum,
                                     _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
                                     _p(ws), _stream()), "ipsx_bn_train_forward")
     return y, mean, invstd
+
+
+_BN_MAX_SLABS = 512      # csrc/bn_train.hip BN_MAX_SLABS (ipsx_bn_train_workspace_floats never exceeds 2 * 512 * C)
 
 
 def bn_train_backward(dy, y, x, gamma, mean, invstd, relu, want_residual):
@@ -772,7 +775,7 @@ def bn_train_backward(dy, y, x, gamma, mean, invstd, relu, want_residual):
     dres = torch.empty_like(x) if want_residual else None
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
-    ws = torch.empty(lib().ipsx_bn_train_workspace_floats(rows, c), dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * _BN_MAX_SLABS * c, dtype=torch.float32, device=x.device)
     _ck(lib().ipsx_bn_train_backward(_p(dy), _p(y), _p(x), rows, c, _p(_f32(gamma)), _p(mean), _p(invstd), int(relu),
                                      _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), _stream()),
         "ipsx_bn_train_backward")

@@ -78,3 +78,17 @@ int main(void) {
     subprocess.check_call(cmd)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("abi ok"), (out.returncode, out.stdout, out.stderr)
+
+
+def test_bn_train_workspace_bound_matches_the_binding():
+    """hip.bn_train_forward/backward allocate the workspace from a constant instead of asking the library per call:
+    the library's own figure never exceeds it, and unsupported channel counts are reported as such (no GPU needed)."""
+    from ips_amd import hip
+    L = hip.lib()
+    for rows in (1, 63, 4096, 262144, 10 ** 7):
+        for c in (4, 64, 128, 512, 1024):
+            assert L.ipsx_bn_train_supported(rows, c) == 1
+            assert 0 < L.ipsx_bn_train_workspace_floats(rows, c) <= 2 * hip._BN_MAX_SLABS * c
+    for c in (0, 3, 6, 48, 2048):
+        assert L.ipsx_bn_train_supported(16, c) == 0
+        assert L.ipsx_bn_train_workspace_floats(16, c) == 0
