@@ -251,6 +251,23 @@ class IPSNet(nn.Module):
         else:
             spans, fetch, prefetch = self._lazy_slabs(patches)
         parts = []
+        import os
+        n_iter = math.ceil((N - self.M) / self.I)
+        # several slabs (lazy loading): the selection loop runs on a side stream over the iterations whose rows have
+        # arrived while the next slab is being encoded, as in _select_hip_overlapped - only the last slab's iterations
+        # are exposed
+        beside = len(spans) > 1 and os.environ.get("IPSX_OVERLAP_SCAN", "1") != "0" and not hip.dedup_blank()
+        if beside:
+            dev = self.device
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != torch.device(dev):
+                self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
+            side, main = self._side_stream, torch.cuda.current_stream(dev)
+            mem_idx = torch.empty((B, self.M), dtype=torch.int64, device=dev)
+            tie = torch.zeros((B,), dtype=torch.int32, device=dev)
+            for t in (logits, mem_idx, tie):
+                t.record_stream(side)
+            side.wait_stream(main)
+            it_prev = 0
         for k, (lo, hi) in enumerate(spans):
             part = fetch(k)
             emb = self._embed(part.reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
@@ -258,7 +275,20 @@ class IPSNet(nn.Module):
             hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
             prefetch(k + 1)          # after the encoder is enqueued: a pageable-memory copy blocks the host, not the GPU
             parts.append(emb)
+            if beside:
+                it_k = n_iter if hi >= N else max(it_prev, (hi - self.M) // self.I)
+                if it_k > it_prev:
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(done)
+                        hip.scan_range(logits, self.M, self.I, ca.H, ca.n_token, it_prev, it_k, mem_idx, tie)
+                    it_prev = it_k
         self._emb_parts = parts
+        if beside:
+            main.wait_stream(side)
+            hip.scan.last_tie = tie
+            return mem_idx
         return hip.scan(logits, self.M, self.I, ca.H, ca.n_token)
 
     # The selection loop is sequential over chunks but only ever needs the logits of the chunks it has
@@ -439,8 +469,17 @@ class IPSNet(nn.Module):
         import os
         B, N = patches.shape[:2]
         row_bytes = patches[0, 0].numel() * patches.element_size()
-        per = max(1, min(N, self._LAZY_SLAB_BYTES // max(1, B * row_bytes)))
-        spans = [(lo, min(lo + per, N)) for lo in range(0, N, per)]
+        slab_bytes = int(os.environ.get("IPSX_LAZY_SLAB_MB", "0")) << 20 or self._LAZY_SLAB_BYTES
+        per = max(1, min(N, slab_bytes // max(1, B * row_bytes)))
+        # The first slab is the only copy nothing hides, so the slabs GROW: the copy engine moves patches ~3x faster than
+        # the fp32 encoder consumes them, i.e. a slab up to 3x the previous one still arrives behind the previous
+        # one's encoding (1/6, 1/2, then full slabs: 8 / 24 / 48 MB - the first is one workgroup round of the fused trunk).
+        spans, lo = [], 0
+        for size in (max(1, per // 6), max(1, per // 2)):
+            if N - lo > per:
+                spans.append((lo, lo + size))
+                lo += size
+        spans += [(a, min(a + per, N)) for a in range(lo, N, per)]
         keep = patches.numel() * patches.element_size() <= int(os.environ.get("IPSX_LAZY_KEEP_MB", "16384")) << 20
         dev = self.device
         if keep:
