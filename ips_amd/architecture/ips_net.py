@@ -27,6 +27,7 @@ only returns the gathered patches).
 """
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -52,7 +53,6 @@ class IPSNet(nn.Module):
         if pretrained:
             # the reference lets torchvision download IMAGENET1K_V1 (:19-27); this framework targets machines
             # without network access, so the same file is read from a local path instead
-            import os
             path = os.environ.get("IPSX_PRETRAINED_" + enc_type.upper()) or os.environ.get("IPSX_PRETRAINED")
             if not path:
                 raise RuntimeError(
@@ -251,7 +251,6 @@ class IPSNet(nn.Module):
         else:
             spans, fetch, prefetch = self._lazy_slabs(patches)
         parts = []
-        import os
         n_iter = math.ceil((N - self.M) / self.I)
         # several slabs (lazy loading): the selection loop runs on a side stream over the iterations whose rows have
         # arrived while the next slab is being encoded, as in _select_hip_overlapped - only the last slab's iterations
@@ -302,7 +301,6 @@ class IPSNet(nn.Module):
     _OVERLAP_PARTS = 4
 
     def _can_overlap(self, patches):
-        import os
         if os.environ.get("IPSX_OVERLAP_SCAN", "1") == "0" or hip.dedup_blank():
             return False
         n_iter = math.ceil((patches.shape[1] - self.M) / self.I)
@@ -337,7 +335,6 @@ class IPSNet(nn.Module):
         if self._plan is None:
             self._plan = hip.EncoderPlan(self.encoder, self.is_image)
         indexed = self.is_image and patches.is_contiguous() and self._plan.fused(patches.shape)
-        import os
         # image encoders: parts shrinking towards the end (only the last scan is exposed).  Projector: the loop is the
         # long pole (it consumes rows about as fast as the projector makes them), so the parts are EQUAL and sized to
         # what fills the GPU exactly once - 256 compute units x 64 rows - because a GEMM launch of 1.2 rounds takes as
@@ -391,7 +388,6 @@ class IPSNet(nn.Module):
         # is launched once, up front, as a persistent kernel that owns its compute unit and waits for the rows as the
         # projector publishes them - no re-launch per part, no waiting for a compute unit to drain, no projector
         # workgroups competing for the loop's issue slots (IPSX_SCAN_PERSIST=0 switches it off).
-        import os
         persistent = (not self.is_image and B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8"))
                       and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
                       and hip.scan_persistent_supported(M, I, ca.H, ca.n_token))
@@ -466,7 +462,6 @@ class IPSNet(nn.Module):
     _LAZY_SLAB_BYTES = 48 << 20
 
     def _lazy_slabs(self, patches):
-        import os
         B, N = patches.shape[:2]
         row_bytes = patches[0, 0].numel() * patches.element_size()
         slab_bytes = int(os.environ.get("IPSX_LAZY_SLAB_MB", "0")) << 20 or self._LAZY_SLAB_BYTES
