@@ -434,14 +434,17 @@ class IPSNet(nn.Module):
                 emb = self._embed(patches[:, lo:hi].reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             parts.append(emb)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
-            hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
             if persistent:
+                hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
                 hip.publish_rows(ready, hi)            # after the kernels that wrote rows [0, hi) of every image
                 continue
+            # logits and loop of this part on the side stream: the main stream goes straight on to the next part's encoder
             done = torch.cuda.Event()
             done.record(main)
+            emb.record_stream(side)
             with torch.cuda.stream(side):
                 side.wait_event(done)
+                hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
                 hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie)
         main.wait_stream(side)
         if persistent:
