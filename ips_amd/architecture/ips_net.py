@@ -173,7 +173,9 @@ class IPSNet(nn.Module):
         if hip.on_device(x) and self.encoder.training and self.is_image and torch.is_grad_enabled():
             # training step (reference training/iterative.py:158-163): same modules, BatchNorm + add + ReLU fused
             from ..training import fused_encoder
-            if fused_encoder.enabled() and fused_encoder.supported(self.encoder):
+            if getattr(self, "_fused_train_ok", None) is None:        # (the module tree does not change after construction)
+                self._fused_train_ok = fused_encoder.supported(self.encoder)
+            if self._fused_train_ok and fused_encoder.enabled():
                 return fused_encoder.encode(self.encoder, x)
         return self.encoder(x).flatten(1)
 
