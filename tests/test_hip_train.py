@@ -19,7 +19,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("P,C,H,relu,res", [(8, 64, 16, True, False), (5, 64, 8, True, True), (3, 128, 4, False, False),
-                                            (7, 256, 2, True, True), (16, 512, 1, True, False), (1024, 64, 16, True, False)])
+                                            (7, 256, 2, True, True), (16, 512, 1, True, False), (1024, 64, 16, True, False),
+                                            (9, 4, 3, True, True), (33, 8, 5, False, True), (3, 1024, 2, True, False)])
 def test_bn_train_kernels_match_torch(P, C, H, relu, res):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(P * 1000 + C)
