@@ -68,7 +68,6 @@ class _BnAct(torch.autograd.Function):
             residual = residual.contiguous(memory_format=_CL)
         y, mean, invstd = hip.bn_train_forward(x, residual, gamma, beta, bn.eps, bn.momentum, bn.running_mean,
                                                bn.running_var, relu)
-        bn.num_batches_tracked.add_(1)
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
         return y
@@ -118,4 +117,6 @@ def encode(encoder, x, taps=None):
             h = bn_act(o, blk.bn2, idt, True)
             if taps is not None:
                 taps.append(h)
+    # num_batches_tracked of every BatchNorm that ran, in one launch (nn.BatchNorm2d adds 1 per forward in train mode)
+    torch._foreach_add_([m.num_batches_tracked for m in encoder.modules() if isinstance(m, nn.BatchNorm2d)], 1)
     return mods[-1](h).flatten(1)
