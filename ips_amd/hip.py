@@ -308,6 +308,7 @@ class EncoderPlan:
         self._sig = None
         self._keep = []
         self._ws = None
+        self._held = 0
 
     def _signature(self):
         sig = [precision(), weights_generation()]
@@ -387,10 +388,26 @@ class EncoderPlan:
         return self._ws
 
     def _refresh(self):
+        if self._held:
+            return
         sig = self._signature()
         if sig != self._sig:
             self._rebuild()
             self._sig = sig
+
+    def hold(self):
+        """Context manager: check the weights once, then skip the check until the block ends - for a caller that makes
+        several encode calls while the weights cannot change (one no-grad ``ips()`` call; the check walks ~80 tensors)."""
+        plan = self
+
+        class _Hold:
+            def __enter__(self):
+                plan._refresh()
+                plan._held += 1
+
+            def __exit__(self, *exc):
+                plan._held -= 1
+        return _Hold()
 
     def fused(self, x_shape):
         """True when encode_indexed is available for patches of this (C, h, w)."""
