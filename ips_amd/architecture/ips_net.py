@@ -490,12 +490,20 @@ class IPSNet(nn.Module):
         spans += [(a, min(a + per, N)) for a in range(lo, N, per)]
         keep = patches.numel() * patches.element_size() <= int(os.environ.get("IPSX_LAZY_KEEP_MB", "16384")) << 20
         dev = self.device
+        # the device-side buffers are kept between calls of the same shape: allocated afresh, a block that the copy stream
+        # has used cannot be recycled until that stream's work is known to be over, and a host that runs many calls ahead
+        # of the GPU piles up one image batch per call (8.6 GB after 300 un-synchronised calls of the headline batch)
+        bkey = (keep, tuple(patches.shape), per, patches.dtype, str(dev))
+        if getattr(self, "_lazy_bufs_key", None) != bkey:
+            self._lazy_bufs = [torch.empty(patches.shape, dtype=patches.dtype, device=dev)] if keep else \
+                [torch.empty((B, per) + tuple(patches.shape[2:]), dtype=patches.dtype, device=dev) for _ in range(2)]
+            self._lazy_bufs_key = bkey
         if keep:
-            store = torch.empty(patches.shape, dtype=patches.dtype, device=dev)
+            store = self._lazy_bufs[0]
             self._device_patches = store
             dst = lambda k, lo, hi: store[:, lo:hi]
         else:
-            ring = [torch.empty((B, per) + tuple(patches.shape[2:]), dtype=patches.dtype, device=dev) for _ in range(2)]
+            ring = self._lazy_bufs
             dst = lambda k, lo, hi: ring[k % 2][:, :hi - lo]
         copy_stream = getattr(self, "_copy_stream", None)
         if copy_stream is None or copy_stream.device != torch.device(dev):
