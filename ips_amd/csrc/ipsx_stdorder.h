@@ -13,8 +13,10 @@
 // the hole-sifting __adjust_heap), on a plain array of pairs, without recursion (explicit stack) - checked
 // against std:: itself on millions of tie-heavy inputs by oracle/check_stdorder.cpp.
 //
-// Sequential by nature: the kernels run it on ONE lane, and only in iterations whose first k+1 ranked scores
-// contain equal neighbours (otherwise the answer is the strict descending order every algorithm agrees on).
+// Sequential as written; the kernels run it only in iterations whose first k+1 ranked scores contain equal neighbours
+// (otherwise the answer is the strict descending order every algorithm agrees on), and then on a whole wavefront:
+// scorer.hip torch_topk_wave evaluates the Hoare partitions with ballots and the final insertion pass leaf by leaf,
+// and calls the routines below on one lane for what is left (median of three, heap fallbacks, partial_sort).
 #pragma once
 
 #if defined(__HIPCC__)

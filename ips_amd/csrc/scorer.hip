@@ -317,7 +317,157 @@ __device__ __forceinline__ bool ranked_ties(const uint64_t* sorted, int L, int m
     return any;
 }
 
-// sorted and other are the two key arrays (>= L entries each); all threads of the workgroup call this together
+// ---- the replay on ONE WAVEFRONT instead of one lane.  libstdc++'s routines are sequential, but what they compute is
+// not: (1) the unguarded Hoare partition pairs the t-th element from the left that stops the upward scan (not greater than
+// the pivot) with the t-th from the right that stops the downward scan (not smaller), for as long as the left one lies
+// before the right one, swaps each pair, and returns where the upward scan stops next - both scans only ever see
+// elements no swap has touched, so the pairs can be read off the ORIGINAL array with two ballots per 64 elements;
+// (2) the final insertion pass of std::sort never moves an element across a partition cut, so every leaf of the
+// introsort loop (<= 16 elements) is insertion-sorted by a lane of its own.  Everything else (median of three, the
+// <= 3-element tail of nth_element, the heap fallbacks at depth 0) stays the sequential restatement on lane 0.
+// oracle/check_stdorder.cpp holds this formulation against std:: itself; tests/test_hip_kernels.py holds the device code
+// against the one-lane replay.  One lane took ~600 k cycles for 512 candidates (a quarter of a millisecond - 10 % of a
+// CAMELYON slide for ONE tie among 255 iterations); the wavefront takes ~30 k.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int last, int pivot, int* la, int* lb, int lane) {
+    const stdorder::E P = q[pivot];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int na = 0, nb = 0;
+    for (int base = first; base < last; base += 64) {                  // ascending: indices that stop the upward scan
+        const int x = base + lane;
+        const bool in = x < last;
+        const stdorder::E e = q[in ? x : first];
+        const bool stop = in && !stdorder::gt(e, P);
+        const unsigned long long mask = __ballot(stop);
+        if (stop) la[na + __popcll(mask & below)] = x;
+        na += __popcll(mask);
+    }
+    for (int top = last - 1; top >= first; top -= 64) {                // descending: indices that stop the downward scan
+        const int x = top - lane;
+        const bool in = x >= first;
+        const stdorder::E e = q[in ? x : first];
+        const bool stop = in && !stdorder::gt(P, e);
+        const unsigned long long mask = __ballot(stop);
+        if (stop) lb[nb + __popcll(mask & below)] = x;
+        nb += __popcll(mask);
+    }
+    wave_lds_fence();
+    const int np = na < nb ? na : nb;
+    int t = 0;                                                         // pairs that are swapped: la[u] < lb[u], a prefix
+    for (int base = 0; base < np; base += 64) {
+        const int u = base + lane;
+        const bool ok = u < np && la[u < np ? u : 0] < lb[u < np ? u : 0];
+        const unsigned long long mask = __ballot(ok);
+        const int valid = np - base < 64 ? np - base : 64;
+        const unsigned long long full = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+        if ((mask & full) == full) { t += valid; continue; }
+        t += __ffsll((long long)(~mask)) - 1;
+        break;
+    }
+    for (int base = 0; base < t; base += 64) {
+        const int u = base + lane;
+        if (u < t) {
+            const int i = la[u], j = lb[u];
+            const stdorder::E ei = q[i], ej = q[j];
+            q[i] = ej;
+            q[j] = ei;
+        }
+    }
+    const int cut = (t < na && (t == 0 || la[t] < lb[t - 1])) ? la[t] : lb[t - 1];
+    wave_lds_fence();
+    return cut;
+}
+
+__device__ __forceinline__ int wave_partition_pivot(stdorder::E* q, int first, int last, int* la, int* lb, int lane) {
+    if (lane == 0) stdorder::move_median_to_first(q, first, first + 1, first + (last - first) / 2, last - 1);
+    wave_lds_fence();
+    return wave_partition(q, first + 1, last, first, la, lb, lane);
+}
+
+// q[0..n) = (score, position) in candidate order on entry; q[0..k) = torch.topk's answer on return.  Called by the 64
+// lanes of ONE wavefront.  la / lb: n ints each; stk: 3 * STACK_RANGES ints (ranges below, leaf bitmap in its upper third).
+__device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, int* la, int* lb, int* stk, int lane) {
+    using namespace stdorder;
+    if (k <= 0 || n <= 0) return;
+    if ((long long)k * 64 <= (long long)n || n > 1024) {               // heap select / sort, or beyond the leaf bitmap
+        if (lane == 0) torch_topk(q, n, k, stk);
+        wave_lds_fence();
+        return;
+    }
+    {   // std::nth_element(q, q + k - 1, q + n)
+        int first = 0, last = n;
+        const int nth = k - 1;
+        bool done = nth == last;
+        int depth = lg2(last - first) * 2;
+        while (!done && last - first > 3) {
+            if (depth == 0) {
+                if (lane == 0) { heap_select(q, first, nth + 1, last); swp(q, first, nth); }
+                done = true;
+                break;
+            }
+            --depth;
+            const int cut = wave_partition_pivot(q, first, last, la, lb, lane);
+            if (cut <= nth) first = cut;
+            else last = cut;
+        }
+        if (!done && lane == 0) insertion_sort(q, first, last);
+        wave_lds_fence();
+    }
+    const int last = k - 1;                                            // std::sort(q, q + k - 1)
+    if (last <= 0) return;
+    unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 2 * STACK_RANGES);     // 1024 bits
+    if (lane < 16) leaf[lane] = 0ull;
+    wave_lds_fence();
+    int sp = 1;
+    if (lane == 0) { stk[0] = 0; stk[1] = last; stk[2] = lg2(last) * 2; }
+    wave_lds_fence();
+    while (sp > 0) {
+        --sp;
+        int rf = stk[3 * sp], rl = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+        while (rl - rf > 16) {
+            if (depth == 0) {
+                if (lane == 0) { make_heap(q, rf, rl); sort_heap(q, rf, rl); }
+                wave_lds_fence();
+                break;
+            }
+            --depth;
+            const int cut = wave_partition_pivot(q, rf, rl, la, lb, lane);
+            if (lane == 0) { stk[3 * sp] = cut; stk[3 * sp + 1] = rl; stk[3 * sp + 2] = depth; }
+            wave_lds_fence();
+            ++sp;
+            rl = cut;
+        }
+        if (lane == 0) {                                               // [rf, rl) is a leaf (a heap-sorted range is one too)
+            leaf[rf >> 6] |= 1ull << (rf & 63);
+            if (rl < last) leaf[rl >> 6] |= 1ull << (rl & 63);
+        }
+        wave_lds_fence();
+    }
+    // every leaf by the lane that owns its first position: linear insertion that stops at the leaf's first element
+    for (int base = 0; base < last; base += 64) {
+        const int s = base + lane;
+        if (s < last && ((leaf[s >> 6] >> (s & 63)) & 1ull)) {
+            int e = last;
+            unsigned long long rest = (s & 63) == 63 ? 0ull : (leaf[s >> 6] >> ((s & 63) + 1)) << ((s & 63) + 1);
+            for (int w = s >> 6; w < 16; ++w) {
+                if (rest) { e = w * 64 + __ffsll((long long)rest) - 1; break; }
+                rest = w + 1 < 16 ? leaf[w + 1] : 0ull;
+            }
+            if (e > last) e = last;
+            for (int i = s + 1; i < e; ++i) {
+                const E val = q[i];
+                int j = i;
+                while (j > s && gt(val, q[j - 1])) { q[j] = q[j - 1]; --j; }
+                q[j] = val;
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
+// sorted and other are the two key arrays (>= L entries each); all threads of the workgroup call this together.
+// NOTE: `sorted` serves as scratch meanwhile - on return only sorted[0, m) is defined.
 template <int NT>
 __device__ __forceinline__ void torch_tie_order(uint64_t* sorted, uint64_t* other, int L, int m, int* stk, int tid) {
     stdorder::E* q = reinterpret_cast<stdorder::E*>(other);
@@ -328,7 +478,10 @@ __device__ __forceinline__ void torch_tie_order(uint64_t* sorted, uint64_t* othe
         q[p].i = p;
     }
     __syncthreads();
-    if (tid == 0) stdorder::torch_topk(q, L, m, stk);
+    if (tid < 64) {
+        int* la = reinterpret_cast<int*>(sorted);
+        torch_topk_wave(q, L, m, la, la + L, stk, tid);
+    }
     __syncthreads();
     for (int j = tid; j < m; j += NT) sorted[j] = rank_key(q[j].v, (uint32_t)q[j].i);
     __syncthreads();
@@ -815,6 +968,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
             SCAN_STAMP(3);
             sorted = sort_desc(keyA, keyB, L, a.n2);
         }
+        if (tid == 0 && L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m])) tie = 1;   // (NaN never equal: harmless)
         if (a.tie_order == 1 && ranked_ties(sorted, L, a.m, lane))
             torch_tie_order<SCAN_NT>(sorted, sorted == keyA ? keyB : keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off), tid);
         SCAN_STAMP(4);
@@ -827,7 +981,6 @@ __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsi
                 SCAN_ADVANCE(j, r);
             }
         }
-        if (tid == 0 && L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m])) tie = 1;   // (NaN never equal: harmless)
         { int* t = cand; cand = cnew; cnew = t; }
         { float* t = cl; cl = clnew; clnew = t; }
         SCAN_STAMP(5);
@@ -892,8 +1045,12 @@ __device__ __attribute__((noinline)) void tie_order_slow(uint64_t* sorted, uint6
 // producer workgroup sharing the loop's compute unit is a straggler that costs about as much).
 template <bool PERSIST>
 __device__ __forceinline__ float scan_load(const float* p) {
+#ifdef IPSX_SCAN_PLAIN_LOADS
+    return *p;
+#else
     if (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
+#endif
 }
 
 template <int R, int T, int EPT, int LCH, bool STAMP, bool PERSIST>
@@ -1198,6 +1355,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             }
         }
         if (STAMP && tid == 0) tacc[7] += (unsigned long long)(Lr - a.m);
+        if (STAMP && PERSIST && tid == 0 && b == 0 && it < 512) stamps[8 * gridDim.x + 4 * it] = __builtin_amdgcn_s_memtime() - tlast;
         FAST_STAMP(4);
         if (Lr <= 192) {                     // counting rank below the crossover of the two rankings (~200 keys)
             int P = 1;
@@ -1236,6 +1394,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             boundary_tie = L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m]);
             tie_order_slow(keyB, keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off));
         }
+        if (STAMP && PERSIST && tid == 0 && b == 0 && it < 512) { stamps[8 * gridDim.x + 4 * it + 1] = __builtin_amdgcn_s_memtime() - tlast; stamps[8 * gridDim.x + 4 * it + 2] = __builtin_amdgcn_s_memrealtime(); }
         FAST_STAMP(5);
         // P6: new memory: indices, logit rows and exponentials of the winners, into the other buffers
         for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
@@ -1549,6 +1708,12 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
                 else IPSX_LAUNCH_FAST_C(RR, TT, 8);                                                                 \
             } while (0)
             // the diagnostic (stamped) build exists for the two benchmark shapes
+            if (st && a.ready && R == 8 && n_token == 1 && ept == 4 && lch == 8) {      // stamped persistent loop (diagnostic)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<8, 1, 4, 8, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);
+                scan_fast_kernel<8, 1, 4, 8, true, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st);
+                return launched("scan");
+            }
             if (st && R == 8 && n_token == 1 && ept == 4 && lch == 8) IPSX_LAUNCH_FAST(8, 1, 4, 8, true);
             if (st && R == 32 && n_token == 4 && ept == 4 && lch == 2) IPSX_LAUNCH_FAST(32, 4, 4, 2, true);
             if (R == 8 && n_token == 1) IPSX_LAUNCH_FAST_E(8, 1);

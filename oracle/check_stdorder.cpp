@@ -29,10 +29,91 @@ static void aten_topk(std::vector<P>& q, int k) {
     }
 }
 
+// ---- the formulation the device runs on a whole wavefront (csrc/scorer.hip torch_topk_wave): the Hoare partition as
+// "pair the t-th element from the left that stops the upward scan with the t-th from the right that stops the downward
+// scan, while the left one lies before the right one", the introsort leaves sorted independently.  Written here as
+// plain loops - the specification - and held against the move-for-move restatement above.
+namespace lists {
+using ipsx::stdorder::E;
+using ipsx::stdorder::gt;
+
+static int partition(E* q, int first, int last, int pivot, std::vector<int>& A, std::vector<int>& B) {
+    const E P = q[pivot];
+    A.clear(); B.clear();
+    for (int x = first; x < last; ++x) if (!gt(q[x], P)) A.push_back(x);          // stops the upward scan
+    for (int x = last - 1; x >= first; --x) if (!gt(P, q[x])) B.push_back(x);     // stops the downward scan
+    size_t t = 0;
+    while (t < A.size() && t < B.size() && A[t] < B[t]) ++t;
+    for (size_t u = 0; u < t; ++u) std::swap(q[A[u]], q[B[u]]);
+    if (t < A.size() && (t == 0 || A[t] < B[t - 1])) return A[t];
+    return B[t - 1];
+}
+
+static int partition_pivot(E* q, int first, int last, std::vector<int>& A, std::vector<int>& B) {
+    const int mid = first + (last - first) / 2;
+    ipsx::stdorder::move_median_to_first(q, first, first + 1, mid, last - 1);
+    return partition(q, first + 1, last, first, A, B);
+}
+
+static void leaf_sort(E* q, int s, int e) {          // linear insertion that stops at the leaf's first element
+    for (int i = s + 1; i < e; ++i) {
+        const E val = q[i];
+        int j = i;
+        while (j > s && gt(val, q[j - 1])) { q[j] = q[j - 1]; --j; }
+        q[j] = val;
+    }
+}
+
+static void topk(E* q, int n, int k, int* stk) {
+    using namespace ipsx::stdorder;
+    if (k <= 0 || n <= 0) return;
+    if ((long long)k * 64 <= (long long)n) { partial_sort(q, 0, k, n); return; }
+    std::vector<int> A, B;
+    {   // nth_element(q, 0, k - 1, n)
+        int first = 0, last = n;
+        const int nth = k - 1;
+        bool done = (first == last || nth == last);
+        int depth = done ? 0 : lg2(last - first) * 2;
+        while (!done && last - first > 3) {
+            if (depth == 0) { heap_select(q, first, nth + 1, last); swp(q, first, nth); done = true; break; }
+            --depth;
+            const int cut = partition_pivot(q, first, last, A, B);
+            if (cut <= nth) first = cut; else last = cut;
+        }
+        if (!done) insertion_sort(q, first, last);
+    }
+    {   // sort(q, 0, k - 1): leaves of the introsort loop, each insertion-sorted on its own
+        const int first = 0, last = k - 1;
+        if (first == last) return;
+        std::vector<char> leaf(last + 1, 0);
+        int sp = 0;
+        stk[0] = first; stk[1] = last; stk[2] = lg2(last - first) * 2; sp = 1;
+        while (sp > 0) {
+            --sp;
+            int rf = stk[3 * sp], rl = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+            bool heap = false;
+            while (rl - rf > 16) {
+                if (depth == 0) { make_heap(q, rf, rl); sort_heap(q, rf, rl); heap = true; break; }
+                --depth;
+                const int cut = partition_pivot(q, rf, rl, A, B);
+                stk[3 * sp] = cut; stk[3 * sp + 1] = rl; stk[3 * sp + 2] = depth; ++sp;
+                rl = cut;
+            }
+            (void)heap;
+            leaf[rf] = 1;                  // [rf, rl) is a leaf (or a heap-sorted range: sorted already, one more boundary)
+            if (rl <= last) leaf[rl] = 1;
+        }
+        int s = first;
+        for (int x = first + 1; x <= last; ++x)
+            if (x == last || leaf[x]) { leaf_sort(q, s, x); s = x; }
+    }
+}
+}  // namespace lists
+
 int main(int argc, char** argv) {
     const long cases = argc > 1 ? atol(argv[1]) : 200000;
     std::mt19937_64 rng(12345);
-    long bad = 0, checked = 0;
+    long bad = 0, bad_lists = 0, checked = 0;
     std::vector<int> stk(3 * ipsx::stdorder::STACK_RANGES);
     for (long c = 0; c < cases; ++c) {
         const int n = 1 + (int)(rng() % (c % 50 == 0 ? 2100 : 600));
@@ -54,11 +135,14 @@ int main(int argc, char** argv) {
             a[i] = P(v, i);
             b[i].v = v; b[i].i = i;
         }
+        std::vector<ipsx::stdorder::E> w(b);
         aten_topk(a, k);
         ipsx::stdorder::torch_topk(b.data(), n, k, stk.data());
+        lists::topk(w.data(), n, k, stk.data());
         for (int j = 0; j < k; ++j) {
             ++checked;
             if (a[j].second != b[j].i) { ++bad; break; }
+            if (a[j].second != w[j].i) { ++bad_lists; break; }
         }
     }
     // the median-of-3 killer sequence drives introsort / introselect to their heap fallbacks
@@ -71,11 +155,14 @@ int main(int argc, char** argv) {
             std::vector<P> a(n);
             std::vector<ipsx::stdorder::E> b(n);
             for (int i = 0; i < n; ++i) { a[i] = P(-v[i], i); b[i].v = -v[i]; b[i].i = i; }
+            std::vector<ipsx::stdorder::E> w(b);
             aten_topk(a, k);
             ipsx::stdorder::torch_topk(b.data(), n, k, stk.data());
+            lists::topk(w.data(), n, k, stk.data());
             for (int j = 0; j < k; ++j) if (a[j].second != b[j].i) { ++bad; break; }
+            for (int j = 0; j < k; ++j) if (a[j].second != w[j].i) { ++bad_lists; break; }
         }
     }
-    printf("cases %ld  compared %ld  mismatching cases %ld\n", cases, checked, bad);
-    return bad ? 1 : 0;
+    printf("cases %ld  compared %ld  mismatching cases %ld  (wavefront formulation: %ld)\n", cases, checked, bad, bad_lists);
+    return (bad || bad_lists) ? 1 : 0;
 }

@@ -580,6 +580,38 @@ def test_topm_under_ties_returns_torch_cpu_order(L, M):
         assert np.array_equal(top[b], orc.topm(s[b], M, aten_ties=True)[0])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_wavefront_tie_replay_equals_torch_cpu_on_many_random_rows(seed):
+    """The tie replay runs on a whole wavefront (Hoare partition by ballots, introsort leaves sorted by a lane each:
+    csrc/scorer.hip torch_topk_wave).  Hundreds of tie-heavy rows per shape - few distinct values, sorted / reversed /
+    organ-pipe patterns that reach the depth-limit heap paths, NaNs, negative zeros - against torch.topk on the CPU."""
+    g = np.random.default_rng(500 + seed)
+    for L, M in ((512, 256), (128, 64), (1000, 333), (1024, 1023), (96, 95), (200, 17), (700, 11)):
+        rows = []
+        for _ in range(40):
+            distinct = int(g.choice([1, 2, 3, 5, 37, 1000]))
+            pattern = int(g.integers(0, 4))
+            i = np.arange(L)
+            if pattern == 0:
+                v = g.integers(0, distinct, L).astype(np.float32) * 0.25
+            elif pattern == 1:
+                v = (i * distinct // L).astype(np.float32)
+            elif pattern == 2:
+                v = ((L - 1 - i) * distinct // L).astype(np.float32)
+            else:
+                v = (np.minimum(i, L - 1 - i) % distinct).astype(np.float32)
+            if g.integers(0, 9) == 0:
+                v[g.integers(0, L, max(1, L // 7))] = np.nan
+            neg = g.integers(0, 31, L) == 0
+            v[neg] = -v[neg]
+            rows.append(v)
+        s = np.stack(rows)
+        top = hip.topm(dev(s), M).cpu().numpy()
+        for b in range(len(s)):
+            want = torch.topk(torch.from_numpy(s[b]), M)[1].numpy()
+            assert np.array_equal(top[b], want), (L, M, b, top[b][:12], want[:12])
+
+
 @pytest.mark.parametrize("N,M,I,H,T", [(300, 16, 16, 8, 4), (301, 16, 24, 8, 4), (40, 16, 64, 8, 4),
                                        (1000, 32, 48, 8, 1), (2500, 64, 64, 8, 4), (3000, 256, 256, 8, 1),
                                        (5000, 900, 900, 8, 1)])

@@ -13,6 +13,42 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ips_amd import hip
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "mnist"
+if kind == "campipe":
+    # the persistent loop INSIDE the CAMELYON pipeline (beside the projector): same phase stamps; time spent waiting for
+    # rows that are not published yet lands in "weights+scores+keys" (where the next-but-one chunk is requested)
+    from ips_amd import synth
+    from ips_amd.architecture import IPSNet
+    dev = torch.device("cuda:0")
+    conf, B = synth.bench_workload("cam")
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    x = synth.make_patches(conf, B, seed=21).to(dev)
+    L = hip.lib()
+    L.ipsx_dbg_scan_stamps.argtypes = [C.c_void_p]
+    st = torch.zeros((B * 8 + 2048,), dtype=torch.int64, device=dev)
+    for _ in range(3):
+        net.ips(x)
+    torch.cuda.synchronize()
+    L.ipsx_dbg_scan_stamps(st.data_ptr())
+    net.ips(x)
+    torch.cuda.synchronize()
+    L.ipsx_dbg_scan_stamps(None)
+    n_iter = 255
+    log = st.cpu().numpy()[B * 8:B * 8 + 4 * n_iter].reshape(n_iter, 4)
+    s = st.cpu().numpy()[:8]
+    print("per iteration (phase 4 incl. waits, phase 5 rank), every 8th:")
+    for it in range(0, n_iter, 16):
+        print("   it %3d   %6d  %6d" % (it, log[it, 0], log[it, 1]))
+    import numpy as np
+    for col, nme in ((0, "phase 4"), (1, "phase 5")):
+        top = np.argsort(-log[:, col])[:8]
+        print("   largest %s: " % nme + ", ".join("it %d: %d" % (i, log[i, col]) for i in sorted(top)))
+    t0 = log[0, 2]
+    print("   end of phase 5 in us since iteration 0 (100 MHz clock): " + ", ".join("it %d: %.1f" % (i, (log[i, 2] - t0) / 100.0) for i in (1, 10, 30, 36, 37, 38, 46, 47, 60, 100, 139, 140, 200, 254)))
+    names = ["stage chunk+barrier", "row maxima", "exp (new rows)", "row sums", "weights+scores+keys (+waits)", "rank", "gather winners"]
+    print("cam pipeline: total %d cycles = %.1f per iteration" % (s[:7].sum(), s[:7].sum() / n_iter))
+    for k, nme in enumerate(names):
+        print("  %-30s %9.0f cycles/iter" % (nme, s[k] / n_iter))
+    sys.exit(0)
 B, N, M, I, H, T = (16, 2500, 64, 64, 8, 4) if kind == "mnist" else (1, 65536, 256, 256, 8, 1)
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
