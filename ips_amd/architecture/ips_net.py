@@ -448,6 +448,13 @@ class IPSNet(nn.Module):
                 hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
                 hip.publish_rows(ready, hi)            # after the kernels that wrote rows [0, hi) of every image
                 continue
+            if k == P - 1:
+                # the last part has nothing to run beside: its logits and iterations stay on the main stream (one
+                # cross-stream hand-over less on the critical path; it only has to follow the side stream's earlier parts)
+                main.wait_stream(side)
+                hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
+                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie)
+                continue
             # logits and loop of this part on the side stream: the main stream goes straight on to the next part's encoder
             done = torch.cuda.Event()
             done.record(main)
