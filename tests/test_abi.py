@@ -92,3 +92,21 @@ def test_bn_train_workspace_bound_matches_the_binding():
     for c in (0, 3, 6, 48, 2048):
         assert L.ipsx_bn_train_supported(16, c) == 0
         assert L.ipsx_bn_train_workspace_floats(16, c) == 0
+
+
+def test_fused_training_path_knows_which_encoders_it_covers():
+    """training/fused_encoder.supported(): BasicBlock trunks (ResNet-18, 2 or 4 stages) yes; Bottleneck trunks and the
+    feature projector no - those keep the stock ops (no GPU needed: the check reads the module tree and asks the
+    library about channel counts)."""
+    import torch
+    from ips_amd import synth
+    from ips_amd.architecture import IPSNet
+    from ips_amd.training import fused_encoder
+    cpu = torch.device("cpu")
+    assert fused_encoder.supported(IPSNet(cpu, synth.mnist_conf(N=64, M=8, I=8)).encoder)
+    assert fused_encoder.supported(IPSNet(cpu, synth.traffic_conf(N=64, M=8, I=8)).encoder)
+    assert not fused_encoder.supported(IPSNet(cpu, synth.traffic_conf(N=64, M=8, I=8, enc_type='resnet50', D=2048, D_k=256, D_v=256)).encoder)
+    assert not fused_encoder.supported(IPSNet(cpu, synth.camelyon_conf(N=64, M=8, I=8)).encoder)
+    # on the CPU the weights keep their default layout (channels-last storage is for the GPU training path only)
+    w = IPSNet(cpu, synth.mnist_conf(N=64, M=8, I=8)).encoder[4][0].conv1.weight
+    assert w.is_contiguous()
