@@ -421,10 +421,12 @@ class IPSNet(nn.Module):
             side.wait_stream(main)
         stats = None
         if not self.is_image and patches.is_contiguous() and P > 1 and B == 1:
-            # LayerNorm moments of ALL rows in one HBM-bound pass up front (0.1 ms per 64 Ki rows of 2048 features) instead
-            # of one small pass per part.  (Tried beside the first part's GEMM on a helper stream: its workgroups
-            # are in the way when the GEMM's are placed, some compute units end up with two of them and the launch takes
-            # twice as long.)
+            # LayerNorm moments (8 bytes per row) by a pass of their own in front of every part's GEMM.  One pass over the
+            # whole slide up front is less work (0.09 ms against 5 x 0.02), but it sits in front of the FIRST rows the loop
+            # is waiting for, and since the loop is the long pole that costs more than it saves: 2.11 -> 2.03 ms per
+            # slide (IPSX_CAM_STATS=all selects the single pass).  (Tried beside the first part's GEMM on a helper
+            # stream: its workgroups are in the way when the GEMM's are placed, some compute units end up with two of
+            # them and the launch takes twice as long.)
             skey = (B, N, str(dev))
             if getattr(self, "_stats_key", None) != skey:
                 self._stats_buf = torch.empty((B * N, 2), dtype=torch.float32, device=dev)
@@ -433,9 +435,14 @@ class IPSNet(nn.Module):
                 #  allocator go back to the driver now and then - tens of milliseconds on the host)
                 self._emb_buf = torch.empty((B, N, self.D), dtype=torch.float32, device=dev)
             self._plan._refresh()
-            stats = self._plan.row_stats(patches.reshape(B * N, -1), out=self._stats_buf)
+            stats = self._stats_buf
+            per_part = os.environ.get("IPSX_CAM_STATS", "part") == "part"
+            if not per_part:
+                self._plan.row_stats(patches.reshape(B * N, -1), out=self._stats_buf)
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
+            if stats is not None and per_part:
+                self._plan.row_stats(patches[0, lo:hi], out=stats[lo:hi])
             if indexed:
                 emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
             elif stats is not None:
