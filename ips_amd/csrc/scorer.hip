@@ -1088,6 +1088,15 @@ __device__ __attribute__((noinline)) void tie_order_slow(uint64_t* sorted, uint6
 // register file of its compute unit, so no producer workgroup is placed beside it: a producer launch must then be sized
 // for the OTHER compute units (one sized for all 256 runs two workgroups on one of them and takes twice as long; a
 // producer workgroup sharing the loop's compute unit is a straggler that costs about as much).
+// The row maxima are kept as order-preserving keys (max_key: a NaN wins, as in the contract's nanmax) in LDS, one word per
+// row for the memory rows and one for the chunk rows: whoever has the values in registers anyway - the gather of the new
+// memory, the prep of the next chunk, the prologue - folds them in with one ds_max_u32 per (wave, row).
+template <int R>
+__device__ __forceinline__ void fold_row_max(uint32_t key, uint32_t* dst, int lane) {
+    for (int off = R; off < 64; off <<= 1) key = max(key, (uint32_t)__shfl_xor((int)key, off, 64));
+    if (lane < R && key != 0u) atomicMax(dst + lane, key);
+}
+
 template <bool PERSIST>
 __device__ __forceinline__ float scan_load(const float* p) {
 #ifdef IPSX_SCAN_PLAIN_LOADS
@@ -1168,13 +1177,23 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
+    uint32_t* const mkey = pmax;                   // [R] max key of the memory rows, [R] of the chunk rows (see fold_row_max)
+    uint32_t* const ckey = pmax + R;
+    if (tid < 2 * R) pmax[tid] = 0u;
+    lds_barrier();
     SCAN_WAIT_ROWS(std::min<long long>(a.n, a.it0 * a.i + a.m + a.i));
-    for (int k = 0; k < EPT; ++k) {
-        const int l = lrow0 + k * lstep;
-        if (l < a.m) {
-            const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
-            xc[l * ld + r] = scan_load<PERSIST>(lg + row * R + r);
+    {
+        uint32_t km = 0u;
+        for (int k = 0; k < EPT; ++k) {
+            const int l = lrow0 + k * lstep;
+            if (l < a.m) {
+                const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
+                const float v = scan_load<PERSIST>(lg + row * R + r);
+                xc[l * ld + r] = v;
+                km = max(km, max_key(v));
+            }
         }
+        fold_row_max<R>(km, mkey, lane);
     }
     for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
     if (tid < 2) { nanflag[tid] = 0; ccount[2 + tid] = 0; }
@@ -1190,11 +1209,17 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
     {
         const long long lo = a.it0 * a.i + a.m;
         const int cnt = n_iter > 0 ? (int)std::min<long long>(a.i, a.n - lo) : 0;
+        uint32_t kc = 0u;
 #pragma unroll
         for (int k = 0; k < SCAN_PF; ++k) {                    // first chunk: straight into its rows
             const int e = tid + SCAN_NT * k;
-            if (e < cnt * R) xc[(a.m + (e >> log2R)) * ld + r] = scan_load<PERSIST>(lg + (size_t)lo * R + e);
+            if (e < cnt * R) {
+                const float v = scan_load<PERSIST>(lg + (size_t)lo * R + e);
+                xc[(a.m + (e >> log2R)) * ld + r] = v;
+                kc = max(kc, max_key(v));
+            }
         }
+        fold_row_max<R>(kc, ckey, lane);
         for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
         const long long lo1 = lo + a.i;
         const int cnt1 = n_iter > 1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
@@ -1217,43 +1242,14 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         // previous iteration's prep (or by the prologue)
         lds_barrier();
         FAST_STAMP(0);
-        // P1: row maxima.  Own elements, then the lanes that hold the same row (offsets R, 2R, .. 32), then the waves.
-        float xv[EPT];
-        float mx = -__builtin_huge_valf();
-        bool seen_nan = false;
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const int l = lrow0 + k * lstep;
-            xv[k] = l < L ? xc[l * ld + r] : -__builtin_huge_valf();
-        }
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            mx = __builtin_fmaxf(mx, xv[k]);
-            seen_nan = seen_nan || (xv[k] != xv[k]);
-        }
-        for (int off = R; off < 64; off <<= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
-        if (lane < R) pmax[lane * 16 + wave] = as_u32(mx);
-        if (__ballot(seen_nan) != 0ull && lane == 0) nanflag[par] = 1;
+        // P1: row maxima = the larger of the two key words of the row (memory rows: folded in by the previous iteration's
+        // gather; chunk rows: by its prep) - two LDS reads instead of a pass over the rows, a cross-lane and a cross-wave
+        // reduction and a barrier.  The words are cleared after the next barrier, when everybody has read them.
         if (tid == 0) {                                        // (all last read several barriers ago)
-            nanflag[par ^ 1] = 0; ccount[0] = 0; ccount[1] = -1; ccount[2 + (par ^ 1)] = 0;
+            ccount[0] = 0; ccount[1] = -1; ccount[2 + (par ^ 1)] = 0;
         }
-        lds_barrier();
-        uint32_t mbits;
-        if (nanflag[par] == 0) {
-            const float4* pm = reinterpret_cast<const float4*>(pmax + r * 16);
-            const float4 p0 = pm[0], p1 = pm[1], p2 = pm[2], p3 = pm[3];
-            const float m01 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(p0.x, p0.y), __builtin_fmaxf(p0.z, p0.w)),
-                                              __builtin_fmaxf(__builtin_fmaxf(p1.x, p1.y), __builtin_fmaxf(p1.z, p1.w)));
-            const float m23 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(p2.x, p2.y), __builtin_fmaxf(p2.z, p2.w)),
-                                              __builtin_fmaxf(__builtin_fmaxf(p3.x, p3.y), __builtin_fmaxf(p3.z, p3.w)));
-            mbits = as_u32(__builtin_fmaxf(m01, m23));
-        } else {
-            // a NaN somewhere: the contract's maximum lets a NaN win (nanmax).  Exact reduction over order-preserving
-            // keys, every thread over the whole row (rare: nobody optimises this path)
-            uint32_t mk = 0u;
-            for (int l = 0; l < L; ++l) mk = max(mk, max_key(xc[l * ld + r]));
-            mbits = as_u32(max_key_value(mk));
-        }
+        const uint32_t mk = max(mkey[r], ckey[r]);
+        const uint32_t mbits = as_u32(max_key_value(mk));
         const float rowmax = as_float(mbits);
         // the exponentials of the memory rows are those of the previous iteration while the row's maximum is the same
         const bool changed = it == a.it0 || prevk[par * R + r] != mbits;
@@ -1268,7 +1264,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             ev[k] = 0.0f;
             if (l < L) {
                 if (changed || (l >= a.m && !spec_valid)) {
-                    ev[k] = det_expf_np(xv[k] - rowmax);
+                    ev[k] = det_expf_np(xc[l * ld + r] - rowmax);
                     ec[l * ld + r] = ev[k];
                 } else {
                     ev[k] = ec[l * ld + r];
@@ -1276,6 +1272,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             }
         }
         lds_barrier();
+        if (tid < 2 * R) pmax[tid] = 0u;                       // the maxima have been read by everybody: clear for the next folds
         FAST_STAMP(2);
         // P3: softmax denominators in the contract's order: lane j adds rows j, j + 64, ... ascending, xor butterfly
         for (int r0 = wave; r0 < R; r0 += 32) {
@@ -1379,6 +1376,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         {
             const long long lo1 = lo + a.i;
             const int cnt1 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+            uint32_t kc = 0u;
 #pragma unroll
             for (int k = 0; k < SCAN_PF; ++k) {
                 const int e = pt + PFT * k;
@@ -1386,8 +1384,10 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
                     const int row = a.m + (e >> log2R);
                     xn[row * ld + r] = pf[k];
                     en[row * ld + r] = det_expf_np(pf[k] - rowmax);
+                    kc = max(kc, max_key(pf[k]));
                 }
             }
+            if (pt >= 0) fold_row_max<R>(kc, ckey, lane);          // (whole waves: PF0 is a multiple of 64)
             for (int j = tid; j < cnt1; j += SCAN_NT) cnew[a.m + j] = (int)(lo1 + j);
             spec_valid = cnt1 > 0;
             const long long lo2 = lo1 + a.i;
@@ -1453,11 +1453,13 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             float gx[EPT], ge[EPT];
 #pragma unroll
             for (int k = 0; k < EPT; ++k) { gx[k] = xc[src[k]]; ge[k] = ec[src[k]]; }
+            uint32_t km = 0u;
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
                 const int j = lrow0 + k * lstep;
-                if (j < a.m) { xn[j * ld + r] = gx[k]; en[j * ld + r] = ge[k]; }
+                if (j < a.m) { xn[j * ld + r] = gx[k]; en[j * ld + r] = ge[k]; km = max(km, max_key(gx[k])); }
             }
+            fold_row_max<R>(km, mkey, lane);                       // maxima of the NEW memory rows, for the next iteration
         }
         if (tid == 0 && boundary_tie) tie = 1;
         { int* t = cand; cand = cnew; cnew = t; }
