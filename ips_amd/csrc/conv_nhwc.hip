@@ -58,6 +58,17 @@ __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
+// (x - mean) * rstd on four operand values as two packed fp32 pairs (v_pk_add_f32 / v_pk_mul_f32: the same two roundings
+// per element, half the instructions - with one wave per SIMD every VALU instruction is matrix-pipe time)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 norm4(f32x4 v, float mean, float rstd) {
+    const f32x2 m = {mean, mean}, r = {rstd, rstd};
+    f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    lo = (lo - m) * r;
+    hi = (hi - m) * r;
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 template <int NTW>
 __device__ __forceinline__ void nhwc_mma(const NhwcStage<NTW>& st, f32x16 (&acc)[2][NTW]) {
 #pragma unroll
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
 #define SGB_LOAD() __builtin_amdgcn_sched_group_barrier(0x020, 1, 0)
 #define NHWC_STAGE(SL, SM)                                                                  \
     NHWC_ISSUE(SL);                                                                         \
-    if (NORM) { SM.a0 = (SM.a0 - mean0) * rstd0; SM.a1 = (SM.a1 - mean1) * rstd1; }         \
+    if (NORM) { SM.a0 = norm4(SM.a0, mean0, rstd0); SM.a1 = norm4(SM.a1, mean1, rstd1); }   \
     nhwc_mma<NTW>(SM, acc);                                                                 \
     if (NTW == 2) {                                                                         \
         SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(4); \
