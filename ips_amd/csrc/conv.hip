@@ -187,6 +187,18 @@ __global__ __launch_bounds__(256) void conv_any_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // Which taps of a pixel's window lie inside the image, as one bit per kernel row / column (kh, kw <= 31): the bounds
+    // test of an operand element is then two shifts and an AND instead of two adds and two compares - the gather is
+    // VALU-bound (one scalar load per element), and every instruction it saves is matrix-pipe time.
+    unsigned rm0 = 0, cm0 = 0, rm1 = 0, cm1 = 0;
+    for (int t = 0; t < a.kh; ++t) {
+        rm0 |= (p0.valid && (unsigned)(p0.iy0 + t) < (unsigned)a.h) ? (1u << t) : 0u;
+        rm1 |= (p1.valid && (unsigned)(p1.iy0 + t) < (unsigned)a.h) ? (1u << t) : 0u;
+    }
+    for (int t = 0; t < a.kw; ++t) {
+        cm0 |= ((unsigned)(p0.ix0 + t) < (unsigned)a.w) ? (1u << t) : 0u;
+        cm1 |= ((unsigned)(p1.ix0 + t) < (unsigned)a.w) ? (1u << t) : 0u;
+    }
     for (int kg = 0; kg < a.kgs; ++kg) {
         const float4 b0 = *wp0;
         const float4 b1 = n1 ? *wp1 : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -199,10 +211,9 @@ __global__ __launch_bounds__(256) void conv_any_kernel(ConvArgs a) {
         float a0[4], a1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ky = pk[j] & 0xFF, kx = (pk[j] >> 8) & 0xFF;
-            const bool kin = (pk[j] >> 16) != 0;
-            const bool ok0 = kin && p0.valid && (unsigned)(p0.iy0 + ky) < (unsigned)a.h && (unsigned)(p0.ix0 + kx) < (unsigned)a.w;
-            const bool ok1 = kin && p1.valid && (unsigned)(p1.iy0 + ky) < (unsigned)a.h && (unsigned)(p1.ix0 + kx) < (unsigned)a.w;
+            const unsigned ky = (unsigned)pk[j] & 0xFFu, kx = ((unsigned)pk[j] >> 8) & 0xFFu, kin = (unsigned)pk[j] >> 16;
+            const bool ok0 = ((rm0 >> ky) & (cm0 >> kx) & kin) != 0u;
+            const bool ok1 = ((rm1 >> ky) & (cm1 >> kx) & kin) != 0u;
             const float v0 = p0.base[ok0 ? o0 + off[j] : 0], v1 = p1.base[ok1 ? o1 + off[j] : 0];
             a0[j] = ok0 ? v0 : 0.0f;
             a1[j] = ok1 ? v1 : 0.0f;
@@ -301,6 +312,7 @@ int ipsx::conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* r
     if (n == 0) return IPSX_OK;
     const int ho = conv_out(h, cv->kh, cv->stride, cv->pad), wo = conv_out(w, cv->kw, cv->stride, cv->pad);
     IPSX_REQUIRE(ho > 0 && wo > 0, "conv2d_affine: empty output (%dx%d input, %dx%d kernel)", h, w, cv->kh, cv->kw);
+    IPSX_REQUIRE(cv->kh <= 31 && cv->kw <= 31, "conv2d_affine: kernel %dx%d larger than 31x31", cv->kh, cv->kw);
     const int64_t howo = (int64_t)ho * wo;
     // keep every launch below 2^31 output pixels / input elements per image group
     const int64_t per = std::max<int64_t>(1, std::min<int64_t>(n, ((int64_t)1 << 30) / std::max<int64_t>(howo, 1)));
