@@ -367,16 +367,15 @@ __device__ __forceinline__ bool ranked_ties(const uint64_t* sorted, int L, int m
 // the pivot) with the t-th from the right that stops the downward scan (not smaller), for as long as the left one lies
 // before the right one, swaps each pair, and returns where the upward scan stops next - both scans only ever see
 // elements no swap has touched, so the pairs can be read off the ORIGINAL array with two ballots per 64 elements;
-// (2) the final insertion pass of std::sort never moves an element across a partition cut, so every leaf of the
-// introsort loop (<= 16 elements) is insertion-sorted by a lane of its own.  Everything else (median of three, the
+// (2) the final insertion pass of std::sort never moves an element across a partition cut and is a stable sort, so every
+// element of a leaf of the introsort loop (<= 16 elements) finds its place by counting, a lane per element.  Everything else (median of three, the
 // <= 3-element tail of nth_element, the heap fallbacks at depth 0) stays the sequential restatement on lane 0.
 // oracle/check_stdorder.cpp holds this formulation against std:: itself; tests/test_hip_kernels.py holds the device code
 // against the one-lane replay.  One lane took ~600 k cycles for 512 candidates (a quarter of a millisecond - 10 % of a
-// CAMELYON slide for ONE tie among 255 iterations); the wavefront takes ~30 k.
+// CAMELYON slide for ONE tie among 255 iterations); the wavefront takes ~130 k.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int last, int pivot, int* la, int* lb, int lane) {
-    const stdorder::E P = q[pivot];
+__device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int last, const stdorder::E P, int* la, int* lb, int lane) {
     const unsigned long long below = (1ull << lane) - 1ull;
     int na = 0, nb = 0;
     for (int base = first; base < last; base += 64) {                  // ascending: indices that stop the upward scan
@@ -400,24 +399,21 @@ __device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int las
     wave_lds_fence();
     const int np = na < nb ? na : nb;
     int t = 0;                                                         // pairs that are swapped: la[u] < lb[u], a prefix
-    for (int base = 0; base < np; base += 64) {
+    for (int base = 0; base < np; base += 64) {                        // (the pairs are disjoint: swapped as they are found)
         const int u = base + lane;
-        const bool ok = u < np && la[u < np ? u : 0] < lb[u < np ? u : 0];
+        const int i = la[u < np ? u : 0], j = lb[u < np ? u : 0];
+        const bool ok = u < np && i < j;
         const unsigned long long mask = __ballot(ok);
+        if (ok) {
+            const stdorder::E ei = q[i], ej = q[j];
+            q[i] = ej;
+            q[j] = ei;
+        }
         const int valid = np - base < 64 ? np - base : 64;
         const unsigned long long full = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
         if ((mask & full) == full) { t += valid; continue; }
         t += __ffsll((long long)(~mask)) - 1;
         break;
-    }
-    for (int base = 0; base < t; base += 64) {
-        const int u = base + lane;
-        if (u < t) {
-            const int i = la[u], j = lb[u];
-            const stdorder::E ei = q[i], ej = q[j];
-            q[i] = ej;
-            q[j] = ei;
-        }
     }
     const int cut = (t < na && (t == 0 || la[t] < lb[t - 1])) ? la[t] : lb[t - 1];
     wave_lds_fence();
@@ -425,9 +421,17 @@ __device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int las
 }
 
 __device__ __forceinline__ int wave_partition_pivot(stdorder::E* q, int first, int last, int* la, int* lb, int lane) {
-    if (lane == 0) stdorder::move_median_to_first(q, first, first + 1, first + (last - first) / 2, last - 1);
+    // std::__move_median_to_first(first, first + 1, mid, last - 1): the four elements are read at once (one round trip,
+    // every lane the same addresses), the decision is the restatement's, lane 0 does the swap
+    const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+    const stdorder::E er = q[first], ea = q[ia], eb = q[ib], ec = q[ic];
+    int sel;
+    if (stdorder::gt(ea, eb)) sel = stdorder::gt(eb, ec) ? ib : (stdorder::gt(ea, ec) ? ic : ia);
+    else sel = stdorder::gt(ea, ec) ? ia : (stdorder::gt(eb, ec) ? ic : ib);
+    const stdorder::E P = sel == ia ? ea : (sel == ib ? eb : ec);
+    if (lane == 0) { q[first] = P; q[sel] = er; }
     wave_lds_fence();
-    return wave_partition(q, first + 1, last, first, la, lb, lane);
+    return wave_partition(q, first + 1, last, P, la, lb, lane);
 }
 
 // q[0..n) = (score, position) in candidate order on entry; q[0..k) = torch.topk's answer on return.  Called by the 64
@@ -489,25 +493,43 @@ __device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, in
         }
         wave_lds_fence();
     }
-    // every leaf by the lane that owns its first position: linear insertion that stops at the leaf's first element
+    // The final insertion pass, leaf by leaf.  Linear insertion is a STABLE sort (an element moves left past strictly smaller
+    // ones only), so an element's place in its leaf is the number of leaf elements that are greater plus the number of
+    // equivalent ones in front of it: one lane per element counts over its leaf (<= 16 independent reads) instead of one
+    // lane per leaf shifting elements one dependent LDS round trip at a time.  Results go to the list scratch and back.
+    // (A range that ended in the heap sort is a "leaf" of more than 16 elements and already in order: it stays.)
+    E* tmp = reinterpret_cast<E*>(la);                                  // la / lb: 2 n ints = n elements
     for (int base = 0; base < last; base += 64) {
-        const int s = base + lane;
-        if (s < last && ((leaf[s >> 6] >> (s & 63)) & 1ull)) {
+        const int x = base + lane;
+        if (x < last) {
+            const E own = q[x];
+            int w = x >> 6;
+            unsigned long long m = leaf[w] & (~0ull >> (63 - (x & 63)));
+            while (m == 0ull && w > 0) m = leaf[--w];
+            const int sfirst = m ? w * 64 + 63 - __clzll((long long)m) : 0;
             int e = last;
-            unsigned long long rest = (s & 63) == 63 ? 0ull : (leaf[s >> 6] >> ((s & 63) + 1)) << ((s & 63) + 1);
-            for (int w = s >> 6; w < 16; ++w) {
-                if (rest) { e = w * 64 + __ffsll((long long)rest) - 1; break; }
-                rest = w + 1 < 16 ? leaf[w + 1] : 0ull;
-            }
+            w = x >> 6;
+            m = (x & 63) == 63 ? 0ull : (leaf[w] >> ((x & 63) + 1)) << ((x & 63) + 1);
+            while (m == 0ull && w < 15) m = leaf[++w];
+            if (m) e = w * 64 + __ffsll((long long)m) - 1;
             if (e > last) e = last;
-            for (int i = s + 1; i < e; ++i) {
-                const E val = q[i];
-                int j = i;
-                while (j > s && gt(val, q[j - 1])) { q[j] = q[j - 1]; --j; }
-                q[j] = val;
+            int dst = x;
+            if (e - sfirst <= 16) {
+                int rank = 0;
+                for (int j = sfirst; j < e; ++j) {
+                    const E o = q[j];
+                    const bool greater = gt(o, own);
+                    const bool equiv = !greater && !gt(own, o);
+                    rank += (greater || (equiv && j < x)) ? 1 : 0;
+                }
+                dst = sfirst + rank;
             }
+            tmp[dst] = own;
         }
     }
+    wave_lds_fence();
+    for (int base = 0; base < last; base += 64)
+        if (base + lane < last) q[base + lane] = tmp[base + lane];
     wave_lds_fence();
 }
 
@@ -1422,6 +1444,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         if (a.tie_order == 1 && ccount[2 + par] != 0) {
             // torch.topk's order under ties depends on the WHOLE candidate array, so every chunk key goes back to its
             // place, all L candidates are ranked and the replay runs on them (rare)
+            const unsigned long long ts0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const int l = (kt * SCAN_NT + tid) >> log2T;
@@ -1437,7 +1460,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             }
             lds_barrier();
             boundary_tie = L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m]);
+            const unsigned long long ts1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
             tie_order_slow(keyB, keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off));
+            if (STAMP && PERSIST && tid == 0 && b == 0) {
+                stamps[8 * gridDim.x + 2044] = ts1 - ts0;
+                stamps[8 * gridDim.x + 2045] = __builtin_amdgcn_s_memtime() - ts1;
+            }
         }
         if (STAMP && PERSIST && tid == 0 && b == 0 && it < 512) { stamps[8 * gridDim.x + 4 * it + 1] = __builtin_amdgcn_s_memtime() - tlast; stamps[8 * gridDim.x + 4 * it + 2] = __builtin_amdgcn_s_memrealtime(); }
         FAST_STAMP(5);

@@ -42,6 +42,9 @@ if kind == "campipe":
     for col, nme in ((0, "phase 4"), (1, "phase 5")):
         top = np.argsort(-log[:, col])[:8]
         print("   largest %s: " % nme + ", ".join("it %d: %d" % (i, log[i, col]) for i in sorted(top)))
+    raw = st.cpu().numpy()
+    print("   last tie replay: re-ranking all candidates %d cycles, replay (un-sort, wavefront routines, write-back) %d cycles" % (
+        raw[B * 8 + 2044], raw[B * 8 + 2045]))
     t0 = log[0, 2]
     print("   end of phase 5 in us since iteration 0 (100 MHz clock): " + ", ".join("it %d: %.1f" % (i, (log[i, 2] - t0) / 100.0) for i in (1, 10, 30, 36, 37, 38, 46, 47, 60, 100, 139, 140, 200, 254)))
     names = ["stage chunk+barrier", "row maxima", "exp (new rows)", "row sums", "weights+scores+keys (+waits)", "rank", "gather winners"]
