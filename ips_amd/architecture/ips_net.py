@@ -439,10 +439,16 @@ class IPSNet(nn.Module):
             per_part = os.environ.get("IPSX_CAM_STATS", "part") == "part"
             if not per_part:
                 self._plan.row_stats(patches.reshape(B * N, -1), out=self._stats_buf)
+        # persistent loop + statistics per part: the statistics launch of part k + 1 publishes part k (everything before it
+        # in the stream has completed) - one launch and one gap less per part
+        piggy = persistent and stats is not None and per_part and os.environ.get("IPSX_CAM_PIGGYBACK", "1") != "0"
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
             if stats is not None and per_part:
-                self._plan.row_stats(patches[0, lo:hi], out=stats[lo:hi])
+                if piggy and k > 0:
+                    self._plan.row_stats_publish(patches[0, lo:hi], stats[lo:hi], ready, lo)
+                else:
+                    self._plan.row_stats(patches[0, lo:hi], out=stats[lo:hi])
             if indexed:
                 emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
             elif stats is not None:
@@ -453,7 +459,8 @@ class IPSNet(nn.Module):
             pos = pos_enc[:, lo:hi] if self.use_pos else None
             if persistent:
                 hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
-                hip.publish_rows(ready, hi)            # after the kernels that wrote rows [0, hi) of every image
+                if not piggy or k == P - 1:
+                    hip.publish_rows(ready, hi)        # after the kernels that wrote rows [0, hi) of every image
                 continue
             if k == P - 1:
                 # the last part has nothing to run beside: its logits and iterations stay on the main stream (one

@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
 // the two passes (every element is read ONCE, 256 B per wave-instruction), longer rows are re-read.
 constexpr int RS_MAX = 32;
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, long long n, int d, float eps,
-                                                        float2* __restrict__ stats) {
+                                                        float2* __restrict__ stats, int* ready, int value) {
+    // (ipsx_projector_stats_publish: everything enqueued before this launch has completed and is visible - that is what
+    //  the stream order of two kernels means - so the first thread can say so on behalf of a launch of its own)
+    if (ready && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ready, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -245,8 +248,17 @@ using namespace ipsx;
 IPSX_API int ipsx_projector_stats(const float* x, int64_t n, int f, float ln_eps, float* stats, void* stream) {
     IPSX_REQUIRE(x && stats && n >= 0 && f > 0, "projector_stats: bad arguments");
     if (n == 0) return IPSX_OK;
-    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, f, ln_eps, reinterpret_cast<float2*>(stats));
+    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, f, ln_eps, reinterpret_cast<float2*>(stats),
+                                                                                     nullptr, 0);
     return launched("projector row statistics");
+}
+
+IPSX_API int ipsx_projector_stats_publish(const float* x, int64_t n, int f, float ln_eps, float* stats, int32_t* ready,
+                                          int32_t value, void* stream) {
+    IPSX_REQUIRE(x && stats && ready && n > 0 && f > 0, "projector_stats_publish: bad arguments");
+    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, f, ln_eps, reinterpret_cast<float2*>(stats),
+                                                                                     ready, value);
+    return launched("projector row statistics + publish");
 }
 
 IPSX_API int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
