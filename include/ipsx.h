@@ -196,6 +196,8 @@ int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const 
 /* ipsx_projector_stats that also does what ipsx_publish_rows(ready, value) does, at its start: the launches enqueued before
  * it (the logits of the previous slab) have completed, which is all a publication says - one launch less per slab in a
  * pipeline that feeds ipsx_scan_persistent. */
+int ipsx_projector_apply_publish(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
+                                 int32_t* ready, int32_t value, void* stream);      /* the same for the GEMM launch */
 int ipsx_projector_stats_publish(const float* x, int64_t n, int f, float ln_eps, float* stats, int32_t* ready,
                                  int32_t value, void* stream);
 
@@ -276,6 +278,12 @@ int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, in
                          int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
                          int32_t* status, void* stream);
 int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream);
+/* ipsx_logits for rows [0, n) and, in the SAME launch, the LayerNorm row moments (ipsx_projector_stats) of stats_n rows
+ * of stats_x - the next slab the projector is about to take: two short latency-bound launches of a slab-by-slab producer
+ * of ipsx_scan_persistent as one. */
+int ipsx_logits_stats(const float* emb, int64_t emb_bstride, const float* pos, int64_t pos_bstride,
+                      const float* v_packed, int b, int64_t n, int d, int r, float* logits, int64_t logits_bstride,
+                      const float* stats_x, int64_t stats_n, int stats_f, float ln_eps, float* stats_out, void* stream);
 /* holds `stream` (one waiting thread, bounded) until the persistent scan that owns `status` is resident: enqueue it on
  * the producing stream right after launching the scan, so that the producers do not take the compute units first */
 int ipsx_scan_gate(const int32_t* status, void* stream);

@@ -442,9 +442,12 @@ class IPSNet(nn.Module):
         # persistent loop + statistics per part: the statistics launch of part k + 1 publishes part k (everything before it
         # in the stream has completed) - one launch and one gap less per part
         piggy = persistent and stats is not None and per_part and os.environ.get("IPSX_CAM_PIGGYBACK", "1") != "0"
+        # ... and, one step further (two launches per part instead of three): the logits of part k and the statistics of
+        # part k + 1 are one launch, and part k is published by the GEMM launch of part k + 1
+        fused2 = piggy and vq.dtype == torch.float32 and os.environ.get("IPSX_CAM_FUSED2", "1") != "0"
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
-            if stats is not None and per_part:
+            if stats is not None and per_part and not (fused2 and k > 0):
                 if piggy and k > 0:
                     self._plan.row_stats_publish(patches[0, lo:hi], stats[lo:hi], ready, lo)
                 else:
@@ -452,13 +455,18 @@ class IPSNet(nn.Module):
             if indexed:
                 emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
             elif stats is not None:
-                emb = self._plan.encode(patches[0, lo:hi], stats=stats[lo:hi], out=self._emb_buf[0, lo:hi]).view(B, hi - lo, -1)
+                emb = self._plan.encode(patches[0, lo:hi], stats=stats[lo:hi], out=self._emb_buf[0, lo:hi],
+                                        publish=(ready, lo) if (fused2 and k > 0) else None).view(B, hi - lo, -1)
             else:
                 emb = self._embed(patches[:, lo:hi].reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             parts.append(emb)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
             if persistent:
-                hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
+                if fused2 and k + 1 < P:
+                    hip.logits_stats(emb, pos, vq, R, logits[:, lo:hi], patches[0, edges[k + 1]:edges[k + 2]],
+                                     stats[edges[k + 1]:edges[k + 2]], self._plan.ln_eps)
+                else:
+                    hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
                 if not piggy or k == P - 1:
                     hip.publish_rows(ready, hi)        # after the kernels that wrote rows [0, hi) of every image
                 continue

@@ -13,6 +13,7 @@
 
 #include "ipsx_common.h"
 #include "ipsx_math.h"
+#include "ipsx_rowstats.h"
 
 namespace ipsx {
 
@@ -44,7 +45,6 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
 // ascending order + xor butterfly; centred second moment) - for consumers that normalise on the fly
 // (conv_nhwc_kernel<.., NORM>).  One wavefront per row; a row of up to 64 * RS_MAX floats stays in registers between
 // the two passes (every element is read ONCE, 256 B per wave-instruction), longer rows are re-read.
-constexpr int RS_MAX = 32;
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, long long n, int d, float eps,
                                                         float2* __restrict__ stats, int* ready, int value) {
     // (ipsx_projector_stats_publish: everything enqueued before this launch has completed and is visible - that is what
@@ -53,26 +53,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
-    const float* xr = x + (size_t)row * d;
-    float s = 0.0f, q = 0.0f, mean;
-    if (d <= 64 * RS_MAX) {
-        float v[RS_MAX];
-#pragma unroll
-        for (int k = 0; k < RS_MAX; ++k) v[k] = (lane + 64 * k < d) ? xr[lane + 64 * k] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < RS_MAX; ++k) if (lane + 64 * k < d) s = s + v[k];
-        mean = wave_butterfly_sum(s) / (float)d;
-#pragma unroll
-        for (int k = 0; k < RS_MAX; ++k)
-            if (lane + 64 * k < d) { const float c = v[k] - mean; const float c2 = c * c; q = q + c2; }
-    } else {
-        for (int i = lane; i < d; i += 64) s = s + xr[i];
-        mean = wave_butterfly_sum(s) / (float)d;
-        for (int i = lane; i < d; i += 64) { const float c = xr[i] - mean; const float c2 = c * c; q = q + c2; }
-    }
-    const float var = wave_butterfly_sum(q) / (float)d;
-    const float rstd = 1.0f / __builtin_sqrtf(var + eps);
-    if (lane == 0) stats[row] = make_float2(mean, rstd);
+    const float2 st = row_stats_wave(x + (size_t)row * d, d, eps, lane);
+    if (lane == 0) stats[row] = st;
 }
 
 // LayerNorm of a row held in LDS by ONE wavefront (all 64 lanes call it)
@@ -218,7 +200,7 @@ __global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ emb,
 
 // conv_nhwc.hip
 int conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* residual, const float* row_stats, float* y,
-                   int64_t n, int h, int w, int relu, void* stream);
+                   int64_t n, int h, int w, int relu, void* stream, int* ready = nullptr, int ready_value = 0);
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -267,6 +249,13 @@ IPSX_API int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t 
     IPSX_REQUIRE(lin->kh == 1 && lin->kw == 1 && lin->stride == 1 && lin->pad == 0, "projector: lin must be 1x1");
     if (n == 0) return IPSX_OK;
     return conv_nhwc_impl(lin, x, nullptr, stats, out, n, 1, 1, 1, stream);
+}
+
+IPSX_API int ipsx_projector_apply_publish(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
+                                          int32_t* ready, int32_t value, void* stream) {
+    IPSX_REQUIRE(lin && x && out && stats && ready && n > 0, "projector_apply_publish: bad arguments");
+    IPSX_REQUIRE(lin->kh == 1 && lin->kw == 1 && lin->stride == 1 && lin->pad == 0, "projector: lin must be 1x1");
+    return conv_nhwc_impl(lin, x, nullptr, stats, out, n, 1, 1, 1, stream, ready, value);
 }
 
 IPSX_API int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps, float* out,

@@ -47,6 +47,8 @@ struct NhwcArgs {
     int spt;               // stages (k-groups) per tap = c_in / 8
     int kgs;               // packed k-groups per n-tile = kh*kw*c_in / 8
     const float* stats;    // NORM kernels: (mean, rstd) per input row (1x1 convolutions = Linear layers only)
+    int* ready;            // NORM kernels, optional: *ready = ready_value by the first thread (see ipsx_projector_apply_publish)
+    int ready_value;
 };
 
 template <int NTW>
@@ -118,6 +120,8 @@ template <int WM, int WN, bool NORM, int NTW>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int wm = __builtin_amdgcn_readfirstlane(wave % WM), wn = __builtin_amdgcn_readfirstlane(wave / WM);
+    if (NORM && a.ready && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.ready, a.ready_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned m_base = (blockIdx.x * WM + wm) * 64u;
     const int nt0 = (blockIdx.y * WN + wn) * NTW;                   // first of this wave's n-tiles
     if (m_base >= a.m_total || nt0 * 32 >= a.c_out) return;         // wave-uniform
@@ -282,7 +286,7 @@ using namespace ipsx;
 
 namespace ipsx {
 int conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* residual, const float* row_stats, float* y,
-                   int64_t n, int h, int w, int relu, void* stream);
+                   int64_t n, int h, int w, int relu, void* stream, int* ready = nullptr, int ready_value = 0);
 }
 
 IPSX_API int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* residual, float* y,
@@ -292,7 +296,7 @@ IPSX_API int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const 
 
 // row_stats != null: x rows are LayerNorm'ed on the fly ((mean, rstd) per row; 1x1 convolution on 1x1 maps)
 int ipsx::conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* residual, const float* row_stats, float* y,
-                         int64_t n, int h, int w, int relu, void* stream) {
+                         int64_t n, int h, int w, int relu, void* stream, int* ready, int ready_value) {
     IPSX_REQUIRE(cv && cv->w_packed && x && y && n >= 0 && h > 0 && w > 0, "conv2d_affine_nhwc: bad arguments");
     IPSX_REQUIRE(!row_stats || (cv->kh == 1 && cv->kw == 1 && cv->pad == 0 && cv->stride == 1 && h == 1 && w == 1),
                  "conv2d_affine_nhwc: row statistics go with a Linear layer (1x1 convolution on rows)");
@@ -322,6 +326,8 @@ int ipsx::conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* resid
         a.kh = cv->kh; a.kw = cv->kw; a.stride = cv->stride; a.pad = cv->pad; a.relu = relu;
         a.spt = cv->c_in / 8; a.kgs = kgs;
         a.stats = row_stats ? row_stats + (size_t)i0 * 2 : nullptr;
+        a.ready = (row_stats && i0 == 0) ? ready : nullptr;      // (the first launch of the call follows what was enqueued before)
+        a.ready_value = ready_value;
         const unsigned mt64 = (unsigned)cdiv(a.m_total, 64), nt64 = (unsigned)cdiv(cv->c_out, 64);
         hipStream_t s = as_stream(stream);
         const unsigned nt128 = (unsigned)cdiv(cv->c_out, 128);

@@ -24,6 +24,7 @@
 
 #include "ipsx_common.h"
 #include "ipsx_math.h"
+#include "ipsx_rowstats.h"
 #include "ipsx_stdorder.h"
 
 namespace ipsx {
@@ -80,11 +81,10 @@ struct LogitsArgs {
 
 // One wavefront = 32 patches x all H*T logits (NT tiles of 32 columns); 4 wavefronts per workgroup.
 template <int NT>
-__global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
+__device__ __forceinline__ void logits_wave(const LogitsArgs& a, unsigned bx, int bi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-    const long long r0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    const long long r0 = ((long long)bx * 4 + wave) * 32;
     if (r0 >= a.n) return;                                           // wave-uniform
-    const int bi = blockIdx.y;
     const long long row = r0 + (lane & 31);
     const bool rv = row < a.n;
     const float* e = a.emb + (size_t)bi * a.emb_bs + (size_t)(rv ? row : 0) * a.d + 4 * half;
@@ -185,6 +185,24 @@ __global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) {
             }
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void logits_kernel(LogitsArgs a) { logits_wave<NT>(a, blockIdx.x, (int)blockIdx.y); }
+
+// The same logits and, in the same launch (workgroups beyond the logits'), the LayerNorm row moments of the NEXT slab of
+// feature rows: two short, latency-bound kernels of the CAMELYON pipeline that sat one after the other between two GEMM
+// parts.  No publication in here (a device-wide release per workgroup costs more than the launch it would save: the next
+// launch in the stream publishes, ipsx_projector_apply_publish).
+template <int NT>
+__global__ __launch_bounds__(256) void logits_stats_kernel(LogitsArgs a, unsigned n_logits_x, const float* __restrict__ sx,
+                                                           long long sn, int sf, float eps, float2* __restrict__ sout) {
+    if (blockIdx.x < n_logits_x) { logits_wave<NT>(a, blockIdx.x, (int)blockIdx.y); return; }
+    if (blockIdx.y != 0) return;
+    const long long row = (long long)(blockIdx.x - n_logits_x) * 4 + (threadIdx.x >> 6);
+    if (row >= sn) return;
+    const float2 st = row_stats_wave(sx + (size_t)row * sf, sf, eps, threadIdx.x & 63);
+    if ((threadIdx.x & 63) == 0) sout[row] = st;
 }
 
 // ---- the same logits on the bf16 matrix pipe (BASELINE configs[4]: "MFMA bf16/fp16 QK^T path").  x = emb (+ pos)
@@ -1618,6 +1636,30 @@ IPSX_API int ipsx_logits(const float* emb, int64_t emb_bstride, const float* pos
     a.kgs = (int)cdiv(d, 8);
     a.out = logits; a.out_bs = logits_bstride;
     return launch_logits(a, b, as_stream(stream));
+}
+
+IPSX_API int ipsx_logits_stats(const float* emb, int64_t emb_bstride, const float* pos, int64_t pos_bstride,
+                               const float* v_packed, int b, int64_t n, int d, int r, float* logits, int64_t logits_bstride,
+                               const float* stats_x, int64_t stats_n, int stats_f, float ln_eps, float* stats_out,
+                               void* stream) {
+    IPSX_REQUIRE(emb && v_packed && logits && stats_x && stats_out, "logits_stats: null pointer");
+    IPSX_REQUIRE(b > 0 && n > 0 && d > 0 && r > 0 && stats_n > 0 && stats_f > 0, "logits_stats: bad sizes");
+    LogitsArgs a;
+    a.emb = emb; a.emb_bs = emb_bstride; a.pos = pos; a.pos_bs = pos_bstride;
+    a.vp = v_packed; a.n = n; a.d = d; a.R = r;
+    a.kgs = (int)cdiv(d, 8);
+    a.out = logits; a.out_bs = logits_bstride;
+    const unsigned nlx = (unsigned)cdiv(n, 128);
+    const int nt = (r + 31) / 32;
+    IPSX_REQUIRE(nt <= 8, "logits_stats: H * n_token = %d > 256 not supported", r);
+    dim3 grid(nlx + (unsigned)cdiv(stats_n, 4), (unsigned)b);
+    hipStream_t s = as_stream(stream);
+    float2* so = reinterpret_cast<float2*>(stats_out);
+    if (nt == 1) logits_stats_kernel<1><<<grid, dim3(256), 0, s>>>(a, nlx, stats_x, stats_n, stats_f, ln_eps, so);
+    else if (nt == 2) logits_stats_kernel<2><<<grid, dim3(256), 0, s>>>(a, nlx, stats_x, stats_n, stats_f, ln_eps, so);
+    else if (nt <= 4) logits_stats_kernel<4><<<grid, dim3(256), 0, s>>>(a, nlx, stats_x, stats_n, stats_f, ln_eps, so);
+    else logits_stats_kernel<8><<<grid, dim3(256), 0, s>>>(a, nlx, stats_x, stats_n, stats_f, ln_eps, so);
+    return launched("logits_stats");
 }
 
 IPSX_API size_t ipsx_folded_query_bf16_bytes(int h, int n_token, int d) {

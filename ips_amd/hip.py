@@ -167,6 +167,11 @@ _EXPORTS = {
     "ipsx_projector_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "ipsx_projector_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "ipsx_projector_apply": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_projector_apply_publish": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int32, C.c_void_p]),
+    "ipsx_logits_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "ipsx_projector_stats_publish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
                                                C.c_void_p]),
     "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
@@ -491,11 +496,12 @@ class EncoderPlan:
             "ipsx_projector_stats")
         return out
 
-    def encode(self, x, nonblank=None, stats=None, out=None):
+    def encode(self, x, nonblank=None, stats=None, out=None, publish=None):
         """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D).
 
         ``nonblank`` (P int32, 1 = the patch has a non-zero element; e.g. from ``patchify_sparse``) switches on
-        the exact blank-patch dedup without the pass that looks for blank patches."""
+        the exact blank-patch dedup without the pass that looks for blank patches.  ``publish`` = (ready, value), with
+        ``stats``: the GEMM launch also does ``publish_rows(ready, value)`` for what was enqueued before it."""
         self._refresh()
         x = _patches(x) if self.is_image else _f32(x)
         n = x.shape[0]
@@ -544,7 +550,11 @@ class EncoderPlan:
         elif stats is not None:
             if stats.shape != (n, 2) or stats.dtype != torch.float32 or not stats.is_contiguous():
                 raise ValueError("stats must be a contiguous (P, 2) float32 tensor")
-            _ck(lib().ipsx_projector_apply(C.byref(self.lin), _p(x), n, _p(stats), _p(out), _stream()), "ipsx_projector_apply")
+            if publish is not None:
+                _ck(lib().ipsx_projector_apply_publish(C.byref(self.lin), _p(x), n, _p(stats), _p(out), _p(publish[0]),
+                                                       int(publish[1]), _stream()), "ipsx_projector_apply_publish")
+            else:
+                _ck(lib().ipsx_projector_apply(C.byref(self.lin), _p(x), n, _p(stats), _p(out), _stream()), "ipsx_projector_apply")
         else:
             nb = lib().ipsx_projector_workspace_bytes(n)
             ws = self._workspace(nb, x.device)
@@ -617,6 +627,27 @@ def logits(emb, pos, vq, R, out=None):
         return out
     _ck(lib().ipsx_logits(_p(emb), n * D, _p(pos), pos_bs, _p(vq), B, n, D, R, _p(out), out.stride(0), _stream()),
         "ipsx_logits")
+    return out
+
+
+def logits_stats(emb, pos, vq, R, out, stats_x, stats_out, ln_eps):
+    """``logits(emb, pos, vq, R, out)`` and, in the same launch, the LayerNorm row moments of ``stats_x`` (P, F) into
+    ``stats_out`` (P, 2).  fp32 folded query only."""
+    B, n, D = emb.shape
+    emb = _f32(emb)
+    if out.stride(2) != 1 or out.stride(1) != R:
+        raise ValueError("logits output must be row-contiguous")
+    pos_bs = 0
+    if pos is not None:
+        if pos.stride(2) != 1 or pos.stride(1) != D:
+            pos = pos.contiguous()
+        pos_bs = pos.stride(0) if pos.shape[0] > 1 else 0
+    stats_x = _f32(stats_x)
+    sn, sf = stats_x.shape
+    if tuple(stats_out.shape) != (sn, 2) or stats_out.dtype != torch.float32 or not stats_out.is_contiguous():
+        raise ValueError("stats_out must be a contiguous (P, 2) float32 tensor")
+    _ck(lib().ipsx_logits_stats(_p(emb), n * D, _p(pos), pos_bs, _p(vq), B, n, D, R, _p(out), out.stride(0),
+                                _p(stats_x), sn, sf, C.c_float(ln_eps), _p(stats_out), _stream()), "ipsx_logits_stats")
     return out
 
 
