@@ -1139,12 +1139,8 @@ __device__ __forceinline__ void fold_row_max(uint32_t key, uint32_t* dst, int la
 
 template <bool PERSIST>
 __device__ __forceinline__ float scan_load(const float* p) {
-#ifdef IPSX_SCAN_PLAIN_LOADS
-    return *p;
-#else
     if (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
-#endif
 }
 
 template <int R, int T, int EPT, int LCH, bool STAMP, bool PERSIST>
