@@ -510,3 +510,24 @@ def test_every_variant_of_the_feature_pipeline_selects_the_same_patches(B, N, mo
             monkeypatch.delenv(k)
     for name, idx in res.items():
         assert torch.equal(idx, res["after"]), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conf_fn,patch,n", [(synth.mnist_conf, 50, 2100), (synth.traffic_conf, 100, 1100)])
+def test_layered_trunk_on_two_streams_gives_the_same_bits(conf_fn, patch, n, monkeypatch):
+    """EncoderPlan.encode_plain sends the batch through the layer-by-layer trunk in two halves on two streams (default)
+    or in one piece (IPSX_LAYERED_STREAMS=1): the same kernels on the same patches, so the embeddings are bit-identical -
+    also across repeated calls (the halves share one workspace buffer)."""
+    dev = torch.device("cuda:0")
+    conf = conf_fn(N=64, M=8, I=8, patch=patch)
+    net = synth.fill_weights(IPSNet(dev, conf), 11).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = torch.rand((n, conf.n_chan_in, patch, patch), generator=g).to(dev)
+    plan = hip.EncoderPlan(net.encoder, True)
+    assert not plan.fused(x.shape)
+    two = [plan.encode(x).clone() for _ in range(3)]
+    monkeypatch.setenv("IPSX_LAYERED_STREAMS", "1")
+    one = plan.encode(x)
+    torch.cuda.synchronize()
+    for t in two:
+        assert torch.equal(t, one)
