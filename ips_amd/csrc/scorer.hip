@@ -1137,6 +1137,12 @@ __device__ __forceinline__ void fold_row_max(uint32_t key, uint32_t* dst, int la
     if (lane < R && key != 0u) atomicMax(dst + lane, key);
 }
 
+// exp(x - max) down one column of the candidate buffers (row stride ld), an element per thread; not inlined: it runs in
+// the minority of iterations, and inlined its registers are the loop's (the same lesson as tie_order_slow)
+__device__ __attribute__((noinline)) void exp_column(const float* xcol, float* ecol, int L, int ld, float mx) {
+    for (int l = threadIdx.x; l < L; l += blockDim.x) ecol[l * ld] = det_expf_np(xcol[l * ld] - mx);
+}
+
 template <bool PERSIST>
 __device__ __forceinline__ float scan_load(const float* p) {
     if (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1266,7 +1272,6 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             pf[k] = (pt >= 0 && e < cnt1 * R) ? scan_load<PERSIST>(lg + (size_t)lo1 * R + e) : 0.0f;
         }
     }
-    bool spec_valid = false;                                   // the chunk rows of `ec` hold exponentials under prevk's maxima
     int tie = 0;
     uint64_t* const sorted = keyB;
     for (long long it = a.it0; it < a.it1; ++it) {
@@ -1291,20 +1296,16 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         const bool changed = it == a.it0 || prevk[par * R + r] != mbits;
         if (tid < R) prevk[(par ^ 1) * R + r] = mbits;
         FAST_STAMP(1);
-        // P2: exp(x - max) where it is new: every row whose maximum moved; the chunk rows only when the prep's speculation
-        // (same maxima as last iteration) does not hold or has not happened (first iteration of a launch)
-        float ev[EPT];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const int l = lrow0 + k * lstep;
-            ev[k] = 0.0f;
-            if (l < L) {
-                if (changed || (l >= a.m && !spec_valid)) {
-                    ev[k] = det_expf_np(xc[l * ld + r] - rowmax);
-                    ec[l * ld + r] = ev[k];
-                } else {
-                    ev[k] = ec[l * ld + r];
-                }
+        // P2: exp(x - max) where it is new: the whole column of every row r whose maximum moved (that includes the chunk
+        // rows, whose speculative exponentials were taken under the old maximum; at the first iteration of a launch every
+        // column).  A column is L elements: one per thread of the first L threads, all lanes busy - done by the thread
+        // that owns the element instead, the lanes of the unchanged rows idle through every exp (7 of 8, on all 16 waves).
+        {
+            unsigned long long moved = __ballot(changed) & (R == 64 ? ~0ull : ((1ull << R) - 1ull));   // lane r < R holds row r
+            while (moved) {
+                const int rr = __ffsll((long long)moved) - 1;
+                moved &= moved - 1ull;
+                exp_column(xc + rr, ec + rr, L, ld, __shfl(rowmax, rr, 64));
             }
         }
         lds_barrier();
@@ -1333,6 +1334,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         // (candidate, token) adds its H weights in ascending head order and the T lanes of a candidate their tokens
         {
             const float den = rden[r];
+            float ev[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {                      // (all reads in flight before the first division)
+                const int l = lrow0 + k * lstep;
+                ev[k] = l < L ? ec[l * ld + r] : 0.0f;
+            }
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
                 const int l = lrow0 + k * lstep;
@@ -1425,7 +1432,6 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             }
             if (pt >= 0) fold_row_max<R>(kc, ckey, lane);          // (whole waves: PF0 is a multiple of 64)
             for (int j = tid; j < cnt1; j += SCAN_NT) cnew[a.m + j] = (int)(lo1 + j);
-            spec_valid = cnt1 > 0;
             const long long lo2 = lo1 + a.i;
             const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
             if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
