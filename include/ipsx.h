@@ -258,14 +258,21 @@ int ipsx_set_tie_order(int mode);
  * straddling a top-m boundary had bit-equal scores (the reference's own order is
  * then implementation-defined, ips_net.py:199).                               */
 int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
-              int64_t* mem_idx, float* mem_score, int32_t* tie_flag, void* stream);
+              int64_t* mem_idx, float* mem_score, int32_t* tie_flag,
+              void* workspace, size_t workspace_bytes, void* stream);
+
+/* Candidate sets that do not fit one compute unit's LDS - m + i above ~4,000, up to 16,384; the reference's shipped
+ * CAMELYON configuration is m = i = 5000 (config/camelyon_config.yml:35-36, torch.topk over 10,000 candidates,
+ * ips_net.py:148) - keep only the ranking in LDS and need a caller-owned device workspace of this many bytes (0 = none
+ * needed, workspace may be NULL).  ipsx_scan / ipsx_scan_range return IPSX_EWORKSPACE when it is missing or too small. */
+size_t ipsx_scan_workspace_bytes(int b, int m, int i, int h, int n_token);
 
 /* Iterations [it_begin, it_end) of the same loop.  it_begin = 0 starts from the first m patches, it_begin > 0
  * resumes from the state a previous call left in mem_idx; only logits rows below m + it_end*i are read, so a
  * range can run (on another stream) while later patches are still being encoded.  tie_flag is only ever SET.  */
 int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                     int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
-                    int32_t* tie_flag, void* stream);
+                    int32_t* tie_flag, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The whole loop as ONE launch that may start before any logits exist (overlap with the encoder without re-launching
  * per part): the kernel waits until *ready (device int32, written with ipsx_publish_rows on another stream after the
@@ -296,9 +303,11 @@ int ipsx_scores(const float* x, const float* wk_packed, const float* qs,
                 void* stream);
 size_t ipsx_scores_workspace_bytes(int b, int l, int d, int h, int n_token);
 
-/* torch.topk(scores, m, dim=-1)[1] (ips_net.py:148): (b,l) -> (b,m) int64 */
+/* torch.topk(scores, m, dim=-1)[1] (ips_net.py:148): (b,l) -> (b,m) int64, l <= 16,384.  Rows beyond the LDS
+ * (l above ~8,000) need ipsx_topm_workspace_bytes(b, l, m) bytes of device workspace (0 = none, NULL allowed). */
 int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_idx,
-              int32_t* tie_flag, void* stream);
+              int32_t* tie_flag, void* workspace, size_t workspace_bytes, void* stream);
+size_t ipsx_topm_workspace_bytes(int b, int l, int m);
 
 /* ------------------------------------------------------------------- gather
  * Replaces the torch.gather calls of ips_net.py:245-250: dst[b][j] = src[b][idx[b][j]]

@@ -268,7 +268,8 @@ class IPSNet(nn.Module):
             side, main = self._side_stream, torch.cuda.current_stream(dev)
             mem_idx = torch.empty((B, self.M), dtype=torch.int64, device=dev)
             tie = torch.zeros((B,), dtype=torch.int32, device=dev)
-            for t in (logits, mem_idx, tie):
+            scan_ws = hip.scan_workspace(B, self.M, self.I, ca.H, ca.n_token, dev)     # None unless M + I exceeds the LDS
+            for t in (logits, mem_idx, tie) + ((scan_ws,) if scan_ws is not None else ()):
                 t.record_stream(side)
             side.wait_stream(main)
             it_prev = 0
@@ -286,7 +287,7 @@ class IPSNet(nn.Module):
                     done.record(main)
                     with torch.cuda.stream(side):
                         side.wait_event(done)
-                        hip.scan_range(logits, self.M, self.I, ca.H, ca.n_token, it_prev, it_k, mem_idx, tie)
+                        hip.scan_range(logits, self.M, self.I, ca.H, ca.n_token, it_prev, it_k, mem_idx, tie, scan_ws)
                     it_prev = it_k
         self._emb_parts = parts
         if beside:
@@ -382,16 +383,18 @@ class IPSNet(nn.Module):
         # per-call device buffers are kept between calls of the same shape: a buffer that another stream has used cannot be
         # re-used by the allocator until that stream's work is known to be over, and allocating afresh in every call makes
         # the host stall in hipMalloc now and then
-        bkey = (B, N, M, R, str(dev))
+        bkey = (B, N, M, I, R, str(dev))
         if getattr(self, "_scan_bufs_key", None) != bkey:
             self._scan_bufs = (torch.empty((B, N, R), dtype=torch.float32, device=dev),
                                torch.empty((B, M), dtype=torch.int64, device=dev),
                                torch.zeros((B,), dtype=torch.int32, device=dev),
-                               torch.zeros((2,), dtype=torch.int32, device=dev))
+                               torch.zeros((2,), dtype=torch.int32, device=dev),
+                               hip.scan_workspace(B, M, I, ca.H, ca.n_token, dev))   # None unless M + I exceeds the LDS
             self._scan_bufs_key = bkey
             for t in self._scan_bufs:
-                t.record_stream(side)
-        logits, mem_idx_buf, tie, words = self._scan_bufs
+                if t is not None:
+                    t.record_stream(side)
+        logits, mem_idx_buf, tie, words, scan_ws = self._scan_bufs
         tie.zero_()
         self._emb_parts = parts = []
         # Feature inputs, few slides (the loop is the long pole and each slide occupies ONE compute unit in it): the loop
@@ -475,7 +478,7 @@ class IPSNet(nn.Module):
                 # cross-stream hand-over less on the critical path; it only has to follow the side stream's earlier parts)
                 main.wait_stream(side)
                 hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
-                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie)
+                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie, scan_ws)
                 continue
             # logits and loop of this part on the side stream: the main stream goes straight on to the next part's encoder
             done = torch.cuda.Event()
@@ -484,7 +487,7 @@ class IPSNet(nn.Module):
             with torch.cuda.stream(side):
                 side.wait_event(done)
                 hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
-                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie)
+                hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie, scan_ws)
         main.wait_stream(side)
         if persistent:
             if getattr(self, "_scan_status_host", None) is None:

@@ -393,6 +393,20 @@ __device__ __forceinline__ bool ranked_ties(const uint64_t* sorted, int L, int m
 // CAMELYON slide for ONE tie among 255 iterations); the wavefront takes ~130 k.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// GL = the index lists la / lb live in GLOBAL memory (candidate sets beyond the LDS, scan_large_kernel): what one lane
+// wrote there must be visible to the lane that reads it next - a workgroup-scope fence (the lists never leave the
+// compute unit's L1 / its write-through path) on top of the LDS wait.  q stays in LDS either way.
+template <bool GL>
+__device__ __forceinline__ void wave_fence() {
+    if (GL) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+        wave_lds_fence();
+    }
+}
+
+template <bool GL>
 __device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int last, const stdorder::E P, int* la, int* lb, int lane) {
     const unsigned long long below = (1ull << lane) - 1ull;
     int na = 0, nb = 0;
@@ -414,7 +428,7 @@ __device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int las
         if (stop) lb[nb + __popcll(mask & below)] = x;
         nb += __popcll(mask);
     }
-    wave_lds_fence();
+    wave_fence<GL>();
     const int np = na < nb ? na : nb;
     int t = 0;                                                         // pairs that are swapped: la[u] < lb[u], a prefix
     for (int base = 0; base < np; base += 64) {                        // (the pairs are disjoint: swapped as they are found)
@@ -434,10 +448,11 @@ __device__ __forceinline__ int wave_partition(stdorder::E* q, int first, int las
         break;
     }
     const int cut = (t < na && (t == 0 || la[t] < lb[t - 1])) ? la[t] : lb[t - 1];
-    wave_lds_fence();
+    wave_fence<GL>();
     return cut;
 }
 
+template <bool GL>
 __device__ __forceinline__ int wave_partition_pivot(stdorder::E* q, int first, int last, int* la, int* lb, int lane) {
     // std::__move_median_to_first(first, first + 1, mid, last - 1): the four elements are read at once (one round trip,
     // every lane the same addresses), the decision is the restatement's, lane 0 does the swap
@@ -448,18 +463,22 @@ __device__ __forceinline__ int wave_partition_pivot(stdorder::E* q, int first, i
     else sel = stdorder::gt(ea, ec) ? ia : (stdorder::gt(eb, ec) ? ic : ib);
     const stdorder::E P = sel == ia ? ea : (sel == ib ? eb : ec);
     if (lane == 0) { q[first] = P; q[sel] = er; }
-    wave_lds_fence();
-    return wave_partition(q, first + 1, last, P, la, lb, lane);
+    wave_fence<GL>();
+    return wave_partition<GL>(q, first + 1, last, P, la, lb, lane);
 }
 
 // q[0..n) = (score, position) in candidate order on entry; q[0..k) = torch.topk's answer on return.  Called by the 64
-// lanes of ONE wavefront.  la / lb: n ints each; stk: 3 * STACK_RANGES ints (ranges below, leaf bitmap in its upper third).
-__device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, int* la, int* lb, int* stk, int lane) {
+// lanes of ONE wavefront.  la / lb: n ints each (lb = la + n: the two together are the n-element scratch of the last
+// pass); stk: 2 * STACK_RANGES ints of pending ranges + the leaf bitmap `leaf` of `leaf_words` 64-bit words (n <= 64 *
+// leaf_words, else one lane runs the sequential restatement).
+template <bool GL>
+__device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, int* la, int* lb, int* stk,
+                                                unsigned long long* leaf, int leaf_words, int lane) {
     using namespace stdorder;
     if (k <= 0 || n <= 0) return;
-    if ((long long)k * 64 <= (long long)n || n > 1024) {               // heap select / sort, or beyond the leaf bitmap
+    if ((long long)k * 64 <= (long long)n || n > 64 * leaf_words) {    // heap select / sort, or beyond the leaf bitmap
         if (lane == 0) torch_topk(q, n, k, stk);
-        wave_lds_fence();
+        wave_fence<GL>();
         return;
     }
     {   // std::nth_element(q, q + k - 1, q + n)
@@ -474,34 +493,33 @@ __device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, in
                 break;
             }
             --depth;
-            const int cut = wave_partition_pivot(q, first, last, la, lb, lane);
+            const int cut = wave_partition_pivot<GL>(q, first, last, la, lb, lane);
             if (cut <= nth) first = cut;
             else last = cut;
         }
         if (!done && lane == 0) insertion_sort(q, first, last);
-        wave_lds_fence();
+        wave_fence<GL>();
     }
     const int last = k - 1;                                            // std::sort(q, q + k - 1)
     if (last <= 0) return;
-    unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 2 * STACK_RANGES);     // 1024 bits
-    if (lane < 16) leaf[lane] = 0ull;
-    wave_lds_fence();
+    for (int w = lane; w < leaf_words; w += 64) leaf[w] = 0ull;
+    wave_fence<GL>();
     int sp = 1;
     if (lane == 0) { stk[0] = 0; stk[1] = last; stk[2] = lg2(last) * 2; }
-    wave_lds_fence();
+    wave_fence<GL>();
     while (sp > 0) {
         --sp;
         int rf = stk[3 * sp], rl = stk[3 * sp + 1], depth = stk[3 * sp + 2];
         while (rl - rf > 16) {
             if (depth == 0) {
                 if (lane == 0) { make_heap(q, rf, rl); sort_heap(q, rf, rl); }
-                wave_lds_fence();
+                wave_fence<GL>();
                 break;
             }
             --depth;
-            const int cut = wave_partition_pivot(q, rf, rl, la, lb, lane);
+            const int cut = wave_partition_pivot<GL>(q, rf, rl, la, lb, lane);
             if (lane == 0) { stk[3 * sp] = cut; stk[3 * sp + 1] = rl; stk[3 * sp + 2] = depth; }
-            wave_lds_fence();
+            wave_fence<GL>();
             ++sp;
             rl = cut;
         }
@@ -509,7 +527,7 @@ __device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, in
             leaf[rf >> 6] |= 1ull << (rf & 63);
             if (rl < last) leaf[rl >> 6] |= 1ull << (rl & 63);
         }
-        wave_lds_fence();
+        wave_fence<GL>();
     }
     // The final insertion pass, leaf by leaf.  Linear insertion is a STABLE sort (an element moves left past strictly smaller
     // ones only), so an element's place in its leaf is the number of leaf elements that are greater plus the number of
@@ -528,7 +546,7 @@ __device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, in
             int e = last;
             w = x >> 6;
             m = (x & 63) == 63 ? 0ull : (leaf[w] >> ((x & 63) + 1)) << ((x & 63) + 1);
-            while (m == 0ull && w < 15) m = leaf[++w];
+            while (m == 0ull && w < leaf_words - 1) m = leaf[++w];
             if (m) e = w * 64 + __ffsll((long long)m) - 1;
             if (e > last) e = last;
             int dst = x;
@@ -545,10 +563,10 @@ __device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, in
             tmp[dst] = own;
         }
     }
-    wave_lds_fence();
+    wave_fence<GL>();
     for (int base = 0; base < last; base += 64)
         if (base + lane < last) q[base + lane] = tmp[base + lane];
-    wave_lds_fence();
+    wave_fence<GL>();
 }
 
 // sorted and other are the two key arrays (>= L entries each); all threads of the workgroup call this together.
@@ -565,7 +583,7 @@ __device__ __forceinline__ void torch_tie_order(uint64_t* sorted, uint64_t* othe
     __syncthreads();
     if (tid < 64) {
         int* la = reinterpret_cast<int*>(sorted);
-        torch_topk_wave(q, L, m, la, la + L, stk, tid);
+        torch_topk_wave<false>(q, L, m, la, la + L, stk, reinterpret_cast<unsigned long long*>(stk + 2 * stdorder::STACK_RANGES), 16, tid);
     }
     __syncthreads();
     for (int j = tid; j < m; j += NT) sorted[j] = rank_key(q[j].v, (uint32_t)q[j].i);
@@ -1582,6 +1600,246 @@ __global__ __launch_bounds__(256) void topm_kernel(TopmArgs a) {
     for (int j = tid; j < a.m; j += 256) a.top[(size_t)b * a.m + j] = key_pos(sorted[j]);
 }
 
+// ------------------------------------------------------------------ candidate sets beyond one compute unit's LDS
+// The reference's shipped CAMELYON configuration keeps M = 5000 patches and scores them against I = 5000 new ones
+// (config/camelyon_config.yml:35-36): torch.topk ranks L = 10,000 candidates per iteration (ips_net.py:148), a few
+// iterations per slide.  Here that is one 1024-thread workgroup per image again, but only the RANKING lives in LDS
+// (one array of next_pow2(L) 64-bit keys, L <= 16,384: 128 KiB); everything else goes through a caller-owned workspace
+// in global memory that stays in the L2: the candidates' logits staged TRANSPOSED ([row][candidate], so that the
+// row-wise passes of the contract - maximum, exponentials, the wave-ordered sum - are coalesced) and the index lists
+// of the tie replay.  Same arithmetic, same order of every sum as scan_kernel and the oracle.
+constexpr int LARGE_NT = 1024;
+constexpr int LARGE_MAX_L = 16384;
+constexpr int LARGE_KPT = LARGE_MAX_L / LARGE_NT;              // keys / memory slots a thread may hold in registers
+constexpr int LARGE_LEAF_WORDS = LARGE_MAX_L / 64;
+
+// bitonic merge of a 64-key block held one key per lane (the strides 32 ... 1 of a level of the network)
+__device__ __forceinline__ uint64_t merge64(uint64_t key, int lane, bool desc) {
+#define IPSX_MERGE_STEP(J)                                             \
+    do {                                                               \
+        const uint64_t other = xor_partner<J>(key, lane);              \
+        const bool take_max = desc == ((lane & J) == 0);               \
+        key = (take_max == (key > other)) ? key : other;               \
+    } while (0)
+    IPSX_MERGE_STEP(32); IPSX_MERGE_STEP(16); IPSX_MERGE_STEP(8); IPSX_MERGE_STEP(4); IPSX_MERGE_STEP(2); IPSX_MERGE_STEP(1);
+#undef IPSX_MERGE_STEP
+    return key;
+}
+
+// keys[0, n2) (n2 a power of two >= 64, padding keys 0) sorted descending in place, by the LARGE_NT threads of the
+// workgroup.  Bitonic network; the levels up to 64 and the strides below 64 of every later level run in registers (a
+// 64-key block per wavefront, cross-lane), only the strides >= 64 exchange through LDS.  Keys are unique.
+__device__ __forceinline__ void sort_desc_large(uint64_t* keys, int n2) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = n2 >> 6;
+    for (int blk = wave; blk < nblk; blk += LARGE_NT / 64) {           // runs of 64; odd runs ascending (stored reversed)
+        const uint64_t k = wave_sort_desc(keys[blk * 64 + lane], lane);
+        keys[blk * 64 + ((blk & 1) ? 63 - lane : lane)] = k;
+    }
+    for (int k = 128; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j >= 64; j >>= 1) {
+            __syncthreads();
+            for (int p = tid; p < (n2 >> 1); p += LARGE_NT) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const uint64_t x = keys[i], y = keys[i | j];
+                const bool desc = (i & k) == 0;
+                if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[i | j] = x; }
+            }
+        }
+        __syncthreads();
+        for (int blk = wave; blk < nblk; blk += LARGE_NT / 64)
+            keys[blk * 64 + lane] = merge64(keys[blk * 64 + lane], lane, ((blk * 64) & k) == 0);
+    }
+    __syncthreads();
+}
+
+// keys = the L ranked keys (canonical order) in LDS.  When two of the first m + 1 ranked scores are equal and the tie
+// order is the reference's, the key array is turned - through registers, in place - into the (score, position) pairs in
+// CANDIDATE order and torch.topk's routines are replayed on them (one wavefront; the index lists in the workspace); q[0, m)
+// is then the answer.  Returns whether that happened (workgroup-uniform).  All threads; contains barriers.
+__device__ __forceinline__ bool large_tie_replay(uint64_t* keys, int L, int m, int tie_order, int* lists, int* stk,
+                                                 unsigned long long* leaf) {
+    const int tid = threadIdx.x;
+    if (tie_order != 1 || !ranked_ties(keys, L, m, tid & 63)) return false;
+    uint64_t hold[LARGE_KPT];
+#pragma unroll
+    for (int s = 0; s < LARGE_KPT; ++s) {
+        const int j = tid + s * LARGE_NT;
+        hold[s] = j < L ? keys[j] : 0ull;
+    }
+    __syncthreads();
+    stdorder::E* q = reinterpret_cast<stdorder::E*>(keys);
+#pragma unroll
+    for (int s = 0; s < LARGE_KPT; ++s) {
+        const int j = tid + s * LARGE_NT;
+        if (j < L) {
+            const int p = (int)key_pos(hold[s]);
+            q[p].v = key_score(hold[s]);
+            q[p].i = p;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) torch_topk_wave<true>(q, L, m, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, tid);
+    __syncthreads();
+    return true;
+}
+
+struct LargeArgs {
+    int tie_order;
+    const float* lg;       // (b, n, R)
+    long long n;
+    long long it0, it1;
+    int m, i, h, T, n2, Lp;
+    long long* mem_idx;
+    float* mem_score;
+    int* tie;
+    unsigned char* ws;     // per image: R * Lp floats (staged logits / exponentials) + 2 * Lp ints (tie replay lists)
+    size_t ws_per_image;
+};
+
+static size_t large_lds_bytes(int n2, int R) {
+    return (size_t)n2 * 8 + (size_t)R * 8 + (size_t)3 * stdorder::STACK_RANGES * 4 + (size_t)LARGE_LEAF_WORDS * 8;
+}
+
+__global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = a.h * a.T, Lp = a.Lp, m = a.m;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    float* rmax = reinterpret_cast<float*>(keys + a.n2);
+    float* rden = rmax + R;
+    int* stk = reinterpret_cast<int*>(rden + R);
+    unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 3 * stdorder::STACK_RANGES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const float* lg = a.lg + (size_t)b * a.n * R;
+    long long* mem = a.mem_idx + (size_t)b * m;
+    float* xT = reinterpret_cast<float*>(a.ws + (size_t)b * a.ws_per_image);
+    int* lists = reinterpret_cast<int*>(xT + (size_t)R * Lp);
+    if (a.it0 == 0)
+        for (int j = tid; j < m; j += LARGE_NT) mem[j] = j;
+    __syncthreads();
+    int tie = 0;
+    float last_score[LARGE_KPT];
+#pragma unroll
+    for (int s = 0; s < LARGE_KPT; ++s) last_score[s] = 0.0f;
+    for (long long it = a.it0; it < a.it1; ++it) {
+        const long long lo = it * a.i + m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+        const int L = m + cnt;
+        // candidates' logits, memory first, transposed into the workspace
+        for (int l = tid; l < L; l += LARGE_NT) {
+            const size_t row = l < m ? (size_t)mem[l] : (size_t)(lo + (l - m));
+            const float* src = lg + row * R;
+            if ((R & 3) == 0) {
+                for (int r = 0; r < R; r += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + r);
+                    xT[(size_t)r * Lp + l] = v.x;
+                    xT[(size_t)(r + 1) * Lp + l] = v.y;
+                    xT[(size_t)(r + 2) * Lp + l] = v.z;
+                    xT[(size_t)(r + 3) * Lp + l] = v.w;
+                }
+            } else {
+                for (int r = 0; r < R; ++r) xT[(size_t)r * Lp + l] = src[r];
+            }
+        }
+        __syncthreads();
+        for (int r = wave; r < R; r += LARGE_NT / 64) {                // row maxima (a NaN wins)
+            const float* x = xT + (size_t)r * Lp;
+            float mx = -__builtin_huge_valf();
+            for (int l = lane; l < L; l += 64) mx = nanmax(mx, x[l]);
+            mx = wave_max(mx);
+            if (lane == 0) rmax[r] = mx;
+        }
+        __syncthreads();
+        for (int r = 0; r < R; ++r) {                                  // exponentials, in place
+            float* x = xT + (size_t)r * Lp;
+            const float mx = rmax[r];
+            for (int l = tid; l < L; l += LARGE_NT) x[l] = det_expf(x[l] - mx);
+        }
+        __syncthreads();
+        for (int r = wave; r < R; r += LARGE_NT / 64) {                // denominators in the wavefront order of the contract
+            const float* x = xT + (size_t)r * Lp;
+            float sum = 0.0f;
+            for (int l = lane; l < L; l += 64) sum = sum + x[l];
+            sum = wave_butterfly_sum(sum);
+            if (lane == 0) rden[r] = sum;
+        }
+        __syncthreads();
+        for (int l = tid; l < a.n2; l += LARGE_NT) {                   // scores: mean over heads, then over tokens
+            uint64_t key = 0ull;
+            if (l < L) {
+                float st = 0.0f;
+                for (int t = 0; t < a.T; ++t) {
+                    float sh = 0.0f;
+                    for (int hh = 0; hh < a.h; ++hh) {
+                        const int r = hh * a.T + t;
+                        sh = sh + xT[(size_t)r * Lp + l] / rden[r];
+                    }
+                    st = st + sh / (float)a.h;
+                }
+                key = rank_key(st / (float)a.T, (uint32_t)l);
+            }
+            keys[l] = key;
+        }
+        __syncthreads();
+        sort_desc_large(keys, a.n2);
+        if (tid == 0 && L > m && (keys[m - 1] >> 32) == (keys[m] >> 32)) tie = 1;
+        const bool replayed = large_tie_replay(keys, L, m, a.tie_order, lists, stk, leaf);
+        const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
+        int nw[LARGE_KPT];
+#pragma unroll
+        for (int s = 0; s < LARGE_KPT; ++s) {
+            const int j = tid + s * LARGE_NT;
+            nw[s] = 0;
+            if (j < m) {
+                int pos;
+                if (replayed) {
+                    pos = q[j].i;
+                    last_score[s] = key_score(rank_key(q[j].v, 0u));
+                } else {
+                    pos = (int)key_pos(keys[j]);
+                    last_score[s] = key_score(keys[j]);
+                }
+                nw[s] = pos < m ? (int)mem[pos] : (int)(lo + (pos - m));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < LARGE_KPT; ++s) {
+            const int j = tid + s * LARGE_NT;
+            if (j < m) mem[j] = nw[s];
+        }
+        __syncthreads();
+    }
+    if (a.mem_score) {
+#pragma unroll
+        for (int s = 0; s < LARGE_KPT; ++s) {
+            const int j = tid + s * LARGE_NT;
+            if (j < m) a.mem_score[(size_t)b * m + j] = last_score[s];
+        }
+    }
+    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
+}
+
+// torch.topk(scores, m)[1] for l <= 16,384 candidates per row: the ranking of scan_large_kernel alone
+__global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsigned char* ws, size_t ws_per_row) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    int* stk = reinterpret_cast<int*>(keys + a.n2);
+    unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 3 * stdorder::STACK_RANGES);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int l = tid; l < a.n2; l += LARGE_NT)
+        keys[l] = l < a.L ? rank_key(a.scores[(size_t)b * a.L + l], (uint32_t)l) : 0ull;
+    __syncthreads();
+    sort_desc_large(keys, a.n2);
+    if (a.tie && tid == 0)
+        a.tie[b] = (a.L > a.m && (keys[a.m - 1] >> 32) == (keys[a.m] >> 32)) ? 1 : 0;
+    int* lists = reinterpret_cast<int*>(ws + (size_t)b * ws_per_row);
+    const bool replayed = large_tie_replay(keys, a.L, a.m, a.tie_order, lists, stk, leaf);
+    const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
+    for (int j = tid; j < a.m; j += LARGE_NT)
+        a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[j]);
+}
+
 static unsigned long long* g_scan_stamps = nullptr;   // diagnostic only (ipsx_dbg_scan_stamps)
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -1699,21 +1957,44 @@ IPSX_API int ipsx_logits_bf16(const float* emb, int64_t emb_bstride, const float
 }
 
 IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
-                       int64_t* mem_idx, float* mem_score, int32_t* tie_flag, void* stream) {
+                       int64_t* mem_idx, float* mem_score, int32_t* tie_flag, void* workspace, size_t workspace_bytes,
+                       void* stream) {
     IPSX_REQUIRE(n > m && i > 0, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
     if (tie_flag && hipMemsetAsync(tie_flag, 0, sizeof(int32_t) * (size_t)std::max(b, 0), as_stream(stream)) != hipSuccess)
         return fail(IPSX_EHIP, "scan: memset failed");
-    return ipsx_scan_range(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, stream);
+    return ipsx_scan_range(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag,
+                           workspace, workspace_bytes, stream);
 }
 
 static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
-                           int32_t* tie_flag, const int32_t* ready, int32_t* status, void* stream);
+                           int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                              int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
-                             int32_t* tie_flag, void* stream) {
-    return scan_range_impl(logits, b, n, m, i, h, n_token, it_begin, it_end, mem_idx, mem_score, tie_flag, nullptr, nullptr, stream);
+                             int32_t* tie_flag, void* workspace, size_t workspace_bytes, void* stream) {
+    return scan_range_impl(logits, b, n, m, i, h, n_token, it_begin, it_end, mem_idx, mem_score, tie_flag, nullptr, nullptr,
+                           workspace, workspace_bytes, stream);
+}
+
+// does the loop for this shape live in LDS alone (scan_fast / scan_resident / scan_kernel)?
+static bool scan_fits_lds(int m, int i, int h, int n_token) {
+    const int R = h * n_token, Lmax = m + i, n2 = next_pow2(Lmax);
+    size_t base = (size_t)n2 * 16 + (size_t)Lmax * 8 + (size_t)R * 8;
+    base = (base + 15) & ~(size_t)15;
+    return base + STK_BYTES <= kLdsLimit;
+}
+
+static size_t scan_large_ws_per_image(int m, int i, int h, int n_token) {
+    const size_t Lp = ((size_t)(m + i) + 63) & ~(size_t)63;
+    return ((size_t)h * n_token * Lp * 4 + 2 * Lp * 4 + 255) & ~(size_t)255;
+}
+
+IPSX_API size_t ipsx_scan_workspace_bytes(int b, int m, int i, int h, int n_token) {
+    if (b <= 0 || m <= 0 || i <= 0 || h <= 0 || n_token <= 0) return 0;
+    if (scan_fits_lds(m, i, h, n_token)) return 0;
+    return (size_t)b * scan_large_ws_per_image(m, i, h, n_token);
 }
 
 __global__ void publish_rows_kernel(int* ready, int value) {
@@ -1738,7 +2019,8 @@ IPSX_API int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, 
     IPSX_REQUIRE(ready && status, "scan_persistent: needs the progress word and the status word");
     IPSX_REQUIRE(n > m && i > 0, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
     IPSX_REQUIRE(ipsx_scan_persistent_supported(m, i, h, n_token), "scan_persistent: shape not covered (use ipsx_scan_range)");
-    return scan_range_impl(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, ready, status, stream);
+    return scan_range_impl(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, ready, status,
+                           nullptr, 0, stream);
 }
 
 // one thread that holds its stream until every workgroup of the persistent scan is resident (bounded: ~0.5 s)
@@ -1764,7 +2046,8 @@ IPSX_API int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream) {
 
 static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
-                           int32_t* tie_flag, const int32_t* ready, int32_t* status, void* stream) {
+                           int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
+                           size_t workspace_bytes, void* stream) {
     IPSX_REQUIRE(logits && mem_idx, "scan: null pointer");
     IPSX_REQUIRE(b > 0 && m > 0 && i > 0 && h > 0 && n_token > 0, "scan: bad sizes");
     IPSX_REQUIRE(n > m, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
@@ -1776,7 +2059,28 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     size_t base = (size_t)n2 * 16 + (size_t)Lmax * 8 + (size_t)R * 8;
     base = (base + 15) & ~(size_t)15;
     const size_t stage = (size_t)Lmax * (R + 1) * 4;
-    IPSX_REQUIRE(base + STK_BYTES <= kLdsLimit, "scan: M+I = %d candidates do not fit the 160 KiB LDS", Lmax);
+    if (!scan_fits_lds(m, i, h, n_token)) {
+        // candidate sets beyond the LDS (the reference's shipped CAMELYON configuration: M = I = 5000): ranking in LDS,
+        // everything else through the caller's workspace (scan_large_kernel)
+        IPSX_REQUIRE(!ready, "scan_persistent: shape not covered");
+        IPSX_REQUIRE(Lmax <= LARGE_MAX_L, "scan: M+I = %d candidates - at most %d are supported", Lmax, LARGE_MAX_L);
+        IPSX_REQUIRE(R <= 256, "scan: H * n_token = %d > 256 not supported", R);
+        const size_t need = ipsx_scan_workspace_bytes(b, m, i, h, n_token);
+        if (!workspace || workspace_bytes < need)
+            return fail(IPSX_EWORKSPACE, "scan: M+I = %d candidates need a workspace of %zu B (ipsx_scan_workspace_bytes), got %zu",
+                        Lmax, need, workspace_bytes);
+        LargeArgs la;
+        la.tie_order = g_tie_order;
+        la.lg = logits; la.n = n; la.it0 = it_begin; la.it1 = it_end;
+        la.m = m; la.i = i; la.h = h; la.T = n_token; la.n2 = n2; la.Lp = (Lmax + 63) & ~63;
+        la.mem_idx = reinterpret_cast<long long*>(mem_idx); la.mem_score = mem_score; la.tie = tie_flag;
+        la.ws = static_cast<unsigned char*>(workspace); la.ws_per_image = scan_large_ws_per_image(m, i, h, n_token);
+        const size_t lds = large_lds_bytes(n2, R);
+        IPSX_REQUIRE(lds <= kLdsLimit, "scan: internal - %zu B of LDS", lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        scan_large_kernel<<<dim3((unsigned)b), dim3(LARGE_NT), lds, as_stream(stream)>>>(la);
+        return launched("scan");
+    }
     ScanArgs a;
     a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
     a.it0 = it_begin; a.it1 = it_end;
@@ -1898,15 +2202,34 @@ IPSX_API int ipsx_scores(const float* x, const float* wk_packed, const float* qs
     return launched("scores");
 }
 
+static size_t topm_large_ws_per_row(int l) { return ((size_t)2 * l * 4 + 255) & ~(size_t)255; }
+
+IPSX_API size_t ipsx_topm_workspace_bytes(int b, int l, int m) {
+    if (b <= 0 || l <= 0 || m <= 0) return 0;
+    if ((size_t)next_pow2(l) * 16 + STK_BYTES <= kLdsLimit) return 0;
+    return (size_t)b * topm_large_ws_per_row(l);
+}
+
 IPSX_API int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_idx, int32_t* tie_flag,
-                       void* stream) {
+                       void* workspace, size_t workspace_bytes, void* stream) {
     IPSX_REQUIRE(scores && top_idx && b > 0 && l > 0 && m > 0 && m <= l, "topm: bad arguments (l=%d m=%d)", l, m);
     TopmArgs a;
     a.scores = scores; a.L = l; a.m = m; a.n2 = next_pow2(l);
     a.top = reinterpret_cast<long long*>(top_idx); a.tie = tie_flag;
     const size_t lds = (size_t)a.n2 * 16 + STK_BYTES;
     a.tie_order = g_tie_order; a.stk_off = (int)(lds - STK_BYTES);
-    IPSX_REQUIRE(lds <= kLdsLimit, "topm: %d candidates do not fit the 160 KiB LDS", l);
+    if (lds > kLdsLimit) {                                             // one key array in LDS, tie lists in the workspace
+        IPSX_REQUIRE(l <= LARGE_MAX_L, "topm: %d candidates - at most %d are supported", l, LARGE_MAX_L);
+        const size_t need = ipsx_topm_workspace_bytes(b, l, m);
+        if (!workspace || workspace_bytes < need)
+            return fail(IPSX_EWORKSPACE, "topm: %d candidates need a workspace of %zu B (ipsx_topm_workspace_bytes), got %zu",
+                        l, need, workspace_bytes);
+        const size_t big = (size_t)a.n2 * 8 + (size_t)3 * stdorder::STACK_RANGES * 4 + (size_t)LARGE_LEAF_WORDS * 8;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+        topm_large_kernel<<<dim3((unsigned)b), dim3(LARGE_NT), big, as_stream(stream)>>>(
+            a, static_cast<unsigned char*>(workspace), topm_large_ws_per_row(l));
+        return launched("topm");
+    }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     topm_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);

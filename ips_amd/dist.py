@@ -134,14 +134,32 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
         if on_gpu:
             R = ca.H * ca.n_token
             vq = ca.folded_query()
-            logits = torch.empty((B, N, R), dtype=torch.float32, device=dev)
-            mem_idx = torch.empty((B, M), dtype=torch.int64, device=dev)
-            tie = torch.zeros((B,), dtype=torch.int32, device=dev)
             if getattr(net, "_side_stream", None) is None or net._side_stream.device != dev:
                 net._side_stream = torch.cuda.Stream(device=dev, priority=-1)
             side, main = net._side_stream, torch.cuda.current_stream(dev)
-            for t in (logits, mem_idx, tie):
-                t.record_stream(side)
+            # Per-call device buffers are KEPT between calls of the same shape (like IPSNet._scan_bufs): a block the side
+            # stream has used cannot be recycled by the allocator until that stream's work is known to be over, so
+            # allocating them afresh in every call piles up one set per un-synchronised call and sends the host into
+            # hipMalloc now and then - at 8 GPUs a call is a few milliseconds.  The exchange buffers of every part too.
+            bkey = (B, N, M, I, R, world, str(dev), tuple(piece))
+            if getattr(net, "_shard_bufs_key", None) != bkey:
+                net._shard_bufs = {
+                    "logits": torch.empty((B, N, R), dtype=torch.float32, device=dev),
+                    "mem_idx": torch.empty((B, M), dtype=torch.int64, device=dev),
+                    "tie": torch.zeros((B,), dtype=torch.int32, device=dev),
+                    "ws": hip.scan_workspace(B, M, I, ca.H, ca.n_token, dev),
+                    "mine": [torch.zeros((B, q, R), dtype=torch.float32, device=dev) for q in piece],
+                    "gathered": [torch.empty((world, B, q, R), dtype=torch.float32, device=dev) for q in piece],
+                }
+                net._shard_bufs_key = bkey
+                for t in [net._shard_bufs[k] for k in ("logits", "mem_idx", "tie", "ws")] + \
+                        net._shard_bufs["mine"] + net._shard_bufs["gathered"]:
+                    if t is not None:
+                        t.record_stream(side)
+            bufs = net._shard_bufs
+            logits, mem_idx_buf, tie, scan_ws = bufs["logits"], bufs["mem_idx"], bufs["tie"], bufs["ws"]
+            tie.zero_()
+            side.wait_stream(main)            # the buffers are the main stream's; the previous call's readers are done
         else:
             all_emb = torch.empty((B, N, D), dtype=torch.float32, device=dev)
 
@@ -162,7 +180,8 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
         for k, (lo, hi) in enumerate(spans):
             n_k, q, part_len = hi - lo, piece[k], edges[k + 1] - edges[k]
             width = R if on_gpu else D
-            mine = torch.zeros((B, q, width), dtype=torch.float32, device=dev)
+            # (padding rows beyond n_k stay zero from construction: only [:, :n_k] is ever written)
+            mine = bufs["mine"][k] if on_gpu else torch.zeros((B, q, width), dtype=torch.float32, device=dev)
             if n_k > 0:
                 if indexed:
                     cols = torch.arange(base, base + n_k, device=dev, dtype=torch.int32)
@@ -181,18 +200,17 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
                 # straight on to encoding the next part (neither the gather nor the scan is on its critical path)
                 done = torch.cuda.Event(enable_timing=ev is not None)
                 done.record(main)
-                mine.record_stream(side)
                 with torch.cuda.stream(side):
                     side.wait_event(done)
                     if ev is not None:
                         ev["enc"].append(done)
                         x0, x1, s1 = mk(), mk(), mk()
                         x0.record(side)
-                    gathered = _all_gather(mine, world, group)
+                    gathered = _all_gather(mine, world, group, out=bufs["gathered"][k])
                     logits[:, edges[k]:edges[k + 1]] = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
                     if ev is not None:
                         x1.record(side)
-                    hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx, tie)
+                    hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie, scan_ws)
                     if ev is not None:
                         s1.record(side)
                         ev["xch"].append((x0, x1))
@@ -202,6 +220,7 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
                 all_emb[:, edges[k]:edges[k + 1]] = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
         if on_gpu:
             main.wait_stream(side)
+            mem_idx = mem_idx_buf.clone()              # the buffer is overwritten by the next call
             hip.scan.last_tie = tie
             if ev is not None:
                 ev["end_select"].record(main)
@@ -251,17 +270,21 @@ def phase_ms(timings):
     return {k: v / len(timings) for k, v in acc.items()}
 
 
-def _all_gather(mine, world, group):
-    """(world, *mine.shape) from every rank's `mine`.  RCCL moves device buffers directly; any other
-    backend (gloo: the CPU tests, and GPU ranks without RCCL between them) goes through host memory."""
+def _all_gather(mine, world, group, out=None):
+    """(world, *mine.shape) from every rank's `mine` (into ``out`` when given).  RCCL moves device buffers directly; any
+    other backend (gloo: the CPU tests, and GPU ranks without RCCL between them) goes through host memory."""
     if dist.get_backend(group) == "nccl":
-        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        gathered = out if out is not None else torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(gathered, mine, group=group)
         return gathered
     host = mine.cpu()
     pieces = [torch.empty_like(host) for _ in range(world)]
     dist.all_gather(pieces, host, group=group)
-    return torch.stack(pieces, 0).to(mine.device)
+    stacked = torch.stack(pieces, 0)
+    if out is not None:
+        out.copy_(stacked)
+        return out
+    return stacked.to(mine.device)
 
 
 def _all_reduce(t, group):

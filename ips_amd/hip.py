@@ -188,9 +188,10 @@ _EXPORTS = {
                                    C.c_void_p, C.c_int64, C.c_void_p]),
     "ipsx_set_tie_order": (C.c_int, [C.c_int]),
     "ipsx_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_scan_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ipsx_scan_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_scan_persistent_supported": (C.c_int, [C.c_int] * 4),
     "ipsx_scan_persistent": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -200,7 +201,8 @@ _EXPORTS = {
     "ipsx_scores_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ipsx_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 +
                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "ipsx_topm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ipsx_topm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_topm_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "ipsx_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                    C.c_int64, C.c_int64, C.c_void_p]),
     "ipsx_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(Transf), C.c_int, C.c_int]),
@@ -651,6 +653,14 @@ def logits_stats(emb, pos, vq, R, out, stats_x, stats_out, ln_eps):
     return out
 
 
+def scan_workspace(B, M, I, H, T, device):
+    """Device workspace of the selection loop for candidate sets beyond the LDS (M + I above ~4,000: the reference's
+    shipped CAMELYON configuration is M = I = 5000), or ``None`` when the shape needs none.  A caller that runs the loop on
+    a side stream keeps it between calls (like its other per-call buffers) instead of allocating it there."""
+    nb = lib().ipsx_scan_workspace_bytes(B, M, I, H, T)
+    return torch.empty(nb, dtype=torch.uint8, device=device) if nb else None
+
+
 def scan(lg, M, I, H, T, want_scores=False):
     """The IPS chunk loop on cached logits (B, N, H*T) -> mem_idx (B, M) int64."""
     lg = _f32(lg)
@@ -658,18 +668,22 @@ def scan(lg, M, I, H, T, want_scores=False):
     mem_idx = torch.empty((B, M), dtype=torch.int64, device=lg.device)
     sc = torch.empty((B, M), dtype=torch.float32, device=lg.device) if want_scores else None
     tie = torch.zeros((B,), dtype=torch.int32, device=lg.device)
-    _ck(lib().ipsx_scan(_p(lg), B, N, M, I, H, T, _p(mem_idx), _p(sc), _p(tie), _stream()), "ipsx_scan")
+    ws = scan_workspace(B, M, I, H, T, lg.device)
+    _ck(lib().ipsx_scan(_p(lg), B, N, M, I, H, T, _p(mem_idx), _p(sc), _p(tie), _p(ws), ws.numel() if ws is not None else 0,
+                        _stream()), "ipsx_scan")
     scan.last_tie = tie
     return (mem_idx, sc) if want_scores else mem_idx
 
 
-def scan_range(lg, M, I, H, T, it_begin, it_end, mem_idx, tie):
-    """Iterations [it_begin, it_end) of the loop, state carried in ``mem_idx`` (B, M) int64 / ``tie`` (B,) int32."""
+def scan_range(lg, M, I, H, T, it_begin, it_end, mem_idx, tie, workspace=None):
+    """Iterations [it_begin, it_end) of the loop, state carried in ``mem_idx`` (B, M) int64 / ``tie`` (B,) int32.
+    ``workspace``: ``scan_workspace(...)`` kept by the caller; allocated here (on the current stream) when missing."""
     B, N = lg.shape[:2]
     if not lg.is_contiguous():
         raise ValueError("scan_range needs the full contiguous (B, N, H*T) logits buffer")
-    _ck(lib().ipsx_scan_range(_p(lg), B, N, M, I, H, T, it_begin, it_end, _p(mem_idx), None, _p(tie), _stream()),
-        "ipsx_scan_range")
+    ws = workspace if workspace is not None else scan_workspace(B, M, I, H, T, lg.device)
+    _ck(lib().ipsx_scan_range(_p(lg), B, N, M, I, H, T, it_begin, it_end, _p(mem_idx), None, _p(tie),
+                              _p(ws), ws.numel() if ws is not None else 0, _stream()), "ipsx_scan_range")
     return mem_idx
 
 
@@ -723,7 +737,9 @@ def topm(sc, M):
     B, L = sc.shape
     top = torch.empty((B, M), dtype=torch.int64, device=sc.device)
     tie = torch.zeros((B,), dtype=torch.int32, device=sc.device)
-    _ck(lib().ipsx_topm(_p(sc), B, L, M, _p(top), _p(tie), _stream()), "ipsx_topm")
+    nb = lib().ipsx_topm_workspace_bytes(B, L, M)
+    ws = torch.empty(nb, dtype=torch.uint8, device=sc.device) if nb else None
+    _ck(lib().ipsx_topm(_p(sc), B, L, M, _p(top), _p(tie), _p(ws), nb, _stream()), "ipsx_topm")
     return top
 
 

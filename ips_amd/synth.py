@@ -73,6 +73,9 @@ BENCH_WORKLOADS = {
     "native50": lambda: (mnist_conf(N=900, M=100, I=100, patch=50), 16),
     "traffic": lambda: (traffic_conf(N=192, M=16, I=32, patch=100), 16),
     "cam": lambda: (camelyon_conf(N=65536, M=256, I=256), 1),           # configs[3]
+    # the reference's SHIPPED CAMELYON memory / chunk sizes (config/camelyon_config.yml:35-36: M = I = 5000, 10,000
+    # candidates per iteration) on a slide of 38,000 tiles: 7 iterations, the last chunk ragged (3,000 rows)
+    "cam_native": lambda: (camelyon_conf(N=38000, M=5000, I=5000), 1),
 }
 
 

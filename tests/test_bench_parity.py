@@ -26,8 +26,14 @@ import torch
 from ips_amd import synth
 from tests.util import GOLDEN_DIR
 
-WORKLOADS = ["mnist", "mnist3000", "native50", "traffic", "cam"]
+WORKLOADS = ["mnist", "mnist3000", "native50", "traffic", "cam", "cam_native"]
 GAP_FLOOR = 1e-5
+# cam_native ranks 10,000 candidates whose scores all lie within a binade or two of 1e-4: in EVERY iteration some
+# neighbours of the reference's sorted top M + 1 are bit-equal (order_gap = 0), so the ORDER inside the memory is the
+# reference's own noise at a percent of the positions, while the SET has a clear boundary (rel_gap 2.5e-5 ... 4e-4 in
+# six of seven iterations).  There the final selection is held to the reference as a set, and position for position
+# on at least this share of the slots:
+SAME_SLOT_SHARE = {"cam_native": 0.98}
 
 
 def load(name):
@@ -49,6 +55,25 @@ def test_fixture_is_what_bench_py_runs(name):
     assert idx.max() < conf.N
     for b in range(B):                               # a memory never holds a patch twice
         assert all(len(set(row)) == conf.M for row in idx[b, ::max(1, n_iter // 7)])
+
+
+def test_oracle_follows_the_reference_on_cam_native():
+    """CPU: the oracle on the reference's shipped CAMELYON memory / chunk sizes (M = I = 5000: 10,000 candidates per
+    iteration) keeps the reference's SET of patches in every iteration and its patch in >= 98 % of the slots (the rest:
+    neighbours with bit-equal or noise-level scores, see SAME_SLOT_SHARE)."""
+    from ips_amd.architecture import IPSNet
+    from oracle.oracle import Oracle
+    z, conf = load("cam_native")
+    net = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 7).eval()
+    x = synth.make_patches(conf, int(z["B"]), seed=21)
+    out = Oracle(net).ips(x.numpy(), None, aten_ties=True)
+    want, trace = z["trace_idx"].astype(np.int64), out["trace_idx"]
+    assert trace.shape == want.shape
+    for it in range(want.shape[1]):
+        if z["rel_gap"][0, it] > GAP_FLOOR:
+            assert np.array_equal(np.sort(trace[0, it]), np.sort(want[0, it])), it
+    assert np.array_equal(np.sort(trace[0, -1]), np.sort(want[0, -1]))
+    assert float((trace[:, -1] == want[:, -1]).mean()) >= SAME_SLOT_SHARE["cam_native"]
 
 
 def hip_trace(net, x, want):
@@ -89,14 +114,23 @@ def test_bench_workload_selects_the_reference_indices(name):
 
     mem_patch, mem_pos = net.ips(x)                                   # the call bench.py times
     got = net.last_mem_idx.cpu().numpy()
-    assert np.array_equal(got, want[:, -1]), "final selection differs on images %s" % (
-        np.nonzero((got != want[:, -1]).any(1))[0].tolist(),)
+    if name in SAME_SLOT_SHARE:
+        assert np.array_equal(np.sort(got, -1), np.sort(want[:, -1], -1)), "final selection keeps other patches"
+        share = float((got == want[:, -1]).mean())
+        print("%s: %.2f %% of the memory slots hold the reference's patch (same set on every image)" % (name, 100 * share))
+        assert share >= SAME_SLOT_SHARE[name]
+    else:
+        assert np.array_equal(got, want[:, -1]), "final selection differs on images %s" % (
+            np.nonzero((got != want[:, -1]).any(1))[0].tolist(),)
     with torch.no_grad():
         preds = net(mem_patch, mem_pos)
     for k in preds:
         assert np.abs(preds[k].cpu().numpy() - z["pred_" + k]).max() <= 1e-4, k
     s = mem_patch.double().sum(dim=tuple(range(2, mem_patch.dim()))).cpu().numpy()
-    assert np.allclose(s, z["mem_patch_sum"], rtol=1e-12, atol=1e-9)
+    if name in SAME_SLOT_SHARE:
+        assert np.allclose(np.sort(s, -1), np.sort(z["mem_patch_sum"], -1), rtol=1e-12, atol=1e-9)
+    else:
+        assert np.allclose(s, z["mem_patch_sum"], rtol=1e-12, atol=1e-9)
 
     trace = hip_trace(net, x, want)
     assert trace.shape == want.shape

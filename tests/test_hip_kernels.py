@@ -681,6 +681,64 @@ def test_scan_random_shapes_with_ties_matches_oracle(seed):
         assert np.array_equal(idx.cpu().numpy(), mem)
 
 
+@pytest.mark.parametrize("N,M,I,H,T,levels", [
+    (38000, 5000, 5000, 8, 1, 0),        # the reference's shipped CAMELYON sizes (config/camelyon_config.yml:35-36), ragged end
+    (21000, 5000, 5000, 8, 1, 4096),     # quantised logits: equal scores in every iteration -> torch.topk's order replayed
+    (20000, 3000, 6000, 8, 4, 0),        # 32 rows per patch, 9,000 candidates
+    (40000, 8192, 8192, 2, 1, 0),        # the largest supported candidate set: 16,384
+    (30000, 100, 9000, 8, 1, 64),        # 64 * M <= L: torch.topk takes partial_sort (heap select) under ties
+    (9000, 4200, 300, 3, 3, 0),          # odd row count, many short chunks on a large memory
+])
+def test_scan_beyond_the_lds_matches_oracle(N, M, I, H, T, levels):
+    """Candidate sets that do not fit one compute unit's LDS (M + I up to 16,384: scan_large_kernel - ranking in LDS,
+    the rest through the caller's workspace) against the oracle's loop, torch.topk's tie order included; a run cut into
+    resumed ranges gives the same memory."""
+    B, R = 2, H * T
+    if levels:
+        g = np.random.default_rng(N + M)
+        lg = (g.integers(0, levels, (B, N, R)).astype(np.float32) - np.float32(levels / 2)) * np.float32(6.0 / levels)
+        if levels <= 64:
+            lg[:, :, 1:] = lg[:, :, :1]
+    else:
+        lg = rnd((B, N, R), N + M, 3.0)
+    assert hip.lib().ipsx_scan_workspace_bytes(B, M, I, H, T) > 0
+    mem, sc = hip.scan(dev(lg), M, I, H, T, want_scores=True)
+    mem, sc = mem.cpu().numpy(), sc.cpu().numpy()
+    n_iter = -(-(N - M) // I)
+    idx = torch.empty((B, M), dtype=torch.int64, device=DEV)
+    tie = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    cut = max(1, n_iter // 2)
+    hip.scan_range(dev(lg), M, I, H, T, 0, cut, idx, tie)
+    hip.scan_range(dev(lg), M, I, H, T, cut, n_iter, idx, tie)
+    L = orc.lib()
+    for b in range(B):
+        cur = np.arange(M, dtype=np.int64)
+        for lo in range(M, N, I):
+            cand = np.concatenate([cur, np.arange(lo, min(lo + I, N), dtype=np.int64)])
+            s = np.empty(len(cand), dtype=np.float32)
+            L.orc_scores_from_logits(orc._f(lg[b][cand])[1], len(cand), H, T, s.ctypes.data_as(orc.f32p), None)
+            top = orc.topm(s, M, aten_ties=True)[0]
+            cur, last = cand[top], s[top]
+        assert np.array_equal(mem[b], cur), (b, int((mem[b] != cur).sum()), np.nonzero(mem[b] != cur)[0][:8])
+        assert ulp_diff(sc[b], last) == 0
+    assert np.array_equal(idx.cpu().numpy(), mem)
+
+
+@pytest.mark.parametrize("L,M", [(10000, 5000), (16384, 8000), (9000, 100), (12345, 12345), (8200, 1)])
+def test_topm_beyond_the_lds_is_torch_topk(L, M):
+    """ipsx_topm for rows that do not fit the LDS twice over (one key array + workspace) == torch.topk on the host,
+    with and without exact ties (both of ATen's branches)."""
+    g = np.random.default_rng(L + M)
+    rows = [g.standard_normal(L).astype(np.float32),
+            (g.integers(0, 50, L)).astype(np.float32),                      # heavy ties
+            np.where(g.integers(0, 40, L) == 0, np.float32(np.nan), g.integers(0, 3000, L).astype(np.float32))]
+    s = np.stack(rows)
+    top = hip.topm(dev(s), M).cpu().numpy()
+    for b in range(len(s)):
+        want = torch.topk(torch.from_numpy(s[b]), M)[1].numpy()
+        assert np.array_equal(top[b], want), (L, M, b, int((top[b] != want).sum()))
+
+
 def test_gather_rows():
     B, N, M = 3, 50, 7
     src = rnd((B, N, 1, 32, 32), 30)
