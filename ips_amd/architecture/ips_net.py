@@ -321,7 +321,9 @@ class IPSNet(nn.Module):
                 self._plan = hip.EncoderPlan(self.encoder, self.is_image)
             return (not self.encoder.training) and self._plan.fused(patches.shape) and \
                 self._small_batch_split(patches.shape[0], patches.shape[1]) is not None
-        return (not self.encoder.training) and n_iter >= 2 * self._OVERLAP_PARTS
+        # (feature inputs: the loop is the long pole whatever its length - a slide at the reference's shipped M = I = 5000 has
+        #  7 iterations of 10,000 candidates - so any loop of a few iterations runs beside the projector's later parts)
+        return (not self.encoder.training) and n_iter >= (2 * self._OVERLAP_PARTS if self.is_image else 3)
 
     def _small_batch_split(self, B, N):
         """Iterations after which to cut a small image batch in two: the first part = as many whole rounds of the fused

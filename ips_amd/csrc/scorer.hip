@@ -569,6 +569,122 @@ __device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, in
     wave_fence<GL>();
 }
 
+// ---- the replay on the whole WORKGROUP (candidate sets beyond the LDS: scan_large_kernel ranks 10,000 candidates whose
+// scores lie within a binade or two, so SOME pair of the first m + 1 is bit-equal in practically every iteration and the
+// replay is part of every iteration there).  std::sort's introsort loop only ever splits a range into two disjoint
+// ranges that never interact again, so the order in which pending ranges are processed is immaterial: instead of one
+// wavefront working through a stack, the ranges of a level are dealt to the 16 wavefronts (two range lists in LDS,
+// breadth first, a barrier per level), each range partitioned by the unchanged wave_partition_pivot with its own stretch
+// of the index lists (la + first, lb + first: ranges are disjoint, so are the stretches).  std::nth_element in front of it is
+// ONE chain of partitions and stays on one wavefront; the final insertion pass runs on all threads.
+constexpr int BLOCK_QCAP = 1024;            // ranges of more than 16 elements pending at one level: <= 16,384 / 17
+
+template <int NT, bool GL>
+__device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, int* la, int* lb, int* stk,
+                                                 unsigned long long* leaf, int leaf_words, int* queue, int* qcount) {
+    using namespace stdorder;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (k <= 0 || n <= 0) return;
+    if ((long long)k * 64 <= (long long)n || n > 64 * leaf_words || (k - 1) / 17 + 1 > BLOCK_QCAP) {
+        if (tid == 0) torch_topk(q, n, k, stk);                       // heap select / sort (partial_sort), or beyond the tables
+        __syncthreads();
+        return;
+    }
+    if (wave == 0) {   // std::nth_element(q, q + k - 1, q + n)
+        int first = 0, last = n;
+        const int nth = k - 1;
+        bool done = nth == last;
+        int depth = lg2(last - first) * 2;
+        while (!done && last - first > 3) {
+            if (depth == 0) {
+                if (lane == 0) { heap_select(q, first, nth + 1, last); swp(q, first, nth); }
+                done = true;
+                break;
+            }
+            --depth;
+            const int cut = wave_partition_pivot<GL>(q, first, last, la, lb, lane);
+            if (cut <= nth) first = cut;
+            else last = cut;
+        }
+        if (!done && lane == 0) insertion_sort(q, first, last);
+        wave_fence<GL>();
+    }
+    const int last = k - 1;                                            // std::sort(q, q + k - 1)
+    for (int w = tid; w < leaf_words; w += NT) leaf[w] = 0ull;
+    if (tid == 0) {
+        qcount[0] = qcount[1] = 0;
+        if (last > 16) {
+            queue[0] = 0; queue[1] = last; queue[2] = lg2(last) * 2;
+            qcount[0] = 1;
+        }
+    }
+    __syncthreads();
+    if (last <= 0) return;
+    for (int cur = 0;; cur ^= 1) {
+        const int ncur = qcount[cur];
+        if (ncur == 0) break;
+        const int* qc = queue + cur * BLOCK_QCAP * 3;
+        int* qn = queue + (cur ^ 1) * BLOCK_QCAP * 3;
+        for (int r = wave; r < ncur; r += NT / 64) {
+            const int rf = qc[3 * r], rl = qc[3 * r + 1];
+            int depth = qc[3 * r + 2];
+            if (depth == 0) {                                          // heap sort of the range: stays as it is afterwards
+                if (lane == 0) { make_heap(q, rf, rl); sort_heap(q, rf, rl); }
+                continue;
+            }
+            --depth;
+            const int cut = wave_partition_pivot<GL>(q, rf, rl, la + rf, lb + rf, lane);
+            if (lane == 0) {
+                if (cut < last) atomicOr(&leaf[cut >> 6], 1ull << (cut & 63));      // every leaf starts at 0 or at a cut
+                if (cut - rf > 16) {
+                    const int slot = atomicAdd(&qcount[cur ^ 1], 1);
+                    qn[3 * slot] = rf; qn[3 * slot + 1] = cut; qn[3 * slot + 2] = depth;
+                }
+                if (rl - cut > 16) {
+                    const int slot = atomicAdd(&qcount[cur ^ 1], 1);
+                    qn[3 * slot] = cut; qn[3 * slot + 1] = rl; qn[3 * slot + 2] = depth;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) qcount[cur] = 0;
+        __syncthreads();
+    }
+    // the final insertion pass, leaf by leaf, an element per thread (see torch_topk_wave)
+    E* tmp = reinterpret_cast<E*>(la);
+    for (int base = 0; base < last; base += NT) {
+        const int x = base + tid;
+        if (x < last) {
+            const E own = q[x];
+            int w = x >> 6;
+            unsigned long long m = leaf[w] & (~0ull >> (63 - (x & 63)));
+            while (m == 0ull && w > 0) m = leaf[--w];
+            const int sfirst = m ? w * 64 + 63 - __clzll((long long)m) : 0;
+            int e = last;
+            w = x >> 6;
+            m = (x & 63) == 63 ? 0ull : (leaf[w] >> ((x & 63) + 1)) << ((x & 63) + 1);
+            while (m == 0ull && w < leaf_words - 1) m = leaf[++w];
+            if (m) e = w * 64 + __ffsll((long long)m) - 1;
+            if (e > last) e = last;
+            int dst = x;
+            if (e - sfirst <= 16) {
+                int rank = 0;
+                for (int j = sfirst; j < e; ++j) {
+                    const E o = q[j];
+                    const bool greater = gt(o, own);
+                    const bool equiv = !greater && !gt(own, o);
+                    rank += (greater || (equiv && j < x)) ? 1 : 0;
+                }
+                dst = sfirst + rank;
+            }
+            tmp[dst] = own;
+        }
+    }
+    __syncthreads();
+    for (int x = tid; x < last; x += NT) q[x] = tmp[x];
+    __syncthreads();
+}
+
 // sorted and other are the two key arrays (>= L entries each); all threads of the workgroup call this together.
 // NOTE: `sorted` serves as scratch meanwhile - on return only sorted[0, m) is defined.
 template <int NT>
@@ -1626,10 +1742,61 @@ __device__ __forceinline__ uint64_t merge64(uint64_t key, int lane, bool desc) {
     return key;
 }
 
+// One LDS pass of the bitonic network of level k: the NST consecutive strides J, J/2, ..., J >> (NST - 1) (all >= 64).  A
+// thread loads the 2^NST keys of a group - the indices that differ in exactly those NST bits - runs the NST stages on them
+// in registers and stores them back: NST stages for one round trip through LDS, unconditional 8-byte accesses at
+// consecutive addresses across the lanes (no bank conflicts, no divergent swap branches).  16 keys per thread in flight.
+template <int NST>
+__device__ __forceinline__ void bitonic_pass(uint64_t* keys, int n2, int k, int J) {
+    constexpr int G = 1 << NST, GP = 16 / G;                 // keys per group, groups a thread works on at once
+    const int jlow = J >> (NST - 1);                         // smallest stride of this pass
+    const int ngroups = n2 >> NST;
+    for (int g0 = threadIdx.x; g0 < ngroups; g0 += LARGE_NT * GP) {
+        uint64_t v[GP][G];
+        int base[GP];
+#pragma unroll
+        for (int p = 0; p < GP; ++p) {
+            const int g = g0 + p * LARGE_NT;
+            const int gg = g < ngroups ? g : g0;
+            base[p] = ((gg & ~(jlow - 1)) << NST) | (gg & (jlow - 1));
+#pragma unroll
+            for (int c = 0; c < G; ++c) v[p][c] = keys[base[p] + c * jlow];
+        }
+#pragma unroll
+        for (int p = 0; p < GP; ++p) {
+            const bool desc = (base[p] & k) == 0;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                constexpr int dummy = 0; (void)dummy;
+                const int bit = G >> (st + 1);
+#pragma unroll
+                for (int c = 0; c < G; ++c) {
+                    if (c & bit) continue;
+                    const uint64_t x = v[p][c], y = v[p][c | bit];
+                    const bool sw = desc ? (x < y) : (x > y);
+                    v[p][c] = sw ? y : x;
+                    v[p][c | bit] = sw ? x : y;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < GP; ++p) {
+            if (g0 + p * LARGE_NT >= ngroups) continue;
+#pragma unroll
+            for (int c = 0; c < G; ++c) keys[base[p] + c * jlow] = v[p][c];
+        }
+    }
+}
+
 // keys[0, n2) (n2 a power of two >= 64, padding keys 0) sorted descending in place, by the LARGE_NT threads of the
 // workgroup.  Bitonic network; the levels up to 64 and the strides below 64 of every later level run in registers (a
-// 64-key block per wavefront, cross-lane), only the strides >= 64 exchange through LDS.  Keys are unique.
-__device__ __forceinline__ void sort_desc_large(uint64_t* keys, int n2) {
+// 64-key block per wavefront, cross-lane), the strides >= 64 go through LDS up to four at a time (bitonic_pass): 21
+// round trips through LDS for 16,384 keys instead of the 105 of one stage per pass.  Keys are unique.
+// (A function of its own, not inlined: the loop around it then keeps its registers - inlined, scan_large_kernel spilled 64
+//  VGPRs at its 128-register budget.  The key array is the start of the dynamic LDS in both kernels that call it.)
+__device__ __attribute__((noinline)) void sort_desc_large(int n2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = n2 >> 6;
     for (int blk = wave; blk < nblk; blk += LARGE_NT / 64) {           // runs of 64; odd runs ascending (stored reversed)
@@ -1637,18 +1804,38 @@ __device__ __forceinline__ void sort_desc_large(uint64_t* keys, int n2) {
         keys[blk * 64 + ((blk & 1) ? 63 - lane : lane)] = k;
     }
     for (int k = 128; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j >= 64; j >>= 1) {
+        int J = k >> 1;
+        int left = 0;                                                  // strides J ... 64 of this level
+        for (int j = J; j >= 64; j >>= 1) ++left;
+        while (left > 0) {
+            const int nst = left >= 4 ? 4 : left;
             __syncthreads();
-            for (int p = tid; p < (n2 >> 1); p += LARGE_NT) {
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const uint64_t x = keys[i], y = keys[i | j];
-                const bool desc = (i & k) == 0;
-                if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[i | j] = x; }
-            }
+            if (nst == 4) bitonic_pass<4>(keys, n2, k, J);
+            else if (nst == 3) bitonic_pass<3>(keys, n2, k, J);
+            else if (nst == 2) bitonic_pass<2>(keys, n2, k, J);
+            else bitonic_pass<1>(keys, n2, k, J);
+            J >>= nst;
+            left -= nst;
         }
         __syncthreads();
-        for (int blk = wave; blk < nblk; blk += LARGE_NT / 64)
-            keys[blk * 64 + lane] = merge64(keys[blk * 64 + lane], lane, ((blk * 64) & k) == 0);
+        for (int b0 = wave; b0 < nblk; b0 += (LARGE_NT / 64) * 4) {    // strides 32 ... 1: four blocks of a wavefront in flight
+            uint64_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int blk = b0 + u * (LARGE_NT / 64);
+                v[u] = keys[(blk < nblk ? blk : b0) * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int blk = b0 + u * (LARGE_NT / 64);
+                v[u] = merge64(v[u], lane, ((blk * 64) & k) == 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int blk = b0 + u * (LARGE_NT / 64);
+                if (blk < nblk) keys[blk * 64 + lane] = v[u];
+            }
+        }
     }
     __syncthreads();
 }
@@ -1657,8 +1844,13 @@ __device__ __forceinline__ void sort_desc_large(uint64_t* keys, int n2) {
 // order is the reference's, the key array is turned - through registers, in place - into the (score, position) pairs in
 // CANDIDATE order and torch.topk's routines are replayed on them (one wavefront; the index lists in the workspace); q[0, m)
 // is then the answer.  Returns whether that happened (workgroup-uniform).  All threads; contains barriers.
-__device__ __forceinline__ bool large_tie_replay(uint64_t* keys, int L, int m, int tie_order, int* lists, int* stk,
-                                                 unsigned long long* leaf) {
+// (Not inlined, like the sort; `tail` = LDS offset of the stack / leaf bitmap / range lists behind the keys.)
+__device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int tie_order, int* lists, int tail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    int* stk = reinterpret_cast<int*>(smem + tail);
+    unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 3 * stdorder::STACK_RANGES);
+    int* queue = reinterpret_cast<int*>(leaf + LARGE_LEAF_WORDS);
     const int tid = threadIdx.x;
     if (tie_order != 1 || !ranked_ties(keys, L, m, tid & 63)) return false;
     uint64_t hold[LARGE_KPT];
@@ -1679,8 +1871,7 @@ __device__ __forceinline__ bool large_tie_replay(uint64_t* keys, int L, int m, i
         }
     }
     __syncthreads();
-    if (tid < 64) torch_topk_wave<true>(q, L, m, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, tid);
-    __syncthreads();
+    torch_topk_block<LARGE_NT, true>(q, L, m, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue);
     return true;
 }
 
@@ -1697,74 +1888,173 @@ struct LargeArgs {
     size_t ws_per_image;
 };
 
-static size_t large_lds_bytes(int n2, int R) {
-    return (size_t)n2 * 8 + (size_t)R * 8 + (size_t)3 * stdorder::STACK_RANGES * 4 + (size_t)LARGE_LEAF_WORDS * 8;
-}
+// keys | row maxima, denominators | stack of the sequential fallbacks | leaf bitmap | two range lists + their counters
+constexpr size_t LARGE_TAIL_BYTES = (size_t)3 * stdorder::STACK_RANGES * 4 + (size_t)LARGE_LEAF_WORDS * 8 +
+                                    (size_t)(2 * BLOCK_QCAP * 3 + 2) * 4;
+static size_t large_lds_bytes(int n2, int R) { return (size_t)n2 * 8 + (size_t)((R + 1) & ~1) * 8 + LARGE_TAIL_BYTES; }
 
-__global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a) {
+// A pass over global memory at 16 waves per compute unit is bound by round trips, not by bandwidth: every loop below
+// keeps LARGE_U independent loads of a thread in flight before it uses the first.
+constexpr int LARGE_U = 8;
+
+#define LARGE_STAMP(k)                                                             \
+    do {                                                                           \
+        if (STAMP) {                                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();            \
+            if (tid == 0) tacc[k] += t_ - tlast;                                   \
+            tlast = t_;                                                            \
+        }                                                                          \
+    } while (0)
+
+template <bool STAMP>
+__global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = a.h * a.T, Lp = a.Lp, m = a.m;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    float* rmax = reinterpret_cast<float*>(keys + a.n2);
-    float* rden = rmax + R;
-    int* stk = reinterpret_cast<int*>(rden + R);
-    unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 3 * stdorder::STACK_RANGES);
+    uint32_t* rmaxkey = reinterpret_cast<uint32_t*>(keys + a.n2);      // row maxima as order-preserving keys (max_key)
+    float* rden = reinterpret_cast<float*>(rmaxkey + ((R + 1) & ~1));
+    const int tail = a.n2 * 8 + ((R + 1) & ~1) * 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    constexpr int NW = LARGE_NT / 64;
     const float* lg = a.lg + (size_t)b * a.n * R;
     long long* mem = a.mem_idx + (size_t)b * m;
     float* xT = reinterpret_cast<float*>(a.ws + (size_t)b * a.ws_per_image);
     int* lists = reinterpret_cast<int*>(xT + (size_t)R * Lp);
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
     if (a.it0 == 0)
         for (int j = tid; j < m; j += LARGE_NT) mem[j] = j;
     __syncthreads();
     int tie = 0;
-    float last_score[LARGE_KPT];
-#pragma unroll
-    for (int s = 0; s < LARGE_KPT; ++s) last_score[s] = 0.0f;
+    // row maxima in `seg` stretches per row so that every wavefront has one (max is order-free; a NaN wins: max_key)
+    const int seg = R >= NW ? 1 : NW / R;
     for (long long it = a.it0; it < a.it1; ++it) {
         const long long lo = it * a.i + m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = m + cnt;
-        // candidates' logits, memory first, transposed into the workspace
-        for (int l = tid; l < L; l += LARGE_NT) {
-            const size_t row = l < m ? (size_t)mem[l] : (size_t)(lo + (l - m));
-            const float* src = lg + row * R;
+        // ---- candidates' logits, memory first, transposed into the workspace: a thread takes 4 candidates at a time
+        for (int l0 = tid; l0 < L; l0 += LARGE_NT * 4) {
+            size_t row[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = l0 + u * LARGE_NT;
+                ok[u] = l < L;
+                row[u] = !ok[u] ? (size_t)0 : (l < m ? (size_t)mem[l] : (size_t)(lo + (l - m)));
+            }
             if ((R & 3) == 0) {
-                for (int r = 0; r < R; r += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(src + r);
-                    xT[(size_t)r * Lp + l] = v.x;
-                    xT[(size_t)(r + 1) * Lp + l] = v.y;
-                    xT[(size_t)(r + 2) * Lp + l] = v.z;
-                    xT[(size_t)(r + 3) * Lp + l] = v.w;
+                for (int r = 0; r < R; r += 8) {
+                    const bool two = r + 4 < R;
+                    float4 v[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4* src = reinterpret_cast<const float4*>(lg + row[u] * R + r);
+                        v[u][0] = src[0];
+                        v[u][1] = src[two ? 1 : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!ok[u]) continue;
+                        float* dst = xT + (size_t)r * Lp + (l0 + u * LARGE_NT);
+                        dst[0] = v[u][0].x; dst[Lp] = v[u][0].y; dst[2 * (size_t)Lp] = v[u][0].z; dst[3 * (size_t)Lp] = v[u][0].w;
+                        if (two) {
+                            dst += 4 * (size_t)Lp;
+                            dst[0] = v[u][1].x; dst[Lp] = v[u][1].y; dst[2 * (size_t)Lp] = v[u][1].z; dst[3 * (size_t)Lp] = v[u][1].w;
+                        }
+                    }
                 }
             } else {
-                for (int r = 0; r < R; ++r) xT[(size_t)r * Lp + l] = src[r];
+                for (int r = 0; r < R; ++r) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = lg[row[u] * R + r];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ok[u]) xT[(size_t)r * Lp + (l0 + u * LARGE_NT)] = v[u];
+                }
+            }
+        }
+        for (int r = tid; r < R; r += LARGE_NT) rmaxkey[r] = 0u;
+        __syncthreads();
+        LARGE_STAMP(0);
+        // ---- row maxima
+        {
+            const int seg_len = ((L + seg - 1) / seg + 63) & ~63;
+            for (int unit = wave; unit < R * seg; unit += NW) {
+                const int r = unit / seg, sg = unit - r * seg;
+                const float* x = xT + (size_t)r * Lp;
+                const int l_end = std::min(L, (sg + 1) * seg_len);
+                uint32_t best = 0u;
+                for (int l0 = sg * seg_len + lane; l0 < l_end; l0 += 64 * LARGE_U) {
+                    float v[LARGE_U];
+#pragma unroll
+                    for (int u = 0; u < LARGE_U; ++u) {
+                        const int l = l0 + 64 * u;
+                        v[u] = x[l < l_end ? l : l0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < LARGE_U; ++u) {
+                        const uint32_t k = max_key(v[u]);
+                        best = k > best ? k : best;
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)best, off, 64);
+                    best = o > best ? o : best;
+                }
+                if (lane == 0) atomicMax(&rmaxkey[r], best);
             }
         }
         __syncthreads();
-        for (int r = wave; r < R; r += LARGE_NT / 64) {                // row maxima (a NaN wins)
-            const float* x = xT + (size_t)r * Lp;
-            float mx = -__builtin_huge_valf();
-            for (int l = lane; l < L; l += 64) mx = nanmax(mx, x[l]);
-            mx = wave_max(mx);
-            if (lane == 0) rmax[r] = mx;
+        LARGE_STAMP(1);
+        // ---- exponentials, in place: blocks of 64 candidates of one row, LARGE_U blocks of a wavefront in flight
+        {
+            const int bpr = Lp >> 6;                                   // blocks per row
+            const int nblk = R * bpr;
+            for (int b0 = wave; b0 < nblk; b0 += NW * LARGE_U) {
+                float v[LARGE_U], mx[LARGE_U];
+                float* px[LARGE_U];
+                bool ok[LARGE_U];
+#pragma unroll
+                for (int u = 0; u < LARGE_U; ++u) {
+                    const int blk = b0 + u * NW;
+                    const int r = blk < nblk ? blk / bpr : 0;
+                    const int l = (blk - r * bpr) * 64 + lane;
+                    ok[u] = blk < nblk && l < L;
+                    px[u] = xT + (size_t)r * Lp + (ok[u] ? l : 0);
+                    mx[u] = max_key_value(rmaxkey[r]);
+                    v[u] = *px[u];
+                }
+#pragma unroll
+                for (int u = 0; u < LARGE_U; ++u)
+                    if (ok[u]) *px[u] = det_expf(v[u] - mx[u]);
+            }
         }
         __syncthreads();
-        for (int r = 0; r < R; ++r) {                                  // exponentials, in place
-            float* x = xT + (size_t)r * Lp;
-            const float mx = rmax[r];
-            for (int l = tid; l < L; l += LARGE_NT) x[l] = det_expf(x[l] - mx);
-        }
-        __syncthreads();
-        for (int r = wave; r < R; r += LARGE_NT / 64) {                // denominators in the wavefront order of the contract
+        LARGE_STAMP(2);
+        // ---- denominators in the wavefront order of the contract: lane j adds elements j, j + 64, ... ascending
+        for (int r = wave; r < R; r += NW) {
             const float* x = xT + (size_t)r * Lp;
             float sum = 0.0f;
-            for (int l = lane; l < L; l += 64) sum = sum + x[l];
+            for (int l0 = lane; l0 < L; l0 += 64 * 2 * LARGE_U) {
+                float v[2 * LARGE_U];
+#pragma unroll
+                for (int u = 0; u < 2 * LARGE_U; ++u) {
+                    const int l = l0 + 64 * u;
+                    v[u] = x[l < L ? l : l0];
+                }
+#pragma unroll
+                for (int u = 0; u < 2 * LARGE_U; ++u)
+                    if (l0 + 64 * u < L) sum = sum + v[u];
+            }
             sum = wave_butterfly_sum(sum);
             if (lane == 0) rden[r] = sum;
         }
         __syncthreads();
-        for (int l = tid; l < a.n2; l += LARGE_NT) {                   // scores: mean over heads, then over tokens
+        LARGE_STAMP(3);
+        // ---- scores: mean over heads, then over tokens; ranking keys
+        for (int l = tid; l < a.n2; l += LARGE_NT) {
             uint64_t key = 0ull;
             if (l < L) {
                 float st = 0.0f;
@@ -1781,10 +2071,14 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a) {
             keys[l] = key;
         }
         __syncthreads();
-        sort_desc_large(keys, a.n2);
+        LARGE_STAMP(4);
+        sort_desc_large(a.n2);
+        LARGE_STAMP(5);
         if (tid == 0 && L > m && (keys[m - 1] >> 32) == (keys[m] >> 32)) tie = 1;
-        const bool replayed = large_tie_replay(keys, L, m, a.tie_order, lists, stk, leaf);
+        const bool replayed = large_tie_replay(L, m, a.tie_order, lists, tail);
+        LARGE_STAMP(6);
         const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
+        const bool want_score = a.mem_score != nullptr && it + 1 == a.it1;
         int nw[LARGE_KPT];
 #pragma unroll
         for (int s = 0; s < LARGE_KPT; ++s) {
@@ -1792,13 +2086,15 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a) {
             nw[s] = 0;
             if (j < m) {
                 int pos;
+                float sc;
                 if (replayed) {
                     pos = q[j].i;
-                    last_score[s] = key_score(rank_key(q[j].v, 0u));
+                    sc = key_score(rank_key(q[j].v, 0u));
                 } else {
                     pos = (int)key_pos(keys[j]);
-                    last_score[s] = key_score(keys[j]);
+                    sc = key_score(keys[j]);
                 }
+                if (want_score) a.mem_score[(size_t)b * m + j] = sc;
                 nw[s] = pos < m ? (int)mem[pos] : (int)(lo + (pos - m));
             }
         }
@@ -1809,32 +2105,27 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a) {
             if (j < m) mem[j] = nw[s];
         }
         __syncthreads();
-    }
-    if (a.mem_score) {
-#pragma unroll
-        for (int s = 0; s < LARGE_KPT; ++s) {
-            const int j = tid + s * LARGE_NT;
-            if (j < m) a.mem_score[(size_t)b * m + j] = last_score[s];
-        }
+        LARGE_STAMP(7);
     }
     if (a.tie && tid == 0 && tie) a.tie[b] = 1;
+    if (STAMP && tid == 0)
+        for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] += tacc[k];
 }
+#undef LARGE_STAMP
 
 // torch.topk(scores, m)[1] for l <= 16,384 candidates per row: the ranking of scan_large_kernel alone
 __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsigned char* ws, size_t ws_per_row) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    int* stk = reinterpret_cast<int*>(keys + a.n2);
-    unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 3 * stdorder::STACK_RANGES);
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int l = tid; l < a.n2; l += LARGE_NT)
         keys[l] = l < a.L ? rank_key(a.scores[(size_t)b * a.L + l], (uint32_t)l) : 0ull;
     __syncthreads();
-    sort_desc_large(keys, a.n2);
+    sort_desc_large(a.n2);
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (keys[a.m - 1] >> 32) == (keys[a.m] >> 32)) ? 1 : 0;
     int* lists = reinterpret_cast<int*>(ws + (size_t)b * ws_per_row);
-    const bool replayed = large_tie_replay(keys, a.L, a.m, a.tie_order, lists, stk, leaf);
+    const bool replayed = large_tie_replay(a.L, a.m, a.tie_order, lists, a.n2 * 8);
     const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
     for (int j = tid; j < a.m; j += LARGE_NT)
         a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[j]);
@@ -2077,8 +2368,13 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         la.ws = static_cast<unsigned char*>(workspace); la.ws_per_image = scan_large_ws_per_image(m, i, h, n_token);
         const size_t lds = large_lds_bytes(n2, R);
         IPSX_REQUIRE(lds <= kLdsLimit, "scan: internal - %zu B of LDS", lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        scan_large_kernel<<<dim3((unsigned)b), dim3(LARGE_NT), lds, as_stream(stream)>>>(la);
+        if (g_scan_stamps) {                                           // diagnostic build (tools/scan_stamps.py large)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_large_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            scan_large_kernel<true><<<dim3((unsigned)b), dim3(LARGE_NT), lds, as_stream(stream)>>>(la, g_scan_stamps);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_large_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            scan_large_kernel<false><<<dim3((unsigned)b), dim3(LARGE_NT), lds, as_stream(stream)>>>(la, nullptr);
+        }
         return launched("scan");
     }
     ScanArgs a;
@@ -2224,7 +2520,7 @@ IPSX_API int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_id
         if (!workspace || workspace_bytes < need)
             return fail(IPSX_EWORKSPACE, "topm: %d candidates need a workspace of %zu B (ipsx_topm_workspace_bytes), got %zu",
                         l, need, workspace_bytes);
-        const size_t big = (size_t)a.n2 * 8 + (size_t)3 * stdorder::STACK_RANGES * 4 + (size_t)LARGE_LEAF_WORDS * 8;
+        const size_t big = (size_t)a.n2 * 8 + LARGE_TAIL_BYTES;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
         topm_large_kernel<<<dim3((unsigned)b), dim3(LARGE_NT), big, as_stream(stream)>>>(
             a, static_cast<unsigned char*>(workspace), topm_large_ws_per_row(l));

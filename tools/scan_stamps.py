@@ -52,6 +52,39 @@ if kind == "campipe":
     for k, nme in enumerate(names):
         print("  %-30s %9.0f cycles/iter" % (nme, s[k] / n_iter))
     sys.exit(0)
+if kind == "large":
+    # scan_large_kernel (candidate sets beyond the LDS): the reference's shipped CAMELYON sizes, or N M I H T on the command line
+    N, M, I, H, T = (int(v) for v in sys.argv[2:7]) if len(sys.argv) >= 7 else (38000, 5000, 5000, 8, 1)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    lg = (torch.randn((1, N, H * T), generator=g) * 1.5).to(dev)
+    L = hip.lib()
+    L.ipsx_dbg_scan_stamps.argtypes = [C.c_void_p]
+    n_iter = -(-(N - M) // I)
+    names = ["stage logits (transposed)", "row maxima", "exponentials", "row sums", "scores + keys", "sort",
+             "tie check + replay", "new memory"]
+    for mode in ("torch", "canonical"):
+        hip.set_tie_order(mode)
+        st = torch.zeros((1, 8), dtype=torch.int64, device=dev)
+        hip.scan(lg, M, I, H, T)
+        L.ipsx_dbg_scan_stamps(st.data_ptr())
+        hip.scan(lg, M, I, H, T)
+        torch.cuda.synchronize()
+        L.ipsx_dbg_scan_stamps(None)
+        s = st.cpu().numpy()[0]
+        print("large, tie order %s: %d iterations, L=%d, R=%d; %.1f k cycles per iteration (100 MHz clock: x %.0f = core cycles)"
+              % (mode, n_iter, M + I, H * T, s.sum() / n_iter / 1e3, 24))
+        for k, nme in enumerate(names):
+            print("  %-28s %9.1f us/iter" % (nme, s[k] / n_iter / 100.0))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            hip.scan(lg, M, I, H, T)
+        b.record()
+        torch.cuda.synchronize()
+        print("  un-instrumented: %.3f ms per launch = %.1f us per iteration" % (a.elapsed_time(b) / 10, 1e2 * a.elapsed_time(b) / n_iter))
+    hip.set_tie_order("torch")
+    sys.exit(0)
 B, N, M, I, H, T = (16, 2500, 64, 64, 8, 4) if kind == "mnist" else (1, 65536, 256, 256, 8, 1)
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
