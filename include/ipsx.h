@@ -285,6 +285,13 @@ int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, in
                          int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
                          int32_t* status, void* stream);
 int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream);
+/* ipsx_scan_range that runs only when (*cond & cond_mask) != 0, tested ON THE DEVICE by every workgroup as it starts (no
+ * host synchronisation): enqueued behind ipsx_scan_persistent with cond = its status word and mask 1, it redoes the loop
+ * with plain launches in the very call whose persistent loop gave up waiting, and costs one empty launch otherwise.
+ * Shapes of the LDS-resident loops (ipsx_scan_workspace_bytes() == 0). */
+int ipsx_scan_range_if(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                       int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                       int32_t* tie_flag, const int32_t* cond, int32_t cond_mask, void* stream);
 /* ipsx_logits for rows [0, n) and, in the SAME launch, the LayerNorm row moments (ipsx_projector_stats) of stats_n rows
  * of stats_x - the next slab the projector is about to take: two short latency-bound launches of a slab-by-slab producer
  * of ipsx_scan_persistent as one. */

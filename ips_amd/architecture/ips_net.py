@@ -87,6 +87,7 @@ class IPSNet(nn.Module):
 
     def __init__(self, device, conf):
         super().__init__()
+        hip.install_optimizer_hook()        # every optimizer step invalidates the packed weights (see hip.py)
         self.device = device
         self.n_class = conf.n_class
         self.M, self.I, self.D = conf.M, conf.I, conf.D
@@ -405,16 +406,20 @@ class IPSNet(nn.Module):
         # workgroups competing for the loop's issue slots (IPSX_SCAN_PERSIST=0 switches it off).
         persistent = (not self.is_image and B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8"))
                       and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
+                      and not hip.kernels_serialised()      # (counter collection, serialising debug switches: it could only time out)
                       and hip.scan_persistent_supported(M, I, ca.H, ca.n_token))
         if persistent:
-            # a loop that gave up waiting (bounded at ~5 s: e.g. an exception between its launch and the last publish)
-            # leaves garbage: the status word of the previous call is mirrored into pinned host memory, asynchronously,
-            # and looked at here - by now that call has long finished, and no synchronisation is added to the pipeline
+            # A loop that gave up waiting (bounded at ~5 s: e.g. something serialises the kernels, so that its producers
+            # cannot run beside it) is REDONE in the same call by the conditional launch behind it (scan_range_if below:
+            # every workgroup leaves at once unless the status word says "timed out"), so this call's results are valid
+            # either way and no host synchronisation is added.  The status word is also mirrored into pinned host memory,
+            # asynchronously, and looked at in the NEXT call - by then it has long arrived - to say so once.
             mirror = getattr(self, "_scan_status_host", None)
-            if mirror is not None and int(mirror.item()) & 1:
-                mirror.zero_()
-                raise RuntimeError("the persistent selection loop of the previous ips() call timed out waiting for rows; "
-                                   "its results were invalid (IPSX_SCAN_PERSIST=0 selects the per-part launches)")
+            if mirror is not None and int(mirror.item()) & 1 and not getattr(self, "_scan_timeout_warned", False):
+                import warnings
+                warnings.warn("the persistent selection loop of an earlier ips() call timed out waiting for rows and was "
+                              "redone with per-call launches (results valid; IPSX_SCAN_PERSIST=0 avoids the wait)")
+                self._scan_timeout_warned = True
             words.zero_()
             ready, status = words[0:1], words[1:2]
             self._scan_status = status
@@ -492,6 +497,7 @@ class IPSNet(nn.Module):
                 hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie, scan_ws)
         main.wait_stream(side)
         if persistent:
+            hip.scan_range_if(logits, M, I, ca.H, ca.n_token, 0, n_iter, mem_idx_buf, tie, status, 1)   # no-op unless timed out
             if getattr(self, "_scan_status_host", None) is None:
                 self._scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
             self._scan_status_host.copy_(status, non_blocking=True)

@@ -135,7 +135,10 @@ def load_torchvision_checkpoint(trunk, path):
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
     own = trunk.state_dict()
-    missing = sorted(set(own) - set(sd))
+    # the official IMAGENET1K_V1 files (resnet18-f37072fd.pth: 102 entries, resnet50-0676ba61.pth) predate BatchNorm's
+    # ``num_batches_tracked`` buffer; BatchNorm._load_from_state_dict fills it in for such files (metadata version < 2),
+    # strict=True included - so those keys may be absent
+    missing = sorted(k for k in set(own) - set(sd) if not k.endswith("num_batches_tracked"))
     extra = sorted(set(sd) - set(own))
     wrong = sorted(k for k in set(own) & set(sd) if tuple(own[k].shape) != tuple(sd[k].shape))
     if missing or extra or wrong:

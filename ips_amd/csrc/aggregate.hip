@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
                                                         float2* __restrict__ stats, int* ready, int value) {
     // (ipsx_projector_stats_publish: everything enqueued before this launch has completed and is visible - that is what
     //  the stream order of two kernels means - so the first thread can say so on behalf of a launch of its own)
-    if (ready && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ready, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ready && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ready, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;

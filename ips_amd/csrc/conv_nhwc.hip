@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int wm = __builtin_amdgcn_readfirstlane(wave % WM), wn = __builtin_amdgcn_readfirstlane(wave / WM);
     if (NORM && a.ready && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        __hip_atomic_store(a.ready, a.ready_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ready, a.ready_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned m_base = (blockIdx.x * WM + wm) * 64u;
     const int nt0 = (blockIdx.y * WN + wn) * NTW;                   // first of this wave's n-tiles
     if (m_base >= a.m_total || nt0 * 32 >= a.c_out) return;         // wave-uniform

@@ -717,12 +717,21 @@ struct ScanArgs {
     int* tie;
     const int* ready;      // persistent launch: number of patches whose logits are in memory (grows while we run)
     int* status;           // persistent launch: set to 1 when the wait for `ready` timed out
+    const int* cond;       // conditional launch (ipsx_scan_range_if): run only when (*cond & cond_mask) != 0, or nullptr
+    int cond_mask;
 };
+
+// ipsx_scan_range_if: the recovery launch behind a persistent loop - every workgroup looks at the word the loop sets when
+// it gave up waiting and leaves at once when it is clear (workgroup-uniform).
+__device__ __forceinline__ bool scan_skipped(const int* cond, int mask) {
+    return cond != nullptr && (__hip_atomic_load(cond, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) == 0;
+}
 
 // Generic scan (any M+I that fits the key arrays): candidates' logits are re-staged from global
 // memory every iteration (or read in place when even that does not fit).
 __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (scan_skipped(a.cond, a.cond_mask)) return;
     const int R = a.h * a.T, Lmax = a.m + a.i;
     uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
     uint64_t* keyB = keyA + a.n2;
@@ -1008,6 +1017,7 @@ __device__ __forceinline__ float head_sum(const float* erow, const float* rden, 
 template <bool STAMP>
 __global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (scan_skipped(a.cond, a.cond_mask)) return;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     const int R = a.h * a.T, Lmax = a.m + a.i, ld = R + 1;
     uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
@@ -1286,6 +1296,7 @@ __device__ __forceinline__ float scan_load(const float* p) {
 template <int R, int T, int EPT, int LCH, bool STAMP, bool PERSIST>
 __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (!PERSIST && scan_skipped(a.cond, a.cond_mask)) return;
     // encoder workgroups share this compute unit (their matrix-pipe work coexists with this VALU-bound loop); where the
     // two compete for issue slots the loop - the serial part of the job - goes first
     __builtin_amdgcn_s_setprio(3);
@@ -1346,9 +1357,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
                 if (lane == 0) ccount[6] = v_;                                                     \
             }                                                                                                  \
             lds_barrier();                                                                                     \
+            /* the rows the producers published: every wave's loads of them are ordered after the poll that saw the */ \
+            /* progress word (one agent-scope acquire per wait - an LDS barrier alone orders nothing in global memory) */ \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                                 \
             ready_known = ccount[6];                                                               \
             if (ready_known < 0) {                                                                             \
-                if (tid == 0 && b == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                if (tid == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
                 return;                                                                                        \
             }                                                                                                  \
         }                                                                                                      \
@@ -2260,7 +2274,7 @@ IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int 
 static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                            int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
-                           size_t workspace_bytes, void* stream);
+                           size_t workspace_bytes, void* stream, const int32_t* cond = nullptr, int32_t cond_mask = 0);
 
 IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                              int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
@@ -2289,7 +2303,7 @@ IPSX_API size_t ipsx_scan_workspace_bytes(int b, int m, int i, int h, int n_toke
 }
 
 __global__ void publish_rows_kernel(int* ready, int value) {
-    __hip_atomic_store(ready, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ready, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 IPSX_API int ipsx_scan_persistent_supported(int m, int i, int h, int n_token) {
@@ -2335,10 +2349,19 @@ IPSX_API int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream) {
     return launched("publish_rows");
 }
 
+IPSX_API int ipsx_scan_range_if(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                                int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                                int32_t* tie_flag, const int32_t* cond, int32_t cond_mask, void* stream) {
+    IPSX_REQUIRE(cond && cond_mask, "scan_range_if: needs the condition word and a mask");
+    IPSX_REQUIRE(scan_fits_lds(m, i, h, n_token), "scan_range_if: shapes of the LDS-resident loops only");
+    return scan_range_impl(logits, b, n, m, i, h, n_token, it_begin, it_end, mem_idx, mem_score, tie_flag, nullptr, nullptr,
+                           nullptr, 0, stream, cond, cond_mask);
+}
+
 static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                            int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+                           size_t workspace_bytes, void* stream, const int32_t* cond, int32_t cond_mask) {
     IPSX_REQUIRE(logits && mem_idx, "scan: null pointer");
     IPSX_REQUIRE(b > 0 && m > 0 && i > 0 && h > 0 && n_token > 0, "scan: bad sizes");
     IPSX_REQUIRE(n > m, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
@@ -2382,6 +2405,7 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     a.ready = ready; a.status = status;
+    a.cond = cond; a.cond_mask = cond_mask;
     a.tie_order = g_tie_order;
     // fast variant (scan_fast_kernel): R a power of two, one thread per element
     {

@@ -83,13 +83,25 @@ def _optimizer_stepped(optimizer, args, kwargs):
 
 
 # Not every in-place update bumps ``_version``: torch's FUSED optimizers (AdamW(fused=True), ...) move the parameters
-# without touching it (checked: version 0 -> 0 across a step), so every optimizer step, of any optimizer, invalidates the
-# packed weights.  (Manual updates through ``.data`` or raw pointers still need an explicit ``weights_changed()``.)
-try:
-    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
-    _register_step_hook(_optimizer_stepped)
-except ImportError:          # older torch: per-optimizer hooks only; ips_amd.training registers them itself
-    _register_step_hook = None
+# without touching it (checked: version 0 -> 0 across a step), so every optimizer step invalidates the packed weights.
+# The hook is process-global in torch (there is no per-module form), so it is installed when the first IPSNet is BUILT
+# (``IPSNet.__init__`` calls ``install_optimizer_hook``), not when this module is imported: a process that merely imports
+# the package keeps its optimizers untouched.  (Manual updates through ``.data`` or raw pointers still need an explicit
+# ``weights_changed()``.)
+_HOOK_INSTALLED = False
+
+
+def install_optimizer_hook():
+    global _HOOK_INSTALLED
+    if _HOOK_INSTALLED:
+        return True
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:      # older torch: per-optimizer hooks only; ips_amd.training registers them itself
+        return False
+    register_optimizer_step_post_hook(_optimizer_stepped)
+    _HOOK_INSTALLED = True
+    return True
 
 
 def on_device(x):
@@ -192,6 +204,8 @@ _EXPORTS = {
     "ipsx_scan_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "ipsx_scan_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_scan_range_if": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ipsx_scan_persistent_supported": (C.c_int, [C.c_int] * 4),
     "ipsx_scan_persistent": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -317,6 +331,7 @@ class EncoderPlan:
         self._sig = None
         self._keep = []
         self._ws = None
+        self._ws_small = 0
         self._held = 0
 
     def _signature(self):
@@ -388,12 +403,15 @@ class EncoderPlan:
             self.d_out = w.shape[0]
 
     def _workspace(self, nbytes, device):
-        # grown on demand; given back when a much smaller request follows (one large evaluation call must not pin
-        # tens of GiB for the rest of a training run)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device or \
-                (self._ws.numel() > (256 << 20) and nbytes < self._ws.numel() // 4):
+        # grown on demand; given back when much smaller requests keep coming (one large evaluation call must not pin
+        # tens of GiB for the rest of a training run) - after several in a row, not after one: lazy slabs of 1/6, 1/2 and
+        # full size, or an eval call between training steps, would otherwise free and re-allocate gigabytes per call
+        small = self._ws is not None and self._ws.numel() > (256 << 20) and nbytes < self._ws.numel() // 4
+        self._ws_small = self._ws_small + 1 if small else 0
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device or self._ws_small >= 8:
             self._ws = None
             self._ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            self._ws_small = 0
         return self._ws
 
     def _refresh(self):
@@ -456,6 +474,11 @@ class EncoderPlan:
             if ns > 1 and n >= 1024 and not lib().ipsx_trunk_kernel(C.byref(self.trunk)).startswith(b"fused"):
                 cuts = [n * k // ns for k in range(ns + 1)]
                 nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), max(cuts[k + 1] - cuts[k] for k in range(ns)))
+                # the library's budget (a share of the free memory) is per CALL: the ns concurrent calls split it - each
+                # chunks its part of the batch to the workspace it is given
+                budget = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), 1 << 40)
+                nb = min(nb, max(budget // ns, lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), 1)))
+                nb -= nb % 256
                 ws = self._workspace(ns * nb, x.device)
                 if len(getattr(self, "_sides", [])) < ns - 1:
                     self._sides = [torch.cuda.Stream(device=x.device) for _ in range(ns - 1)]
@@ -687,6 +710,25 @@ def scan_range(lg, M, I, H, T, it_begin, it_end, mem_idx, tie, workspace=None):
     return mem_idx
 
 
+def scan_range_if(lg, M, I, H, T, it_begin, it_end, mem_idx, tie, cond, mask=1):
+    """``scan_range`` that every workgroup abandons at once unless ``cond`` (int32 device scalar) has a bit of ``mask``
+    set: the in-call recovery of a persistent loop that gave up waiting (its status word, bit 0)."""
+    B, N = lg.shape[:2]
+    _ck(lib().ipsx_scan_range_if(_p(lg), B, N, M, I, H, T, it_begin, it_end, _p(mem_idx), None, _p(tie), _p(cond), mask,
+                                 _stream()), "ipsx_scan_range_if")
+    return mem_idx
+
+
+def kernels_serialised():
+    """Does the environment make kernels run one at a time?  (Counter collection and thread traces of rocprofv3, the
+    runtime's serialising debug switches.)  A persistent selection loop that waits for rows its producers publish can
+    then only time out - the producers cannot run while it waits - so callers do not use it."""
+    env = os.environ
+    on = lambda k: env.get(k, "0").strip().lower() not in ("", "0", "false", "no")
+    return (on("AMD_SERIALIZE_KERNEL") or on("HIP_LAUNCH_BLOCKING") or on("ROCPROF_COUNTER_COLLECTION") or
+            bool(env.get("ROCPROF_COUNTERS")) or on("ROCPROF_ADVANCED_THREAD_TRACE") or bool(env.get("ROCPROF_PC_SAMPLING_METHOD")))
+
+
 def scan_persistent_supported(M, I, H, T):
     return bool(lib().ipsx_scan_persistent_supported(M, I, H, T))
 
@@ -853,9 +895,11 @@ def bn_train_forward(x, residual, gamma, beta, eps, momentum, running_mean, runn
     if residual is not None and _rows_cl(residual) != (rows, c):
         raise ValueError("residual shape")
     y = torch.empty_like(x)                        # (preserves channels-last)
-    # one allocation: mean | invstd | workspace (at most _BN_MAX_SLABS x 2 x C partial sums - the library checks)
-    buf = torch.empty((2 + 2 * _BN_MAX_SLABS) * c, dtype=torch.float32, device=x.device)
-    mean, invstd, ws = buf[:c], buf[c:2 * c], buf[2 * c:]
+    # mean | invstd are saved for backward, so they are an allocation of their own (2 C floats): carved out of the
+    # workspace they would keep its ~4 KB x C alive until backward, per BatchNorm (~20 MB per ResNet-18 step)
+    stat = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    mean, invstd = stat[:c], stat[c:]
+    ws = torch.empty(max(1, _bn_workspace_floats(rows, c)), dtype=torch.float32, device=x.device)
     _ck(lib().ipsx_bn_train_forward(_p(x), _p(residual), rows, c, _p(_f32(gamma)), _p(_f32(beta)), eps, momentum,
                                     _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
                                     _p(ws), _stream()), "ipsx_bn_train_forward")
@@ -863,6 +907,16 @@ def bn_train_forward(x, residual, gamma, beta, eps, momentum, running_mean, runn
 
 
 _BN_MAX_SLABS = 512      # csrc/bn_train.hip BN_MAX_SLABS (ipsx_bn_train_workspace_floats never exceeds 2 * 512 * C)
+_BN_WS_FLOATS = {}
+
+
+def _bn_workspace_floats(rows, c):
+    """ipsx_bn_train_workspace_floats(rows, c), remembered per shape (a training step asks for the same few shapes)."""
+    key = (rows, c)
+    n = _BN_WS_FLOATS.get(key)
+    if n is None:
+        n = _BN_WS_FLOATS[key] = int(lib().ipsx_bn_train_workspace_floats(rows, c))
+    return n
 
 
 def bn_train_backward(dy, y, x, gamma, mean, invstd, relu, want_residual):
@@ -874,7 +928,7 @@ def bn_train_backward(dy, y, x, gamma, mean, invstd, relu, want_residual):
     dres = torch.empty_like(x) if want_residual else None
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
-    ws = torch.empty(2 * _BN_MAX_SLABS * c, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(1, _bn_workspace_floats(rows, c)), dtype=torch.float32, device=x.device)
     _ck(lib().ipsx_bn_train_backward(_p(dy), _p(y), _p(x), rows, c, _p(_f32(gamma)), _p(mean), _p(invstd), int(relu),
                                      _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), _stream()),
         "ipsx_bn_train_backward")

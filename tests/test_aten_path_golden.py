@@ -114,8 +114,42 @@ def test_pretrained_reads_a_local_torchvision_checkpoint(tmp_path, monkeypatch):
     net1 = IPSNet(torch.device("cpu"), synth.mnist_conf(N=64, M=8, I=8, pretrained=True))
     assert tuple(net1.encoder[0].weight.shape) == (64, 1, 7, 7)
     assert torch.equal(net1.encoder[4][0].conv1.weight, sd["layer1.0.conv1.weight"])
+    # the official IMAGENET1K_V1 files predate BatchNorm's num_batches_tracked (resnet18-f37072fd.pth: 102 entries incl.
+    # fc.*): such a file loads like the full one
+    old = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    assert len(old) == 102
+    torch.save(old, path)
+    net2 = IPSNet(torch.device("cpu"), conf)
+    assert torch.equal(net2.encoder[0].weight, sd["conv1.weight"])
+    assert torch.equal(net2.encoder[7][1].bn2.running_var, sd["layer4.1.bn2.running_var"])
     bad = dict(sd)
     del bad["layer2.0.downsample.0.weight"]
     torch.save(bad, path)
     with pytest.raises(RuntimeError, match="not a torchvision checkpoint"):
         IPSNet(torch.device("cpu"), conf)
+
+
+def test_optimizer_hook_is_installed_by_building_a_net_not_by_importing(tmp_path):
+    """torch's optimizer step hook is process-global: importing ips_amd must not install it (a host process that only
+    imports the package keeps its optimizers untouched); building an IPSNet does, and a step then invalidates the packed
+    weights (fused optimizers do not bump tensor versions)."""
+    import subprocess
+    import sys
+    code = ("import torch, ips_amd.hip as hip\n"
+            "from torch.optim import optimizer as O\n"
+            "assert len(O._global_optimizer_post_hooks) == 0 and not hip._HOOK_INSTALLED\n"
+            "from ips_amd import synth\n"
+            "from ips_amd.architecture import IPSNet\n"
+            "net = IPSNet(torch.device('cpu'), synth.mnist_conf(N=64, M=8, I=8))\n"
+            "assert len(O._global_optimizer_post_hooks) == 1 and hip._HOOK_INSTALLED\n"
+            "IPSNet(torch.device('cpu'), synth.mnist_conf(N=64, M=8, I=8))\n"
+            "assert len(O._global_optimizer_post_hooks) == 1\n"
+            "g = hip.weights_generation()\n"
+            "opt = torch.optim.SGD(net.parameters(), lr=0.1)\n"
+            "opt.step()\n"
+            "assert hip.weights_generation() == g + 1\n"
+            "print('ok')\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

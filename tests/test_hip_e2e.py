@@ -453,10 +453,11 @@ def test_configs4_half_storage_and_bf16_logits_end_to_end(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_persistent_loop_equals_per_part_launches_and_reports_a_timeout(monkeypatch):
+def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(monkeypatch):
     """Feature inputs: the selection loop as ONE persistent launch that follows the projector (ipsx_scan_persistent +
-    gate + published row counts) selects exactly what the per-part launches select; a loop whose rows never arrive ends
-    by itself (bounded wait), sets its status word, and the next ips() call reports it."""
+    gate + published row counts) selects exactly what the per-part launches select.  A loop whose rows never arrive ends
+    by itself (bounded wait) and sets its status word - from EVERY workgroup - and the conditional launch behind it
+    (ipsx_scan_range_if) redoes the loop in the same call; with the status word clear that launch changes nothing."""
     conf = synth.camelyon_conf(N=8192, M=64, I=64)
     net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 5).to(DEV).eval()
     x = synth.make_patches(conf, 1, seed=9).to(DEV)
@@ -468,19 +469,36 @@ def test_persistent_loop_equals_per_part_launches_and_reports_a_timeout(monkeypa
         net.ips(x)
         assert torch.equal(net.last_mem_idx, want)
     assert int(net._scan_status.item()) & 1 == 0 and int(net._scan_status.item()) & 2 == 2
-    # a loop nobody feeds: negative progress word = cancelled -> it ends at once with the failure bit set
-    lg = torch.randn((1, 1024, 8), device=DEV)
-    mem = torch.empty((1, 64), dtype=torch.int64, device=DEV)
-    tie = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    # a loop nobody feeds: negative progress word = cancelled -> it ends at once with the failure bit set ...
+    B = 3
+    lg = torch.randn((B, 1024, 8), device=DEV)
+    plain = hip.scan(lg, 64, 64, 8, 1)
+    mem = torch.full((B, 64), -7, dtype=torch.int64, device=DEV)
+    tie = torch.zeros((B,), dtype=torch.int32, device=DEV)
     words = torch.tensor([-1, 0], dtype=torch.int32, device=DEV)
     hip.scan_persistent(lg, 64, 64, 8, 1, mem, tie, words[0:1], words[1:2])
     torch.cuda.synchronize()
     assert int(words[1].item()) & 1 == 1
-    net._scan_status_host.fill_(1)                      # what the mirror would hold after such a call
-    with pytest.raises(RuntimeError, match="timed out"):
+    assert not torch.equal(mem, plain)
+    # ... and the conditional launch behind it repairs the result without the host looking at anything
+    n_iter = (1024 - 64) // 64
+    hip.scan_range_if(lg, 64, 64, 8, 1, 0, n_iter, mem, tie, words[1:2], 1)
+    assert torch.equal(mem, plain)
+    mem.fill_(-7)
+    words.zero_()
+    hip.scan_range_if(lg, 64, 64, 8, 1, 0, n_iter, mem, tie, words[1:2], 1)        # status clear: every workgroup leaves
+    assert int((mem != -7).sum().item()) == 0
+    # the host learns of a timeout from the mirrored status word, one call later, and says so once - results stay valid
+    net._scan_status_host.fill_(1)
+    with pytest.warns(UserWarning, match="timed out"):
         net.ips(x)
-    net.ips(x)                                          # ... and the call after that works again
     assert torch.equal(net.last_mem_idx, want)
+    # kernels serialised (counter collection, debugging switches): the persistent loop is not used at all
+    monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
+    assert hip.kernels_serialised()
+    net._scan_status = None
+    net.ips(x)
+    assert net._scan_status is None and torch.equal(net.last_mem_idx, want)
 
 
 @pytest.mark.gpu
