@@ -93,9 +93,25 @@ def parse():
     return ap.parse_args()
 
 
+def host_description():
+    """CPU model, logical CPUs of the machine, CPUs this process may run on."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cpus_available": avail}
+
+
 def cpu_baseline(conf, x, budget_s):
-    """The reference's CPU path (ATen restatement) on a bounded sample of the same workload: whole calls on the
-    headline batch itself, repeated until the budget is used."""
+    """The reference's CPU path (ATen restatement, oracle/ips_torch.py) on a BOUNDED sample of the same workload: whole
+    ``ips()`` calls on the batch itself when one call fits the budget, otherwise on a prefix of it - fewer images first,
+    then a shorter patch axis cut at a chunk boundary (the per-patch cost of the loop does not depend on N: every
+    iteration embeds I patches and scores M + I) - repeated until the budget is used."""
     from ips_amd import synth
     from ips_amd.architecture import IPSNet
     from oracle import ips_torch
@@ -103,35 +119,49 @@ def cpu_baseline(conf, x, budget_s):
     net = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 7).eval()
     sd = dict(net.state_dict())
     B, N = x.shape[:2]
+    host = host_description()
+    avail = host["cpus_available"]
     # The reference loop feeds the encoder I patches per image per call: too little work for every core of a big
     # host (256 threads measured 14 patches/s).  Probe a few thread counts on a short prefix of the same batch and keep
     # the fastest - that is the reference's best case on this host.
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n_probe = min(N, conf.M + 4 * conf.I)
+    b_probe = min(B, 2)
     best, probe = None, conf.clone(N=n_probe)
     pos = net.pos_enc[:, :n_probe] if conf.use_pos else None
     for thr in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(thr)
-        ips_torch.ips(sd, probe, x[:, :n_probe], pos)
+        ips_torch.ips(sd, probe, x[:b_probe, :n_probe], pos)
         t0 = time.perf_counter()
-        ips_torch.ips(sd, probe, x[:, :n_probe], pos)
+        ips_torch.ips(sd, probe, x[:b_probe, :n_probe], pos)
         dt = time.perf_counter() - t0
         if best is None or dt < best[1]:
             best = (thr, dt)
         if dt > 4 * best[1]:
             break
     torch.set_num_threads(best[0])
+    per_patch = best[1] / (b_probe * n_probe)                   # seconds per patch at the probe's size
+    # the sample: as much of the batch as one call can take in about a third of the budget
+    room = max(1, int(budget_s / 3 / per_patch))                # patches
+    b_s = max(1, min(B, room // N))
+    n_s = N if b_s * N <= room else max(conf.M + conf.I, min(N, conf.M + (room - conf.M) // conf.I * conf.I))
+    sample_conf = conf if n_s == N else conf.clone(N=n_s)
+    xs = x[:b_s, :n_s]
+    pos_s = net.pos_enc[:, :n_s] if conf.use_pos else None
     reps, t0 = 0, time.perf_counter()
     while True:
-        ips_torch.ips(sd, conf, x, net.pos_enc)
+        ips_torch.ips(sd, sample_conf, xs, pos_s)
         reps += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or reps >= 50:
             break
-    return {"value": B * N * reps / dt, "unit": "patches/s", "cores": torch.get_num_threads(),
+    whole = b_s == B and n_s == N
+    return {"value": b_s * n_s * reps / dt, "unit": "patches/s", "cores": torch.get_num_threads(),
+            "threads": torch.get_num_threads(), "nproc": host["nproc"], "cpus_available": avail, "cpu_model": host["cpu_model"],
             "kind": "port",
-            "sample": "%d x ips() on the headline batch itself, %d images x %d patches (oracle/ips_torch.py, ATen/oneDNN, "
-                      "%.1f s; thread count = fastest of 4..64 on a %d-patch prefix)" % (reps, B, N, dt, n_probe)}
+            "sample": "%d x ips() on %s, %d image(s) x %d patches (oracle/ips_torch.py: the reference's ATen/oneDNN CPU path "
+                      "restated, %.1f s; thread count = fastest of 4..64 on a %d x %d-patch prefix)"
+                      % (reps, "the bench batch itself" if whole else "a prefix of the bench batch (first images, patch axis cut at a chunk boundary)",
+                         b_s, n_s, dt, b_probe, n_probe)}
 
 
 def parity(name, mem_idx, images=None):
@@ -192,17 +222,25 @@ def measure_precision(net, x, args, precision, fixture):
             "same_indices_as_f32": same, "parity": par, "what": _ALSO[precision]}
 
 
-def pmc_traffic(kernel_name, enc_patches, n_launch):
-    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process; they are
-    collected with separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command
-    (tools/pmc_traffic.py, gfx950 correction applied) and committed under profiles/ together with a hash of the kernel's
-    source: a figure measured on another version of the kernel is reported as null, not silently reused."""
+def pmc_traffic(workload, kernel_name, enc_patches, n_launch):
+    """HBM bytes from the PMC counters.  They cannot be read from inside this process; they are collected with separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very command (tools/pmc_traffic.py, gfx950 correction
+    applied) and committed under profiles/pmc_traffic.json, one record per workload, each with a hash of the kernel sources
+    it was measured on: a figure measured on another version of the kernels is reported as null, not silently reused.
+    Returns (bytes, note): bytes per launch of the dominant kernel where the encoder is ONE kernel (the fused trunk),
+    bytes per step over all kernels otherwise."""
     try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-        src = os.path.join(REPO, "ips_amd", "csrc", pmc["source"])
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
-        if sha != pmc["source_sha16"]:
-            return None, "profiles/pmc_traffic.json was measured on another version of %s (stale)" % pmc["source"]
+        allrec = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        pmc = allrec.get(workload) if "kernel" not in allrec else (allrec if workload == "mnist" else None)
+        if pmc is None:
+            return None, "no PMC record for this workload"
+        h = hashlib.sha256()
+        for src in pmc["source"].split(","):
+            h.update(open(os.path.join(REPO, "ips_amd", "csrc", src), "rb").read())
+        if h.hexdigest()[:16] != pmc["source_sha16"]:
+            return None, "profiles/pmc_traffic.json[%s] was measured on another version of %s (stale)" % (workload, pmc["source"])
+        if "hbm_bytes_per_step" in pmc:
+            return pmc["hbm_bytes_per_step"], "bytes per step, all kernels of ips() (PMC, profiles/pmc_traffic.json)"
         if pmc["kernel"] in (kernel_name or "") and enc_patches == pmc["patches_per_launch"] * n_launch:
             return pmc["hbm_bytes_per_launch"], "bytes per launch (PMC, profiles/pmc_traffic.json)"
         return None, "profiles/pmc_traffic.json holds %s at %d patches per launch" % (pmc["kernel"], pmc["patches_per_launch"])
@@ -378,12 +416,13 @@ def main():
 
     if world > 1:                                               # every rank's verdict and phase times travel to rank 0
         mine_rec = {"rank": rank, "patches_per_image": n_mine, "phases": phases,
-                    "indices_equal": par["indices_equal"] if par else None}
+                    "indices_equal": par["indices_equal"] if par else None,
+                    "device_index": dev.index, "device": torch.cuda.get_device_name(dev)}
         recs = [None] * world
         dist.all_gather_object(recs, mine_rec)
     kernel_name = hip.encoder_kernel_name(net._plan)
-    traffic, traffic_note = pmc_traffic(kernel_name, enc_patches, n_launch)
-    if not (name == "mnist" and args.precision == "fp32" and not args.dedup_blank and world == 1):
+    traffic, traffic_note = pmc_traffic(name, kernel_name, enc_patches, n_launch)
+    if not (args.precision == "fp32" and not args.dedup_blank and not args.lazy and world == 1 and batch == (1 if name == "b1" else B)):
         traffic = None
 
     if rank == 0:
@@ -423,6 +462,17 @@ def main():
         if world > 1:
             out["parity_all_ranks"] = all(r["indices_equal"] for r in recs) if par else None
             out["per_rank"] = recs
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "devices": [r["device"] for r in recs], "one_gpu_per_rank": not share}
+        # the WHOLE call priced against the work it executes: encoder FLOP + the logits' folded-query contraction
+        # (2 * D * H * n_token per patch - the reference's per-iteration K projection is not executed here)
+        call_flop = FLOP_PER_PATCH[name] + 2 * conf.D * conf.H * conf.n_token
+        call_tflops = patches_per_step * args.steps / elapsed * call_flop / 1e12
+        out["roofline_call"] = {"bound": "mfma", "achieved": call_tflops, "peak": FP32_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                                "frac": call_tflops / (FP32_MFMA_PEAK_TFLOPS * world),
+                                "what": "patches/s of the whole ips() call x executed FLOP per patch (encoder %d + logits %d)"
+                                        % (FLOP_PER_PATCH[name], 2 * conf.D * conf.H * conf.n_token),
+                                "algorithmic_bytes_per_step": patches_per_step * per_patch_bytes}
         if args.precision == "bf16":    # priced against the dense bf16 MFMA peak
             out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
             out["roofline"]["frac"] = achieved / BF16_MFMA_PEAK_TFLOPS
@@ -436,8 +486,9 @@ def main():
                                             % (int(net._plan.n_encoded.item()), enc_patches // n_launch)})
         if world == 1 and name == "mnist" and args.precision == "fp32" and not (args.dedup_blank or args.lazy) and batch == B:
             out["also_measured"] = {p: measure_precision(net, x, args, p, fixture) for p in ("fp32x3", "bf16")}
-        if world == 1 and args.cpu_seconds > 0 and name == "mnist" and batch == B:
+        if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(conf, x_host, args.cpu_seconds)
+        out["host"] = host_description()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -148,3 +148,35 @@ def test_bench_workload_selects_the_reference_indices(name):
           "in %d (%d of them in another order)" % (name, gap.size, GAP_FLOOR, int((gap <= GAP_FLOOR).sum()),
                                                    int(((gap <= GAP_FLOOR) & ~same_set).sum()),
                                                    int((ogap <= GAP_FLOOR).sum()), int(((ogap <= GAP_FLOOR) & ~same_seq).sum())))
+
+
+@pytest.mark.gpu
+def test_configs2_with_this_hosts_own_positional_table():
+    """BASELINE configs[2] (10,000 patches per image) with the positional table THIS host builds (the product never
+    swaps tables; the other tests install the recording machine's, ``synth.use_fixture_pos_table``, because the table's
+    last ulp differs between CPU models and at N = 10,000 that reorders near-identical blank patches).  What can be
+    held here without the reference: the HIP path equals the oracle's loop on the same embeddings and the same
+    host-made table, index for index and iteration by iteration's end; against the recorded reference run the
+    differences are counted - none where this host's table equals the recording machine's."""
+    from ips_amd.architecture import IPSNet
+    from oracle.oracle import Oracle
+    z, conf = load("mnist3000")
+    dev = torch.device("cuda:0")
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    B = 4
+    x = synth.make_patches(conf, int(z["B"]), seed=21)[:B].to(dev)
+    same_table = bool(torch.equal(synth.pos_table_from(z["pos_freq"], conf.N).unsqueeze(0).to(dev), net.pos_enc))
+    net.ips(x)                                                        # the product call, host-made table
+    got = net.last_mem_idx.cpu().numpy()
+    emb = net._embed(x.reshape(-1, *x.shape[2:])).view(B, conf.N, -1).cpu().numpy()
+    cpu = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 7).eval()
+    assert torch.equal(cpu.pos_enc, net.pos_enc.cpu())                # built by the same ATen ops on the same host
+    want = Oracle(cpu).scan(emb, cpu.pos_enc.numpy(), aten_ties=True)["mem_idx"]
+    assert np.array_equal(got, want), "HIP loop differs from the oracle's on images %s" % np.nonzero((got != want).any(1))[0].tolist()
+    ref = z["trace_idx"][:B, -1].astype(np.int64)
+    equal = (got == ref).all(1)
+    print("mnist3000, host-made positional table (%s the recording machine's): %d of %d images select the reference's "
+          "patches in the reference's order, %.2f %% of all slots" % ("equal to" if same_table else "DIFFERENT from",
+                                                                    int(equal.sum()), B, 100 * float((got == ref).mean())))
+    if same_table:
+        assert equal.all()

@@ -316,6 +316,40 @@ def test_sharded_path_world_size_2_on_one_gpu():
     assert out.stdout.count("tournament ok") == 6 and "MISMATCH" not in out.stdout
 
 
+def test_sharded_path_over_rccl_one_gpu_per_rank():
+    """The N > 1 path as it is deployed: one process per GPU, ``torch.distributed`` backend ``nccl`` (= RCCL over xGMI).
+    Runs wherever at least two GPUs are visible (the 8-GPU node of the scaling bench) and skips on a 1-GPU box, where
+    ``test_sharded_path_world_size_2_on_one_gpu`` covers the same code over gloo.  Every rank must reproduce the
+    reference-recorded fixtures and its own single-GPU ``ips()``; then ``bench.py --gpus N`` itself (configs[2],
+    patch-sharded) must report the reference's selection on every rank, and say which backend and devices it ran on."""
+    import json
+    import os
+    import subprocess
+    import sys
+    n_gpu = torch.cuda.device_count()
+    if n_gpu < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL needs one GPU per rank); this box has %d" % n_gpu)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    worlds = [2] + ([n_gpu] if n_gpu >= 4 else [])
+    for k, world in enumerate(worlds):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29551 + k), os.path.join(repo, "tools", "dist_check.py"),
+               "--backend", "nccl", "--cases", "mnist_ragged,mnist_full,cam_b2"]
+        out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert out.stdout.count(" ok") == 3 * world and "MISMATCH" not in out.stdout
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29559", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["parity_all_ranks"] is True
+    assert line["distributed"]["backend"] == "nccl" and line["distributed"]["world_size"] == 2
+    assert len({r["device_index"] for r in line["per_rank"]}) == 2
+
+
 def test_training_step_between_ips_calls():
     """What training/iterative.py does (reference :135-163): ips() in train mode, forward with autograd on the
     stock ROCm ops, backward, optimizer.step().  Weights and BatchNorm running statistics have moved, so the

@@ -1,12 +1,15 @@
 #!/usr/bin/env python
-"""Summarise `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of bench.py into
-profiles/pmc_traffic.json: HBM bytes per launch of the dominant kernel, corrected as
-/opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE reports
-half of a wide coalesced read stream -> x2; WRITE_SIZE is exact; both are in KB.
+"""Summarise `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of bench.py into profiles/pmc_traffic.json (one
+record per workload): HBM bytes, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for
+gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> x2; WRITE_SIZE is exact; both are in KB.
 
-    tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel substring> <out.json> <kernel source file in ips_amd/csrc> <patches per launch>
+    tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <ips() calls in the profiled run> <kernel sources, comma separated>
+                         [<dominant kernel substring> <patches per launch>]
 
-The record carries a hash of the kernel's source file; bench.py reports `traffic` only while that file is unchanged.
+With a dominant kernel (the fused trunk: the encoder IS one kernel) the record holds bytes per launch of that kernel;
+otherwise bytes per step summed over every kernel of the run (calls = 1 + warmup + 2 * steps of bench.py: the first
+call, the warm-up, the timed loop and the synchronised-latency loop).  The record carries a hash of the kernel sources;
+bench.py reports `traffic` only while they are unchanged.
 """
 import csv
 import glob
@@ -14,26 +17,60 @@ import hashlib
 import json
 import os
 import sys
+from collections import defaultdict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def mean_counter(d, name, kernel):
+def per_kernel(d, name):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-         if r["Counter_Name"] == name and kernel in r["Kernel_Name"]]
-    return sum(v) / len(v), len(v)
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == name:
+            k = r["Kernel_Name"].split("(")[0][:80]
+            acc[k][0] += float(r["Counter_Value"])
+            acc[k][1] += 1
+    return acc
 
 
-fetch_dir, write_dir, kernel, out, source, per_launch = sys.argv[1:7]
-src_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ips_amd", "csrc", source)
-fetch_kb, n1 = mean_counter(fetch_dir, "FETCH_SIZE", kernel)
-write_kb, n2 = mean_counter(write_dir, "WRITE_SIZE", kernel)
-res = {"kernel": kernel, "launches_averaged": [n1, n2],
-       "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
-       "hbm_read_bytes": 2 * fetch_kb * 1024, "hbm_write_bytes": write_kb * 1024,
-       "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
-       "correction": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), WRITE_SIZE x1, KB = 1024 B",
-       "source": source, "source_sha16": hashlib.sha256(open(src_path, "rb").read()).hexdigest()[:16],
-       "patches_per_launch": int(per_launch),
-       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0"}
-json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res))
+def main():
+    fetch_dir, write_dir, workload, calls, sources = sys.argv[1:6]
+    calls = int(calls)
+    dominant = sys.argv[6] if len(sys.argv) > 6 else None
+    fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    h = hashlib.sha256()
+    for src in sources.split(","):
+        h.update(open(os.path.join(REPO, "ips_amd", "csrc", src), "rb").read())
+    rec = {"correction": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), WRITE_SIZE x1, KB = 1024 B",
+           "source": sources, "source_sha16": h.hexdigest()[:16],
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --config %s --steps 3 --warmup 1 --cpu-seconds 0" % workload}
+    if dominant:
+        fk = [v for k, v in fetch.items() if dominant in k]
+        wk = [v for k, v in write.items() if dominant in k]
+        fetch_kb = sum(v[0] for v in fk) / sum(v[1] for v in fk)
+        write_kb = sum(v[0] for v in wk) / sum(v[1] for v in wk)
+        rec.update({"kernel": dominant, "launches_averaged": [sum(v[1] for v in fk), sum(v[1] for v in wk)],
+                    "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
+                    "hbm_read_bytes": 2 * fetch_kb * 1024, "hbm_write_bytes": write_kb * 1024,
+                    "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+                    "patches_per_launch": int(sys.argv[7])})
+    else:
+        rd = sum(v[0] for v in fetch.values()) * 2 * 1024 / calls
+        wr = sum(v[0] for v in write.values()) * 1024 / calls
+        top = sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch[k][0] + write[k][0]))[:8]
+        rec.update({"ips_calls": calls, "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
+                    "hbm_bytes_per_step": rd + wr,
+                    "kernels": [{"kernel": k, "launches_per_step": fetch[k][1] / calls,
+                                 "read_bytes_per_step": 2 * 1024 * fetch[k][0] / calls,
+                                 "write_bytes_per_step": 1024 * write[k][0] / calls} for k in top]})
+    out = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    allrec = json.load(open(out)) if os.path.exists(out) else {}
+    if "kernel" in allrec:                     # the single-record file of rounds 1-2: it was the headline's
+        allrec = {"mnist": allrec}
+    allrec[workload] = rec
+    json.dump(allrec, open(out, "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
