@@ -361,14 +361,52 @@ class IPSNet(nn.Module):
             # (persistent loop: every slide's loop owns a compute unit, the projector has the others - and a launch of one
             #  workgroup too many takes twice as long)
             cus = 256 - (B if B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8")) else 0)
+            if cus < 256:
+                # workgroups go to the 8 XCDs round-robin whatever is free there (timeline of a 252-workgroup part beside
+                # one loop: two rounds), so what a launch can count on is the free units of the FULLEST XCD, eight times
+                cus = 8 * (32 - -(-B // 8))
             cap = max(I, (cus * 64 // max(B, 1)) // I * I)       # most rows of every image one launch can take, whole chunks
-            n_part = min(16, max(1, math.ceil(N / cap)))
+            half = max(I, (cus * 32 // max(B, 1)) // I * I)      # ... one launch of half-size workgroups (<= 127 row tiles:
+            #                                                        conv_nhwc_impl then halves the tile and the launch time)
             its = [0]
-            for k in range(1, n_part):                           # equal parts: edge k at about k * N / n_part rows
-                nxt = max(its[-1] + 1, round((k * N / n_part - M) / I))
-                if nxt >= n_iter:
-                    break
-                its.append(nxt)
+            if B == 1 and self.D >= 512 and N > cap + half and os.environ.get("IPSX_CAM_PARTS", "equal") == "latency":
+                # (opt-in, measured in round 3 and NOT the default.)  A launch costs one workgroup's time whatever its size,
+                # the loop can only take a part once ALL of it is published, and what is left of the loop after the last
+                # publication is serial time.  So: a HALF-TILE launch first (the loop starts after half the time), full
+                # launches in the middle, and the end of the slide as half-tile launches with the smallest last: the
+                # projector's chain shrinks from 1.55 + a 0.29 ms tail to 1.70 + 0.03 ms (kernel timeline,
+                # profiles/r03c_cam_timeline_latency.txt) - and the slide takes 1.98 ms instead of 1.95, because with
+                # its rows always there the LOOP is the bound: 255 iterations x 5.4 - 6.3 us beside the GEMM.  Back to
+                # back it is worse (2.6 ms per slide: the next slide's loop cannot become resident while the padded
+                # GEMM workgroups of this one hold every unit's LDS).  It pays once the loop is faster.
+                rows = [half]
+                left = N - half
+                while left > cap + half:
+                    rows.append(cap)
+                    left -= cap
+                if left > cap:                               # a full launch and a small rest
+                    rows.append(cap)
+                    left -= cap
+                while left > 0:
+                    take = min(half, left)
+                    rows.append(take)
+                    left -= take
+                if len(rows) >= 2 and rows[-1] > rows[-2]:   # the smallest part last
+                    rows[-1], rows[-2] = rows[-2], rows[-1]
+                edge = 0
+                for rws in rows[:-1]:
+                    edge += rws
+                    nxt = max(its[-1] + 1, (edge - M) // I)
+                    if nxt >= n_iter:
+                        break
+                    its.append(nxt)
+            else:
+                n_part = min(16, max(1, math.ceil(N / cap)))
+                for k in range(1, n_part):                       # equal parts: edge k at about k * N / n_part rows
+                    nxt = max(its[-1] + 1, round((k * N / n_part - M) / I))
+                    if nxt >= n_iter:
+                        break
+                    its.append(nxt)
             its.append(n_iter)
         P = len(its) - 1
         edges = [0] + [min(N, M + it * I) for it in its[1:]]

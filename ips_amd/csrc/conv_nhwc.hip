@@ -332,10 +332,28 @@ int ipsx::conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* resid
         hipStream_t s = as_stream(stream);
         const unsigned nt128 = (unsigned)cdiv(cv->c_out, 128);
         if (row_stats) {
-            if (cv->c_out >= 512)       // Linear layers with LayerNorm in the operand load (projector): wave tile 64 x 128
-                conv_nhwc_kernel<1, 4, true, 4><<<dim3(mt64, (unsigned)cdiv(nt128, 4)), dim3(256), 0, s>>>(a);
-            else if (cv->c_out >= 256)
-                conv_nhwc_kernel<1, 4, true, 2><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), 0, s>>>(a);
+            // Linear layers with LayerNorm in the operand load (projector): wave tile 64 x 128, a workgroup = 64 rows x 512
+            // columns.  A launch is as long as ONE workgroup takes, however few there are: one that would leave half the
+            // compute units idle anyway (<= 127 row tiles) runs as twice as many workgroups of 64 rows x 256 columns (wave
+            // tile 64 x 64) and is over in half the time - what a slab-by-slab producer wants for the slab a consumer is
+            // waiting for (the first and the last rows of a slide, IPSNet._select_hip_overlapped).  Same fma chain per output.
+            // A launch of at most one workgroup per compute unit asks for more than half of the LDS it does not use: the
+            // dispatcher then CANNOT put two of them on one unit (it otherwise does, now and then, long before the units run
+            // out - a part of 232 workgroups beside the resident loop took twice as long) nor one beside a
+            // persistent selection loop, whose buffers fill most of its unit's LDS.
+            const size_t lds_pad = 96 * 1024;
+            const bool big = cv->c_out >= 512 && mt64 > 127;
+            const unsigned wgs = big ? mt64 * (unsigned)cdiv(nt128, 4) : mt64 * (unsigned)cdiv(nt64, 4);
+            const size_t lds = (cv->c_out >= 256 && wgs <= 256) ? lds_pad : 0;
+            if (big) {
+                if (lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nhwc_kernel<1, 4, true, 4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad);
+                conv_nhwc_kernel<1, 4, true, 4><<<dim3(mt64, (unsigned)cdiv(nt128, 4)), dim3(256), lds, s>>>(a);
+            } else if (cv->c_out >= 256) {
+                if (lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nhwc_kernel<1, 4, true, 2>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad);
+                conv_nhwc_kernel<1, 4, true, 2><<<dim3(mt64, (unsigned)cdiv(nt64, 4)), dim3(256), lds, s>>>(a);
+            }
             else
                 conv_nhwc_kernel<2, 2, true, 2><<<dim3((unsigned)cdiv(mt64, 2), (unsigned)cdiv(nt64, 2)), dim3(256), 0, s>>>(a);
         } else if (cv->c_out >= 256)        // wide layer: the 4 waves share the activation rows
