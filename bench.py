@@ -468,8 +468,11 @@ def main():
         # (2 * D * H * n_token per patch - the reference's per-iteration K projection is not executed here)
         call_flop = FLOP_PER_PATCH[name] + 2 * conf.D * conf.H * conf.n_token
         call_tflops = patches_per_step * args.steps / elapsed * call_flop / 1e12
-        out["roofline_call"] = {"bound": "mfma", "achieved": call_tflops, "peak": FP32_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
-                                "frac": call_tflops / (FP32_MFMA_PEAK_TFLOPS * world),
+        call_peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "fp32x3": BF16_MFMA_PEAK_TFLOPS / 6, "bf16": BF16_MFMA_PEAK_TFLOPS}[args.precision] * world
+        if args.dedup_blank:                        # the encoder skipped most patches: no meaningful FLOP rate
+            call_tflops = None
+        out["roofline_call"] = {"bound": "mfma", "achieved": call_tflops, "peak": call_peak, "unit": "TFLOP/s",
+                                "frac": call_tflops / call_peak if call_tflops is not None else None,
                                 "what": "patches/s of the whole ips() call x executed FLOP per patch (encoder %d + logits %d)"
                                         % (FLOP_PER_PATCH[name], 2 * conf.D * conf.H * conf.n_token),
                                 "algorithmic_bytes_per_step": patches_per_step * per_patch_bytes}

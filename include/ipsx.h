@@ -193,13 +193,11 @@ size_t ipsx_projector_workspace_bytes(int64_t n);      /* 8 bytes per row: (mean
  * the GEMM - e.g. on another stream, beside the GEMM of an earlier slab (the pass is HBM-bound, the GEMM MFMA-bound) */
 int ipsx_projector_stats(const float* x, int64_t n, int f, float ln_eps, float* stats, void* stream);
 int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out, void* stream);
-/* ipsx_projector_stats that also does what ipsx_publish_rows(ready, value) does, at its start: the launches enqueued before
+/* ipsx_projector_apply that also does what ipsx_publish_rows(ready, value) does, at its start: the launches enqueued before
  * it (the logits of the previous slab) have completed, which is all a publication says - one launch less per slab in a
  * pipeline that feeds ipsx_scan_persistent. */
 int ipsx_projector_apply_publish(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
-                                 int32_t* ready, int32_t value, void* stream);      /* the same for the GEMM launch */
-int ipsx_projector_stats_publish(const float* x, int64_t n, int f, float ln_eps, float* stats, int32_t* ready,
-                                 int32_t value, void* stream);
+                                 int32_t* ready, int32_t value, void* stream);
 
 /* ------------------------------------------------------------------- scorer
  * Replaces MultiHeadCrossAttention.get_attn + ScaledDotProductAttention.

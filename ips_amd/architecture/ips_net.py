@@ -469,12 +469,8 @@ class IPSNet(nn.Module):
             side.wait_stream(main)
         stats = None
         if not self.is_image and patches.is_contiguous() and P > 1 and B == 1:
-            # LayerNorm moments (8 bytes per row) by a pass of their own in front of every part's GEMM.  One pass over the
-            # whole slide up front is less work (0.09 ms against 5 x 0.02), but it sits in front of the FIRST rows the loop
-            # is waiting for, and since the loop is the long pole that costs more than it saves: 2.11 -> 2.03 ms per
-            # slide (IPSX_CAM_STATS=all selects the single pass).  (Tried beside the first part's GEMM on a helper
-            # stream: its workgroups are in the way when the GEMM's are placed, some compute units end up with two of
-            # them and the launch takes twice as long.)
+            # LayerNorm moments (8 bytes per row) by a pass of their own in front of every part's GEMM (from the second
+            # part on inside the previous part's logits launch, below)
             skey = (B, N, str(dev))
             if getattr(self, "_stats_key", None) != skey:
                 self._stats_buf = torch.empty((B * N, 2), dtype=torch.float32, device=dev)
@@ -484,22 +480,16 @@ class IPSNet(nn.Module):
                 self._emb_buf = torch.empty((B, N, self.D), dtype=torch.float32, device=dev)
             self._plan._refresh()
             stats = self._stats_buf
-            per_part = os.environ.get("IPSX_CAM_STATS", "part") == "part"
-            if not per_part:
-                self._plan.row_stats(patches.reshape(B * N, -1), out=self._stats_buf)
-        # persistent loop + statistics per part: the statistics launch of part k + 1 publishes part k (everything before it
-        # in the stream has completed) - one launch and one gap less per part
-        piggy = persistent and stats is not None and per_part and os.environ.get("IPSX_CAM_PIGGYBACK", "1") != "0"
-        # ... and, one step further (two launches per part instead of three): the logits of part k and the statistics of
-        # part k + 1 are one launch, and part k is published by the GEMM launch of part k + 1
-        fused2 = piggy and vq.dtype == torch.float32 and os.environ.get("IPSX_CAM_FUSED2", "1") != "0"
+        # persistent loop + statistics per part: the logits of part k and the statistics of part k + 1 are ONE launch, and
+        # part k is published by the GEMM launch of part k + 1 (everything before it in the stream has completed): two
+        # launches per part.  (Measured against it in round 2 and removed in round 3: one statistics pass over the whole
+        # slide up front - it sits in front of the first rows the loop waits for, 2.11 vs 2.03 ms per slide; a publishing
+        # statistics launch per part, three launches per part: 1.94 vs 1.91 ms; a separate publish kernel, four.)
+        fused2 = persistent and stats is not None and vq.dtype == torch.float32
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
-            if stats is not None and per_part and not (fused2 and k > 0):
-                if piggy and k > 0:
-                    self._plan.row_stats_publish(patches[0, lo:hi], stats[lo:hi], ready, lo)
-                else:
-                    self._plan.row_stats(patches[0, lo:hi], out=stats[lo:hi])
+            if stats is not None and not (fused2 and k > 0):
+                self._plan.row_stats(patches[0, lo:hi], out=stats[lo:hi])
             if indexed:
                 emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
             elif stats is not None:
@@ -515,7 +505,7 @@ class IPSNet(nn.Module):
                                      stats[edges[k + 1]:edges[k + 2]], self._plan.ln_eps)
                 else:
                     hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
-                if not piggy or k == P - 1:
+                if not fused2 or k == P - 1:
                     hip.publish_rows(ready, hi)        # after the kernels that wrote rows [0, hi) of every image
                 continue
             if k == P - 1:

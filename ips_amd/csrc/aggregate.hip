@@ -235,14 +235,6 @@ IPSX_API int ipsx_projector_stats(const float* x, int64_t n, int f, float ln_eps
     return launched("projector row statistics");
 }
 
-IPSX_API int ipsx_projector_stats_publish(const float* x, int64_t n, int f, float ln_eps, float* stats, int32_t* ready,
-                                          int32_t value, void* stream) {
-    IPSX_REQUIRE(x && stats && ready && n > 0 && f > 0, "projector_stats_publish: bad arguments");
-    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, f, ln_eps, reinterpret_cast<float2*>(stats),
-                                                                                     ready, value);
-    return launched("projector row statistics + publish");
-}
-
 IPSX_API int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
                                   void* stream) {
     IPSX_REQUIRE(lin && x && out && stats && n >= 0, "projector_apply: bad arguments");

@@ -9,10 +9,10 @@
 // that patch alone; only the softmax denominator depends on the candidate set.  So
 //   logits_kernel  computes them once per patch (K projection on the fp32 matrix
 //                  cores, q.k reduction from LDS), and
-//   scan_kernel    replays the reference loop on those cached logits with ONE
-//                  persistent workgroup per image: stage the candidates' logits in
-//                  LDS, per-(h,t) softmax statistics by wavefront reductions, mean over
-//                  heads then tokens, rank, keep the top M - no host round trips.
+//   scan_fast_kernel / scan_large_kernel  replay the reference loop on those cached
+//                  logits with ONE workgroup per image: per-(h,t) softmax statistics by
+//                  wavefront reductions, mean over heads then tokens, rank, keep the
+//                  top M - no host round trips.
 // Arithmetic order is the oracle's (oracle/ips_oracle.cpp orc_logits,
 // orc_scores_from_logits, orc_topm).
 //
@@ -727,70 +727,12 @@ __device__ __forceinline__ bool scan_skipped(const int* cond, int mask) {
     return cond != nullptr && (__hip_atomic_load(cond, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) == 0;
 }
 
-// Generic scan (any M+I that fits the key arrays): candidates' logits are re-staged from global
-// memory every iteration (or read in place when even that does not fit).
-__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (scan_skipped(a.cond, a.cond_mask)) return;
-    const int R = a.h * a.T, Lmax = a.m + a.i;
-    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* keyB = keyA + a.n2;
-    int* candA = reinterpret_cast<int*>(keyB + a.n2);
-    int* candB = candA + Lmax;
-    float* rmax = reinterpret_cast<float*>(candB + Lmax);
-    float* rden = rmax + R;
-    float* cl = a.use_lds ? rden + R : nullptr;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const float* lg = a.lg + (size_t)b * a.n * R;
-
-    int* cand = candA;
-    int* cnew = candB;
-    for (int j = tid; j < a.m; j += 256) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
-    int tie = 0;
-    uint64_t* sorted = keyA;
-    const long long n_iter = a.it1 - a.it0;
-    for (long long it = a.it0; it < a.it1; ++it) {
-        const long long lo = it * a.i + a.m;
-        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
-        const int L = a.m + cnt;
-        for (int j = tid; j < cnt; j += 256) cand[a.m + j] = (int)(lo + j);
-        __syncthreads();
-        CandView v;
-        v.cl = cl; v.lg = lg; v.cand = cand; v.R = R;
-        if (cl) {
-            for (int e = tid; e < L * R; e += 256) {
-                const int l = e / R, r = e - l * R;
-                cl[l * (R + 1) + r] = lg[(size_t)cand[l] * R + r];
-            }
-            __syncthreads();
-        }
-        row_stats(v, L, rmax, rden);
-        __syncthreads();
-        for (int l = tid; l < a.n2; l += 256)
-            keyA[l] = l < L ? rank_key(cand_score(v, l, a.h, a.T, rmax, rden, nullptr, L), (uint32_t)l) : 0ull;
-        sorted = sort_desc(keyA, keyB, L, a.n2);
-        if (tid == 0 && L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) tie = 1;
-        if (a.tie_order == 1 && ranked_ties(sorted, L, a.m, tid & 63))
-            torch_tie_order<256>(sorted, sorted == keyA ? keyB : keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off), tid);
-        for (int j = tid; j < a.m; j += 256) cnew[j] = cand[key_pos(sorted[j])];
-        __syncthreads();
-        int* t = cand; cand = cnew; cnew = t;
-    }
-    for (int j = tid; j < a.m; j += 256) {
-        a.mem_idx[(size_t)b * a.m + j] = cand[j];
-        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
-    }
-    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
-}
-
-// Resident scan: the logits of the M memory patches stay in LDS from one iteration to the next
-// (two candidate buffers of (M+I) rows, row stride R+1), so an iteration reads only its new chunk
-// from global memory - one contiguous, coalesced block that is prefetched into registers during
-// the previous iteration.  1024 threads (16 wavefronts) per image: the loop is a chain of short
-// VALU-bound phases (two exp + one division per candidate x (head, token)), and 4 waves per SIMD
-// give them 4x the issue slots of a 256-thread block.  Same arithmetic order as the generic
-// kernel and the oracle: wave-order row sums, ascending sums over heads then tokens.
+// The selection loop kernels: 1024 threads (16 wavefronts) per image - the loop is a chain of short VALU-bound phases
+// (two exp + one division per candidate x (head, token)), and 4 waves per SIMD give them 4x the issue slots of a
+// 256-thread block.  scan_fast_kernel keeps the candidates' logits and exponentials in LDS (every shape the reference
+// ships); scan_large_kernel is the generic one (any head / token count, up to 16,384 candidates, staging through a
+// caller workspace).  Same arithmetic order in both and in the oracle: wave-order row sums, ascending sums over heads
+// then tokens.
 constexpr int SCAN_NT = 1024;
 constexpr int SCAN_PF = 4;     // prefetch registers per thread: chunk <= 1024 * 4 floats
 
@@ -988,247 +930,8 @@ __device__ __forceinline__ void rank_runs4(const uint64_t* src, uint64_t* dst, u
     }
 }
 
-// STAMP = true: diagnostic build, wave 0 accumulates s_memtime deltas per phase into stamps[b*8 + k]
-#define SCAN_STAMP(k)                                                              \
-    do {                                                                           \
-        if (STAMP) {                                                               \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();            \
-            if (tid == 0) { tacc[k] += t_ - tlast; }                               \
-            tlast = t_;                                                            \
-        }                                                                          \
-    } while (0)
-
-// sum over the heads of one (candidate, token): attention weights exp(x - max) / sum, added in ascending head order (the
-// contract); HMAX bounds the unrolled slots
-template <int HMAX>
-__device__ __forceinline__ float head_sum(const float* erow, const float* rden, int h, int T) {
-    float v[HMAX];
-#pragma unroll
-    for (int hh = 0; hh < HMAX; ++hh) {
-        const int r = (hh < h ? hh : 0) * T;
-        v[hh] = erow[r] / rden[r];                      // erow: exp(x - max) left by the statistics pass
-    }
-    float sh = 0.0f;
-#pragma unroll
-    for (int hh = 0; hh < HMAX; ++hh) if (hh < h) sh = sh + v[hh];
-    return sh;
-}
-
-template <bool STAMP>
-__global__ __launch_bounds__(SCAN_NT) void scan_resident_kernel(ScanArgs a, unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (scan_skipped(a.cond, a.cond_mask)) return;
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-    const int R = a.h * a.T, Lmax = a.m + a.i, ld = R + 1;
-    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* keyB = keyA + a.n2;
-    int* candA = reinterpret_cast<int*>(keyB + a.n2);
-    int* candB = candA + Lmax;
-    float* rmax = reinterpret_cast<float*>(candB + Lmax);
-    float* rden = rmax + R;
-    float* abuf = rden + R;                       // Lmax x (R + 1): exp(x - max) of the candidates; later the run scratch
-    float* clA = abuf + (size_t)Lmax * ld;
-    float* clB = clA + (size_t)Lmax * ld;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const float* lg = a.lg + (size_t)b * a.n * R;
-
-    int* cand = candA;
-    int* cnew = candB;
-    float* cl = clA;
-    float* clnew = clB;
-    // memory: the first m patches (it0 == 0) or the state a previous range left in mem_idx
-    for (int e = tid; e < a.m * R; e += SCAN_NT) {
-        const int l = e / R;
-        const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
-        cl[l * ld + (e - l * R)] = lg[row * R + (e - l * R)];
-    }
-    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
-    const long long n_iter = a.it1 - a.it0;
-    float pf[SCAN_PF];
-    {
-        const long long lo = a.it0 * a.i + a.m;
-        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
-#pragma unroll
-        for (int k = 0; k < SCAN_PF; ++k) {
-            const int e = tid + SCAN_NT * k;
-            pf[k] = (n_iter > 0 && e < cnt * R) ? lg[(size_t)lo * R + e] : 0.0f;
-        }
-    }
-    // lanes per candidate for the counting rank (uniform)
-    int P = 1;
-    while (P < 64 && 2 * P * std::min(Lmax, 192) <= SCAN_NT) P <<= 1;
-    // element e = tid + SCAN_NT * k of an (rows, R) array is (row, column) = (e / R, e % R): the split of tid is made
-    // once, and a step of SCAN_NT elements advances it by (dq, dr) - no integer division inside the loop
-    const int dq = SCAN_NT / R, dr = SCAN_NT - dq * R;
-    const int row0 = tid / R, col0 = tid - row0 * R;
-    const int log2T = __ffs(a.T) - 1;                  // used only when T is a power of two
-#define SCAN_ADVANCE(l, r) do { l += dq; r += dr; if (r >= R) { r -= R; ++l; } } while (0)
-    int tie = 0;
-    uint64_t* sorted = keyA;
-    for (long long it = a.it0; it < a.it1; ++it) {
-        const long long lo = it * a.i + a.m;
-        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
-        const int L = a.m + cnt;
-        // chunk registers -> candidate rows m.., next chunk -> registers
-        {
-            int l = row0, r = col0;
-#pragma unroll
-            for (int k = 0; k < SCAN_PF; ++k) {
-                const int e = tid + SCAN_NT * k;
-                if (e < cnt * R) cl[(a.m + l) * ld + r] = pf[k];
-                SCAN_ADVANCE(l, r);
-            }
-        }
-        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
-        {
-            const long long lo2 = lo + a.i;          // the range's last iteration prefetches nothing: those rows may not exist yet
-            const int cnt2 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
-#pragma unroll
-            for (int k = 0; k < SCAN_PF; ++k) {
-                const int e = tid + SCAN_NT * k;
-                pf[k] = e < cnt2 * R ? lg[(size_t)lo2 * R + e] : 0.0f;
-            }
-        }
-        __syncthreads();
-        SCAN_STAMP(0);
-        // row statistics: wave w owns rows w, w+16, ...; two rows in flight together
-        for (int r0 = wave; r0 < R; r0 += 32) {
-            const int r1 = r0 + 16;
-            const bool has1 = r1 < R;
-            float m0 = -__builtin_huge_valf(), m1 = m0;
-            for (int i = lane; i < L; i += 64) {
-                m0 = nanmax(m0, cl[i * ld + r0]);
-                if (has1) m1 = nanmax(m1, cl[i * ld + r1]);
-            }
-            wave_max2(m0, m1, lane);
-            // lane j sums its strided elements in ascending order (the contract); four exponentials are computed at a
-            // time so their dependent chains overlap - out-of-range slots add an exact + 0.0
-            float s0 = 0.0f, s1 = 0.0f;
-            for (int i0 = lane; i0 < L; i0 += 256) {
-                float e0[4], e1[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + 64 * u;
-                    const bool ok = i < L;
-                    e0[u] = ok ? det_expf(cl[(ok ? i : 0) * ld + r0] - m0) : 0.0f;
-                    e1[u] = (ok && has1) ? det_expf(cl[(ok ? i : 0) * ld + r1] - m1) : 0.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { s0 = s0 + e0[u]; s1 = s1 + e1[u]; }
-                // kept for the score phase, so exp(x - max) is not evaluated twice (row stride R + 1: the 64 lanes of a
-                // row hit different banks; slots beyond L are never read)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + 64 * u;
-                    if (i < Lmax) {
-                        abuf[i * ld + r0] = e0[u];
-                        if (has1) abuf[i * ld + r1] = e1[u];
-                    }
-                }
-            }
-            wave_sum2(s0, s1, lane);
-            if (lane == 0) {
-                rmax[r0] = m0; rden[r0] = s0;
-                if (has1) { rmax[r1] = m1; rden[r1] = s1; }
-            }
-        }
-        __syncthreads();
-        SCAN_STAMP(1);
-        // score = mean over tokens of (mean over heads) of the attention weights exp(x - max) / sum, ascending sums;
-        // ranking key.  One lane per (candidate, token) evaluates its H weights and sums them (the ascending chain);
-        // the T lanes of a candidate are adjacent, so the token sum is a few lane reads.
-        const bool lane_per_token = (a.T & (a.T - 1)) == 0 && a.T <= 64 && a.h <= 16;
-        if (lane_per_token) {
-            SCAN_STAMP(2);
-            for (int e0 = 0; e0 < a.n2 * a.T; e0 += SCAN_NT) {
-                const int e = e0 + tid, l = e >> log2T, t = e - (l << log2T);
-                float q = 0.0f;
-                if (l < L) {
-                    const float* erow = abuf + l * ld + t;
-                    float sh;
-                    if (a.h <= 4) sh = head_sum<4>(erow, rden + t, a.h, a.T);        // workgroup-uniform choice: no work for
-                    else if (a.h <= 8) sh = head_sum<8>(erow, rden + t, a.h, a.T);   // head slots that do not exist
-                    else sh = head_sum<16>(erow, rden + t, a.h, a.T);
-                    q = sh / (float)a.h;
-                }
-                float st = 0.0f;
-                for (int tt = 0; tt < a.T; ++tt) st = st + __shfl(q, (lane & ~(a.T - 1)) + tt, 64);
-                if (t == 0 && l < a.n2) keyA[l] = l < L ? rank_key(st / (float)a.T, (uint32_t)l) : 0ull;
-            }
-        } else {
-            // general shapes: attention weight of every (candidate, head, token) first, then one lane per candidate
-            {
-                int l = row0, r = col0;
-                for (int e = tid; e < L * R; e += SCAN_NT) {
-                    abuf[l * ld + r] = abuf[l * ld + r] / rden[r];      // abuf holds exp(x - max) from the statistics pass
-                    SCAN_ADVANCE(l, r);
-                }
-            }
-            __syncthreads();
-            SCAN_STAMP(2);
-            for (int l = tid; l < a.n2; l += SCAN_NT) {
-                uint64_t key = 0ull;
-                if (l < L) {
-                    float st = 0.0f;
-                    for (int t = 0; t < a.T; ++t) {
-                        float sh = 0.0f;
-                        for (int hh = 0; hh < a.h; ++hh) sh = sh + abuf[l * ld + hh * a.T + t];
-                        st = st + sh / (float)a.h;
-                    }
-                    key = rank_key(st / (float)a.T, (uint32_t)l);
-                }
-                keyA[l] = key;
-            }
-        }
-        if (L <= 192) {                      // measured crossover of the two rankings (stamps): ~200 keys
-            __syncthreads();
-            SCAN_STAMP(3);
-            rank_scatter(keyA, keyB, L, P);
-            __syncthreads();
-            sorted = keyB;
-        } else if (L <= SCAN_NT) {
-            __syncthreads();
-            SCAN_STAMP(3);
-            rank_runs(keyA, keyB, reinterpret_cast<uint64_t*>(abuf), L);
-            __syncthreads();
-            sorted = keyB;
-        } else {
-            SCAN_STAMP(3);
-            sorted = sort_desc(keyA, keyB, L, a.n2);
-        }
-        if (tid == 0 && L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m])) tie = 1;   // (NaN never equal: harmless)
-        if (a.tie_order == 1 && ranked_ties(sorted, L, a.m, lane))
-            torch_tie_order<SCAN_NT>(sorted, sorted == keyA ? keyB : keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off), tid);
-        SCAN_STAMP(4);
-        // new memory: indices and logit rows of the winners, into the other buffers
-        for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
-        {
-            int j = row0, r = col0;
-            for (int e = tid; e < a.m * R; e += SCAN_NT) {
-                clnew[j * ld + r] = cl[key_pos(sorted[j]) * ld + r];
-                SCAN_ADVANCE(j, r);
-            }
-        }
-        { int* t = cand; cand = cnew; cnew = t; }
-        { float* t = cl; cl = clnew; clnew = t; }
-        SCAN_STAMP(5);
-        // no barrier here: the next iteration's first phase writes rows m.. of the new buffers only,
-        // and its barrier orders everything before the statistics pass
-    }
-    __syncthreads();
-    for (int j = tid; j < a.m; j += SCAN_NT) {
-        a.mem_idx[(size_t)b * a.m + j] = cand[j];
-        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
-    }
-    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
-    if (STAMP && tid == 0)
-        for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Fast resident scan (R = H*T a power of two <= 64, (M+I)*R <= 1024*EPT, M+I <= 64*LCH): the same loop, same
-// arithmetic.  One image runs on ONE compute unit, 16 waves on 4 SIMDs: an instruction every thread executes costs
+// The LDS-resident loop (R = H*T a power of two <= 64, (M+I)*R <= 1024*EPT, M+I <= 64*LCH).  One image runs on ONE compute unit, 16 waves on 4 SIMDs: an instruction every thread executes costs
 // 16 issue slots, so the loop is bound by instructions per thread and by dependent LDS round trips
 // (tools/scan_stamps.py).  What this organisation does about it:
 //   * one thread per ELEMENT (candidate l, row r) with r fixed per thread (1024 % R == 0), EPT elements per thread: the
@@ -1737,7 +1440,7 @@ __global__ __launch_bounds__(256) void topm_kernel(TopmArgs a) {
 // (one array of next_pow2(L) 64-bit keys, L <= 16,384: 128 KiB); everything else goes through a caller-owned workspace
 // in global memory that stays in the L2: the candidates' logits staged TRANSPOSED ([row][candidate], so that the
 // row-wise passes of the contract - maximum, exponentials, the wave-ordered sum - are coalesced) and the index lists
-// of the tie replay.  Same arithmetic, same order of every sum as scan_kernel and the oracle.
+// of the tie replay.  Same arithmetic, same order of every sum as scan_fast_kernel and the oracle.
 constexpr int LARGE_NT = 1024;
 constexpr int LARGE_MAX_L = 16384;
 constexpr int LARGE_KPT = LARGE_MAX_L / LARGE_NT;              // keys / memory slots a thread may hold in registers
@@ -2283,12 +1986,29 @@ IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i
                            workspace, workspace_bytes, stream);
 }
 
-// does the loop for this shape live in LDS alone (scan_fast / scan_resident / scan_kernel)?
-static bool scan_fits_lds(int m, int i, int h, int n_token) {
+// Is this shape the LDS-resident loop's (scan_fast_kernel)?  Otherwise scan_large_kernel takes it (and needs a workspace).
+struct FastPlan {
+    bool ok;
+    int ept, lch;
+    size_t lds;
+};
+
+static bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
+
+static FastPlan scan_fast_plan(int m, int i, int h, int n_token) {
+    FastPlan p = {false, 1, 2, 0};
     const int R = h * n_token, Lmax = m + i, n2 = next_pow2(Lmax);
-    size_t base = (size_t)n2 * 16 + (size_t)Lmax * 8 + (size_t)R * 8;
-    base = (base + 15) & ~(size_t)15;
-    return base + STK_BYTES <= kLdsLimit;
+    if (!((R == 8 && n_token == 1) || (R == 32 && n_token == 4))) return p;      // the instantiated (R, T) pairs
+    while ((size_t)p.ept * SCAN_NT < (size_t)Lmax * R) p.ept <<= 1;
+    p.lch = Lmax <= 128 ? 2 : (Lmax <= 512 ? 8 : 16);
+    const size_t stage = (size_t)Lmax * (R + 1) * 4;
+    const int pad = (4 - ((2 * Lmax) & 3)) & 3;
+    const size_t fixed = (size_t)n2 * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
+    p.lds = ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES;
+    const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)m * (R + 1) * 4;     // inside the memory rows
+    const bool pf_fits = (size_t)i * R <= (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * SCAN_PF;
+    p.ok = p.ept <= 8 && Lmax <= SCAN_NT && pf_fits && scratch_fits && p.lds <= kLdsLimit;
+    return p;
 }
 
 static size_t scan_large_ws_per_image(int m, int i, int h, int n_token) {
@@ -2298,7 +2018,7 @@ static size_t scan_large_ws_per_image(int m, int i, int h, int n_token) {
 
 IPSX_API size_t ipsx_scan_workspace_bytes(int b, int m, int i, int h, int n_token) {
     if (b <= 0 || m <= 0 || i <= 0 || h <= 0 || n_token <= 0) return 0;
-    if (scan_fits_lds(m, i, h, n_token)) return 0;
+    if (scan_fast_plan(m, i, h, n_token).ok && !g_scan_generic) return 0;
     return (size_t)b * scan_large_ws_per_image(m, i, h, n_token);
 }
 
@@ -2307,15 +2027,8 @@ __global__ void publish_rows_kernel(int* ready, int value) {
 }
 
 IPSX_API int ipsx_scan_persistent_supported(int m, int i, int h, int n_token) {
-    const int R = h * n_token, Lmax = m + i;
-    if (!((R == 8 && n_token == 1) || (R == 32 && n_token == 4))) return 0;
-    if (Lmax > SCAN_NT || (size_t)Lmax * R > (size_t)SCAN_NT * 8) return 0;
-    const size_t stage = (size_t)Lmax * (R + 1) * 4;
-    if ((size_t)((Lmax + 63) / 64) * 64 * 8 > (size_t)m * (R + 1) * 4) return 0;
-    if ((size_t)i * R > (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * SCAN_PF) return 0;
-    const int pad = (4 - ((2 * Lmax) & 3)) & 3;
-    const size_t fixed = (size_t)next_pow2(Lmax) * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
-    return ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES <= kLdsLimit;
+    if (m <= 0 || i <= 0 || h <= 0 || n_token <= 0) return 0;
+    return scan_fast_plan(m, i, h, n_token).ok ? 1 : 0;
 }
 
 IPSX_API int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
@@ -2353,7 +2066,7 @@ IPSX_API int ipsx_scan_range_if(const float* logits, int b, int64_t n, int m, in
                                 int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                                 int32_t* tie_flag, const int32_t* cond, int32_t cond_mask, void* stream) {
     IPSX_REQUIRE(cond && cond_mask, "scan_range_if: needs the condition word and a mask");
-    IPSX_REQUIRE(scan_fits_lds(m, i, h, n_token), "scan_range_if: shapes of the LDS-resident loops only");
+    IPSX_REQUIRE(scan_fast_plan(m, i, h, n_token).ok, "scan_range_if: shapes of the LDS-resident loop only");
     return scan_range_impl(logits, b, n, m, i, h, n_token, it_begin, it_end, mem_idx, mem_score, tie_flag, nullptr, nullptr,
                            nullptr, 0, stream, cond, cond_mask);
 }
@@ -2369,20 +2082,19 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     IPSX_REQUIRE(it_begin >= 0 && it_begin <= it_end && it_end <= (n - m + i - 1) / i,
                  "scan: iteration range [%lld, %lld) outside the loop", (long long)it_begin, (long long)it_end);
     if (it_begin == it_end) return IPSX_OK;
-    const int R = h * n_token, Lmax = m + i, n2 = next_pow2(Lmax);
-    size_t base = (size_t)n2 * 16 + (size_t)Lmax * 8 + (size_t)R * 8;
-    base = (base + 15) & ~(size_t)15;
-    const size_t stage = (size_t)Lmax * (R + 1) * 4;
-    if (!scan_fits_lds(m, i, h, n_token)) {
-        // candidate sets beyond the LDS (the reference's shipped CAMELYON configuration: M = I = 5000): ranking in LDS,
-        // everything else through the caller's workspace (scan_large_kernel)
-        IPSX_REQUIRE(!ready, "scan_persistent: shape not covered");
+    const int R = h * n_token, Lmax = m + i, n2 = std::max(64, next_pow2(Lmax));
+    const FastPlan fp = scan_fast_plan(m, i, h, n_token);
+    if (!fp.ok || (g_scan_generic && !ready && !cond)) {
+        // every shape the LDS-resident loop does not cover - other head / token counts, candidate sets beyond the LDS (the
+        // reference's shipped CAMELYON configuration: M = I = 5000): ranking in LDS, everything else through the
+        // caller's workspace (scan_large_kernel)
+        IPSX_REQUIRE(!ready && !cond, "scan_persistent / scan_range_if: shape not covered");
         IPSX_REQUIRE(Lmax <= LARGE_MAX_L, "scan: M+I = %d candidates - at most %d are supported", Lmax, LARGE_MAX_L);
         IPSX_REQUIRE(R <= 256, "scan: H * n_token = %d > 256 not supported", R);
-        const size_t need = ipsx_scan_workspace_bytes(b, m, i, h, n_token);
+        const size_t need = (size_t)b * scan_large_ws_per_image(m, i, h, n_token);
         if (!workspace || workspace_bytes < need)
-            return fail(IPSX_EWORKSPACE, "scan: M+I = %d candidates need a workspace of %zu B (ipsx_scan_workspace_bytes), got %zu",
-                        Lmax, need, workspace_bytes);
+            return fail(IPSX_EWORKSPACE, "scan: M=%d I=%d H=%d n_token=%d needs a workspace of %zu B (ipsx_scan_workspace_bytes), got %zu",
+                        m, i, h, n_token, need, workspace_bytes);
         LargeArgs la;
         la.tie_order = g_tie_order;
         la.lg = logits; la.n = n; la.it0 = it_begin; la.it1 = it_end;
@@ -2401,97 +2113,57 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         return launched("scan");
     }
     ScanArgs a;
-    a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = n2;
+    a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = next_pow2(Lmax);
     a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     a.ready = ready; a.status = status;
     a.cond = cond; a.cond_mask = cond_mask;
     a.tie_order = g_tie_order;
-    // fast variant (scan_fast_kernel): R a power of two, one thread per element
-    {
-        const bool pow2 = (R & (R - 1)) == 0 && R <= 64;
-        int ept = 1;
-        while ((size_t)ept * SCAN_NT < (size_t)Lmax * R) ept <<= 1;
-        const int pad = (4 - ((2 * Lmax) & 3)) & 3;
-        const size_t fixed = (size_t)n2 * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
-        const size_t fast = ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES;
-        const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)m * (R + 1) * 4;     // inside the memory rows
-        const bool pf_fits = (size_t)i * R <= (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * SCAN_PF;
-        static const bool fast_off = getenv("IPSX_SCAN_FAST") && getenv("IPSX_SCAN_FAST")[0] == '0';
-        if (pow2 && ept <= 8 && Lmax <= SCAN_NT && pf_fits && scratch_fits &&
-            fast <= kLdsLimit && (!fast_off || ready)) {
-            a.use_lds = 1;
-            a.stk_off = (int)(fast - STK_BYTES);
-            unsigned long long* st = g_scan_stamps;
-            const int lch = Lmax <= 128 ? 2 : (Lmax <= 512 ? 8 : 16);
+    a.use_lds = 1;
+    a.stk_off = (int)(fp.lds - STK_BYTES);
+    const size_t fast = fp.lds;
+    const int ept = fp.ept, lch = fp.lch;
+    unsigned long long* st = g_scan_stamps;
 #define IPSX_LAUNCH_FAST(RR, TT, E, C, S)                                                                           \
-            do {                                                                                                    \
-                if (a.ready) {                                                                                      \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, false, true>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);               \
-                    scan_fast_kernel<RR, TT, E, C, false, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, nullptr); \
-                } else {                                                                                            \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, S, false>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);               \
-                    scan_fast_kernel<RR, TT, E, C, S, false><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st); \
-                }                                                                                                   \
-                return launched("scan");                                                                            \
-            } while (0)
+    do {                                                                                                            \
+        if (a.ready) {                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, false, true>),   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                       \
+            scan_fast_kernel<RR, TT, E, C, false, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, nullptr); \
+        } else {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, S, false>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                       \
+            scan_fast_kernel<RR, TT, E, C, S, false><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st); \
+        }                                                                                                           \
+        return launched("scan");                                                                                    \
+    } while (0)
 #define IPSX_LAUNCH_FAST_C(RR, TT, E)                                                                               \
-            do {                                                                                                    \
-                if (lch == 2) IPSX_LAUNCH_FAST(RR, TT, E, 2, false);                                                \
-                else if (lch == 8) IPSX_LAUNCH_FAST(RR, TT, E, 8, false);                                           \
-                else IPSX_LAUNCH_FAST(RR, TT, E, 16, false);                                                        \
-            } while (0)
+    do {                                                                                                            \
+        if (lch == 2) IPSX_LAUNCH_FAST(RR, TT, E, 2, false);                                                        \
+        else if (lch == 8) IPSX_LAUNCH_FAST(RR, TT, E, 8, false);                                                   \
+        else IPSX_LAUNCH_FAST(RR, TT, E, 16, false);                                                                \
+    } while (0)
 #define IPSX_LAUNCH_FAST_E(RR, TT)                                                                                  \
-            do {                                                                                                    \
-                if (ept == 1) IPSX_LAUNCH_FAST_C(RR, TT, 1);                                                        \
-                else if (ept == 2) IPSX_LAUNCH_FAST_C(RR, TT, 2);                                                   \
-                else if (ept == 4) IPSX_LAUNCH_FAST_C(RR, TT, 4);                                                   \
-                else IPSX_LAUNCH_FAST_C(RR, TT, 8);                                                                 \
-            } while (0)
-            // the diagnostic (stamped) build exists for the two benchmark shapes
-            if (st && a.ready && R == 8 && n_token == 1 && ept == 4 && lch == 8) {      // stamped persistent loop (diagnostic)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<8, 1, 4, 8, true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);
-                scan_fast_kernel<8, 1, 4, 8, true, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st);
-                return launched("scan");
-            }
-            if (st && R == 8 && n_token == 1 && ept == 4 && lch == 8) IPSX_LAUNCH_FAST(8, 1, 4, 8, true);
-            if (st && R == 32 && n_token == 4 && ept == 4 && lch == 2) IPSX_LAUNCH_FAST(32, 4, 4, 2, true);
-            if (R == 8 && n_token == 1) IPSX_LAUNCH_FAST_E(8, 1);
-            if (R == 32 && n_token == 4) IPSX_LAUNCH_FAST_E(32, 4);
+    do {                                                                                                            \
+        if (ept == 1) IPSX_LAUNCH_FAST_C(RR, TT, 1);                                                                \
+        else if (ept == 2) IPSX_LAUNCH_FAST_C(RR, TT, 2);                                                           \
+        else if (ept == 4) IPSX_LAUNCH_FAST_C(RR, TT, 4);                                                           \
+        else IPSX_LAUNCH_FAST_C(RR, TT, 8);                                                                         \
+    } while (0)
+    // the diagnostic (stamped) build exists for the two benchmark shapes
+    if (st && a.ready && R == 8 && n_token == 1 && ept == 4 && lch == 8) {      // stamped persistent loop (diagnostic)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<8, 1, 4, 8, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);
+        scan_fast_kernel<8, 1, 4, 8, true, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st);
+        return launched("scan");
+    }
+    if (st && R == 8 && n_token == 1 && ept == 4 && lch == 8) IPSX_LAUNCH_FAST(8, 1, 4, 8, true);
+    if (st && R == 32 && n_token == 4 && ept == 4 && lch == 2) IPSX_LAUNCH_FAST(32, 4, 4, 2, true);
+    if (R == 8 && n_token == 1) IPSX_LAUNCH_FAST_E(8, 1);
+    IPSX_LAUNCH_FAST_E(32, 4);
 #undef IPSX_LAUNCH_FAST_C
 #undef IPSX_LAUNCH_FAST_E
 #undef IPSX_LAUNCH_FAST
-        }
-    }
-    IPSX_REQUIRE(!ready, "scan_persistent: shape not covered");
-    // resident variant: two candidate buffers + per-(candidate, token) means, chunk prefetch in registers
-    const size_t resident = base + 3 * stage + STK_BYTES;          // exp buffer + two candidate buffers, (R + 1)-strided
-    const bool runs_fit = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)Lmax * R * 4;   // run scratch aliases the weight buffer
-    if (resident <= kLdsLimit && (size_t)i * R <= (size_t)SCAN_NT * SCAN_PF && runs_fit) {
-        a.use_lds = 1;
-        a.stk_off = (int)(resident - STK_BYTES);
-        if (resident > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
-        if (g_scan_stamps) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_resident_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
-            scan_resident_kernel<true><<<dim3((unsigned)b), dim3(SCAN_NT), resident, as_stream(stream)>>>(a, g_scan_stamps);
-        } else {
-            scan_resident_kernel<false><<<dim3((unsigned)b), dim3(SCAN_NT), resident, as_stream(stream)>>>(a, nullptr);
-        }
-        return launched("scan");
-    }
-    a.use_lds = base + stage + STK_BYTES <= kLdsLimit;
-    const size_t lds = base + (a.use_lds ? stage : 0) + STK_BYTES;
-    a.stk_off = (int)(lds - STK_BYTES);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    scan_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
-    return launched("scan");
 }
 
 IPSX_API size_t ipsx_scores_workspace_bytes(int b, int l, int d, int h, int n_token) {
@@ -2567,3 +2239,7 @@ IPSX_API int ipsx_set_tie_order(int mode) {
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_stamps(unsigned long long* buf) {
     ipsx::g_scan_stamps = buf;
 }
+
+// Diagnostic entry point (not part of include/ipsx.h): nonzero sends every shape through the generic loop kernel
+// (scan_large_kernel) - tools/scan_compare.py holds the two loop kernels against each other this way.
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int on) { g_scan_generic = on != 0; }

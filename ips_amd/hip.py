@@ -184,8 +184,6 @@ _EXPORTS = {
     "ipsx_logits_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
-    "ipsx_projector_stats_publish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
-                                               C.c_void_p]),
     "ipsx_query_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
     "ipsx_folded_query_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -499,15 +497,6 @@ class EncoderPlan:
             _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()), "ipsx_trunk_encode")
         finally:
             self.trunk.patch_dtype = 0
-        return out
-
-    def row_stats_publish(self, x, out, ready, value):
-        """``row_stats(x, out)`` whose launch also publishes ``value`` to ``ready`` (``publish_rows``) on behalf of what
-        was enqueued before it."""
-        self._refresh()
-        x = _f32(x)
-        _ck(lib().ipsx_projector_stats_publish(_p(x), x.shape[0], x.shape[1], C.c_float(self.ln_eps), _p(out), _p(ready),
-                                               int(value), _stream()), "ipsx_projector_stats_publish")
         return out
 
     def row_stats(self, x, out=None):

@@ -168,7 +168,8 @@ def test_configs2_with_this_hosts_own_positional_table():
     same_table = bool(torch.equal(synth.pos_table_from(z["pos_freq"], conf.N).unsqueeze(0).to(dev), net.pos_enc))
     net.ips(x)                                                        # the product call, host-made table
     got = net.last_mem_idx.cpu().numpy()
-    emb = net._embed(x.reshape(-1, *x.shape[2:])).view(B, conf.N, -1).cpu().numpy()
+    with torch.no_grad():
+        emb = net._embed(x.reshape(-1, *x.shape[2:])).view(B, conf.N, -1).cpu().numpy()
     cpu = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 7).eval()
     assert torch.equal(cpu.pos_enc, net.pos_enc.cpu())                # built by the same ATen ops on the same host
     want = Oracle(cpu).scan(emb, cpu.pos_enc.numpy(), aten_ties=True)["mem_idx"]

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round evidence in one GPU call: every bench line, rocprofv3 kernel statistics of the headline / cam / native50 commands,
+# HBM traffic from separate --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_traffic.py applies the gfx950 correction and
+# updates profiles/pmc_traffic.json), the loop stamps, and the parity rates the tests print.
+#   bash tools/collect_profiles.sh <out dir under gpurun_out>
+set -u
+cd "$(dirname "$0")/.."
+OUT=${1:-gpurun_out/profiles}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+bash tools/bench_all.sh > "$OUT/bench_all.jsonl" 2> "$OUT/bench_all.err"
+for c in mnist cam native50 cam_native; do
+  rm -rf /tmp/ks_$c
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -o ks -- python3 "$OLDPWD/bench.py" --config $c --steps 10 --warmup 3 --cpu-seconds 0 > "$OLDPWD/$OUT/bench_${c}_profiled.json" 2>/dev/null)
+  cp $(find /tmp/ks_$c -name "*kernel_stats.csv" | head -1) "$OUT/${c}_kernel_stats.csv" 2>/dev/null
+done
+for c in mnist cam native50; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${c}_$ctr
+    (cd /tmp && rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_${c}_$ctr -o pmc -- python3 "$OLDPWD/bench.py" --config $c --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1)
+  done
+done
+cp profiles/pmc_traffic.json "$OUT/pmc_traffic_before.json"
+python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip fused_trunk_kernel 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err"
+python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam 8 conv_nhwc.hip,aggregate.hip,scorer.hip > "$OUT/pmc_cam.json" 2> "$OUT/pmc_cam.err"
+python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err"
+cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
+python tools/scan_stamps.py cam > "$OUT/scan_stamps_cam.txt" 2>&1
+python tools/scan_stamps.py mnist >> "$OUT/scan_stamps_cam.txt" 2>&1
+python tools/scan_stamps.py large > "$OUT/scan_stamps_large.txt" 2>&1
+python -m pytest tests/test_bench_parity.py tests/test_seed_sweep.py -q -m gpu -s 2>&1 | grep -v "amdgpu.ids" > "$OUT/parity_rates.txt"
+echo done

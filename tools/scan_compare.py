@@ -1,15 +1,17 @@
 #!/usr/bin/env python
-"""scan_fast_kernel against scan_resident_kernel (IPSX_SCAN_FAST=0 in a child process) on random logits of several
-shapes, incl. ragged last chunks, resumed ranges and NaN / infinity rows: identical indices, scores and tie flags."""
+"""The two loop kernels against each other: scan_fast_kernel (LDS-resident, the shapes the reference ships) and the generic
+scan_large_kernel (forced through the diagnostic switch ipsx_dbg_scan_generic) on random logits of several shapes, incl.
+ragged last chunks, resumed ranges, exact ties and NaN / infinity rows: identical indices, scores and tie flags."""
+import ctypes as C
 import os
-import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+# (B, N, M, I, H, T): every one is a shape scan_fast_kernel covers (R = H*T in {8, 32} with T in {1, 4})
 SHAPES = [(2, 2500, 64, 64, 8, 4), (1, 8000, 256, 256, 8, 1), (3, 333, 16, 24, 8, 1), (2, 700, 100, 100, 8, 4),
-          (2, 300, 16, 16, 4, 2), (1, 500, 8, 100, 2, 1), (2, 260, 16, 32, 16, 4)]
+          (2, 300, 16, 16, 8, 4), (1, 500, 8, 100, 8, 1), (2, 1500, 300, 500, 8, 1)]
 
 
 def run():
@@ -36,13 +38,23 @@ def run():
     return out
 
 
-if len(sys.argv) > 1:
-    torch.save(run(), sys.argv[1])
-else:
-    env = dict(os.environ, IPSX_SCAN_FAST="0")
-    subprocess.check_call([sys.executable, __file__, "/tmp/scan_old.pt"], env=env)
-    new, old = run(), torch.load("/tmp/scan_old.pt")
-    for k, (a, b) in enumerate(zip(new, old)):
+def main():
+    from ips_amd import hip
+    L = hip.lib()
+    L.ipsx_dbg_scan_generic.argtypes = [C.c_int]
+    for s in SHAPES:
+        assert L.ipsx_scan_workspace_bytes(*[s[0], s[2], s[3], s[4], s[5]]) == 0, "not a scan_fast_kernel shape: %s" % (s,)
+    fast = run()
+    L.ipsx_dbg_scan_generic(1)
+    try:
+        generic = run()
+    finally:
+        L.ipsx_dbg_scan_generic(0)
+    for k, (a, b) in enumerate(zip(fast, generic)):
         same = torch.equal(a, b) or (a.dtype.is_floating_point and torch.equal(a.view(torch.int32), b.view(torch.int32)))
         assert same, "output %d of shape %s differs" % (k % 3, SHAPES[k // 3])
-    print("scan_fast_kernel == scan_resident_kernel on %d shapes (indices, scores, tie flags; resumed ranges)" % len(SHAPES))
+    print("scan_fast_kernel == scan_large_kernel on %d shapes (indices, scores, tie flags; resumed ranges)" % len(SHAPES))
+
+
+if __name__ == "__main__":
+    main()

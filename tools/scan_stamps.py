@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Diagnostic: per-phase cycles of the selection-loop kernel (STAMP build), summed over iterations.
-    python tools/scan_stamps.py mnist|cam          # scan_fast_kernel; IPSX_SCAN_FAST=0 in the environment: scan_resident_kernel
+    python tools/scan_stamps.py mnist|cam|campipe|large    # scan_fast_kernel alone / inside the CAMELYON pipeline; scan_large_kernel
 Also times the un-instrumented kernel (HIP events) and checks that both kernels select the same indices.
 """
 import ctypes as C
@@ -98,10 +98,7 @@ hip.scan(lg, M, I, H, T)
 torch.cuda.synchronize()
 L.ipsx_dbg_scan_stamps(None)
 n_iter = -(-(N - M) // I)
-if os.environ.get("IPSX_SCAN_FAST", "1") == "0":
-    names = ["stage chunk+barrier", "row stats", "attention weights", "scores+keys", "rank", "gather winners"]
-else:
-    names = ["stage chunk+barrier", "row maxima", "exp (new rows)", "row sums", "weights+scores+keys", "rank", "gather winners"]
+names = ["stage chunk+barrier", "row maxima", "exp (new rows)", "row sums", "weights+scores+keys", "rank", "gather winners"]
 s = st.cpu().numpy()[0]
 tot = s[:7].sum()
 print("%s: %d iterations, L=%d, R=%d; total %d cycles = %.1f per iteration" % (kind, n_iter, M + I, H * T, tot, tot / n_iter))
