@@ -1,0 +1,328 @@
+// fused_stage.hip - the 64-channel residual stage of a ResNet-18 trunk (layer1: BasicBlocks 64 -> 64, 3x3, stride 1) on
+// SMALL feature maps in ONE kernel, activations resident in LDS.
+//
+// Reference: the `layer1` entry of the nn.Sequential that architecture/ips_net.py:35-50 builds, at the reference's shipped
+// Megapixel-MNIST patch size (config/mnist_config.yml:34-38: 50-px patches -> 25x25 after the stem -> 13x13 after the
+// max-pool).  Layer by layer (conv_nhwc.hip) these four convolutions are the slowest part of that trunk: every
+// activation is fetched once per tap from L2 and feeds only 64 output channels - 32 FLOP per operand byte, bound by the
+// L2-to-CU traffic, 0.69 of the fp32 MFMA peak - and they are 47 % of its arithmetic.  Here a workgroup keeps G = 3
+// patches' 13x13x64 maps in LDS (508 pixel rows of 68 floats: 135 KiB, one workgroup per compute unit) and runs all four
+// convolutions on them in place:
+//   * the 3 x 169 = 507 pixel rows are PACKED into 16 M-tiles of 32 (99 % full - a tile may straddle two patches: every
+//     lane computes its own source rows);
+//   * wave w owns M-tiles 4 w .. 4 w + 3 and both n-tiles (64 output channels): 4 x 2 accumulators; a stage = one k-group
+//     (8 k) = 4 ds_read_b128 + two 16-byte weight loads + 32 MFMAs, operands one stage ahead, weights two (the data path of
+//     fused_trunk.hip's 8x8 stage with twice the M per wave.  First version: 8 M-tiles x 1 n-tile per wave - 8 LDS reads
+//     per stage, 64 operand registers, and the compiler parked operands in AccVGPRs: 128 v_accvgpr_read per 256 MFMAs,
+//     1.5 other instructions per MFMA, 0.77 of peak);
+//   * halo lanes read an all-zero pixel row (no select), per-lane tap validity is a 9-bit mask computed once;
+//   * the identity of a block is NOT held in registers (there are none left): block 1's is the kernel's own input in
+//     global memory, block 2's the output of block 1, which goes to the output buffer anyway - each thread re-reads exactly
+//     the elements it wrote.
+// Arithmetic: v_mfma_f32_32x32x2_f32 in the contract's k order (tap-major, 0,4,1,5,2,6,3,7 inside a group), padded taps
+// contribute fma(0, w, acc), BatchNorm = fma(acc, alpha, shift), + identity, ReLU - bit-identical to conv_nhwc.hip and to
+// the oracle.  Algorithmic work: 4 x 169 x 576 x 64 MAC per patch; bytes 43 KB in + 43 KB out per patch.
+
+#include "ipsx_common.h"
+#include "ipsx_math.h"
+
+namespace ipsx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define FS_SB() __builtin_amdgcn_sched_barrier(0)
+#define FS_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define FS_SG_LDS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define FS_SG_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+
+struct StageArgs {
+    const float* x;          // (n, H, W, 64) channels-last
+    float* y;                // (n, H, W, 64)
+    long long n;
+    int n_block;             // BasicBlocks (1 or 2)
+    const float *w[4], *al[4], *sh[4];   // b0.c1 b0.c2 b1.c1 b1.c2: packed weights (2 n-tiles x 72 k-groups), BN alpha / shift
+    unsigned long long* stamps;          // diagnostic (ipsx_dbg_fused_stage_stamps): s_memtime of wave 0 of workgroup 0 at its
+                                         // phase boundaries, or nullptr
+};
+
+#define FS_STAMP(k)                                                                                \
+    do {                                                                                           \
+        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[k] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+template <int H, int W, int G>
+struct FS {
+    static constexpr int P = H * W;               // pixels per patch
+    static constexpr int ROWS = G * P;            // packed pixel rows of a workgroup
+    static constexpr int MT = (ROWS + 31) / 32;   // M-tiles
+    static constexpr int MTW = (MT + 3) / 4;      // M-tiles per wave (each wave: MTW M-tiles x both n-tiles)
+    static constexpr int PS = 68;                 // floats per pixel row: 64 channels + 4 pad (conflict-free b128 reads)
+    static constexpr int TROWS = MT * 32;         // rows the tiles cover: [ROWS, TROWS) are written (garbage) and never read
+    static constexpr int ZROW = TROWS;            // the all-zero pixel row
+    static constexpr int LDS_BYTES = (TROWS + 1) * PS * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "stage does not fit the LDS");
+};
+
+template <int MTW>
+struct FSOperands {
+    float4 a[MTW];
+};
+
+// one 3x3 convolution 64 -> 64 over the slab: acc[t][nt] = this wave's M-tiles x the two n-tiles
+template <int H, int W, int G>
+__device__ __forceinline__ void fs_conv(const float* __restrict__ wp, const char* lds, const unsigned (&rowb)[FS<H, W, G>::MTW],
+                                        const unsigned (&mask)[FS<H, W, G>::MTW], f32x16 (&acc)[FS<H, W, G>::MTW][2], int lane) {
+    using F = FS<H, W, G>;
+    constexpr int MTW = F::MTW;
+    const int half = lane >> 5;
+    const char* w = reinterpret_cast<const char*>(wp) + lane * 16;
+    const unsigned zb = (unsigned)F::ZROW * F::PS * 4 + 16u * half;
+#pragma unroll
+    for (int t = 0; t < MTW; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.0f;
+    unsigned off[MTW];
+#define FS_TAP(tap)                                                                            \
+    do {                                                                                       \
+        const int dy_ = (tap) / 3 - 1, dx_ = (tap) % 3 - 1;                                    \
+        const int delta_ = (dy_ * W + dx_) * F::PS * 4;                                        \
+        _Pragma("unroll") for (int t = 0; t < MTW; ++t)                                        \
+            off[t] = ((mask[t] >> (tap)) & 1u) ? (unsigned)((int)rowb[t] + delta_) : zb;       \
+    } while (0)
+#define FS_LOAD(S, CG)                                                                         \
+    do {                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < MTW; ++t)                                        \
+            S.a[t] = *reinterpret_cast<const float4*>(lds + off[t] + (CG) * 32);               \
+    } while (0)
+#define FS_LOADB(B, g)                                                                         \
+    do {                                                                                       \
+        const int g_ = (g) < 72 ? (g) : 71;                                                    \
+        B[0] = *reinterpret_cast<const float4*>(w + (size_t)g_ * 1024);                        \
+        B[1] = *reinterpret_cast<const float4*>(w + (size_t)(72 + g_) * 1024);                 \
+    } while (0)
+#define FS_MMA(S, B)                                                                           \
+    do {                                                                                       \
+        const float b0_[4] = {B[0].x, B[0].y, B[0].z, B[0].w}, b1_[4] = {B[1].x, B[1].y, B[1].z, B[1].w}; \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+            _Pragma("unroll") for (int t = 0; t < MTW; ++t) {                                  \
+                const float av_ = j == 0 ? S.a[t].x : (j == 1 ? S.a[t].y : (j == 2 ? S.a[t].z : S.a[t].w)); \
+                acc[t][0] = FS_MFMA(av_, b0_[j], acc[t][0]);                                   \
+                acc[t][1] = FS_MFMA(av_, b1_[j], acc[t][1]);                                   \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+// the MTW LDS loads and the two weight loads of the next stage, spread between this stage's 8 * MTW MFMAs
+#define FS_POST()                                                                              \
+    do {                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < MTW; ++t) { FS_SG_MFMA(4); FS_SG_LDS(1); }       \
+        FS_SG_MFMA(MTW); FS_SG_VMEM(1); FS_SG_MFMA(MTW); FS_SG_VMEM(1); FS_SG_MFMA(2 * MTW);   \
+        FS_SB();                                                                               \
+    } while (0)
+    FSOperands<MTW> sa, sb;
+    float4 b0[2], b1[2], b2[2], b3[2];           // weight ring (both n-tiles): slot = stage & 3, refilled two stages ahead
+    FS_TAP(0);
+    FS_LOADB(b0, 0);
+    FS_LOADB(b1, 1);
+    FS_LOAD(sa, 0);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int g = tap * 8;
+        FS_LOAD(sb, 1); FS_LOADB(b2, g + 2); FS_MMA(sa, b0); FS_POST();
+        FS_LOAD(sa, 2); FS_LOADB(b3, g + 3); FS_MMA(sb, b1); FS_POST();
+        FS_LOAD(sb, 3); FS_LOADB(b0, g + 4); FS_MMA(sa, b2); FS_POST();
+        FS_LOAD(sa, 4); FS_LOADB(b1, g + 5); FS_MMA(sb, b3); FS_POST();
+        FS_LOAD(sb, 5); FS_LOADB(b2, g + 6); FS_MMA(sa, b0); FS_POST();
+        FS_LOAD(sa, 6); FS_LOADB(b3, g + 7); FS_MMA(sb, b1); FS_POST();
+        FS_LOAD(sb, 7); FS_LOADB(b0, g + 8); FS_MMA(sa, b2); FS_POST();
+        {   // the next tap's source rows (the last tap re-reads its own: the prefetch past the end is never used)
+            const int nx = tap < 8 ? tap + 1 : 8;
+            const int dy_ = nx / 3 - 1, dx_ = nx % 3 - 1;
+            const int delta_ = (dy_ * W + dx_) * F::PS * 4;
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) off[t] = ((mask[t] >> nx) & 1u) ? (unsigned)((int)rowb[t] + delta_) : zb;
+        }
+        FS_LOAD(sa, 0); FS_LOADB(b1, g + 9); FS_MMA(sb, b3); FS_POST();
+    }
+#undef FS_TAP
+#undef FS_LOAD
+#undef FS_LOADB
+#undef FS_MMA
+#undef FS_POST
+}
+
+template <int H, int W, int G>
+__global__ __launch_bounds__(256, 1) void fused_stage64_kernel(StageArgs a) {
+    using F = FS<H, W, G>;
+    constexpr int MTW = F::MTW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int mt0 = wave * MTW;
+    const long long p0 = (long long)blockIdx.x * G;
+    const int np = (int)(a.n - p0 < G ? a.n - p0 : G);                  // patches of this workgroup
+    const int rows_valid = np * F::P;
+    const float* xin = a.x + (size_t)p0 * F::P * 64;
+    float* yout = a.y + (size_t)p0 * F::P * 64;
+    FS_STAMP(0);
+
+    // global accesses are raw buffer operations on a buffer that ends with the last VALID row: one 32-bit offset per lane
+    // (the per-element part is a scalar offset) instead of 128 64-bit addresses, and the rows of a short last workgroup
+    // read as zeros / are not stored by the hardware's bounds check
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, rows_valid * 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yout, 0, rows_valid * 256, 0x00020000);
+    // ---- the patches' maps -> LDS rows [pix][68]; rows beyond the valid ones and the zero row: zeros
+    {   // (8 loads of a thread in flight: one at a time this was 38 k cycles of a workgroup's 730 k)
+        typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(rx, 0, 0, 0)) vec16;
+        constexpr int TOTAL = (F::TROWS + 1) * 16;
+        for (int e0 = threadIdx.x; e0 < TOTAL; e0 += 256 * 8) {
+            vec16 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (e < F::TROWS * 16) ? e * 16 : (int)0x7fffffff, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < TOTAL) *reinterpret_cast<vec16*>(lds + (e >> 4) * F::PS + 4 * (e & 15)) = v[u];
+            }
+        }
+    }
+    // ---- per lane and M-tile: byte offset of its own pixel row (+ its half's 16 bytes) and the 9-bit tap mask
+    unsigned rowb[MTW], mask[MTW];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+        const int m = (mt0 + t) * 32 + i;
+        const bool valid = m < rows_valid;
+        const int pix = m % F::P, y = pix / W, x = pix % W;
+        unsigned mk = 0u;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if (valid && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) mk |= 1u << tap;
+        }
+        mask[t] = mk;
+        rowb[t] = (unsigned)m * F::PS * 4 + 16u * half;
+    }
+    __syncthreads();
+    FS_STAMP(1);
+
+    f32x16 acc[MTW][2];
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+#pragma unroll 1
+    for (int cv = 0; cv < 2 * a.n_block; ++cv) {
+        fs_conv<H, W, G>(a.w[cv], ldsb, rowb, mask, acc, lane);
+        FS_STAMP(2 + 2 * cv);
+        const float A0 = a.al[cv][i], B0 = a.sh[cv][i], A1 = a.al[cv][32 + i], B1 = a.sh[cv][32 + i];
+        const bool second = (cv & 1) != 0;                             // conv2 of a block: + identity, result also to y
+        const bool last = cv + 1 == 2 * a.n_block;                     // nothing reads the slab after the last convolution
+        const __amdgpu_buffer_rsrc_t ri = cv == 1 ? rx : ry;           // block 1: the kernel's input; block 2: block 1's output
+        const int voff = ((mt0 * 32 + 4 * half) * 64 + i) * 4;         // this lane's part of every element offset (n-tile 0)
+        // the identity of unit (t, nt) is requested one unit ahead (two 16-register buffers): its L2 round trip - 16 strided
+        // 4-byte loads per lane - hides behind the previous unit's arithmetic and stores instead of 8 exposed waits per conv
+        float idA[16], idB[16];
+#define FS_IDLOAD(BUF, u)                                                                          \
+        do {                                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                         \
+                BUF[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(           \
+                    ri, voff, (((u) >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * 256 + ((u) & 1) * 128, 0)); \
+        } while (0)
+#define FS_UNIT(BUF, u)                                                                            \
+        do {                                                                                       \
+            constexpr int t_ = (u) >> 1, nt_ = (u) & 1;                                            \
+            const float A = nt_ ? A1 : A0, B = nt_ ? B1 : B0;                                      \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
+                const int m = (mt0 + t_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                 \
+                float v = __builtin_fmaf(acc[t_][nt_][r], A, B);                                   \
+                if (second) v = v + BUF[r];                                                        \
+                v = v > 0.0f ? v : 0.0f;                                                           \
+                if (!last) lds[m * F::PS + nt_ * 32 + i] = v;                                      \
+                if (second)                                                                        \
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, \
+                                                          (t_ * 32 + (r & 3) + 8 * (r >> 2)) * 256 + nt_ * 128, 0); \
+            }                                                                                      \
+            FS_SB();                                                                               \
+        } while (0)
+        if (second) FS_IDLOAD(idA, 0);
+        __syncthreads();                                               // every wave has read what it needs of the old map
+        static_assert(MTW == 4, "the epilogue below is written out for 4 M-tiles per wave");
+        if (second) FS_IDLOAD(idB, 1);
+        FS_UNIT(idA, 0);
+        if (second) FS_IDLOAD(idA, 2);
+        FS_UNIT(idB, 1);
+        if (second) FS_IDLOAD(idB, 3);
+        FS_UNIT(idA, 2);
+        if (second) FS_IDLOAD(idA, 4);
+        FS_UNIT(idB, 3);
+        if (second) FS_IDLOAD(idB, 5);
+        FS_UNIT(idA, 4);
+        if (second) FS_IDLOAD(idA, 6);
+        FS_UNIT(idB, 5);
+        if (second) FS_IDLOAD(idB, 7);
+        FS_UNIT(idA, 6);
+        FS_UNIT(idB, 7);
+#undef FS_IDLOAD
+#undef FS_UNIT
+        if (last) FS_STAMP(3 + 2 * cv);
+        __syncthreads();
+        if (!last) FS_STAMP(3 + 2 * cv);
+    }
+}
+
+// the leading run of plain 64 -> 64 BasicBlocks of `blocks` that the kernel covers on an h x w map (0 = none)
+int fused_stage64_blocks(const ipsx_block* blocks, int n_block, int h, int w) {
+    const char* e = getenv("IPSX_NO_FUSED");           // (read per call: tests switch it)
+    const bool off = e && e[0] == '1';
+    if (off || !blocks || !(h == 13 && w == 13)) return 0;
+    int k = 0;
+    for (; k < n_block && k < 2; ++k) {
+        const ipsx_block& b = blocks[k];
+        if (b.n_conv != 2 || b.has_down) break;
+        bool ok = true;
+        for (int j = 0; j < 2; ++j) {
+            const ipsx_conv& c = b.conv[j];
+            ok = ok && c.c_in == 64 && c.c_out == 64 && c.kh == 3 && c.kw == 3 && c.stride == 1 && c.pad == 1 && c.w_packed &&
+                 c.alpha && c.shift;
+        }
+        if (!ok) break;
+    }
+    return k;
+}
+
+static unsigned long long* g_stage_stamps = nullptr;     // diagnostic only (ipsx_dbg_fused_stage_stamps)
+
+int fused_stage64(const ipsx_block* blocks, int n_block, const float* x, float* y, int64_t n, int h, int w, hipStream_t s) {
+    IPSX_REQUIRE(blocks && x && y && n >= 0 && x != y, "fused_stage64: bad arguments");
+    IPSX_REQUIRE(fused_stage64_blocks(blocks, n_block, h, w) == n_block && n_block >= 1, "fused_stage64: shape not covered");
+    if (n == 0) return IPSX_OK;
+    StageArgs a;
+    a.x = x; a.y = y; a.n = n; a.n_block = n_block;
+    a.stamps = g_stage_stamps;
+    for (int k = 0; k < 4; ++k) { a.w[k] = nullptr; a.al[k] = nullptr; a.sh[k] = nullptr; }
+    for (int k = 0; k < n_block; ++k)
+        for (int j = 0; j < 2; ++j) {
+            a.w[2 * k + j] = blocks[k].conv[j].w_packed;
+            a.al[2 * k + j] = blocks[k].conv[j].alpha;
+            a.sh[2 * k + j] = blocks[k].conv[j].shift;
+        }
+    using F = FS<13, 13, 3>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_stage64_kernel<13, 13, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS_BYTES);
+        attr = true;
+    }
+    fused_stage64_kernel<13, 13, 3><<<dim3((unsigned)cdiv(n, 3)), dim3(256), F::LDS_BYTES, s>>>(a);
+    return launched("fused_stage64");
+}
+
+}  // namespace ipsx
+
+// Diagnostic entry point (not part of include/ipsx.h): a device buffer of 16 uint64 that the next fused_stage64 launches
+// fill with the s_memtime of workgroup 0 / wave 0 at its phase boundaries (tools/stage_stamps.py); NULL switches it off.
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_fused_stage_stamps(unsigned long long* buf) {
+    ipsx::g_stage_stamps = buf;
+}

@@ -16,6 +16,9 @@ namespace ipsx {
 // conv.hip
 int conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* residual, float* y, int64_t n, int h,
                        int w, int relu, int out_nhwc, void* stream);
+// fused_stage.hip: the leading 64 -> 64 BasicBlocks on a small map, LDS-resident (50-px patches: 13x13)
+int fused_stage64_blocks(const ipsx_block* blocks, int n_block, int h, int w);
+int fused_stage64(const ipsx_block* blocks, int n_block, const float* x, float* y, int64_t n, int h, int w, hipStream_t s);
 // fused_trunk.hip
 bool fused_trunk_supported(const ipsx_trunk* t);
 int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s);
@@ -135,7 +138,16 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
         IPSX_TRY(ipsx_maxpool_3x3s2_nhwc(buf[0], buf[1], n, c, h, w, stream));
         h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
         int cur = 1;                                   // buf[cur] holds the block input
-        for (int b = 0; b < t->n_block; ++b) {
+        int b_first = 0;
+        if (c == 64) {                                 // layer1 on a small map: all of its convolutions in one LDS-resident kernel
+            const int nf = fused_stage64_blocks(t->blocks, t->n_block, h, w);
+            if (nf > 0) {
+                IPSX_TRY(fused_stage64(t->blocks, nf, buf[1], buf[0], n, h, w, as_stream(stream)));
+                cur = 0;
+                b_first = nf;
+            }
+        }
+        for (int b = b_first; b < t->n_block; ++b) {
             const ipsx_block& B = t->blocks[b];
             // free buffers: the three that are not `cur`
             int fr[3], k = 0;

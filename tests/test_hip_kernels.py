@@ -183,6 +183,25 @@ def test_encoder_bit_exact(case, n):
     assert ulp_diff(got, want) == 0, "max abs diff %g" % np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 100])
+def test_fused_64_channel_stage_equals_layered_kernels(n, monkeypatch):
+    """50-px patches (the reference's shipped Megapixel-MNIST patch size): layer1 - four 64 -> 64 convolutions on 13x13
+    maps - runs as ONE LDS-resident kernel (fused_stage.hip, 3 patches per workgroup: 1, 2 patches and a multiple of 3
+    exercise the short last workgroup).  Same bits as the layer-by-layer kernels and as the oracle."""
+    g = Golden("mnist_native50")
+    net = g.net(DEV)
+    x = g.patches()[0, :n].to(DEV)
+    plan = hip.EncoderPlan(net.encoder, True)
+    fused = plan.encode(x)
+    monkeypatch.setenv("IPSX_NO_FUSED", "1")
+    layered = plan.encode(x)
+    monkeypatch.delenv("IPSX_NO_FUSED")
+    assert torch.equal(fused, layered), "max abs diff %g" % float((fused - layered).abs().max())
+    if n <= 7:
+        want = orc.Oracle(g.net("cpu")).encode(x.cpu().numpy())
+        assert ulp_diff(fused.cpu().numpy(), want) == 0
+
+
 def test_fused_trunk_equals_layered_kernels(monkeypatch):
     """The LDS-resident fused trunk (1x32x32 patches) vs the layer-by-layer kernels vs the oracle."""
     g = Golden("mnist_full")
