@@ -272,6 +272,167 @@ __global__ __launch_bounds__(256, 1) void fused_stage64_kernel(StageArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stem + max-pool, 50 px
+// conv7x7/2 (1 -> 64) + BatchNorm + ReLU + max-pool 3x3/2 of a 1x50x50 patch in one kernel, the 25x25x64 stem output never
+// in memory: wave = patch, the zero-padded 56x56 input in LDS (every tap address = base + immediate, no halo mask - the
+// scheme of fused_trunk.hip's stem_pool), one M-tile = ONE stem row (25 of 32 pixel lanes), 25 MFMA k-steps x 2 n-tiles per
+// row; rows go through in pairs (2t, 2t+1): with the previous pair's last row that is the vertical window of pooled row t;
+// the horizontal window needs the other lane half's columns (one exchange of 16 registers per n-tile), and the 13 pooled
+// columns x 64 channels leave as channels-last rows for the stage kernel above.  Replaces conv_any_kernel (the gather-bound
+// generic stem: 0.36 of peak, 1.13 ms per 14,400 patches) + maxpool_3x3s2_nhwc_kernel (0.63 ms).
+// Exactness: the same fma chain per stem output as conv.hip / the oracle (k order 0,4,1,5,2,6,3,7 inside a group, K = 49);
+// max-pool padding is -inf in the contract and 0 here - identical, because every window holds a real post-ReLU value >= 0.
+struct StemArgs {
+    const float* patches;     // (n, 1, 50, 50)
+    float* y;                 // (n, 13, 13, 64) channels-last
+    long long n;
+    const float *w, *al, *sh; // packed stem weights (2 n-tiles x 7 k-groups), BN alpha / shift
+};
+
+constexpr int SPW = 56;                   // padded input width (50 + 2 x 3)
+constexpr int SP_SLAB = SPW * SPW + 64;   // floats per wave (+ slack: lanes 25..31 of a row read past its end)
+
+__device__ __forceinline__ float fs_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+__global__ __launch_bounds__(256, 2) void stem_pool50_kernel(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    long long p = (long long)blockIdx.x * 4 + wave;
+    const bool live = p < a.n;
+    if (!live) p = a.n - 1;                                  // tail: recompute the last patch, store nothing
+    float* S = lds + wave * SP_SLAB;
+    // ---- the patch -> LDS, zero-padded (image at rows / columns 3..52)
+    for (int z = lane; z < SP_SLAB / 4; z += 64) reinterpret_cast<float4*>(S)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const float2* src = reinterpret_cast<const float2*>(a.patches + (size_t)p * 2500);
+        for (int e0 = lane; e0 < 1250; e0 += 64 * 5) {
+            float2 v[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) v[u] = src[e0 + 64 * u < 1250 ? e0 + 64 * u : e0];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int e = e0 + 64 * u;
+                if (e < 1250) {
+                    const int yy = e / 25, xx = 2 * (e - yy * 25);
+                    S[(yy + 3) * SPW + xx + 3] = v[u].x;
+                    S[(yy + 3) * SPW + xx + 4] = v[u].y;
+                }
+            }
+        }
+    }
+    // ---- weights of the 25 k-steps (k = 8 kg + 4 half + j; step 24 is k = 48 / the non-existent 52), BN of this lane's channels
+    float bw0[28], bw1[28];
+    {
+        const float4* wp0 = reinterpret_cast<const float4*>(a.w) + lane;
+        const float4* wp1 = wp0 + 7 * 64;
+#pragma unroll
+        for (int kg = 0; kg < 7; ++kg) {
+            const float4 v0 = wp0[kg * 64], v1 = wp1[kg * 64];
+            bw0[4 * kg] = v0.x; bw0[4 * kg + 1] = v0.y; bw0[4 * kg + 2] = v0.z; bw0[4 * kg + 3] = v0.w;
+            bw1[4 * kg] = v1.x; bw1[4 * kg + 1] = v1.y; bw1[4 * kg + 2] = v1.z; bw1[4 * kg + 3] = v1.w;
+        }
+    }
+    const float al0 = a.al[i], sh0 = a.sh[i], al1 = a.al[32 + i], sh1 = a.sh[32 + i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // one stem row `oy` -> BN + ReLU'd values of this lane's 16 columns x = 4 half + (r & 3) + 8 (r >> 2), per n-tile;
+    // columns >= 25 do not exist (their lanes read beside the image): 0
+    auto stem_row = [&](int oy, float (&v0)[16], float (&v1)[16]) {
+        const float* base = S + (2 * oy) * SPW + 2 * i;
+        const float* baseN = base + half * 4;
+        const float* baseW = base + half * (SPW - 3);
+        float av[25];
+#pragma unroll
+        for (int st = 0; st < 25; ++st) {
+            const int k0 = 8 * (st >> 2) + (st & 3), ky0 = k0 / 7, kx0 = k0 % 7;
+            av[st] = (kx0 <= 2) ? baseN[ky0 * SPW + kx0] : baseW[ky0 * SPW + kx0];
+        }
+        av[24] = half ? 0.0f : av[24];
+        FS_SB();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+#pragma unroll
+        for (int st = 0; st < 25; ++st) {
+            acc0 = FS_MFMA(av[st], bw0[st], acc0);
+            acc1 = FS_MFMA(av[st], bw1[st], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool beyond = (r >> 2) == 3 && (half != 0 || (r & 3) >= 1);        // column >= 25
+            const float x0 = __builtin_fmaf(acc0[r], al0, sh0), x1 = __builtin_fmaf(acc1[r], al1, sh1);
+            v0[r] = (beyond || !(x0 > 0.0f)) ? 0.0f : x0;
+            v1[r] = (beyond || !(x1 > 0.0f)) ? 0.0f : x1;
+        }
+    };
+
+    float prev0[16], prev1[16];                              // stem row 2t - 1 (row -1: padding)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { prev0[r] = 0.0f; prev1[r] = 0.0f; }
+    float* yout = a.y + (size_t)p * 169 * 64;
+#pragma unroll 1
+    for (int t = 0; t < 13; ++t) {
+        float va0[16], va1[16], vb0[16], vb1[16];
+        stem_row(2 * t, va0, va1);
+        if (t < 12) {
+            stem_row(2 * t + 1, vb0, vb1);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { vb0[r] = 0.0f; vb1[r] = 0.0f; }            // row 25: padding
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float vm[16], oth[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                vm[r] = nt ? fs_max3(prev1[r], va1[r], vb1[r]) : fs_max3(prev0[r], va0[r], vb0[r]);
+                oth[r] = __shfl_xor(vm[r], 32, 64);
+            }
+            // the row's columns -1 .. 25 in order: column x lives in half (x >> 2) & 1, register (x & 3) + 4 (x >> 3)
+            float full[27];
+            full[0] = 0.0f;
+#pragma unroll
+            for (int x = 0; x < 26; ++x) {
+                const int own = (x >> 2) & 1, r = (x & 3) + 4 * (x >> 3);
+                full[1 + x] = x >= 25 ? 0.0f : ((half == own) ? vm[r] : oth[r]);
+            }
+            // pooled columns: half 0 stores tx = 0..6, half 1 stores tx = 7..12
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float lo = fs_max3(full[2 * j], full[2 * j + 1], full[2 * j + 2]);
+                const float hi = j < 6 ? fs_max3(full[2 * (7 + j)], full[2 * (7 + j) + 1], full[2 * (7 + j) + 2]) : 0.0f;
+                const int tx = half ? 7 + j : j;
+                if (live && tx < 13) yout[(size_t)(t * 13 + tx) * 64 + nt * 32 + i] = half ? hi : lo;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { prev0[r] = vb0[r]; prev1[r] = vb1[r]; }
+    }
+}
+
+static bool stem_pool50_supported(const ipsx_trunk* t) {
+    const char* e = getenv("IPSX_NO_FUSED");
+    if (e && e[0] == '1') return false;
+    const ipsx_conv& c = t->stem;
+    return t->c_in == 1 && t->h == 50 && t->w == 50 && t->patch_dtype == 0 && c.c_in == 1 && c.c_out == 64 && c.kh == 7 &&
+           c.kw == 7 && c.stride == 2 && c.pad == 3 && c.w_packed && c.alpha && c.shift;
+}
+
+bool fused_stem_pool50_covers(const ipsx_trunk* t) { return t && stem_pool50_supported(t); }
+
+// stem + max-pool of 1x50x50 patches -> (n, 13, 13, 64) channels-last; returns 1 when it ran, 0 when the trunk is another shape
+int fused_stem_pool50(const ipsx_trunk* t, const float* patches, float* y, int64_t n, hipStream_t s) {
+    if (!t || !stem_pool50_supported(t)) return 0;
+    if (n <= 0) return 1;
+    StemArgs a;
+    a.patches = patches; a.y = y; a.n = n;
+    a.w = t->stem.w_packed; a.al = t->stem.alpha; a.sh = t->stem.shift;
+    stem_pool50_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 4 * SP_SLAB * sizeof(float), s>>>(a);
+    return launched("stem_pool50") == IPSX_OK ? 1 : -1;
+}
+
 // the leading run of plain 64 -> 64 BasicBlocks of `blocks` that the kernel covers on an h x w map (0 = none)
 int fused_stage64_blocks(const ipsx_block* blocks, int n_block, int h, int w) {
     const char* e = getenv("IPSX_NO_FUSED");           // (read per call: tests switch it)

@@ -19,6 +19,8 @@ int conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* residua
 // fused_stage.hip: the leading 64 -> 64 BasicBlocks on a small map, LDS-resident (50-px patches: 13x13)
 int fused_stage64_blocks(const ipsx_block* blocks, int n_block, int h, int w);
 int fused_stage64(const ipsx_block* blocks, int n_block, const float* x, float* y, int64_t n, int h, int w, hipStream_t s);
+int fused_stem_pool50(const ipsx_trunk* t, const float* patches, float* y, int64_t n, hipStream_t s);   // 1 = ran, 0 = other shape
+bool fused_stem_pool50_covers(const ipsx_trunk* t);
 // fused_trunk.hip
 bool fused_trunk_supported(const ipsx_trunk* t);
 int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s);
@@ -105,6 +107,9 @@ IPSX_API size_t ipsx_trunk_workspace_bytes(const ipsx_trunk* t, int64_t n_patch)
 IPSX_API const char* ipsx_trunk_kernel(const ipsx_trunk* t) {
     if (t && fused_trunk_supported(t))
         return t->precision == 2 ? "fused_trunk_x3_kernel" : (t->precision == 1 ? "fused_trunk_bf16_kernel" : "fused_trunk_kernel");
+    if (t && t->n_block >= 2 && fused_stem_pool50_covers(t) &&
+        fused_stage64_blocks(t->blocks, t->n_block, 13, 13) > 0)          // the reference's shipped 50-px Megapixel-MNIST trunk
+        return "stem_pool50_kernel + fused_stage64_kernel (layer1, LDS-resident) + conv_nhwc_kernel (layer2, layer by layer)";
     return "conv_nhwc_kernel (layer by layer)";
 }
 
@@ -134,8 +139,12 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
         int w = conv_out(t->w, t->stem.kw, t->stem.stride, t->stem.pad);
         int c = t->stem.c_out;
         // stem reads the NCHW patches and writes channels-last; everything after it is channels-last
-        IPSX_TRY(conv2d_affine_impl(&t->stem, patches + p0 * patch_elems, nullptr, buf[0], n, t->h, t->w, 1, 1, stream));
-        IPSX_TRY(ipsx_maxpool_3x3s2_nhwc(buf[0], buf[1], n, c, h, w, stream));
+        const int fused_stem = fused_stem_pool50(t, patches + p0 * patch_elems, buf[1], n, as_stream(stream));
+        if (fused_stem < 0) return IPSX_EHIP;
+        if (!fused_stem) {
+            IPSX_TRY(conv2d_affine_impl(&t->stem, patches + p0 * patch_elems, nullptr, buf[0], n, t->h, t->w, 1, 1, stream));
+            IPSX_TRY(ipsx_maxpool_3x3s2_nhwc(buf[0], buf[1], n, c, h, w, stream));
+        }
         h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1);
         int cur = 1;                                   // buf[cur] holds the block input
         int b_first = 0;
