@@ -577,11 +577,104 @@ __device__ __forceinline__ void torch_topk_wave(stdorder::E* q, int n, int k, in
 // breadth first, a barrier per level), each range partitioned by the unchanged wave_partition_pivot with its own stretch
 // of the index lists (la + first, lb + first: ranges are disjoint, so are the stretches).  std::nth_element in front of it is
 // ONE chain of partitions and stays on one wavefront; the final insertion pass runs on all threads.
+// The unguarded partition of q[first + 1, last) around the median of three, by ALL NT threads (16 wavefronts): what
+// wave_partition does with one - the t-th element from the left that stops the upward scan paired with the t-th from the
+// right that stops the downward scan, swapped while the left one lies before the right one - with the stretch cut into
+// one slice per wavefront: ballots per 64 elements (kept in registers), the slices' counts through LDS, an exclusive sum,
+// the two index lists written in one go, the pair swaps an element per thread.  Lists in GLOBAL memory (they are as long
+// as the range; every access is a coalesced bulk access behind a barrier).  For the long stretches of std::nth_element's
+// chain (10,000, 5,000, 2,500 candidates: 80 k cycles on one wavefront with its lists in global memory, ~10 k here).
+// `sc`: 2 * (NT / 64) + 2 ints of LDS scratch.  Returns the cut (workgroup-uniform).  Contains barriers.
+constexpr int BLOCK_PART_CHUNKS = 16;       // 64-element chunks per wavefront slice: stretches up to 16 * 16 * 64 = 16,384
+
+template <int NT>
+__device__ __forceinline__ int block_partition_pivot(stdorder::E* q, int first, int last, int* la, int* lb, int* sc) {
+    using namespace stdorder;
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {   // std::__move_median_to_first(first, first + 1, mid, last - 1)
+        const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+        const E er = q[first], ea = q[ia], eb = q[ib], ec = q[ic];
+        int sel;
+        if (gt(ea, eb)) sel = gt(eb, ec) ? ib : (gt(ea, ec) ? ic : ia);
+        else sel = gt(ea, ec) ? ia : (gt(eb, ec) ? ic : ib);
+        const E P = sel == ia ? ea : (sel == ib ? eb : ec);
+        q[first] = P; q[sel] = er;
+        sc[2 * NW] = 0x7fffffff;                                       // t: first pair that is not swapped
+    }
+    __syncthreads();
+    const E P = q[first];
+    const int f = first + 1, len = last - f;
+    const int per = ((len + NW - 1) / NW + 63) & ~63;                  // slice length, whole chunks
+    const int s0 = f + wave * per, s1 = min(last, s0 + per);           // this wavefront's slice
+    int ca = 0, cb = 0;                                                // (two passes over the slice: the ballots are taken again
+    for (int c = 0; c < BLOCK_PART_CHUNKS; ++c) {                      //  in the second instead of living in 64 registers)
+        const int x = s0 + c * 64 + lane;
+        if (s0 + c * 64 >= s1) break;
+        const bool in = x < s1;
+        const E e = q[in ? x : first];
+        ca += __popcll(__ballot(in && !gt(e, P)));                     // stops the upward scan
+        cb += __popcll(__ballot(in && !gt(P, e)));                     // stops the downward scan
+    }
+    if (lane == 0) { sc[wave] = ca; sc[NW + wave] = cb; }
+    __syncthreads();
+    int base_a = 0, base_b = 0, na = 0, nb = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int a_ = sc[w], b_ = sc[NW + w];
+        base_a += w < wave ? a_ : 0;                                   // la ascends: lower slices first
+        base_b += w > wave ? b_ : 0;                                   // lb descends: higher slices first
+        na += a_; nb += b_;
+    }
+    {
+        const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+        int pa = base_a, pb = base_b + cb;                             // pb: end of this slice's stretch of lb
+        for (int c = 0; c < BLOCK_PART_CHUNKS; ++c) {
+            const int x = s0 + c * 64 + lane;
+            if (s0 + c * 64 >= s1) break;
+            const bool in = x < s1;
+            const E e = q[in ? x : first];
+            const unsigned long long ma = __ballot(in && !gt(e, P)), mb = __ballot(in && !gt(P, e));
+            if ((ma >> lane) & 1ull) la[pa + __popcll(ma & below)] = x;
+            pa += __popcll(ma);
+            pb -= __popcll(mb);                                        // the chunk's stops, highest index first, start here
+            if ((mb >> lane) & 1ull) lb[pb + __popcll(mb & above)] = x;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    const int np = na < nb ? na : nb;
+    int tmin = 0x7fffffff;
+    for (int u = tid; u < np; u += NT) {
+        const int i = la[u], j = lb[u];
+        if (i < j) {
+            const E ei = q[i], ej = q[j];
+            q[i] = ej;
+            q[j] = ei;
+        } else {
+            tmin = u < tmin ? u : tmin;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) tmin = min(tmin, __shfl_xor(tmin, off, 64));
+    if (lane == 0 && tmin != 0x7fffffff) atomicMin(&sc[2 * NW], tmin);
+    __syncthreads();
+    int t = sc[2 * NW];
+    t = t < np ? t : np;
+    const int cut = (t < na && (t == 0 || la[t] < lb[t - 1])) ? la[t] : lb[t - 1];
+    __syncthreads();                                                   // sc and the lists are reused by the next call
+    return cut;
+}
+
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane);        // (defined with the ranking helpers below)
+
 constexpr int BLOCK_QCAP = 1024;            // ranges of more than 16 elements pending at one level: <= 16,384 / 17
 
+// la_n / lb_n: the lists of std::nth_element's chain (n ints each, GLOBAL memory); la / lb: the lists of std::sort's
+// ranges and, together, the scratch of the final pass (k - 1 ints each; GL = in global memory, else in LDS).
 template <int NT, bool GL>
-__device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, int* la, int* lb, int* stk,
-                                                 unsigned long long* leaf, int leaf_words, int* queue, int* qcount) {
+__device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, int* la_n, int* lb_n, int* la, int* lb, int* stk,
+                                                 unsigned long long* leaf, int leaf_words, int* queue, int* qcount,
+                                                 const unsigned long long* tiebits) {
     using namespace stdorder;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k <= 0 || n <= 0) return;
@@ -590,25 +683,34 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
         __syncthreads();
         return;
     }
-    if (wave == 0) {   // std::nth_element(q, q + k - 1, q + n)
+    {   // std::nth_element(q, q + k - 1, q + n): long stretches by the whole workgroup, the rest of the chain by wave 0
         int first = 0, last = n;
         const int nth = k - 1;
         bool done = nth == last;
         int depth = lg2(last - first) * 2;
-        while (!done && last - first > 3) {
-            if (depth == 0) {
-                if (lane == 0) { heap_select(q, first, nth + 1, last); swp(q, first, nth); }
-                done = true;
-                break;
-            }
+        while (!done && last - first > 2048 && depth > 0) {            // (workgroup-uniform)
             --depth;
-            const int cut = wave_partition_pivot<GL>(q, first, last, la, lb, lane);
+            const int cut = block_partition_pivot<NT>(q, first, last, la_n, lb_n, queue);
             if (cut <= nth) first = cut;
             else last = cut;
         }
-        if (!done && lane == 0) insertion_sort(q, first, last);
-        wave_fence<GL>();
+        if (wave == 0) {
+            while (!done && last - first > 3) {
+                if (depth == 0) {
+                    if (lane == 0) { heap_select(q, first, nth + 1, last); swp(q, first, nth); }
+                    done = true;
+                    break;
+                }
+                --depth;
+                const int cut = wave_partition_pivot<true>(q, first, last, la_n, lb_n, lane);
+                if (cut <= nth) first = cut;
+                else last = cut;
+            }
+            if (!done && lane == 0) insertion_sort(q, first, last);
+            wave_fence<true>();
+        }
     }
+    __syncthreads();
     const int last = k - 1;                                            // std::sort(q, q + k - 1)
     for (int w = tid; w < leaf_words; w += NT) leaf[w] = 0ull;
     if (tid == 0) {
@@ -631,6 +733,27 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
             if (depth == 0) {                                          // heap sort of the range: stays as it is afterwards
                 if (lane == 0) { make_heap(q, rf, rl); sort_heap(q, rf, rl); }
                 continue;
+            }
+            if (tiebits && rl - rf <= 64) {
+                // A range of introsort holds exactly the elements of final ranks [rf, rl) - and when no two neighbouring
+                // ranks in there have equal scores (tiebits: bit j = canonical rank j and j + 1 tie), std::sort can only
+                // leave them in the one strictly descending order: one in-register wave sort instead of replaying two
+                // more levels of partitions and the leaves.  (With ties inside, the replay goes on.)
+                const int lo_w = rf >> 6, hi_w = (rl - 2) >> 6;                              // pairs (j, j + 1), j in [rf, rl - 2]
+                unsigned long long any = 0ull;
+                for (int w = lo_w; w <= hi_w; ++w) {
+                    unsigned long long m = tiebits[w];
+                    if (w == lo_w) m &= ~0ull << (rf & 63);
+                    if (w == hi_w) m &= ~0ull >> (63 - ((rl - 2) & 63));
+                    any |= m;
+                }
+                if (any == 0ull) {
+                    const int x = rf + lane;
+                    const E e = q[x < rl ? x : rf];
+                    const uint64_t key = wave_sort_desc(x < rl ? rank_key(e.v, (uint32_t)e.i) : 0ull, lane);
+                    if (x < rl) { E o; o.v = key_score(key); o.i = (int)key_pos(key); q[x] = o; }
+                    continue;                                          // (a "leaf" of more than 16 elements: the last pass leaves it)
+                }
             }
             --depth;
             const int cut = wave_partition_pivot<GL>(q, rf, rl, la + rf, lb + rf, lane);
@@ -735,6 +858,7 @@ __device__ __forceinline__ bool scan_skipped(const int* cond, int mask) {
 // then tokens.
 constexpr int SCAN_NT = 1024;
 constexpr int SCAN_PF = 4;     // prefetch registers per thread: chunk <= 1024 * 4 floats
+__host__ __device__ constexpr int scan_pf(int R, int lch) { return (R == 32 && lch == 8) ? 5 : SCAN_PF; }
 
 // Small candidate sets: rank by counting with P lanes per candidate (P = power of two <= 64,
 // P * L <= blockDim): lane `part` counts the keys j = part, part+P, ... that are larger; the partial
@@ -999,6 +1123,9 @@ __device__ __forceinline__ float scan_load(const float* p) {
 template <int R, int T, int EPT, int LCH, bool STAMP, bool PERSIST>
 __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // prefetch registers per (prefetching) thread: 4, 5 for 32 rows x up to 512 candidates - the reference's shipped
+    // Megapixel-MNIST sizes (M = I = 100, 4 tokens: a chunk is 3,200 logits for 704 prefetching threads)
+    constexpr int PF = scan_pf(R, LCH);
     if (!PERSIST && scan_skipped(a.cond, a.cond_mask)) return;
     // encoder workgroups share this compute unit (their matrix-pipe work coexists with this VALU-bound loop); where the
     // two compete for issue slots the loop - the serial part of the job - goes first
@@ -1098,13 +1225,13 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
     // thread's elements belong to its own row r).
     constexpr int PF0 = LCH > 2 ? 320 : 0, PFT = SCAN_NT - PF0;
     const int pt = tid - PF0;                                  // < 0: this thread prefetches nothing
-    float pf[SCAN_PF];
+    float pf[PF];
     {
         const long long lo = a.it0 * a.i + a.m;
         const int cnt = n_iter > 0 ? (int)std::min<long long>(a.i, a.n - lo) : 0;
         uint32_t kc = 0u;
 #pragma unroll
-        for (int k = 0; k < SCAN_PF; ++k) {                    // first chunk: straight into its rows
+        for (int k = 0; k < PF; ++k) {                    // first chunk: straight into its rows
             const int e = tid + SCAN_NT * k;
             if (e < cnt * R) {
                 const float v = scan_load<PERSIST>(lg + (size_t)lo * R + e);
@@ -1118,7 +1245,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         const int cnt1 = n_iter > 1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
         if (cnt1 > 0) SCAN_WAIT_ROWS(lo1 + cnt1);
 #pragma unroll
-        for (int k = 0; k < SCAN_PF; ++k) {
+        for (int k = 0; k < PF; ++k) {
             const int e = pt + PFT * k;
             pf[k] = (pt >= 0 && e < cnt1 * R) ? scan_load<PERSIST>(lg + (size_t)lo1 * R + e) : 0.0f;
         }
@@ -1272,7 +1399,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             const int cnt1 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
             uint32_t kc = 0u;
 #pragma unroll
-            for (int k = 0; k < SCAN_PF; ++k) {
+            for (int k = 0; k < PF; ++k) {
                 const int e = pt + PFT * k;
                 if (pt >= 0 && e < cnt1 * R) {
                     const int row = a.m + (e >> log2R);
@@ -1287,7 +1414,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
             if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
 #pragma unroll
-            for (int k = 0; k < SCAN_PF; ++k) {
+            for (int k = 0; k < PF; ++k) {
                 const int e = pt + PFT * k;
                 pf[k] = (pt >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
             }
@@ -1562,7 +1689,7 @@ __device__ __attribute__((noinline)) void sort_desc_large(int n2) {
 // CANDIDATE order and torch.topk's routines are replayed on them (one wavefront; the index lists in the workspace); q[0, m)
 // is then the answer.  Returns whether that happened (workgroup-uniform).  All threads; contains barriers.
 // (Not inlined, like the sort; `tail` = LDS offset of the stack / leaf bitmap / range lists behind the keys.)
-__device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int tie_order, int* lists, int tail) {
+__device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2, int tie_order, int* lists, int tail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     int* stk = reinterpret_cast<int*>(smem + tail);
@@ -1570,11 +1697,15 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int tie
     int* queue = reinterpret_cast<int*>(leaf + LARGE_LEAF_WORDS);
     const int tid = threadIdx.x;
     if (tie_order != 1 || !ranked_ties(keys, L, m, tid & 63)) return false;
+    unsigned long long* tiebits = reinterpret_cast<unsigned long long*>(queue + 2 + 2 * BLOCK_QCAP * 3);
     uint64_t hold[LARGE_KPT];
 #pragma unroll
     for (int s = 0; s < LARGE_KPT; ++s) {
         const int j = tid + s * LARGE_NT;
         hold[s] = j < L ? keys[j] : 0ull;
+        const uint64_t next = j + 1 < L ? keys[j + 1] : 0ull;          // (a wavefront's 64 ranks are one word of the bitmap)
+        const unsigned long long word = __ballot(j + 1 < L && (hold[s] >> 32) == (next >> 32));
+        if ((tid & 63) == 0) tiebits[(tid >> 6) + s * (LARGE_NT / 64)] = word;
     }
     __syncthreads();
     stdorder::E* q = reinterpret_cast<stdorder::E*>(keys);
@@ -1588,7 +1719,15 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int tie
         }
     }
     __syncthreads();
-    torch_topk_block<LARGE_NT, true>(q, L, m, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue);
+    // the lists of the sort phase (2 (m - 1) ints) live in LDS behind the L pairs when the power-of-two key array has that
+    // much room (10,000 candidates in 16,384 slots: yes) - a partition of a short range is then a few LDS round trips instead
+    // of a few L2 round trips, and there are hundreds of them
+    if (n2 - L >= m) {
+        int* ls = reinterpret_cast<int*>(keys + L);
+        torch_topk_block<LARGE_NT, false>(q, L, m, lists, lists + L, ls, ls + (m - 1), stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits);
+    } else {
+        torch_topk_block<LARGE_NT, true>(q, L, m, lists, lists + L, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits);
+    }
     return true;
 }
 
@@ -1607,7 +1746,7 @@ struct LargeArgs {
 
 // keys | row maxima, denominators | stack of the sequential fallbacks | leaf bitmap | two range lists + their counters
 constexpr size_t LARGE_TAIL_BYTES = (size_t)3 * stdorder::STACK_RANGES * 4 + (size_t)LARGE_LEAF_WORDS * 8 +
-                                    (size_t)(2 * BLOCK_QCAP * 3 + 2) * 4;
+                                    (size_t)(2 * BLOCK_QCAP * 3 + 2) * 4 + (size_t)LARGE_LEAF_WORDS * 8;     // ... | tie bitmap
 static size_t large_lds_bytes(int n2, int R) { return (size_t)n2 * 8 + (size_t)((R + 1) & ~1) * 8 + LARGE_TAIL_BYTES; }
 
 // A pass over global memory at 16 waves per compute unit is bound by round trips, not by bandwidth: every loop below
@@ -1792,7 +1931,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         sort_desc_large(a.n2);
         LARGE_STAMP(5);
         if (tid == 0 && L > m && (keys[m - 1] >> 32) == (keys[m] >> 32)) tie = 1;
-        const bool replayed = large_tie_replay(L, m, a.tie_order, lists, tail);
+        const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail);
         LARGE_STAMP(6);
         const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
         const bool want_score = a.mem_score != nullptr && it + 1 == a.it1;
@@ -1842,7 +1981,7 @@ __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsign
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (keys[a.m - 1] >> 32) == (keys[a.m] >> 32)) ? 1 : 0;
     int* lists = reinterpret_cast<int*>(ws + (size_t)b * ws_per_row);
-    const bool replayed = large_tie_replay(a.L, a.m, a.tie_order, lists, a.n2 * 8);
+    const bool replayed = large_tie_replay(a.L, a.m, a.n2, a.tie_order, lists, a.n2 * 8);
     const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
     for (int j = tid; j < a.m; j += LARGE_NT)
         a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[j]);
@@ -2006,7 +2145,7 @@ static FastPlan scan_fast_plan(int m, int i, int h, int n_token) {
     const size_t fixed = (size_t)n2 * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
     p.lds = ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES;
     const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)m * (R + 1) * 4;     // inside the memory rows
-    const bool pf_fits = (size_t)i * R <= (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * SCAN_PF;
+    const bool pf_fits = (size_t)i * R <= (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * scan_pf(R, p.lch);
     p.ok = p.ept <= 8 && Lmax <= SCAN_NT && pf_fits && scratch_fits && p.lds <= kLdsLimit;
     return p;
 }
