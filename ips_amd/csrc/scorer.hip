@@ -380,6 +380,18 @@ __device__ __forceinline__ bool ranked_ties(const uint64_t* sorted, int L, int m
     return any;
 }
 
+// the same test on the padded key array of the large kernels (key j at slot j + (j >> 4))
+__device__ __forceinline__ bool ranked_ties_padded(const uint64_t* sorted, int L, int m, int lane) {
+    const int n = m < L - 1 ? m : L - 1;
+    bool any = false;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool e = j < n && (sorted[j + (j >> 4)] >> 32) == (sorted[j + 1 + ((j + 1) >> 4)] >> 32);
+        any = any || (__ballot(e) != 0ull);
+    }
+    return any;
+}
+
 // ---- the replay on ONE WAVEFRONT instead of one lane.  libstdc++'s routines are sequential, but what they compute is
 // not: (1) the unguarded Hoare partition pairs the t-th element from the left that stops the upward scan (not greater than
 // the pivot) with the t-th from the right that stops the downward scan (not smaller), for as long as the left one lies
@@ -713,24 +725,26 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
     __syncthreads();
     const int last = k - 1;                                            // std::sort(q, q + k - 1)
     for (int w = tid; w < leaf_words; w += NT) leaf[w] = 0ull;
+    // range lists: one word per range, first | last << 16 (both < 2^15); the depth budget of std::sort's introsort loop
+    // falls by one per partition, i.e. it is the same for every range of a level
     if (tid == 0) {
         qcount[0] = qcount[1] = 0;
         if (last > 16) {
-            queue[0] = 0; queue[1] = last; queue[2] = lg2(last) * 2;
+            queue[0] = 0 | (last << 16);
             qcount[0] = 1;
         }
     }
     __syncthreads();
     if (last <= 0) return;
-    for (int cur = 0;; cur ^= 1) {
+    int depth = lg2(last) * 2;
+    for (int cur = 0;; cur ^= 1, --depth) {
         const int ncur = qcount[cur];
         if (ncur == 0) break;
-        const int* qc = queue + cur * BLOCK_QCAP * 3;
-        int* qn = queue + (cur ^ 1) * BLOCK_QCAP * 3;
+        const int* qc = queue + cur * BLOCK_QCAP;
+        int* qn = queue + (cur ^ 1) * BLOCK_QCAP;
         for (int r = wave; r < ncur; r += NT / 64) {
-            const int rf = qc[3 * r], rl = qc[3 * r + 1];
-            int depth = qc[3 * r + 2];
-            if (depth == 0) {                                          // heap sort of the range: stays as it is afterwards
+            const int rf = qc[r] & 0xFFFF, rl = (int)((unsigned)qc[r] >> 16);
+            if (depth <= 0) {                                          // heap sort of the range: stays as it is afterwards
                 if (lane == 0) { make_heap(q, rf, rl); sort_heap(q, rf, rl); }
                 continue;
             }
@@ -755,18 +769,11 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
                     continue;                                          // (a "leaf" of more than 16 elements: the last pass leaves it)
                 }
             }
-            --depth;
             const int cut = wave_partition_pivot<GL>(q, rf, rl, la + rf, lb + rf, lane);
             if (lane == 0) {
                 if (cut < last) atomicOr(&leaf[cut >> 6], 1ull << (cut & 63));      // every leaf starts at 0 or at a cut
-                if (cut - rf > 16) {
-                    const int slot = atomicAdd(&qcount[cur ^ 1], 1);
-                    qn[3 * slot] = rf; qn[3 * slot + 1] = cut; qn[3 * slot + 2] = depth;
-                }
-                if (rl - cut > 16) {
-                    const int slot = atomicAdd(&qcount[cur ^ 1], 1);
-                    qn[3 * slot] = cut; qn[3 * slot + 1] = rl; qn[3 * slot + 2] = depth;
-                }
+                if (cut - rf > 16) qn[atomicAdd(&qcount[cur ^ 1], 1)] = rf | (cut << 16);
+                if (rl - cut > 16) qn[atomicAdd(&qcount[cur ^ 1], 1)] = cut | (rl << 16);
             }
         }
         __syncthreads();
@@ -1438,7 +1445,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             if (__ballot(hit) != 0ull && lane == 0) ccount[2 + par] = 1;
         }
         lds_barrier();
-        bool boundary_tie = Lr > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m]);   // (NaN never equal: harmless)
+        bool boundary_tie = Lr > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);   // bit-equal score keys (the oracle's rule: two NaNs tie)
         if (a.tie_order == 1 && ccount[2 + par] != 0) {
             // torch.topk's order under ties depends on the WHOLE candidate array, so every chunk key goes back to its
             // place, all L candidates are ranked and the replay runs on them (rare)
@@ -1457,7 +1464,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
                 rank_runs(keyA, keyB, reinterpret_cast<uint64_t*>(en), L);
             }
             lds_barrier();
-            boundary_tie = L > a.m && key_score(sorted[a.m - 1]) == key_score(sorted[a.m]);
+            boundary_tie = L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);
             const unsigned long long ts1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
             tie_order_slow(keyB, keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off));
             if (STAMP && PERSIST && tid == 0 && b == 0) {
@@ -1573,116 +1580,100 @@ constexpr int LARGE_MAX_L = 16384;
 constexpr int LARGE_KPT = LARGE_MAX_L / LARGE_NT;              // keys / memory slots a thread may hold in registers
 constexpr int LARGE_LEAF_WORDS = LARGE_MAX_L / 64;
 
-// bitonic merge of a 64-key block held one key per lane (the strides 32 ... 1 of a level of the network)
-__device__ __forceinline__ uint64_t merge64(uint64_t key, int lane, bool desc) {
-#define IPSX_MERGE_STEP(J)                                             \
-    do {                                                               \
-        const uint64_t other = xor_partner<J>(key, lane);              \
-        const bool take_max = desc == ((lane & J) == 0);               \
-        key = (take_max == (key > other)) ? key : other;               \
+// The ranking keys live in LDS with one 8-byte pad per 16 keys: key i at slot i + (i >> 4).  A thread of the sort owns 16
+// consecutive keys = 136 consecutive bytes, and 16 lanes at a stride of 136 B cover all 32 banks once - unpadded (128 B)
+// every lane of a wavefront would hit the same bank.
+__device__ __forceinline__ int large_slot(int i) { return i + (i >> 4); }
+static size_t large_key_bytes(int n2) { return (size_t)(n2 + (n2 >> 4)) * 8; }
+
+// compare-exchange so that x >= y afterwards (descending)
+#define IPSX_CE_DESC(x, y)                                     \
+    do {                                                       \
+        const uint64_t x_ = (x), y_ = (y);                     \
+        const bool sw_ = x_ < y_;                              \
+        (x) = sw_ ? y_ : x_;                                   \
+        (y) = sw_ ? x_ : y_;                                   \
     } while (0)
-    IPSX_MERGE_STEP(32); IPSX_MERGE_STEP(16); IPSX_MERGE_STEP(8); IPSX_MERGE_STEP(4); IPSX_MERGE_STEP(2); IPSX_MERGE_STEP(1);
-#undef IPSX_MERGE_STEP
-    return key;
-}
 
-// One LDS pass of the bitonic network of level k: the NST consecutive strides J, J/2, ..., J >> (NST - 1) (all >= 64).  A
-// thread loads the 2^NST keys of a group - the indices that differ in exactly those NST bits - runs the NST stages on them
-// in registers and stores them back: NST stages for one round trip through LDS, unconditional 8-byte accesses at
-// consecutive addresses across the lanes (no bank conflicts, no divergent swap branches).  16 keys per thread in flight.
-template <int NST>
-__device__ __forceinline__ void bitonic_pass(uint64_t* keys, int n2, int k, int J) {
-    constexpr int G = 1 << NST, GP = 16 / G;                 // keys per group, groups a thread works on at once
-    const int jlow = J >> (NST - 1);                         // smallest stride of this pass
-    const int ngroups = n2 >> NST;
-    for (int g0 = threadIdx.x; g0 < ngroups; g0 += LARGE_NT * GP) {
-        uint64_t v[GP][G];
-        int base[GP];
+// 16 keys in registers, descending: bitonic network (80 compare-exchanges, static indices)
+__device__ __forceinline__ void sort16_desc(uint64_t (&k)[16]) {
 #pragma unroll
-        for (int p = 0; p < GP; ++p) {
-            const int g = g0 + p * LARGE_NT;
-            const int gg = g < ngroups ? g : g0;
-            base[p] = ((gg & ~(jlow - 1)) << NST) | (gg & (jlow - 1));
+    for (int kk = 2; kk <= 16; kk <<= 1)
 #pragma unroll
-            for (int c = 0; c < G; ++c) v[p][c] = keys[base[p] + c * jlow];
-        }
+        for (int j = kk >> 1; j >= 1; j >>= 1)
 #pragma unroll
-        for (int p = 0; p < GP; ++p) {
-            const bool desc = (base[p] & k) == 0;
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                constexpr int dummy = 0; (void)dummy;
-                const int bit = G >> (st + 1);
-#pragma unroll
-                for (int c = 0; c < G; ++c) {
-                    if (c & bit) continue;
-                    const uint64_t x = v[p][c], y = v[p][c | bit];
-                    const bool sw = desc ? (x < y) : (x > y);
-                    v[p][c] = sw ? y : x;
-                    v[p][c | bit] = sw ? x : y;
-                }
+            for (int c = 0; c < 16; ++c) {
+                if ((c ^ j) <= c) continue;
+                if ((c & kk) == 0 || kk == 16) IPSX_CE_DESC(k[c], k[c ^ j]);
+                else IPSX_CE_DESC(k[c ^ j], k[c]);
             }
-        }
-#pragma unroll
-        for (int p = 0; p < GP; ++p) {
-            if (g0 + p * LARGE_NT >= ngroups) continue;
-#pragma unroll
-            for (int c = 0; c < G; ++c) keys[base[p] + c * jlow] = v[p][c];
-        }
-    }
 }
 
-// keys[0, n2) (n2 a power of two >= 64, padding keys 0) sorted descending in place, by the LARGE_NT threads of the
-// workgroup.  Bitonic network; the levels up to 64 and the strides below 64 of every later level run in registers (a
-// 64-key block per wavefront, cross-lane), the strides >= 64 go through LDS up to four at a time (bitonic_pass): 21
-// round trips through LDS for 16,384 keys instead of the 105 of one stage per pass.  Keys are unique.
-// (A function of its own, not inlined: the loop around it then keeps its registers - inlined, scan_large_kernel spilled 64
-//  VGPRs at its 128-register budget.  The key array is the start of the dynamic LDS in both kernels that call it.)
+// keys[0, n2) (n2 a power of two >= 64, padded slots, padding keys 0) sorted descending in place by the workgroup: a MERGE
+// sort.  Every thread sorts its 16 keys in registers, then log2(n2 / 16) rounds merge neighbouring runs: a thread produces
+// the 16 outputs [16 t, 16 t + 16) of its pair of runs - where they start in the two runs is a binary search along the
+// merge path (two LDS reads per step), the next 16 keys of either run are read at once (32 independent reads, no dependent
+// chain) and the 16 largest of the 32 fall out of half a bitonic merge in registers (max(a[c], b[15 - c]), then four
+// compare-exchange stages).  n log n comparisons instead of the bitonic network's n log^2 n: the network's cross-lane
+// stages alone were ~10 k VALU instructions per wavefront (200 k cycles for 16,384 keys; this: 3 k).  Keys are unique
+// (equal padding zeros aside).  Not inlined (see large_tie_replay); the key array is the start of the dynamic LDS.
 __device__ __attribute__((noinline)) void sort_desc_large(int n2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = n2 >> 6;
-    for (int blk = wave; blk < nblk; blk += LARGE_NT / 64) {           // runs of 64; odd runs ascending (stored reversed)
-        const uint64_t k = wave_sort_desc(keys[blk * 64 + lane], lane);
-        keys[blk * 64 + ((blk & 1) ? 63 - lane : lane)] = k;
+    const int tid = threadIdx.x;
+    const bool act = tid < (n2 >> 4);                                 // threads that own a run of 16
+    const int o = tid * 16;                                           // first output position of this thread, every round
+    uint64_t k[16];
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) k[c] = keys[17 * tid + c];
+        sort16_desc(k);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) keys[17 * tid + c] = k[c];
     }
-    for (int k = 128; k <= n2; k <<= 1) {
-        int J = k >> 1;
-        int left = 0;                                                  // strides J ... 64 of this level
-        for (int j = J; j >= 64; j >>= 1) ++left;
-        while (left > 0) {
-            const int nst = left >= 4 ? 4 : left;
-            __syncthreads();
-            if (nst == 4) bitonic_pass<4>(keys, n2, k, J);
-            else if (nst == 3) bitonic_pass<3>(keys, n2, k, J);
-            else if (nst == 2) bitonic_pass<2>(keys, n2, k, J);
-            else bitonic_pass<1>(keys, n2, k, J);
-            J >>= nst;
-            left -= nst;
-        }
+    int steps = 5;                                                    // binary-search steps of a round: log2(len) + 1
+    for (int len = 16; len < n2; len <<= 1, ++steps) {
         __syncthreads();
-        for (int b0 = wave; b0 < nblk; b0 += (LARGE_NT / 64) * 4) {    // strides 32 ... 1: four blocks of a wavefront in flight
-            uint64_t v[4];
+        if (act) {
+            const int base = o & ~(2 * len - 1), diag = o - base;
+            const int bA = base, bB = base + len;
+            int lo = diag > len ? diag - len : 0, hi = diag < len ? diag : len;
+            for (int it = 0; it < steps; ++it) {                      // (uniform trip count; finished lanes idle)
+                const int mid = (lo + hi) >> 1;
+                const bool go = lo < hi;
+                const uint64_t av = keys[large_slot(bA + (go ? mid : 0))];
+                const uint64_t bv = keys[large_slot(bB + (go ? diag - 1 - mid : 0))];
+                if (go) { if (av > bv) lo = mid + 1; else hi = mid; }
+            }
+            const int ai = lo, bi = diag - lo;
+            uint64_t av[16], bv[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int blk = b0 + u * (LARGE_NT / 64);
-                v[u] = keys[(blk < nblk ? blk : b0) * 64 + lane];
+            for (int c = 0; c < 16; ++c) {
+                av[c] = keys[large_slot(bA + (ai + c < len ? ai + c : len - 1))];
+                bv[c] = keys[large_slot(bB + (bi + c < len ? bi + c : len - 1))];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int blk = b0 + u * (LARGE_NT / 64);
-                v[u] = merge64(v[u], lane, ((blk * 64) & k) == 0);
+            for (int c = 0; c < 16; ++c) {
+                if (ai + c >= len) av[c] = 0ull;
+                if (bi + c >= len) bv[c] = 0ull;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int blk = b0 + u * (LARGE_NT / 64);
-                if (blk < nblk) keys[blk * 64 + lane] = v[u];
-            }
+            for (int c = 0; c < 16; ++c) k[c] = av[c] > bv[15 - c] ? av[c] : bv[15 - c];   // the 16 largest, a bitonic sequence
+#pragma unroll
+            for (int j = 8; j >= 1; j >>= 1)
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if ((c & j) == 0) IPSX_CE_DESC(k[c], k[c | j]);
+        }
+        __syncthreads();                                              // every read of this round is done
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) keys[17 * tid + c] = k[c];
         }
     }
     __syncthreads();
 }
+#undef IPSX_CE_DESC
 
 // keys = the L ranked keys (canonical order) in LDS.  When two of the first m + 1 ranked scores are equal and the tie
 // order is the reference's, the key array is turned - through registers, in place - into the (score, position) pairs in
@@ -1696,14 +1687,14 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2,
     unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 3 * stdorder::STACK_RANGES);
     int* queue = reinterpret_cast<int*>(leaf + LARGE_LEAF_WORDS);
     const int tid = threadIdx.x;
-    if (tie_order != 1 || !ranked_ties(keys, L, m, tid & 63)) return false;
-    unsigned long long* tiebits = reinterpret_cast<unsigned long long*>(queue + 2 + 2 * BLOCK_QCAP * 3);
+    if (tie_order != 1 || !ranked_ties_padded(keys, L, m, tid & 63)) return false;
+    unsigned long long* tiebits = reinterpret_cast<unsigned long long*>(queue + 2 + 2 * BLOCK_QCAP);
     uint64_t hold[LARGE_KPT];
 #pragma unroll
     for (int s = 0; s < LARGE_KPT; ++s) {
         const int j = tid + s * LARGE_NT;
-        hold[s] = j < L ? keys[j] : 0ull;
-        const uint64_t next = j + 1 < L ? keys[j + 1] : 0ull;          // (a wavefront's 64 ranks are one word of the bitmap)
+        hold[s] = j < L ? keys[large_slot(j)] : 0ull;
+        const uint64_t next = j + 1 < L ? keys[large_slot(j + 1)] : 0ull;   // (a wavefront's 64 ranks are one word of the bitmap)
         const unsigned long long word = __ballot(j + 1 < L && (hold[s] >> 32) == (next >> 32));
         if ((tid & 63) == 0) tiebits[(tid >> 6) + s * (LARGE_NT / 64)] = word;
     }
@@ -1744,10 +1735,10 @@ struct LargeArgs {
     size_t ws_per_image;
 };
 
-// keys | row maxima, denominators | stack of the sequential fallbacks | leaf bitmap | two range lists + their counters
+// keys (padded) | row maxima, denominators | stack of the sequential fallbacks | leaf bitmap | two range lists + counters
 constexpr size_t LARGE_TAIL_BYTES = (size_t)3 * stdorder::STACK_RANGES * 4 + (size_t)LARGE_LEAF_WORDS * 8 +
-                                    (size_t)(2 * BLOCK_QCAP * 3 + 2) * 4 + (size_t)LARGE_LEAF_WORDS * 8;     // ... | tie bitmap
-static size_t large_lds_bytes(int n2, int R) { return (size_t)n2 * 8 + (size_t)((R + 1) & ~1) * 8 + LARGE_TAIL_BYTES; }
+                                    (size_t)(2 * BLOCK_QCAP + 2) * 4 + (size_t)LARGE_LEAF_WORDS * 8;         // ... | tie bitmap
+static size_t large_lds_bytes(int n2, int R) { return large_key_bytes(n2) + (size_t)((R + 1) & ~1) * 8 + LARGE_TAIL_BYTES; }
 
 // A pass over global memory at 16 waves per compute unit is bound by round trips, not by bandwidth: every loop below
 // keeps LARGE_U independent loads of a thread in flight before it uses the first.
@@ -1767,9 +1758,9 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = a.h * a.T, Lp = a.Lp, m = a.m;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    uint32_t* rmaxkey = reinterpret_cast<uint32_t*>(keys + a.n2);      // row maxima as order-preserving keys (max_key)
+    uint32_t* rmaxkey = reinterpret_cast<uint32_t*>(keys + a.n2 + (a.n2 >> 4));   // row maxima as order-preserving keys (max_key)
     float* rden = reinterpret_cast<float*>(rmaxkey + ((R + 1) & ~1));
-    const int tail = a.n2 * 8 + ((R + 1) & ~1) * 8;
+    const int tail = (a.n2 + (a.n2 >> 4)) * 8 + ((R + 1) & ~1) * 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     constexpr int NW = LARGE_NT / 64;
     const float* lg = a.lg + (size_t)b * a.n * R;
@@ -1924,13 +1915,13 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
                 }
                 key = rank_key(st / (float)a.T, (uint32_t)l);
             }
-            keys[l] = key;
+            keys[large_slot(l)] = key;
         }
         __syncthreads();
         LARGE_STAMP(4);
         sort_desc_large(a.n2);
         LARGE_STAMP(5);
-        if (tid == 0 && L > m && (keys[m - 1] >> 32) == (keys[m] >> 32)) tie = 1;
+        if (tid == 0 && L > m && (keys[large_slot(m - 1)] >> 32) == (keys[large_slot(m)] >> 32)) tie = 1;
         const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail);
         LARGE_STAMP(6);
         const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
@@ -1947,8 +1938,8 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
                     pos = q[j].i;
                     sc = key_score(rank_key(q[j].v, 0u));
                 } else {
-                    pos = (int)key_pos(keys[j]);
-                    sc = key_score(keys[j]);
+                    pos = (int)key_pos(keys[large_slot(j)]);
+                    sc = key_score(keys[large_slot(j)]);
                 }
                 if (want_score) a.mem_score[(size_t)b * m + j] = sc;
                 nw[s] = pos < m ? (int)mem[pos] : (int)(lo + (pos - m));
@@ -1975,16 +1966,16 @@ __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsign
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int l = tid; l < a.n2; l += LARGE_NT)
-        keys[l] = l < a.L ? rank_key(a.scores[(size_t)b * a.L + l], (uint32_t)l) : 0ull;
+        keys[large_slot(l)] = l < a.L ? rank_key(a.scores[(size_t)b * a.L + l], (uint32_t)l) : 0ull;
     __syncthreads();
     sort_desc_large(a.n2);
     if (a.tie && tid == 0)
-        a.tie[b] = (a.L > a.m && (keys[a.m - 1] >> 32) == (keys[a.m] >> 32)) ? 1 : 0;
+        a.tie[b] = (a.L > a.m && (keys[large_slot(a.m - 1)] >> 32) == (keys[large_slot(a.m)] >> 32)) ? 1 : 0;
     int* lists = reinterpret_cast<int*>(ws + (size_t)b * ws_per_row);
-    const bool replayed = large_tie_replay(a.L, a.m, a.n2, a.tie_order, lists, a.n2 * 8);
+    const bool replayed = large_tie_replay(a.L, a.m, a.n2, a.tie_order, lists, (a.n2 + (a.n2 >> 4)) * 8);
     const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
     for (int j = tid; j < a.m; j += LARGE_NT)
-        a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[j]);
+        a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[large_slot(j)]);
 }
 
 static unsigned long long* g_scan_stamps = nullptr;   // diagnostic only (ipsx_dbg_scan_stamps)
@@ -2355,7 +2346,7 @@ IPSX_API int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_id
         if (!workspace || workspace_bytes < need)
             return fail(IPSX_EWORKSPACE, "topm: %d candidates need a workspace of %zu B (ipsx_topm_workspace_bytes), got %zu",
                         l, need, workspace_bytes);
-        const size_t big = (size_t)a.n2 * 8 + LARGE_TAIL_BYTES;
+        const size_t big = large_key_bytes(a.n2) + LARGE_TAIL_BYTES;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
         topm_large_kernel<<<dim3((unsigned)b), dim3(LARGE_NT), big, as_stream(stream)>>>(
             a, static_cast<unsigned char*>(workspace), topm_large_ws_per_row(l));
