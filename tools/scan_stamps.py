@@ -72,10 +72,11 @@ if kind == "large":
         torch.cuda.synchronize()
         L.ipsx_dbg_scan_stamps(None)
         s = st.cpu().numpy()[0]
-        print("large, tie order %s: %d iterations, L=%d, R=%d; %.1f k cycles per iteration (100 MHz clock: x %.0f = core cycles)"
-              % (mode, n_iter, M + I, H * T, s.sum() / n_iter / 1e3, 24))
+        print("large, tie order %s: %d iterations, L=%d, R=%d; %.1f k shader cycles per iteration in the STAMPED build (it spills "
+              "registers the product build does not: its passes over the workspace read slower than they are)"
+              % (mode, n_iter, M + I, H * T, s.sum() / n_iter / 1e3))
         for k, nme in enumerate(names):
-            print("  %-28s %9.1f us/iter" % (nme, s[k] / n_iter / 100.0))
+            print("  %-28s %9.1f k cycles/iter" % (nme, s[k] / n_iter / 1e3))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(10):
