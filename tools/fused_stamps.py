@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Diagnostic: per-phase cycle breakdown of fused_trunk_kernel from in-kernel s_memtime stamps.
 
-    python tools/fused_stamps.py [n_patches] [fp32|fp32x3]
+    python tools/fused_stamps.py [n_patches] [fp32|fp32x3|bf16]
 
 Runs the STAMP build (ipsx_dbg_fused_trunk_stamps) on synthetic patches and prints, per phase,
 the median wave-cycles and the matrix-pipe cycles the phase's MFMAs need alone (64 cycles each).
@@ -42,8 +42,10 @@ s = st.cpu().numpy().astype(np.int64)
 names = ["load", "stem+pool", "l1.0.c1", "l1.0.c1 epi", "l1.0.c2", "l1.0.c2 epi", "l1.1.c1", "l1.1.c1 epi",
          "l1.1.c2", "l1.1.c2 epi", "l2.0.c1+down", "l2.0 epi+c2", "l2.1.c1", "l2.1.c2", "avgpool"]
 mfma = [0, 400, 1152, 0, 1152, 0, 1152, 0, 1152, 0, 640, 1152, 1152, 1152, 0]
-if prec == "fp32x3":      # bf16 MFMAs of 32 cycles, 6 per 8 fp32 MFMAs of 64 -> in units of 64 cycles: x 6/16; the stem stays fp32
-    mfma = [m if k == 1 else m * 6 / 16 for k, m in enumerate(mfma)]
+if prec == "fp32x3":      # bf16 MFMAs of 32 cycles, 6 per 8 fp32 MFMAs of 64 -> in units of 64 cycles: x 6/16 (stem: 4 K-steps x 6 x 2 n-tiles x 8 tiles)
+    mfma = [(8 * 2 * 4 * 6 / 2) if k == 1 else m * 6 / 16 for k, m in enumerate(mfma)]
+if prec == "bf16":        # one bf16 MFMA of 32 cycles per 8 fp32 MFMAs of 64: x 1/16 (stem: 4 K-steps x 2 n-tiles x 8 tiles)
+    mfma = [(8 * 2 * 4 / 2) if k == 1 else m / 16 for k, m in enumerate(mfma)]
 # stamps: 0 start,1 loaded,2 stem,3 c1,4 epi,5 c2,6 epi(+barrier),7..10 block 1,11 l2.0 c1+down,12 cv5,13 cv6,14 cv7,15 end
 life = s[:, 15] - s[:, 0]
 print("waves %d  median life %d cycles  (matrix-pipe cycles alone: %d)" % (len(s), np.median(life), sum(mfma) * 64))
