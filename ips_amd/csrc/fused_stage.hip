@@ -412,6 +412,191 @@ __global__ __launch_bounds__(256, 2) void stem_pool50_kernel(StemArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stem + max-pool, 3 x 100 px
+// The traffic-sign configuration's stem (config/traffic_config.yml: 3x100x100 patches -> 50x50x64 -> 25x25x64 pooled), same
+// scheme as stem_pool50_kernel with three input planes: ONE patch per workgroup (the zero-padded 3 x 106 x 106 image fills
+// 132 KiB of LDS), its four wavefronts take bands of 7 / 6 / 6 / 6 pooled rows (each computes the stem row above its band
+// itself); a stem row is 2 M-tiles (50 of 64 pixel lanes) x 2 n-tiles x 75 MFMA k-steps (K = 147, k = 3 tap + channel:
+// every tap address is base + a constant that depends on the lane half only); rows go through in pairs, the pool runs on the
+// accumulators.  Replaces conv_any_kernel (0.36 of peak) + maxpool_3x3s2_nhwc_kernel: 11.5 % of that trunk's kernel time.
+struct Stem3Args {
+    const float* patches;     // (n, 3, 100, 100)
+    float* y;                 // (n, 25, 25, 64) channels-last
+    long long n;
+    const float *w, *al, *sh; // packed stem weights (2 n-tiles x 19 k-groups), BN alpha / shift
+};
+
+constexpr int S3W = 106;                       // padded width / height
+constexpr int S3PLANE = S3W * S3W;             // floats per channel plane
+constexpr int S3_FLOATS = 3 * S3PLANE + 64;    // + slack: pixel lanes 50..63 of the last row read past the image
+
+// offset (floats) of contraction index k inside the padded planes, relative to the receptive field's top-left corner
+__host__ __device__ constexpr int s3_off(int k) {
+    return k >= 147 ? 0 : (k % 3) * S3PLANE + ((k / 3) / 7) * S3W + (k / 3) % 7;
+}
+
+__global__ __launch_bounds__(256, 1) void stem_pool100x3_kernel(Stem3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const long long p = blockIdx.x;
+    float* S = lds;
+    for (int z = threadIdx.x; z < S3_FLOATS / 4; z += 256) reinterpret_cast<float4*>(S)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    {   // 3 x 100 x 100 floats, rows of 25 float4 -> image at rows / columns 3..102 of every plane
+        const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)p * 30000);
+        for (int e0 = threadIdx.x; e0 < 7500; e0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[e0 + 256 * u < 7500 ? e0 + 256 * u : e0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < 7500) {
+                    const int c = e / 2500, rem = e - c * 2500, yy = rem / 25, xx = 4 * (rem - yy * 25);
+                    float* d = S + c * S3PLANE + (yy + 3) * S3W + xx + 3;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        }
+    }
+    // weights: 19 k-groups x 2 n-tiles of 16 bytes per lane (k = 8 g + 4 half + j; zeros from k = 147 on), streamed from
+    // L2 one group ahead of its MFMAs (152 registers if held - the first version did, and spilled); BN of this lane's channels
+    const float4* wp0 = reinterpret_cast<const float4*>(a.w) + lane;
+    const float4* wp1 = wp0 + 19 * 64;
+    const float al0 = a.al[i], sh0 = a.sh[i], al1 = a.al[32 + i], sh1 = a.sh[32 + i];
+    __syncthreads();
+
+    // one stem row `oy` -> BN + ReLU'd values, v[mt][nt][r] = column 32 mt + 4 half + (r & 3) + 8 (r >> 2); columns >= 50: 0
+    auto stem_row = [&](int oy, float (&v)[2][2][16]) {
+        const float* base = S + (2 * oy) * S3W + 2 * i;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+        float4 w0 = wp0[0], w1 = wp1[0];
+        float a0[4], a1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = half ? s3_off(4 + j) : s3_off(j);
+            a0[j] = base[off];
+            a1[j] = base[off + 64];
+        }
+#pragma unroll
+        for (int g = 0; g < 19; ++g) {
+            // operands of the NEXT k-group are requested before this group's MFMAs
+            float4 nw0 = w0, nw1 = w1;
+            float n0[4] = {0.f, 0.f, 0.f, 0.f}, n1[4] = {0.f, 0.f, 0.f, 0.f};
+            if (g + 1 < 19) {
+                nw0 = wp0[(g + 1) * 64];
+                nw1 = wp1[(g + 1) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (g + 1 == 18 && j == 3) continue;                           // k = 147 / 151: both halves beyond K
+                    const int off = half ? s3_off(8 * (g + 1) + 4 + j) : s3_off(8 * (g + 1) + j);
+                    n0[j] = base[off];
+                    n1[j] = base[off + 64];
+                }
+            }
+            const float b0[4] = {w0.x, w0.y, w0.z, w0.w}, b1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (g == 18 && j == 3) continue;
+                acc[0][0] = FS_MFMA(a0[j], b0[j], acc[0][0]);
+                acc[0][1] = FS_MFMA(a0[j], b1[j], acc[0][1]);
+                acc[1][0] = FS_MFMA(a1[j], b0[j], acc[1][0]);
+                acc[1][1] = FS_MFMA(a1[j], b1[j], acc[1][1]);
+            }
+            w0 = nw0; w1 = nw1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] = n0[j]; a1[j] = n1[j]; }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // column >= 50 <=> tile 1 and 4 half + (r & 3) + 8 (r >> 2) >= 18
+                const bool beyond = mt == 1 && ((r >> 2) == 3 || ((r >> 2) == 2 && (half != 0 || (r & 3) >= 2)));
+                const float x0 = __builtin_fmaf(acc[mt][0][r], al0, sh0), x1 = __builtin_fmaf(acc[mt][1][r], al1, sh1);
+                v[mt][0][r] = (beyond || !(x0 > 0.0f)) ? 0.0f : x0;
+                v[mt][1][r] = (beyond || !(x1 > 0.0f)) ? 0.0f : x1;
+            }
+    };
+
+    const int t0 = wave == 0 ? 0 : 1 + 6 * wave, t1 = 7 + 6 * wave;      // pooled rows [t0, t1): 0-6, 7-12, 13-18, 19-24
+    float prev[2][2][16];
+    if (t0 > 0) {
+        stem_row(2 * t0 - 1, prev);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) prev[mt][nt][r] = 0.0f;                // row -1: padding
+    }
+    float* yout = a.y + (size_t)p * 625 * 64;
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        float vb[2][2][16];
+        {   // vertical window, as the rows arrive: prev <- max(prev, row 2t), then max with row 2t + 1
+            float va[2][2][16];
+            stem_row(2 * t, va);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) prev[mt][nt][r] = __builtin_fmaxf(prev[mt][nt][r], va[mt][nt][r]);
+        }
+        stem_row(2 * t + 1, vb);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float vm[2][16], oth[2][16];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    vm[mt][r] = __builtin_fmaxf(prev[mt][nt][r], vb[mt][nt][r]);
+                    oth[mt][r] = __shfl_xor(vm[mt][r], 32, 64);
+                }
+            // the row's columns -1 .. 50 in order: column x lives in tile x >> 5, half (x >> 2) & 1, register (x & 3) + 4 ((x & 31) >> 3)
+            float full[52];
+            full[0] = 0.0f;
+#pragma unroll
+            for (int x = 0; x < 51; ++x) {
+                const int mt = x >> 5, own = (x >> 2) & 1, r = (x & 3) + 4 * ((x & 31) >> 3);
+                full[1 + x] = x >= 50 ? 0.0f : ((half == own) ? vm[mt & 1][r] : oth[mt & 1][r]);
+            }
+            // pooled columns: half 0 stores tx = 0..12, half 1 stores tx = 13..24
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                const float lo = fs_max3(full[2 * j], full[2 * j + 1], full[2 * j + 2]);
+                const float hi = j < 12 ? fs_max3(full[2 * (13 + j)], full[2 * (13 + j) + 1], full[2 * (13 + j) + 2]) : 0.0f;
+                const int tx = half ? 13 + j : j;
+                if (tx < 25) yout[(size_t)(t * 25 + tx) * 64 + nt * 32 + i] = half ? hi : lo;
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) prev[mt][nt][r] = vb[mt][nt][r];
+    }
+}
+
+static bool stem_pool100x3_supported(const ipsx_trunk* t) {
+    const char* e = getenv("IPSX_NO_FUSED");
+    if (e && e[0] == '1') return false;
+    const ipsx_conv& c = t->stem;
+    return t->c_in == 3 && t->h == 100 && t->w == 100 && t->patch_dtype == 0 && c.c_in == 3 && c.c_out == 64 && c.kh == 7 &&
+           c.kw == 7 && c.stride == 2 && c.pad == 3 && c.w_packed && c.alpha && c.shift;
+}
+
 static bool stem_pool50_supported(const ipsx_trunk* t) {
     const char* e = getenv("IPSX_NO_FUSED");
     if (e && e[0] == '1') return false;
@@ -421,9 +606,24 @@ static bool stem_pool50_supported(const ipsx_trunk* t) {
 }
 
 bool fused_stem_pool50_covers(const ipsx_trunk* t) { return t && stem_pool50_supported(t); }
+bool fused_stem_pool100x3_covers(const ipsx_trunk* t) { return t && stem_pool100x3_supported(t); }
 
 // stem + max-pool of 1x50x50 patches -> (n, 13, 13, 64) channels-last; returns 1 when it ran, 0 when the trunk is another shape
 int fused_stem_pool50(const ipsx_trunk* t, const float* patches, float* y, int64_t n, hipStream_t s) {
+    if (t && stem_pool100x3_supported(t)) {                            // the traffic-sign stem: one patch per workgroup
+        if (n <= 0) return 1;
+        Stem3Args a3;
+        a3.patches = patches; a3.y = y; a3.n = n;
+        a3.w = t->stem.w_packed; a3.al = t->stem.alpha; a3.sh = t->stem.shift;
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool100x3_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S3_FLOATS * sizeof(float)));
+            attr3 = true;
+        }
+        stem_pool100x3_kernel<<<dim3((unsigned)n), dim3(256), S3_FLOATS * sizeof(float), s>>>(a3);
+        return launched("stem_pool100x3") == IPSX_OK ? 1 : -1;
+    }
     if (!t || !stem_pool50_supported(t)) return 0;
     if (n <= 0) return 1;
     StemArgs a;

@@ -21,6 +21,7 @@ int fused_stage64_blocks(const ipsx_block* blocks, int n_block, int h, int w);
 int fused_stage64(const ipsx_block* blocks, int n_block, const float* x, float* y, int64_t n, int h, int w, hipStream_t s);
 int fused_stem_pool50(const ipsx_trunk* t, const float* patches, float* y, int64_t n, hipStream_t s);   // 1 = ran, 0 = other shape
 bool fused_stem_pool50_covers(const ipsx_trunk* t);
+bool fused_stem_pool100x3_covers(const ipsx_trunk* t);
 // fused_trunk.hip
 bool fused_trunk_supported(const ipsx_trunk* t);
 int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s);
@@ -110,6 +111,8 @@ IPSX_API const char* ipsx_trunk_kernel(const ipsx_trunk* t) {
     if (t && t->n_block >= 2 && fused_stem_pool50_covers(t) &&
         fused_stage64_blocks(t->blocks, t->n_block, 13, 13) > 0)          // the reference's shipped 50-px Megapixel-MNIST trunk
         return "stem_pool50_kernel + fused_stage64_kernel (layer1, LDS-resident) + conv_nhwc_kernel (layer2, layer by layer)";
+    if (t && fused_stem_pool100x3_covers(t))                               // the traffic-sign trunk: fused stem + pool, then layer by layer
+        return "stem_pool100x3_kernel + conv_nhwc_kernel (layer by layer)";
     return "conv_nhwc_kernel (layer by layer)";
 }
 

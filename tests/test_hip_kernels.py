@@ -202,6 +202,27 @@ def test_fused_64_channel_stage_equals_layered_kernels(n, monkeypatch):
         assert ulp_diff(fused.cpu().numpy(), want) == 0
 
 
+@pytest.mark.parametrize("n", [1, 5])
+def test_fused_traffic_stem_equals_layered_kernels(n, monkeypatch):
+    """3x100x100 patches (config/traffic_config.yml): conv7x7/2 + BN + ReLU + max-pool as one kernel
+    (stem_pool100x3_kernel, one patch per workgroup, pool on the accumulators) - same bits as conv_any_kernel +
+    maxpool_3x3s2_nhwc_kernel through the whole ResNet-18 x 4 trunk, and as the oracle."""
+    g = Golden("traffic_full")
+    net = g.net(DEV)
+    x = g.patches()[0, :n].to(DEV)
+    plan = hip.EncoderPlan(net.encoder, True)
+    fused = plan.encode(x)
+    assert hip.encoder_kernel_name(plan).startswith("stem_pool100x3_kernel")
+    monkeypatch.setenv("IPSX_NO_FUSED", "1")
+    layered = plan.encode(x)
+    assert hip.encoder_kernel_name(plan).startswith("conv_nhwc_kernel")
+    monkeypatch.delenv("IPSX_NO_FUSED")
+    assert torch.equal(fused, layered), "max abs diff %g" % float((fused - layered).abs().max())
+    if n == 1:
+        want = orc.Oracle(g.net("cpu")).encode(x.cpu().numpy())
+        assert ulp_diff(fused.cpu().numpy(), want) == 0
+
+
 def test_fused_trunk_equals_layered_kernels(monkeypatch):
     """The LDS-resident fused trunk (1x32x32 patches) vs the layer-by-layer kernels vs the oracle."""
     g = Golden("mnist_full")
