@@ -402,7 +402,8 @@ def main():
     n_launch = max(len(enc_events), 1)
     achieved = enc_patches * FLOP_PER_PATCH[name] / (enc_ms * 1e-3) / 1e12
     phases = ipsd.phase_ms(timings) if timings else None
-    par = parity(fixture, net.last_mem_idx, images) if fixture else None
+    # (more images than the fixture holds, --batch: its images are the first of the batch - the generator draws image by image)
+    par = parity(fixture, net.last_mem_idx[:B] if (world == 1 and batch > B) else net.last_mem_idx, images) if fixture else None
 
     # SURVEY d-1 protocol next to the throughput figure: device sync around every call, median
     lat = []

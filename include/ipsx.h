@@ -276,12 +276,14 @@ int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, 
  * per part): the kernel waits until *ready (device int32, written with ipsx_publish_rows on another stream after the
  * kernels that produced the rows) says the rows it is about to read are in memory.  The wait is bounded (~5 s); on a
  * timeout, or when *ready is set negative, the kernel ends and sets bit 0 of *status (results are then invalid; bit 1 =
- * the kernel is resident).
+ * the kernel is resident).  ready_per_image != 0: `ready` is an array of b words and image k follows ready[k] - a
+ * producer that works through the images one after the other publishes each image's rows as it goes, and image k's loop
+ * runs beside the production of image k + 1.
  * Shapes: ipsx_scan_persistent_supported() != 0.     */
 int ipsx_scan_persistent_supported(int m, int i, int h, int n_token);
 int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                          int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
-                         int32_t* status, void* stream);
+                         int32_t ready_per_image, int32_t* status, void* stream);
 int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream);
 /* ipsx_scan_range that runs only when (*cond & cond_mask) != 0, tested ON THE DEVICE by every workgroup as it starts (no
  * host synchronisation): enqueued behind ipsx_scan_persistent with cond = its status word and mask 1, it redoes the loop

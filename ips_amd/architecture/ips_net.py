@@ -339,75 +339,194 @@ class IPSNet(nn.Module):
             return None
         return it
 
+    def _scan_side_stream(self, dev):
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
+            self._side_stream = torch.cuda.Stream(device=dev, priority=-1)   # its few workgroups must not queue behind the encoder grid
+        return self._side_stream, torch.cuda.current_stream(dev)
+
+    def _feature_parts(self, B, N):
+        """Iterations at which ONE slide's rows are cut into projector launches (the persistent feature pipeline)."""
+        M, I = self.M, self.I
+        n_iter = math.ceil((N - M) / I)
+        # persistent loops: every slide's loop owns a compute unit, the projector - which goes slide by slide - has the
+        # others.  Workgroups go to the 8 XCDs round-robin whatever is free there (timeline of a 252-workgroup launch beside
+        # one loop: two rounds), so what a single-round launch can count on is the free units of the FULLEST XCD, eight times
+        cus = 8 * (32 - -(-B // 8))
+        cap = max(I, (cus * 64) // I * I)                    # most rows of a slide one launch can take, whole chunks
+        half = max(I, (cus * 32) // I * I)                   # ... one launch of half-size workgroups (<= 127 row tiles:
+        #                                                        conv_nhwc_impl then halves the tile and the launch time)
+        its = [0]
+        if self.D >= 512 and N > cap + half and os.environ.get("IPSX_CAM_PARTS", "equal") == "latency":
+            # (opt-in, measured in round 3 and NOT the default.)  A launch costs one workgroup's time whatever its size,
+            # the loop can only take a part once ALL of it is published, and what is left of the loop after the last
+            # publication is serial time.  So: a HALF-TILE launch first (the loop starts after half the time), full
+            # launches in the middle, and the end of the slide as half-tile launches with the smallest last: the
+            # projector's chain shrinks from 1.55 + a 0.29 ms tail to 1.70 + 0.03 ms (kernel timeline,
+            # profiles/r03c_cam_timeline_latency.txt) - and the slide takes 1.98 ms instead of 1.95, because with
+            # its rows always there the LOOP is the bound: 255 iterations x 5.4 - 6.3 us beside the GEMM.  It pays
+            # once the loop is faster.
+            rows = [half]
+            left = N - half
+            while left > cap + half:
+                rows.append(cap)
+                left -= cap
+            if left > cap:                               # a full launch and a small rest
+                rows.append(cap)
+                left -= cap
+            while left > 0:
+                take = min(half, left)
+                rows.append(take)
+                left -= take
+            if len(rows) >= 2 and rows[-1] > rows[-2]:   # the smallest part last
+                rows[-1], rows[-2] = rows[-2], rows[-1]
+            edge = 0
+            for rws in rows[:-1]:
+                edge += rws
+                nxt = max(its[-1] + 1, (edge - M) // I)
+                if nxt >= n_iter:
+                    break
+                its.append(nxt)
+        else:
+            n_part = min(16, max(1, math.ceil(N / cap)))
+            for k in range(1, n_part):                       # equal parts: edge k at about k * N / n_part rows
+                nxt = max(its[-1] + 1, round((k * N / n_part - M) / I))
+                if nxt >= n_iter:
+                    break
+                its.append(nxt)
+        its.append(n_iter)
+        return its
+
+    def _feature_parts_plain(self, B, N):
+        """Feature inputs WITHOUT the persistent loop: equal parts, every launch takes its rows of all B slides and is sized
+        to fill the 256 compute units once."""
+        M, I = self.M, self.I
+        n_iter = math.ceil((N - M) / I)
+        cap = max(I, (256 * 64 // max(B, 1)) // I * I)
+        n_part = min(16, max(1, math.ceil(N / cap)))
+        its = [0]
+        for k in range(1, n_part):
+            nxt = max(its[-1] + 1, round((k * N / n_part - M) / I))
+            if nxt >= n_iter:
+                break
+            its.append(nxt)
+        its.append(n_iter)
+        return its
+
+    def _select_features_persistent(self, patches, pos_enc):
+        """Feature inputs, up to IPSX_PERSIST_MAX_B slides (the loop is the long pole and a slide's loop occupies ONE
+        compute unit): every slide's loop is launched once, up front, as a persistent kernel that owns its compute unit and
+        waits for the rows as the projector publishes them - no re-launch per part, no waiting for a compute unit to drain,
+        no projector workgroups competing for the loop's issue slots.  The projector works through the slides ONE AFTER THE
+        OTHER (a slide's parts fill the other compute units exactly once each), publishing to the slide's own progress word:
+        the loop of slide b runs beside the projector of slide b + 1, so from the second slide on the call runs at the
+        projector's rate.  (Until round 3 more than one slide went through a copy of the part and un-fused launches, and was
+        SLOWER per patch than one slide: 30 / 25 / 34.5 M patches/s at 2 / 4 / 8 slides against 34.7 M at one.)
+        Per part two launches: the GEMM (LayerNorm in its operand load; its first thread publishes what was enqueued before
+        it) and the logits of the part together with the row moments of the NEXT part (of this slide or the next one)."""
+        B, N = patches.shape[:2]
+        M, I, dev = self.M, self.I, patches.device
+        ca = self.transf.crs_attn
+        vq, R = ca.folded_query(), ca.H * ca.n_token
+        n_iter = math.ceil((N - M) / I)
+        its = self._feature_parts(B, N)
+        P = len(its) - 1
+        edges = [0] + [min(N, M + it * I) for it in its[1:]]
+        edges[-1] = N
+        side, main = self._scan_side_stream(dev)
+        # per-call device buffers are kept between calls of the same shape: a buffer that another stream has used cannot be
+        # re-used by the allocator until that stream's work is known to be over, and allocating afresh in every call makes
+        # the host stall in hipMalloc now and then (embeddings of the whole batch too: five 27 MB parts per call made the
+        # caching allocator go back to the driver - tens of milliseconds on the host)
+        bkey = ("features", B, N, M, I, R, self.D, str(dev))
+        if getattr(self, "_feat_bufs_key", None) != bkey:
+            self._feat_bufs = (torch.empty((B, N, R), dtype=torch.float32, device=dev),
+                               torch.empty((B, M), dtype=torch.int64, device=dev),
+                               torch.zeros((B,), dtype=torch.int32, device=dev),
+                               torch.zeros((B + 1,), dtype=torch.int32, device=dev),          # progress word per slide | status
+                               torch.empty((B * N, 2), dtype=torch.float32, device=dev),      # LayerNorm moments
+                               torch.empty((B, N, self.D), dtype=torch.float32, device=dev))
+            self._feat_bufs_key = bkey
+            for t in self._feat_bufs:
+                t.record_stream(side)
+        logits, mem_idx_buf, tie, words, stats, emb_buf = self._feat_bufs
+        tie.zero_()
+        # A loop that gave up waiting (bounded at ~5 s: e.g. something serialises the kernels, so that its producers
+        # cannot run beside it) is REDONE in the same call by the conditional launch behind it (scan_range_if below:
+        # every workgroup leaves at once unless the status word says "timed out"), so this call's results are valid
+        # either way and no host synchronisation is added.  The status word is also mirrored into pinned host memory,
+        # asynchronously, and looked at in the NEXT call - by then it has long arrived - to say so once.
+        mirror = getattr(self, "_scan_status_host", None)
+        if mirror is not None and int(mirror.item()) & 1 and not getattr(self, "_scan_timeout_warned", False):
+            import warnings
+            warnings.warn("the persistent selection loop of an earlier ips() call timed out waiting for rows and was "
+                          "redone with per-call launches (results valid; IPSX_SCAN_PERSIST=0 avoids the wait)")
+            self._scan_timeout_warned = True
+        words.zero_()
+        ready, status = words[:B], words[B:B + 1]
+        self._scan_status = status
+        side.wait_stream(main)                     # the buffers above are the main stream's; previous readers are done
+        with torch.cuda.stream(side):
+            hip.scan_persistent(logits, M, I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status)
+        hip.scan_gate(status)                      # the projector must not take the compute units before a loop has its own
+        self._plan._refresh()
+        fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)
+        steps = [(b, k) for b in range(B) for k in range(P)]
+        srow = lambda b, k: slice(b * N + edges[k], b * N + edges[k + 1])
+        if fused2:
+            self._plan.row_stats(patches[0, edges[0]:edges[1]], out=stats[srow(0, 0)])
+        published = None                           # (slide, rows) whose publication rides on the next GEMM launch
+        for n_step, (b, k) in enumerate(steps):
+            lo, hi = edges[k], edges[k + 1]
+            if not fused2:
+                self._plan.row_stats(patches[b, lo:hi], out=stats[srow(b, k)])
+            emb = self._plan.encode(patches[b, lo:hi], stats=stats[srow(b, k)], out=emb_buf[b, lo:hi],
+                                    publish=(ready[published[0]:published[0] + 1], published[1]) if published else None)
+            published = None
+            emb = emb.view(1, hi - lo, -1)
+            pos = pos_enc[b:b + 1, lo:hi] if self.use_pos else None
+            nxt = steps[n_step + 1] if n_step + 1 < len(steps) else None
+            if fused2 and nxt is not None:
+                hip.logits_stats(emb, pos, vq, R, logits[b:b + 1, lo:hi], patches[nxt[0], edges[nxt[1]]:edges[nxt[1] + 1]],
+                                 stats[srow(*nxt)], self._plan.ln_eps)
+                published = (b, hi)
+            else:
+                hip.logits(emb, pos, vq, R, out=logits[b:b + 1, lo:hi])
+                hip.publish_rows(ready[b:b + 1], hi)   # after the kernels that wrote rows [0, hi) of slide b
+        self._emb_parts = [emb_buf]
+        main.wait_stream(side)
+        hip.scan_range_if(logits, M, I, ca.H, ca.n_token, 0, n_iter, mem_idx_buf, tie, status, 1)   # no-op unless timed out
+        if getattr(self, "_scan_status_host", None) is None:
+            self._scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self._scan_status_host.copy_(status, non_blocking=True)
+        mem_idx = mem_idx_buf.clone()                  # the buffer is overwritten by the next call
+        hip.scan.last_tie = tie
+        return mem_idx
+
     def _select_hip_overlapped(self, patches, pos_enc):
         B, N = patches.shape[:2]
         M, I, dev = self.M, self.I, patches.device
         ca = self.transf.crs_attn
         vq, R = ca.folded_query(), ca.H * ca.n_token
         n_iter = math.ceil((N - M) / I)
-        from ..dist import PART_SHARES_LOOP_BOUND, part_iterations
+        from ..dist import part_iterations
         if self._plan is None:
             self._plan = hip.EncoderPlan(self.encoder, self.is_image)
+        if (not self.is_image and patches.is_contiguous() and B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8"))
+                and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
+                and not hip.kernels_serialised()      # (counter collection, serialising debug switches: it could only time out)
+                and hip.scan_persistent_supported(M, I, ca.H, ca.n_token)):
+            return self._select_features_persistent(patches, pos_enc)
         indexed = self.is_image and patches.is_contiguous() and self._plan.fused(patches.shape)
-        # image encoders: parts shrinking towards the end (only the last scan is exposed).  Projector: the loop is the
-        # long pole (it consumes rows about as fast as the projector makes them), so the parts are EQUAL and sized to
-        # what fills the GPU exactly once - 256 compute units x 64 rows - because a GEMM launch of 1.2 rounds takes as
-        # long as one of 2.
+        # image encoders: parts shrinking towards the end (only the last scan is exposed); a small batch: the whole rounds
+        # of the fused trunk first, the loop over them beside the remainder (_small_batch_split); feature inputs without
+        # the persistent loop (more slides than IPSX_PERSIST_MAX_B, candidate sets beyond the LDS, serialised kernels):
+        # equal parts, each slide's share of a launch sized to fill the GPU once
         if self.is_image and B * N < 32768 and n_iter < 100:
             its = [0, self._small_batch_split(B, N), n_iter]
         elif self.is_image:
             its = part_iterations(n_iter, self._OVERLAP_PARTS)
         else:
-            # (persistent loop: every slide's loop owns a compute unit, the projector has the others - and a launch of one
-            #  workgroup too many takes twice as long)
-            cus = 256 - (B if B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8")) else 0)
-            if cus < 256:
-                # workgroups go to the 8 XCDs round-robin whatever is free there (timeline of a 252-workgroup part beside
-                # one loop: two rounds), so what a launch can count on is the free units of the FULLEST XCD, eight times
-                cus = 8 * (32 - -(-B // 8))
-            cap = max(I, (cus * 64 // max(B, 1)) // I * I)       # most rows of every image one launch can take, whole chunks
-            half = max(I, (cus * 32 // max(B, 1)) // I * I)      # ... one launch of half-size workgroups (<= 127 row tiles:
-            #                                                        conv_nhwc_impl then halves the tile and the launch time)
-            its = [0]
-            if B == 1 and self.D >= 512 and N > cap + half and os.environ.get("IPSX_CAM_PARTS", "equal") == "latency":
-                # (opt-in, measured in round 3 and NOT the default.)  A launch costs one workgroup's time whatever its size,
-                # the loop can only take a part once ALL of it is published, and what is left of the loop after the last
-                # publication is serial time.  So: a HALF-TILE launch first (the loop starts after half the time), full
-                # launches in the middle, and the end of the slide as half-tile launches with the smallest last: the
-                # projector's chain shrinks from 1.55 + a 0.29 ms tail to 1.70 + 0.03 ms (kernel timeline,
-                # profiles/r03c_cam_timeline_latency.txt) - and the slide takes 1.98 ms instead of 1.95, because with
-                # its rows always there the LOOP is the bound: 255 iterations x 5.4 - 6.3 us beside the GEMM.  Back to
-                # back it is worse (2.6 ms per slide: the next slide's loop cannot become resident while the padded
-                # GEMM workgroups of this one hold every unit's LDS).  It pays once the loop is faster.
-                rows = [half]
-                left = N - half
-                while left > cap + half:
-                    rows.append(cap)
-                    left -= cap
-                if left > cap:                               # a full launch and a small rest
-                    rows.append(cap)
-                    left -= cap
-                while left > 0:
-                    take = min(half, left)
-                    rows.append(take)
-                    left -= take
-                if len(rows) >= 2 and rows[-1] > rows[-2]:   # the smallest part last
-                    rows[-1], rows[-2] = rows[-2], rows[-1]
-                edge = 0
-                for rws in rows[:-1]:
-                    edge += rws
-                    nxt = max(its[-1] + 1, (edge - M) // I)
-                    if nxt >= n_iter:
-                        break
-                    its.append(nxt)
-            else:
-                n_part = min(16, max(1, math.ceil(N / cap)))
-                for k in range(1, n_part):                       # equal parts: edge k at about k * N / n_part rows
-                    nxt = max(its[-1] + 1, round((k * N / n_part - M) / I))
-                    if nxt >= n_iter:
-                        break
-                    its.append(nxt)
-            its.append(n_iter)
+            its = self._feature_parts_plain(B, N)
         P = len(its) - 1
         edges = [0] + [min(N, M + it * I) for it in its[1:]]
         edges[-1] = N
@@ -417,97 +536,31 @@ class IPSNet(nn.Module):
             self._part_index = [(rows + torch.arange(edges[k], edges[k + 1], device=dev, dtype=torch.int32)).reshape(-1)
                                 for k in range(P)]
             self._part_index_key = key
-        if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
-            self._side_stream = torch.cuda.Stream(device=dev, priority=-1)   # its few workgroups must not queue behind the encoder grid
-        side, main = self._side_stream, torch.cuda.current_stream(dev)
+        side, main = self._scan_side_stream(dev)
         flat = patches.reshape(B * N, *patches.shape[2:]) if indexed else None
-        # per-call device buffers are kept between calls of the same shape: a buffer that another stream has used cannot be
-        # re-used by the allocator until that stream's work is known to be over, and allocating afresh in every call makes
-        # the host stall in hipMalloc now and then
+        # per-call device buffers are kept between calls of the same shape (see _select_features_persistent)
         bkey = (B, N, M, I, R, str(dev))
         if getattr(self, "_scan_bufs_key", None) != bkey:
             self._scan_bufs = (torch.empty((B, N, R), dtype=torch.float32, device=dev),
                                torch.empty((B, M), dtype=torch.int64, device=dev),
                                torch.zeros((B,), dtype=torch.int32, device=dev),
-                               torch.zeros((2,), dtype=torch.int32, device=dev),
                                hip.scan_workspace(B, M, I, ca.H, ca.n_token, dev))   # None unless M + I exceeds the LDS
             self._scan_bufs_key = bkey
             for t in self._scan_bufs:
                 if t is not None:
                     t.record_stream(side)
-        logits, mem_idx_buf, tie, words, scan_ws = self._scan_bufs
+        logits, mem_idx_buf, tie, scan_ws = self._scan_bufs
         tie.zero_()
         self._emb_parts = parts = []
-        # Feature inputs, few slides (the loop is the long pole and each slide occupies ONE compute unit in it): the loop
-        # is launched once, up front, as a persistent kernel that owns its compute unit and waits for the rows as the
-        # projector publishes them - no re-launch per part, no waiting for a compute unit to drain, no projector
-        # workgroups competing for the loop's issue slots (IPSX_SCAN_PERSIST=0 switches it off).
-        persistent = (not self.is_image and B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8"))
-                      and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
-                      and not hip.kernels_serialised()      # (counter collection, serialising debug switches: it could only time out)
-                      and hip.scan_persistent_supported(M, I, ca.H, ca.n_token))
-        if persistent:
-            # A loop that gave up waiting (bounded at ~5 s: e.g. something serialises the kernels, so that its producers
-            # cannot run beside it) is REDONE in the same call by the conditional launch behind it (scan_range_if below:
-            # every workgroup leaves at once unless the status word says "timed out"), so this call's results are valid
-            # either way and no host synchronisation is added.  The status word is also mirrored into pinned host memory,
-            # asynchronously, and looked at in the NEXT call - by then it has long arrived - to say so once.
-            mirror = getattr(self, "_scan_status_host", None)
-            if mirror is not None and int(mirror.item()) & 1 and not getattr(self, "_scan_timeout_warned", False):
-                import warnings
-                warnings.warn("the persistent selection loop of an earlier ips() call timed out waiting for rows and was "
-                              "redone with per-call launches (results valid; IPSX_SCAN_PERSIST=0 avoids the wait)")
-                self._scan_timeout_warned = True
-            words.zero_()
-            ready, status = words[0:1], words[1:2]
-            self._scan_status = status
-            side.wait_stream(main)                     # the buffers above are the main stream's; previous readers are done
-            with torch.cuda.stream(side):
-                hip.scan_persistent(logits, M, I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status)
-            hip.scan_gate(status)                      # the encoder must not take the compute units before the loop has its own
-        else:
-            side.wait_stream(main)
-        stats = None
-        if not self.is_image and patches.is_contiguous() and P > 1 and B == 1:
-            # LayerNorm moments (8 bytes per row) by a pass of their own in front of every part's GEMM (from the second
-            # part on inside the previous part's logits launch, below)
-            skey = (B, N, str(dev))
-            if getattr(self, "_stats_key", None) != skey:
-                self._stats_buf = torch.empty((B * N, 2), dtype=torch.float32, device=dev)
-                self._stats_key = skey
-                # (embeddings of the whole slide too: allocating five 27 MB parts afresh in every call makes the caching
-                #  allocator go back to the driver now and then - tens of milliseconds on the host)
-                self._emb_buf = torch.empty((B, N, self.D), dtype=torch.float32, device=dev)
-            self._plan._refresh()
-            stats = self._stats_buf
-        # persistent loop + statistics per part: the logits of part k and the statistics of part k + 1 are ONE launch, and
-        # part k is published by the GEMM launch of part k + 1 (everything before it in the stream has completed): two
-        # launches per part.  (Measured against it in round 2 and removed in round 3: one statistics pass over the whole
-        # slide up front - it sits in front of the first rows the loop waits for, 2.11 vs 2.03 ms per slide; a publishing
-        # statistics launch per part, three launches per part: 1.94 vs 1.91 ms; a separate publish kernel, four.)
-        fused2 = persistent and stats is not None and vq.dtype == torch.float32
+        side.wait_stream(main)
         for k in range(P):
             lo, hi = edges[k], edges[k + 1]
-            if stats is not None and not (fused2 and k > 0):
-                self._plan.row_stats(patches[0, lo:hi], out=stats[lo:hi])
             if indexed:
                 emb = self._plan.encode_indexed(flat, self._part_index[k]).view(B, hi - lo, -1)
-            elif stats is not None:
-                emb = self._plan.encode(patches[0, lo:hi], stats=stats[lo:hi], out=self._emb_buf[0, lo:hi],
-                                        publish=(ready, lo) if (fused2 and k > 0) else None).view(B, hi - lo, -1)
             else:
                 emb = self._embed(patches[:, lo:hi].reshape(-1, *patches.shape[2:])).view(B, hi - lo, -1)
             parts.append(emb)
             pos = pos_enc[:, lo:hi] if self.use_pos else None
-            if persistent:
-                if fused2 and k + 1 < P:
-                    hip.logits_stats(emb, pos, vq, R, logits[:, lo:hi], patches[0, edges[k + 1]:edges[k + 2]],
-                                     stats[edges[k + 1]:edges[k + 2]], self._plan.ln_eps)
-                else:
-                    hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
-                if not fused2 or k == P - 1:
-                    hip.publish_rows(ready, hi)        # after the kernels that wrote rows [0, hi) of every image
-                continue
             if k == P - 1:
                 # the last part has nothing to run beside: its logits and iterations stay on the main stream (one
                 # cross-stream hand-over less on the critical path; it only has to follow the side stream's earlier parts)
@@ -524,13 +577,7 @@ class IPSNet(nn.Module):
                 hip.logits(emb, pos, vq, R, out=logits[:, lo:hi])
                 hip.scan_range(logits, M, I, ca.H, ca.n_token, its[k], its[k + 1], mem_idx_buf, tie, scan_ws)
         main.wait_stream(side)
-        if persistent:
-            hip.scan_range_if(logits, M, I, ca.H, ca.n_token, 0, n_iter, mem_idx_buf, tie, status, 1)   # no-op unless timed out
-            if getattr(self, "_scan_status_host", None) is None:
-                self._scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
-            self._scan_status_host.copy_(status, non_blocking=True)
         mem_idx = mem_idx_buf.clone()                  # the buffer is overwritten by the next call
-        main.wait_stream(side)
         hip.scan.last_tie = tie
         return mem_idx
 

@@ -845,7 +845,8 @@ struct ScanArgs {
     long long* mem_idx;
     float* mem_score;
     int* tie;
-    const int* ready;      // persistent launch: number of patches whose logits are in memory (grows while we run)
+    const int* ready;      // persistent launch: number of patches whose logits are in memory (grows while we run);
+    int ready_stride;      //   image b polls ready[b * ready_stride] (0: one word for all images, 1: a word per image)
     int* status;           // persistent launch: set to 1 when the wait for `ready` timed out
     const int* cond;       // conditional launch (ipsx_scan_range_if): run only when (*cond & cond_mask) != 0, or nullptr
     int cond_mask;
@@ -1185,11 +1186,11 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         if (PERSIST && (long long)(need) > ready_known) {                                                      \
             if (wave == 0) {                                                                                   \
                 const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();                               \
-                int v_ = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+                int v_ = __hip_atomic_load(a.ready + b * a.ready_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
                 while (v_ >= 0 && v_ < (need)) {                                                               \
                     __builtin_amdgcn_s_sleep(16);                                                              \
                     if (__builtin_amdgcn_s_memrealtime() - t0_ > 500000000ull) { v_ = -1; break; }             \
-                    v_ = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+                    v_ = __hip_atomic_load(a.ready + b * a.ready_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
                 }                                                                                              \
                 if (lane == 0) ccount[6] = v_;                                                     \
             }                                                                                                  \
@@ -2107,7 +2108,8 @@ IPSX_API int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int 
 static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                            int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
-                           size_t workspace_bytes, void* stream, const int32_t* cond = nullptr, int32_t cond_mask = 0);
+                           size_t workspace_bytes, void* stream, const int32_t* cond = nullptr, int32_t cond_mask = 0,
+                           int ready_stride = 0);
 
 IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                              int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
@@ -2163,12 +2165,12 @@ IPSX_API int ipsx_scan_persistent_supported(int m, int i, int h, int n_token) {
 
 IPSX_API int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                                   int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
-                                  int32_t* status, void* stream) {
-    IPSX_REQUIRE(ready && status, "scan_persistent: needs the progress word and the status word");
+                                  int32_t ready_per_image, int32_t* status, void* stream) {
+    IPSX_REQUIRE(ready && status, "scan_persistent: needs the progress word(s) and the status word");
     IPSX_REQUIRE(n > m && i > 0, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
     IPSX_REQUIRE(ipsx_scan_persistent_supported(m, i, h, n_token), "scan_persistent: shape not covered (use ipsx_scan_range)");
     return scan_range_impl(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, ready, status,
-                           nullptr, 0, stream);
+                           nullptr, 0, stream, nullptr, 0, ready_per_image ? 1 : 0);
 }
 
 // one thread that holds its stream until every workgroup of the persistent scan is resident (bounded: ~0.5 s)
@@ -2204,7 +2206,7 @@ IPSX_API int ipsx_scan_range_if(const float* logits, int b, int64_t n, int m, in
 static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                            int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
-                           size_t workspace_bytes, void* stream, const int32_t* cond, int32_t cond_mask) {
+                           size_t workspace_bytes, void* stream, const int32_t* cond, int32_t cond_mask, int ready_stride) {
     IPSX_REQUIRE(logits && mem_idx, "scan: null pointer");
     IPSX_REQUIRE(b > 0 && m > 0 && i > 0 && h > 0 && n_token > 0, "scan: bad sizes");
     IPSX_REQUIRE(n > m, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
@@ -2246,7 +2248,7 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     a.lg = logits; a.n = n; a.m = m; a.i = i; a.h = h; a.T = n_token; a.n2 = next_pow2(Lmax);
     a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
-    a.ready = ready; a.status = status;
+    a.ready = ready; a.status = status; a.ready_stride = ready_stride;
     a.cond = cond; a.cond_mask = cond_mask;
     a.tie_order = g_tie_order;
     a.use_lds = 1;
