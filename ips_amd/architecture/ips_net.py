@@ -511,7 +511,7 @@ class IPSNet(nn.Module):
         from ..dist import part_iterations
         if self._plan is None:
             self._plan = hip.EncoderPlan(self.encoder, self.is_image)
-        if (not self.is_image and patches.is_contiguous() and B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "8"))
+        if (not self.is_image and patches.is_contiguous() and B <= int(os.environ.get("IPSX_PERSIST_MAX_B", "16"))
                 and os.environ.get("IPSX_SCAN_PERSIST", "1") != "0"
                 and not hip.kernels_serialised()      # (counter collection, serialising debug switches: it could only time out)
                 and hip.scan_persistent_supported(M, I, ca.H, ca.n_token)):
