@@ -470,28 +470,49 @@ class IPSNet(nn.Module):
         hip.scan_gate(status)                      # the projector must not take the compute units before a loop has its own
         self._plan._refresh()
         fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)
-        steps = [(b, k) for b in range(B) for k in range(P)]
-        srow = lambda b, k: slice(b * N + edges[k], b * N + edges[k + 1])
+        # The launches: (first row, end row) in the FLAT (B * N) row space + what each makes visible, [(slide, rows)].  One
+        # slide, or positional encodings (a table per slide position): a slide's parts.  Several slides without them: the
+        # slides are one stream of rows cut into full launches wherever a slide ends (the patch tensor is contiguous, a
+        # launch may take the end of one slide and the start of the next) - 4.13 launches per 65,536-row slide instead of 5.
+        launches = []
+        if B == 1 or self.use_pos:
+            for b_ in range(B):
+                for k in range(P):
+                    launches.append((b_ * N + edges[k], b_ * N + edges[k + 1], [(b_, edges[k + 1])]))
+        else:
+            # rows of a full launch: 224 workgroups (28 per XCD).  Measured at 2 / 16 slides: 208 -> 36.3 / 43.1 M patches/s,
+            # 224 -> 36.5 / 45.9, 240 -> 30.4 / 37.8 (now and then a workgroup waits for a second round: the free units of
+            # the fullest XCD are a bound, not a promise - round 2 had found the same cliff between 224 and 232)
+            cap = max(I, min(224, 8 * (32 - -(-B // 8))) * 64 // I * I)
+            r0 = 0
+            while r0 < B * N:
+                # the first launch of the call stays short: the first loop starts after M + I rows' worth of projector
+                r1 = min(B * N, r0 + (cap if r0 > 0 else min(cap, edges[1])))
+                pubs = [(b_, min(N, r1 - b_ * N)) for b_ in range(r0 // N, (r1 - 1) // N + 1)]
+                launches.append((r0, r1, pubs))
+                r0 = r1
+        xf, ef, lf = patches.view(B * N, -1), emb_buf.view(B * N, -1), logits.view(1, B * N, R)
         if fused2:
-            self._plan.row_stats(patches[0, edges[0]:edges[1]], out=stats[srow(0, 0)])
+            self._plan.row_stats(xf[launches[0][0]:launches[0][1]], out=stats[launches[0][0]:launches[0][1]])
         published = None                           # (slide, rows) whose publication rides on the next GEMM launch
-        for n_step, (b, k) in enumerate(steps):
-            lo, hi = edges[k], edges[k + 1]
+        for n_step, (r0, r1, pubs) in enumerate(launches):
             if not fused2:
-                self._plan.row_stats(patches[b, lo:hi], out=stats[srow(b, k)])
-            emb = self._plan.encode(patches[b, lo:hi], stats=stats[srow(b, k)], out=emb_buf[b, lo:hi],
+                self._plan.row_stats(xf[r0:r1], out=stats[r0:r1])
+            emb = self._plan.encode(xf[r0:r1], stats=stats[r0:r1], out=ef[r0:r1],
                                     publish=(ready[published[0]:published[0] + 1], published[1]) if published else None)
             published = None
-            emb = emb.view(1, hi - lo, -1)
-            pos = pos_enc[b:b + 1, lo:hi] if self.use_pos else None
-            nxt = steps[n_step + 1] if n_step + 1 < len(steps) else None
+            emb = emb.view(1, r1 - r0, -1)
+            pos = pos_enc[r0 // N:r0 // N + 1, r0 % N:r0 % N + (r1 - r0)] if self.use_pos else None
+            nxt = launches[n_step + 1] if n_step + 1 < len(launches) else None
             if fused2 and nxt is not None:
-                hip.logits_stats(emb, pos, vq, R, logits[b:b + 1, lo:hi], patches[nxt[0], edges[nxt[1]]:edges[nxt[1] + 1]],
-                                 stats[srow(*nxt)], self._plan.ln_eps)
-                published = (b, hi)
+                hip.logits_stats(emb, pos, vq, R, lf[:, r0:r1], xf[nxt[0]:nxt[1]], stats[nxt[0]:nxt[1]], self._plan.ln_eps)
+                for b_, rows in pubs[:-1]:         # (a launch across a slide's end: the finished slide is published at once)
+                    hip.publish_rows(ready[b_:b_ + 1], rows)
+                published = pubs[-1]
             else:
-                hip.logits(emb, pos, vq, R, out=logits[b:b + 1, lo:hi])
-                hip.publish_rows(ready[b:b + 1], hi)   # after the kernels that wrote rows [0, hi) of slide b
+                hip.logits(emb, pos, vq, R, out=lf[:, r0:r1])
+                for b_, rows in pubs:              # after the kernels that wrote those rows
+                    hip.publish_rows(ready[b_:b_ + 1], rows)
         self._emb_parts = [emb_buf]
         main.wait_stream(side)
         hip.scan_range_if(logits, M, I, ca.H, ca.n_token, 0, n_iter, mem_idx_buf, tie, status, 1)   # no-op unless timed out
