@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--lazy", action="store_true",
                     help="secondary measurement: lazy loading - the patch tensor starts in pinned HOST memory and "
                          "is streamed over PCIe inside every step (the PCIe-inclusive rate; never the headline)")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket the encoder launches with HIP events (no `roofline.achieved`): what the events themselves "
+                         "cost - at one image per call they move the dispatcher's placement of the loop's workgroup, DESIGN 6")
     ap.add_argument("--config", default=None, choices=sorted(FLOP_PER_PATCH),
                     help="default: mnist at --gpus 1 (the headline, BASELINE configs[1], B=16), mnist3000 at --gpus N > 1 "
                          "(configs[2], patch-sharded); the others are secondary single-GPU measurements: b1 (headline "
@@ -341,7 +344,8 @@ def main():
         enc_events.append((a, b, t.shape[0]))
         return out
 
-    net._plan.encode = timed_encode
+    if not args.no_kernel_events:
+        net._plan.encode = timed_encode
     plan_encode_indexed = net._plan.encode_indexed
 
     def timed_encode_indexed(flat, index):                      # the overlapped path encodes the image in parts
@@ -352,7 +356,8 @@ def main():
         enc_events.append((a, b, index.numel()))
         return out
 
-    net._plan.encode_indexed = timed_encode_indexed
+    if not args.no_kernel_events:
+        net._plan.encode_indexed = timed_encode_indexed
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
@@ -400,7 +405,7 @@ def main():
     enc_ms = sum(a.elapsed_time(b) for a, b, _ in enc_events)
     enc_patches = sum(n for _, _, n in enc_events)
     n_launch = max(len(enc_events), 1)
-    achieved = enc_patches * FLOP_PER_PATCH[name] / (enc_ms * 1e-3) / 1e12
+    achieved = enc_patches * FLOP_PER_PATCH[name] / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0       # (0: --no-kernel-events)
     phases = ipsd.phase_ms(timings) if timings else None
     # (more images than the fixture holds, --batch: its images are the first of the batch - the generator draws image by image)
     par = parity(fixture, net.last_mem_idx[:B] if (world == 1 and batch > B) else net.last_mem_idx, images) if fixture else None
@@ -484,7 +489,10 @@ def main():
             out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS / 6
             out["roofline"]["frac"] = achieved / (BF16_MFMA_PEAK_TFLOPS / 6)
             out["roofline"]["note"] = "algorithmic fp32 FLOP priced against dense bf16 peak / 6 (6 MFMA products per fp32 product)"
-        if args.dedup_blank:        # fewer patches are encoded than scored: an algorithmic FLOP rate would be wrong
+        if args.no_kernel_events:
+            out["roofline"].update({"achieved": None, "frac": None, "traffic": None, "launch_ms": None,
+                                    "note": "--no-kernel-events: the encoder launches were not timed"})
+        elif args.dedup_blank:      # fewer patches are encoded than scored: an algorithmic FLOP rate would be wrong
             out["roofline"].update({"achieved": None, "frac": None, "traffic": None,
                                     "note": "blank-patch dedup: encoder ran on %d of %d patches per launch"
                                             % (int(net._plan.n_encoded.item()), enc_patches // n_launch)})

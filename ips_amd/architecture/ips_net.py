@@ -327,17 +327,33 @@ class IPSNet(nn.Module):
         return (not self.encoder.training) and n_iter >= (2 * self._OVERLAP_PARTS if self.is_image else 3)
 
     def _small_batch_split(self, B, N):
-        """Iterations after which to cut a small image batch in two: the first part = as many whole rounds of the fused
-        trunk (512 workgroups x 4 patches) as the batch fills, cut at a chunk boundary; None when that leaves nothing on
-        either side."""
+        """How to cut a small image batch (one to two rounds of the fused trunk): (edges, its) - part k encodes rows
+        edges[k]..edges[k+1] of every image and the loop then runs iterations its[k]..its[k+1], those whose rows are
+        encoded by then - or None when that leaves nothing on either side.  The parts are the ENCODER's units, not the
+        loop's: half a round first (1,024 patches: one wavefront per SIMD), then 992 - 248 workgroups, a compute unit of
+        every XCD stays free for the loop of the part before, which runs beside it - then the rest.  One image of the
+        headline workload: 1,024 + 992 + 484 rows, iterations 15 + 15 + 9; the 484 go through the
+        two-wavefronts-per-patch kernel (csrc/fused_trunk_pair.h).
+        Why a free unit: the loop's workgroup on a unit it shares with fp32 MFMA wavefronts takes 24 us per iteration
+        instead of 6.7 (tools/scan_beside.py; both want the same fp32 lanes).  Whether it FINDS the free unit is the
+        dispatcher's business: workgroups are dealt to XCDs and their shader engines in turn, and only a launch of at most
+        224 workgroups (7 per engine) leaves a unit free wherever the next workgroup lands.  Parts of 896 would cost more
+        than they save here (measured, one image: 1,024 + 896 + 448 + 132 -> 1.00 ms, this split 0.91, and 1.00 when the
+        caller's own event records shift the dispatcher's turn - bench.py --no-kernel-events tells the two apart)."""
         n_iter = math.ceil((N - self.M) / self.I)
         rounds = (B * N) // 2048
         if rounds != 1:        # measured (bench.py --config b1 / --batch 2): +8 % at one round + remainder, -4 % at two
             return None
-        it = (rounds * 2048 // B - self.M) // self.I           # iterations whose rows lie inside the whole rounds
-        if it < 1 or n_iter - it < 1:
+        edges, its = [0], [0]
+        for total in (1024, 1024 + 992):
+            e = total // B
+            it = (e - self.M) // self.I                        # iterations whose rows lie inside the first e of every image
+            if e < N and its[-1] < it < n_iter:
+                edges.append(e)
+                its.append(it)
+        if len(its) == 1:
             return None
-        return it
+        return edges + [N], its + [n_iter]
 
     def _scan_side_stream(self, dev):
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
@@ -542,15 +558,17 @@ class IPSNet(nn.Module):
         # of the fused trunk first, the loop over them beside the remainder (_small_batch_split); feature inputs without
         # the persistent loop (more slides than IPSX_PERSIST_MAX_B, candidate sets beyond the LDS, serialised kernels):
         # equal parts, each slide's share of a launch sized to fill the GPU once
+        edges = None
         if self.is_image and B * N < 32768 and n_iter < 100:
-            its = [0, self._small_batch_split(B, N), n_iter]
+            edges, its = self._small_batch_split(B, N)
         elif self.is_image:
             its = part_iterations(n_iter, self._OVERLAP_PARTS)
         else:
             its = self._feature_parts_plain(B, N)
         P = len(its) - 1
-        edges = [0] + [min(N, M + it * I) for it in its[1:]]
-        edges[-1] = N
+        if edges is None:                                      # parts cut at the loop's chunk boundaries
+            edges = [0] + [min(N, M + it * I) for it in its[1:]]
+            edges[-1] = N
         key = (B, N, tuple(edges), str(dev))
         if indexed and getattr(self, "_part_index_key", None) != key:  # int32 patch indices of every part, cached
             rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1) * N

@@ -622,6 +622,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
 }
 
 #include "fused_trunk_split.h"
+#include "fused_trunk_pair.h"
 
 static bool is_conv(const ipsx_conv& c, int ci, int co, int k, int s, int p) {
     return c.c_in == ci && c.c_out == co && c.kh == k && c.kw == k && c.stride == s && c.pad == p && c.w_packed &&
@@ -642,6 +643,19 @@ bool fused_trunk_supported(const ipsx_trunk* t) {
     if (b[3].has_down || !is_conv(b[3].conv[0], 128, 128, 3, 1, 1) || !is_conv(b[3].conv[1], 128, 128, 3, 1, 1)) return false;
     const char* off = getenv("IPSX_NO_FUSED");
     return !(off && off[0] == '1');
+}
+
+static int g_pair_mode = 0;       // diagnostic (ipsx_dbg_fused_trunk_pair): 0 the rule below, 1 never, 2 every patch through the pair kernel
+
+static int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int v = 0;
+        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cus[dev];
 }
 
 static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, float* emb,
@@ -698,10 +712,32 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    const int cus = device_cus();
+    // What is left over after the whole rounds (8 patches per CU) goes to the two-wavefronts-per-patch kernel when that takes
+    // fewer wavefront slots per SIMD: at most a quarter round (one workgroup per CU, one wavefront per SIMD, half a patch
+    // each) or between a half and three quarters (three per SIMD) - fused_trunk_pair.h; a device-side count (blank-patch
+    // dedup) leaves the launch as it is.
+    int64_t rest = 0;
+    if (!stamps && !count && g_pair_mode != 1) {
+        const int64_t round = 8 * (int64_t)cus;
+        rest = g_pair_mode == 2 ? n : n % round;
+        // measured, patches -> ms: one wavefront per patch 1024 0.29, 2048 0.54; two per patch 512 0.15, 1024 0.28, 1536 0.43
+        // (three workgroups per CU), 2048 0.57
+        if (g_pair_mode != 2 && !(rest <= round / 4 || (rest > round / 2 && rest <= 3 * round / 4))) rest = 0;
+    }
+    const int64_t n_full = n - rest;
+    a.n = n_full;
     if (stamps)
         fused_trunk_kernel<true><<<dim3((unsigned)cdiv(n, 4)), dim3(256), lds, s>>>(a, stamps);
-    else
-        fused_trunk_kernel<false><<<dim3((unsigned)cdiv(n, 4)), dim3(256), lds, s>>>(a, nullptr);
+    else if (n_full)
+        fused_trunk_kernel<false><<<dim3((unsigned)cdiv(n_full, 4)), dim3(256), lds, s>>>(a, nullptr);
+    if (rest) {
+        a.n = rest;
+        if (index) a.index = index + n_full;
+        else a.patches = patches + (size_t)n_full * 1024;
+        a.emb = emb + (size_t)n_full * 128;
+        fused_trunk_pair_kernel<<<dim3((unsigned)cdiv(rest, 2)), dim3(256), lds / 2, s>>>(a);
+    }
     return launched("fused_trunk");
 }
 
@@ -756,6 +792,10 @@ IPSX_API int ipsx_pack_stem_weight_split(const float* w, int c_out, int planes, 
         ipsx::pack_stem_weight_split_kernel<1><<<grid, block, 0, ipsx::as_stream(stream)>>>(w, c_out, total, static_cast<unsigned short*>(packed));
     return ipsx::launched("pack_stem_weight_split");
 }
+
+// Diagnostic switch (not part of include/ipsx.h; tests/test_hip_kernels.py, tools): which of the two exact fp32 kernels
+// encodes - 0 the product's rule, 1 fused_trunk_kernel only, 2 fused_trunk_pair_kernel only.
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_fused_trunk_pair(int mode) { ipsx::g_pair_mode = mode; }
 
 // Diagnostic entry point (not part of include/ipsx.h): the fused trunk with s_memtime stamps,
 // 16 x uint64 per wavefront = per patch, in launch order.  Used by tools/fused_stamps.py only.

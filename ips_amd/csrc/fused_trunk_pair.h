@@ -1,0 +1,344 @@
+// fused_trunk_pair.h - the fused 1x32x32 trunk (fused_trunk.hip) for the patches that do not fill the GPU: TWO
+// wavefronts per patch.  Included by fused_trunk.hip.
+//
+// The fused trunk's unit is one patch per wavefront, two wavefronts per SIMD: a launch of up to 2,048 patches (256 CUs)
+// takes one patch-pair time whatever its size.  One image of the headline workload is 2,500 patches = 2,048 + 452: the
+// 452 would occupy 452 of 1,024 SIMDs for a whole patch time (0.31 ms beside the 0.56 ms of the full round).  Here a
+// patch is split over the two wavefronts of a pair BY OUTPUT CHANNEL - wave `nh` owns channels 32 nh .. 32 nh + 31 of the
+// stem and of every 64-channel convolution (two m-tiles x one n-tile of accumulators instead of 2 x 2), the slab is
+// shared by the pair - and the 4x4 stage gives each of the workgroup's four wavefronts 32 of the 128 channels of its TWO
+// patches (one 32-row tile).  Every output's fma chain runs over k in the contract's order exactly as in
+// fused_trunk_kernel, so the embeddings are bit-identical to it (tests/test_hip_kernels.py); only the operand traffic per
+// MFMA differs (6 loads per 16 MFMAs at 8x8 instead of 4, 8 per 16 at 4x4 instead of 6), which is why this is the
+// kernel for a remainder of at most a quarter round (one workgroup per CU, one wavefront per SIMD) and not the kernel.
+#pragma once
+
+// ------------------------------------------------------------------ stem + max-pool, one n-tile per wavefront
+// stem_pool<0> of fused_trunk.hip with the n-tile fixed to `nh`; idn[mt] = pooled 8x8 activation, channels 32 nh + lane%32.
+__device__ __forceinline__ void stem_pool_pair(const FusedArgs& a, const float* S, f32x16 (&idn)[2], int lane, int nh) {
+    const int i = lane & 31, half = lane >> 5;
+    const int ox = i & 15;
+    float bw[28];
+    const float4* wp = reinterpret_cast<const float4*>(a.w_stem) + nh * 7 * 64 + lane;
+#pragma unroll
+    for (int kg = 0; kg < 7; ++kg) {
+        const float4 v = wp[kg * 64];
+        bw[4 * kg] = v.x; bw[4 * kg + 1] = v.y; bw[4 * kg + 2] = v.z; bw[4 * kg + 3] = v.w;
+    }
+    const float al = a.a_stem[32 * nh + i], sh = a.s_stem[32 * nh + i];
+    float prev[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) prev[x] = -__builtin_huge_valf();
+
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+        const int oy = 2 * t + (i >> 4);
+        const float* base = S + (2 * oy) * PW + 2 * ox;
+        const float* baseN = base + half * 4;
+        const float* baseW = base + half * (PW - 3);
+        float av[25];
+#pragma unroll
+        for (int st = 0; st < 25; ++st) {
+            const int k0 = 8 * (st >> 2) + (st & 3), ky0 = k0 / 7, kx0 = k0 % 7;
+            av[st] = (kx0 <= 2) ? baseN[ky0 * PW + kx0] : baseW[ky0 * PW + kx0];
+        }
+        av[24] = half ? 0.0f : av[24];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+        zero(acc);
+#pragma unroll
+        for (int st = 0; st < 25; ++st) acc = MFMA(av[st], bw[st], acc);
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = __builtin_fmaf(acc[r], al, sh);
+            v[r] = x > 0.0f ? x : 0.0f;
+        }
+        float own[8], oth[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            own[j] = max3(prev[j], v[j], v[8 + j]);
+            own[4 + j] = max3(prev[4 + j], v[4 + j], v[12 + j]);
+            prev[j] = v[8 + j];
+            prev[4 + j] = v[12 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oth[j] = __shfl_xor(own[j], 32, 64);
+        float L[9];
+        L[0] = half ? own[3] : -__builtin_huge_valf();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            L[1 + j] = half ? oth[4 + j] : own[j];
+            L[5 + j] = half ? own[4 + j] : oth[j];
+        }
+        float pooled[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pooled[q] = max3(L[2 * q], L[2 * q + 1], L[2 * q + 2]);
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            if (tt == t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) idn[tt >> 2][4 * (tt & 3) + q] = pooled[q];
+            }
+        }
+    }
+}
+
+// the wave's 64 px x 32 ch (C layout) into the pair's slab as [pix][c]
+__device__ __forceinline__ void store_l1_pair(float* S, const f32x16 (&v)[2], int lane, int nh) {
+    const int i = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            S[pix * PS1 + nh * 32 + i] = v[mt][r];
+        }
+}
+
+// ------------------------------------------------------------------ 8x8 stage, wave = (patch, n-tile)
+// conv3x3 over K = 9 * 64 for the wave's 32 channels and both m-tiles: the stage of conv_l2 (two packed k-groups, 2 tiles)
+// with the 8x8 stage's tap addresses.
+__device__ __forceinline__ L2Tap l1_tap_pair(int tap, const float* S, int i, int half) {
+    const L1Tap t = l1_tap(tap, S, i, half);
+    L2Tap d;
+    d.s0 = t.s0;
+    d.s1 = t.s1;
+    return d;
+}
+
+__device__ __forceinline__ void conv_l1_pair(const float* __restrict__ wp, const float* S, f32x16 (&acc)[2], int lane, int nh) {
+    constexpr int G2 = 36;
+    const int i = lane & 31, half = lane >> 5;
+    const char* w = reinterpret_cast<const char*>(wp) + (size_t)__builtin_amdgcn_readfirstlane(nh) * 72 * 1024;
+    const unsigned lo = lane * 16;
+    zero(acc[0]); zero(acc[1]);
+    L2Tap cur = l1_tap_pair(0, S, i, half);
+    L2Stage sa, sb;
+    float4 b0[2], b1[2], b2[2], b3[2];
+    l2_loadb<G2>(b0, w, lo, 0);
+    l2_loadb<G2>(b1, w, lo, 1);
+    l2_load<0>(sa, cur);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const L2Tap nxt = l1_tap_pair(tap < 8 ? tap + 1 : 8, S, i, half);
+        const int g = tap * 4;
+        l2_load<1>(sb, cur); l2_loadb<G2>(b2, w, lo, g + 2); L2_PRE(); l2_mma(sa, b0, acc); L2_POST();
+        l2_load<2>(sa, cur); l2_loadb<G2>(b3, w, lo, g + 3); L2_PRE(); l2_mma(sb, b1, acc); L2_POST();
+        l2_load<3>(sb, cur); l2_loadb<G2>(b0, w, lo, g + 4); L2_PRE(); l2_mma(sa, b2, acc); L2_POST();
+        l2_load<0>(sa, nxt); l2_loadb<G2>(b1, w, lo, g + 5); L2_PRE(); l2_mma(sb, b3, acc); L2_POST();
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------ 4x4 stage, 4 waves x 2 patches
+// One tile: row i -> patch i >> 4, pixel i & 15; wave `wave` accumulates output channels 32 wave .. 32 wave + 31.
+// Stage = KPS packed k-groups: 4 (16 MFMAs) for 128 input channels, 2 (8 MFMAs) for 64 - four stages per tap either way.
+template <int KPS>
+struct P2Stage {
+    float4 a[KPS];
+};
+
+template <int KPS, int C>
+__device__ __forceinline__ void p2_load(P2Stage<KPS>& st, const float* d) {
+#pragma unroll
+    for (int q = 0; q < KPS; ++q) st.a[q] = *reinterpret_cast<const float4*>(d + (C * KPS + q) * 8);
+}
+
+template <int KPS, int NST>
+__device__ __forceinline__ void p2_loadb(float4 (&b)[KPS], const char* wb, unsigned loff, int s) {
+    s = s < NST ? s : NST - 1;
+    const char* p = wb + (size_t)s * (KPS * 1024);
+#pragma unroll
+    for (int q = 0; q < KPS; ++q) b[q] = *reinterpret_cast<const float4*>(p + q * 1024 + loff);
+}
+
+template <int KPS>
+__device__ __forceinline__ void p2_mma(const P2Stage<KPS>& st, const float4 (&b)[KPS], f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < KPS; ++q) {
+        const float av[4] = {st.a[q].x, st.a[q].y, st.a[q].z, st.a[q].w};
+        const float bv[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = MFMA(av[j], bv[j], acc);
+    }
+}
+
+#if IPSX_SPREAD
+#define P2_POST4()                                                                                          \
+    SG_MFMA(2); SG_LDS(1); SG_MFMA(2); SG_VMEM(1); SG_MFMA(2); SG_LDS(1); SG_MFMA(2); SG_VMEM(1); SG_MFMA(2); \
+    SG_LDS(1); SG_MFMA(2); SG_VMEM(1); SG_MFMA(1); SG_LDS(1); SG_MFMA(1); SG_VMEM(1); SG_MFMA(2); SB();
+#define P2_POST2() SG_MFMA(2); SG_LDS(1); SG_MFMA(2); SG_VMEM(1); SG_MFMA(1); SG_LDS(1); SG_MFMA(1); SG_VMEM(1); SG_MFMA(2); SB();
+#else
+#define P2_POST4() SB()
+#define P2_POST2() SB()
+#endif
+
+template <int CIN, int WIN, int PS, int ZP, int STRIDE, int KS>
+__device__ __forceinline__ void conv_l2_pair(const float* __restrict__ wp, const float* lds, f32x16& acc, int lane, int wave) {
+    constexpr int KPS = CIN / 32, KGS = KS * KS * CIN / 8, NST = KGS / KPS, TAPS = KS * KS, PAD = KS / 2;
+    static_assert(KPS == 2 || KPS == 4, "stage schedule is written for 64 or 128 input channels");
+    const int i = lane & 31, half = lane >> 5;
+    const int pix = i & 15, oy = pix >> 2, ox = pix & 3;
+    const float* S0 = lds + (i >> 4) * SLAB + 4 * half;
+    const char* w = reinterpret_cast<const char*>(wp) + (size_t)__builtin_amdgcn_readfirstlane(wave) * KGS * 1024;
+    const unsigned lo = lane * 16;
+    auto tap_src = [&](int tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int iy = oy * STRIDE + ky - PAD, ix = ox * STRIDE + kx - PAD;
+        const bool ok = (unsigned)iy < (unsigned)WIN && (unsigned)ix < (unsigned)WIN;
+        return S0 + (ok ? iy * WIN + ix : ZP) * PS;
+    };
+    zero(acc);
+    const float* cur = tap_src(0);
+    P2Stage<KPS> sa, sb;
+    float4 b0[KPS], b1[KPS], b2[KPS], b3[KPS];
+    p2_loadb<KPS, NST>(b0, w, lo, 0);
+    p2_loadb<KPS, NST>(b1, w, lo, 1);
+    p2_load<KPS, 0>(sa, cur);
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const float* nxt = tap_src(tap < TAPS - 1 ? tap + 1 : TAPS - 1);
+        const int g = tap * 4;
+        if (KPS == 4) {
+            p2_load<KPS, 1>(sb, cur); p2_loadb<KPS, NST>(b2, w, lo, g + 2); p2_mma<KPS>(sa, b0, acc); P2_POST4();
+            p2_load<KPS, 2>(sa, cur); p2_loadb<KPS, NST>(b3, w, lo, g + 3); p2_mma<KPS>(sb, b1, acc); P2_POST4();
+            p2_load<KPS, 3>(sb, cur); p2_loadb<KPS, NST>(b0, w, lo, g + 4); p2_mma<KPS>(sa, b2, acc); P2_POST4();
+            p2_load<KPS, 0>(sa, nxt); p2_loadb<KPS, NST>(b1, w, lo, g + 5); p2_mma<KPS>(sb, b3, acc); P2_POST4();
+        } else {
+            p2_load<KPS, 1>(sb, cur); p2_loadb<KPS, NST>(b2, w, lo, g + 2); p2_mma<KPS>(sa, b0, acc); P2_POST2();
+            p2_load<KPS, 2>(sa, cur); p2_loadb<KPS, NST>(b3, w, lo, g + 3); p2_mma<KPS>(sb, b1, acc); P2_POST2();
+            p2_load<KPS, 3>(sb, cur); p2_loadb<KPS, NST>(b0, w, lo, g + 4); p2_mma<KPS>(sa, b2, acc); P2_POST2();
+            p2_load<KPS, 0>(sa, nxt); p2_loadb<KPS, NST>(b1, w, lo, g + 5); p2_mma<KPS>(sb, b3, acc); P2_POST2();
+        }
+        cur = nxt;
+    }
+}
+
+// the wave's tile (C layout) into the two slabs in 4x4-stage layout [pix][c] (row stride PS2)
+__device__ __forceinline__ void store_l2_pair(float* lds, const f32x16& v, int lane, int wave) {
+    const int i = lane & 31, half = lane >> 5;
+    const int n = 32 * wave + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int pl = r >> 3, pix = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+        lds[pl * SLAB + pix * PS2 + n] = v[r];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void fused_trunk_pair_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 2 slabs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ps = wave >> 1, nh = wave & 1;                              // patch slot of the workgroup, n-tile of the pair
+    const int i = lane & 31;
+    const long long p_first = (long long)blockIdx.x * 2;
+    long long pi = p_first + ps;
+    if (pi >= a.n) pi = a.n - 1;                                          // odd tail: recompute a valid patch, store nothing
+    if (a.index) pi = a.index[pi];
+    float* S = lds + ps * SLAB;
+
+    // ---- input patch -> slab as a zero-padded 38x38 image, half of it per wavefront
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.patches + (size_t)pi * 1024);
+        float4 px[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) px[k] = src[(2 * nh + k) * 64 + lane];
+        for (int z = lane + 64 * nh; z < (PW * PW + 3) / 4; z += 128) reinterpret_cast<float4*>(S)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = lane + 64 * nh; z < PS1; z += 128) S[ZP1 * PS1 + z] = 0.0f;
+        __syncthreads();                                                  // the padding is laid by both waves of the pair
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = ((2 * nh + k) * 64 + lane) * 4, y = e >> 5, x = e & 31;
+            float* d = S + (y + 3) * PW + x + 3;
+            d[0] = px[k].x; d[1] = px[k].y; d[2] = px[k].z; d[3] = px[k].w;
+        }
+    }
+    __syncthreads();
+
+    f32x16 idn[2], acc[2];
+    stem_pool_pair(a, S, idn, lane, nh);
+    __syncthreads();                                                      // the input is dead for both waves
+    store_l1_pair(S, idn, lane, nh);
+    __syncthreads();
+
+    // ---- layer1: two BasicBlocks at 8x8
+#pragma unroll 1
+    for (int blk = 0; blk < 2; ++blk) {
+        conv_l1_pair(a.w[2 * blk], S, acc, lane, nh);
+        {
+            const float A = a.al[2 * blk][nh * 32 + i], B = a.sh[2 * blk][nh * 32 + i];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = __builtin_fmaf(acc[mt][r], A, B);
+                    acc[mt][r] = v > 0.0f ? v : 0.0f;
+                }
+        }
+        __syncthreads();
+        store_l1_pair(S, acc, lane, nh);
+        __syncthreads();
+        conv_l1_pair(a.w[2 * blk + 1], S, acc, lane, nh);
+        {
+            const float A = a.al[2 * blk + 1][nh * 32 + i], B = a.sh[2 * blk + 1][nh * 32 + i];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = __builtin_fmaf(acc[mt][r], A, B);
+                    v = v + idn[mt][r];
+                    idn[mt][r] = v > 0.0f ? v : 0.0f;
+                }
+        }
+        __syncthreads();
+        store_l1_pair(S, idn, lane, nh);
+        __syncthreads();
+    }
+
+    // ---- layer2 block 0: conv3x3/2 (64->128) and the 1x1/2 projection read the 8x8 stage of both patches
+    f32x16 t2, id2;
+    const int n2 = 32 * wave + i;
+    conv_l2_pair<64, 8, PS1, ZP1, 2, 3>(a.w[4], lds, t2, lane, wave);
+    conv_l2_pair<64, 8, PS1, ZP1, 2, 1>(a.w_down, lds, id2, lane, wave);
+    {
+        const float A = a.al[4][n2], B = a.sh[4][n2], Ad = a.a_down[n2], Bd = a.s_down[n2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = __builtin_fmaf(t2[r], A, B);
+            t2[r] = v > 0.0f ? v : 0.0f;
+            id2[r] = __builtin_fmaf(id2[r], Ad, Bd);
+        }
+    }
+    __syncthreads();
+    store_l2_pair(lds, t2, lane, wave);
+    if (wave < 2)
+        for (int z = lane; z < PS2; z += 64) lds[wave * SLAB + ZP2 * PS2 + z] = 0.0f;   // zero pixel row of the 4x4 stage
+    __syncthreads();
+#pragma unroll 1
+    for (int cv = 5; cv < 8; ++cv) {
+        conv_l2_pair<128, 4, PS2, ZP2, 1, 3>(a.w[cv], lds, t2, lane, wave);
+        const float A = a.al[cv][n2], B = a.sh[cv][n2];
+        const bool plain = (cv == 6);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = __builtin_fmaf(t2[r], A, B);
+            if (!plain) v = v + id2[r];
+            v = v > 0.0f ? v : 0.0f;
+            t2[r] = v;
+            if (!plain) id2[r] = v;
+        }
+        __syncthreads();
+        store_l2_pair(lds, t2, lane, wave);
+        __syncthreads();
+    }
+
+    // ---- global average pool over the 16 pixels, sequential order: one output per thread
+    {
+        const int pl = threadIdx.x >> 7, n = threadIdx.x & 127;
+        const float* s = lds + pl * SLAB + n;
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum = sum + s[k * PS2];
+        if (p_first + pl < a.n) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
+    }
+}

@@ -223,12 +223,25 @@ def test_fused_traffic_stem_equals_layered_kernels(n, monkeypatch):
         assert ulp_diff(fused.cpu().numpy(), want) == 0
 
 
-def test_fused_trunk_equals_layered_kernels(monkeypatch):
-    """The LDS-resident fused trunk (1x32x32 patches) vs the layer-by-layer kernels vs the oracle."""
+@pytest.fixture
+def trunk_kernel_choice():
+    """ipsx_dbg_fused_trunk_pair: 0 the product's rule, 1 fused_trunk_kernel only, 2 fused_trunk_pair_kernel only."""
+    fn = hip.lib().ipsx_dbg_fused_trunk_pair
+    fn.restype, fn.argtypes = None, [C.c_int]
+    yield fn
+    fn(0)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_trunk_equals_layered_kernels(mode, monkeypatch, trunk_kernel_choice):
+    """The LDS-resident fused trunk (1x32x32 patches) vs the layer-by-layer kernels vs the oracle: the kernel with one
+    wavefront per patch (mode 1) and the one with two (mode 2, fused_trunk_pair.h; by the product's rule only what is
+    left over after the whole rounds of the first)."""
     g = Golden("mnist_full")
     net = g.net(DEV)
-    x = g.patches()[0, :203].to(DEV)                 # 203 = 50*4 + 3: exercises the tail workgroup
+    x = g.patches()[0, :203].to(DEV)                 # 203 = 50*4 + 3 = 101*2 + 1: exercises the tail workgroup of either
     plan = hip.EncoderPlan(net.encoder, True)
+    trunk_kernel_choice(mode)
     fused = plan.encode(x)
     assert hip.encoder_kernel_name(plan) == "fused_trunk_kernel"
     monkeypatch.setenv("IPSX_NO_FUSED", "1")
@@ -238,6 +251,27 @@ def test_fused_trunk_equals_layered_kernels(monkeypatch):
     assert torch.equal(fused, layered)
     want = orc.Oracle(g.net("cpu")).encode(x.cpu().numpy())
     assert ulp_diff(fused.cpu().numpy(), want) == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 453, 2048 + 452, 2048 + 513, 4096 + 37])
+def test_fused_trunk_remainder_rule_is_bit_neutral(n, trunk_kernel_choice):
+    """What does not fill a round of fused_trunk_kernel (8 patches per CU) is encoded by fused_trunk_pair_kernel when it is
+    at most a quarter round: one image of the headline workload is 2,048 + 452 patches.  Whatever the rule picks, the
+    embeddings are those of the one-wavefront-per-patch kernel bit for bit - plain and through an index list."""
+    g = Golden("mnist_full")
+    plan = hip.EncoderPlan(g.net(DEV).encoder, True)
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn((n, 1, 32, 32), generator=gen)
+    x[torch.rand(n, generator=gen) < 0.3] = 0.0                       # blank patches as on the canvases
+    x = x.to(DEV)
+    index = torch.randperm(n, generator=gen).to(torch.int32).to(DEV)
+    trunk_kernel_choice(1)
+    want, want_ix = plan.encode(x), plan.encode_indexed(x, index)
+    assert torch.equal(want[index.long()], want_ix)
+    for mode in (0, 2):
+        trunk_kernel_choice(mode)
+        assert torch.equal(plan.encode(x), want), mode
+        assert torch.equal(plan.encode_indexed(x, index), want_ix), mode
 
 
 @pytest.mark.parametrize("blank_frac", [0.93, 0.0, 1.0, 0.5])
