@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool50_kernel(StemArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 vm[r] = nt ? fs_max3(prev1[r], va1[r], vb1[r]) : fs_max3(prev0[r], va0[r], vb0[r]);
-                oth[r] = __shfl_xor(vm[r], 32, 64);
+                oth[r] = lane_xor_f32<32>(vm[r], lane);
             }
             // the row's columns -1 .. 25 in order: column x lives in half (x >> 2) & 1, register (x & 3) + 4 (x >> 3)
             float full[27];
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void stem_pool100x3_kernel(Stem3Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     vm[mt][r] = __builtin_fmaxf(prev[mt][nt][r], vb[mt][nt][r]);
-                    oth[mt][r] = __shfl_xor(vm[mt][r], 32, 64);
+                    oth[mt][r] = lane_xor_f32<32>(vm[mt][r], lane);
                 }
             // the row's columns -1 .. 50 in order: column x lives in tile x >> 5, half (x >> 2) & 1, register (x & 3) + 4 ((x & 31) >> 3)
             float full[52];

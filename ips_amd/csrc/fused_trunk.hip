@@ -101,6 +101,14 @@ constexpr int SPLANE = PW * SPW * 2; // bytes per plane
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
+// v_permlane32_swap: lo_keeps = (a of this lane | b of the lane 32 below), hi_keeps = (a of the lane 32 above | b of this
+// lane), for the lower | upper lane half - the two cross-half exchanges of the pool in ONE instruction, no LDS round trip
+__device__ __forceinline__ void half_swap(float a, float b, float& lo_keeps, float& hi_keeps) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    lo_keeps = __uint_as_float(r[0]);
+    hi_keeps = __uint_as_float(r[1]);
+}
+
 template <int PL>
 __device__ __forceinline__ void stem_pool(const FusedArgs& a, const void* Sv, f32x16 (&idn)[2][2], int lane) {
     constexpr int PLN = PL > 0 ? PL : 1, NP = PL == 3 ? 6 : 1;
@@ -194,7 +202,7 @@ __device__ __forceinline__ void stem_pool(const FusedArgs& a, const void* Sv, f3
                 const float x = nt ? __builtin_fmaf(acc1[r], al1, sh1) : __builtin_fmaf(acc0[r], al0, sh0);
                 v[r] = x > 0.0f ? x : 0.0f;
             }
-            float own[8], oth[8];
+            float own[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 own[j] = max3(prev[nt][j], v[j], v[8 + j]);                 // columns 4*half + j
@@ -202,18 +210,13 @@ __device__ __forceinline__ void stem_pool(const FusedArgs& a, const void* Sv, f3
                 prev[nt][j] = v[8 + j];
                 prev[nt][4 + j] = v[12 + j];
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) oth[j] = __shfl_xor(own[j], 32, 64);
-            // pooled columns 4*half + q need stem columns 8*half - 1 .. 8*half + 7:
+            // pooled columns 4*half + q need stem columns 8*half - 1 .. 8*half + 7 (oth = the other lane half's own):
             //   half 0: [-inf, own0..3 (cols 0-3), oth0..3 (cols 4-7)]
             //   half 1: [own3 (col 7), oth4..7 (cols 8-11), own4..7 (cols 12-15)]
             float L[9];
             L[0] = half ? own[3] : -__builtin_huge_valf();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                L[1 + j] = half ? oth[4 + j] : own[j];
-                L[5 + j] = half ? own[4 + j] : oth[j];
-            }
+            for (int j = 0; j < 4; ++j) half_swap(own[j], own[4 + j], L[1 + j], L[5 + j]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) pooled[nt][q] = max3(L[2 * q], L[2 * q + 1], L[2 * q + 2]);
         }

@@ -54,7 +54,7 @@ __device__ __forceinline__ void stem_pool_pair(const FusedArgs& a, const float* 
             const float x = __builtin_fmaf(acc[r], al, sh);
             v[r] = x > 0.0f ? x : 0.0f;
         }
-        float own[8], oth[8];
+        float own[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             own[j] = max3(prev[j], v[j], v[8 + j]);
@@ -62,15 +62,10 @@ __device__ __forceinline__ void stem_pool_pair(const FusedArgs& a, const float* 
             prev[j] = v[8 + j];
             prev[4 + j] = v[12 + j];
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) oth[j] = __shfl_xor(own[j], 32, 64);
         float L[9];
         L[0] = half ? own[3] : -__builtin_huge_valf();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            L[1 + j] = half ? oth[4 + j] : own[j];
-            L[5 + j] = half ? own[4 + j] : oth[j];
-        }
+        for (int j = 0; j < 4; ++j) half_swap(own[j], own[4 + j], L[1 + j], L[5 + j]);
         float pooled[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pooled[q] = max3(L[2 * q], L[2 * q + 1], L[2 * q + 2]);

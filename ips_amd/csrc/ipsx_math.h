@@ -87,11 +87,44 @@ __device__ __forceinline__ float max_key_value(uint32_t k) {
     return as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
 
+// The value lane ^ J holds, register to register (no LDS crossbar as __shfl_xor's ds_bpermute takes): strides 1, 2, 4
+// and 8 stay inside a DPP row of 16 lanes (quad permutes, a row shift pair, a row rotate); 16 and 32 are gfx950's
+// v_permlane16_swap / v_permlane32_swap of the value with itself (which leave rows (0,0,2,2) | (1,1,3,3), halves
+// (lo,lo) | (hi,hi) in the two results) and one select.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int lane) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "stride");
+    const int x = (int)v;
+    if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    if (J == 4) {                                                // row_shl:4 (lane i <- i+4) / row_shr:4 (lane i <- i-4)
+        const int up = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0xF, true);
+        const int down = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+        return (uint32_t)((lane & 4) ? down : up);
+    }
+    if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);      // row_ror:8
+    if (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+
+template <int J>
+__device__ __forceinline__ float lane_xor_f32(float v, int lane) { return as_float(lane_xor_u32<J>(as_u32(v), lane)); }
+
+template <int J>
+__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v, int lane) {
+    return ((uint64_t)lane_xor_u32<J>((uint32_t)(v >> 32), lane) << 32) | lane_xor_u32<J>((uint32_t)v, lane);
+}
+
 // xor-butterfly sum over the 64 lanes, offsets 32,16,...,1: every lane ends with
 // the same total (the second half of wave_sum64 of the oracle).
 __device__ __forceinline__ float wave_butterfly_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    const int lane = (int)__lane_id();
+    v = v + lane_xor_f32<32>(v, lane); v = v + lane_xor_f32<16>(v, lane); v = v + lane_xor_f32<8>(v, lane);
+    v = v + lane_xor_f32<4>(v, lane); v = v + lane_xor_f32<2>(v, lane); v = v + lane_xor_f32<1>(v, lane);
     return v;
 }
 
@@ -99,8 +132,9 @@ __device__ __forceinline__ float wave_butterfly_sum(float v) {
 __device__ __forceinline__ float nanmax(float a, float b) { return (b > a || b != b) ? b : a; }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = nanmax(v, __shfl_xor(v, off, 64));
+    const int lane = (int)__lane_id();
+    v = nanmax(v, lane_xor_f32<32>(v, lane)); v = nanmax(v, lane_xor_f32<16>(v, lane)); v = nanmax(v, lane_xor_f32<8>(v, lane));
+    v = nanmax(v, lane_xor_f32<4>(v, lane)); v = nanmax(v, lane_xor_f32<2>(v, lane)); v = nanmax(v, lane_xor_f32<1>(v, lane));
     return v;
 }
 

@@ -891,44 +891,14 @@ __device__ __forceinline__ void rank_scatter(const uint64_t* src, uint64_t* dst,
 //      larger keys there, found by a branch-free binary search (7 LDS reads per run, the
 //      searches of all runs in flight together).
 // src/dst hold L keys (dst gets them sorted); runs is scratch for 64 * ceil(L/64) keys.
-// partner's key for the exchange with lane ^ J.  Strides 1, 2, 4 and 8 stay inside a row of 16 lanes and use DPP
-// (register-to-register, no LDS crossbar): quad permutes, a row shift pair, a row rotate; 16 and 32 go through
-// ds_bpermute (__shfl_xor).
-template <int CTRL>
-__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
-    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-}
+// partner's key for the exchange with lane ^ J: register to register for every stride (lane_xor_*, ipsx_math.h)
+template <int J>
+__device__ __forceinline__ uint64_t xor_partner(uint64_t key, int lane) { return lane_xor_u64<J>(key, lane); }
 
 template <int J>
-__device__ __forceinline__ uint64_t xor_partner(uint64_t key, int lane) {
-    if (J == 1) return dpp64<0xB1>(key);                         // quad_perm [1,0,3,2]
-    if (J == 2) return dpp64<0x4E>(key);                         // quad_perm [2,3,0,1]
-    if (J == 4) {                                                // row_shl:4 (lane i <- i+4) / row_shr:4 (lane i <- i-4)
-        const uint64_t up = dpp64<0x104>(key), down = dpp64<0x114>(key);
-        return (lane & 4) ? down : up;
-    }
-    if (J == 8) return dpp64<0x128>(key);                        // row_ror:8 inside the row of 16
-    return __shfl_xor(key, J, 64);
-}
+__device__ __forceinline__ float xor_partner_f32(float v, int lane) { return lane_xor_f32<J>(v, lane); }
 
-template <int J>
-__device__ __forceinline__ float xor_partner_f32(float v, int lane) {
-    const int x = __float_as_int(v);
-    if (J == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));
-    if (J == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));
-    if (J == 4) {
-        const int up = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0xF, true);
-        const int down = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
-        return __int_as_float((lane & 4) ? down : up);
-    }
-    if (J == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true));
-    return __shfl_xor(v, J, 64);
-}
-
-// the wavefront reductions of the contract (xor butterfly, offsets 32 ... 1) on two values at once; the four short
-// strides stay in the row of 16 lanes (DPP), only 32 and 16 cross it
+// the wavefront reductions of the contract (xor butterfly, offsets 32 ... 1) on two values at once
 __device__ __forceinline__ void wave_max2(float& a, float& b, int lane) {
     a = nanmax(a, xor_partner_f32<32>(a, lane)); b = nanmax(b, xor_partner_f32<32>(b, lane));
     a = nanmax(a, xor_partner_f32<16>(a, lane)); b = nanmax(b, xor_partner_f32<16>(b, lane));
@@ -1112,7 +1082,9 @@ __device__ __attribute__((noinline)) void tie_order_slow(uint64_t* sorted, uint6
 // memory, the prep of the next chunk, the prologue - folds them in with one ds_max_u32 per (wave, row).
 template <int R>
 __device__ __forceinline__ void fold_row_max(uint32_t key, uint32_t* dst, int lane) {
-    for (int off = R; off < 64; off <<= 1) key = max(key, (uint32_t)__shfl_xor((int)key, off, 64));
+    if (R <= 8) key = max(key, lane_xor_u32<8>(key, lane));
+    if (R <= 16) key = max(key, lane_xor_u32<16>(key, lane));
+    key = max(key, lane_xor_u32<32>(key, lane));
     if (lane < R && key != 0u) atomicMax(dst + lane, key);
 }
 
@@ -1374,8 +1346,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
         lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x124, 0xF, 0xF, false));    // row_ror:4
         lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x128, 0xF, 0xF, false));    // row_ror:8
-        lowest = min(lowest, (uint32_t)__shfl_xor((int)lowest, 16, 64));
-        lowest = min(lowest, (uint32_t)__shfl_xor((int)lowest, 32, 64));
+        lowest = min(lowest, lane_xor_u32<16>(lowest, lane));
+        lowest = min(lowest, lane_xor_u32<32>(lowest, lane));
         if (lane == 0 && lowest != 0xFFFFFFFFu) atomicMin(reinterpret_cast<unsigned int*>(ccount + 1), lowest);
         lds_barrier();
         // A chunk candidate whose score is below the lowest memory score cannot be among the M best of memory + chunk
@@ -1846,11 +1818,9 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
                         best = k > best ? k : best;
                     }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)best, off, 64);
-                    best = o > best ? o : best;
-                }
+                best = max(best, lane_xor_u32<32>(best, lane)); best = max(best, lane_xor_u32<16>(best, lane));
+                best = max(best, lane_xor_u32<8>(best, lane)); best = max(best, lane_xor_u32<4>(best, lane));
+                best = max(best, lane_xor_u32<2>(best, lane)); best = max(best, lane_xor_u32<1>(best, lane));
                 if (lane == 0) atomicMax(&rmaxkey[r], best);
             }
         }
