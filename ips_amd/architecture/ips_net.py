@@ -428,6 +428,29 @@ class IPSNet(nn.Module):
         its.append(n_iter)
         return its
 
+    def _feature_launches(self, B, N, P, edges):
+        """The projector launches of _select_features_persistent: (first row, end row) in the FLAT (B * N) row space + what
+        each makes visible, [(slide, rows)]."""
+        I = self.I
+        launches = []
+        if B == 1 or self.use_pos:
+            for b_ in range(B):
+                for k in range(P):
+                    launches.append((b_ * N + edges[k], b_ * N + edges[k + 1], [(b_, edges[k + 1])]))
+        else:
+            # rows of a full launch: 224 workgroups (28 per XCD).  Measured at 2 / 16 slides: 208 -> 36.3 / 43.1 M patches/s,
+            # 224 -> 36.5 / 45.9, 240 -> 30.4 / 37.8 (now and then a workgroup waits for a second round: the free units of
+            # the fullest XCD are a bound, not a promise - round 2 had found the same cliff between 224 and 232)
+            cap = max(I, min(224, 8 * (32 - -(-B // 8))) * 64 // I * I)
+            r0 = 0
+            while r0 < B * N:
+                # the first launch of the call stays short: the first loop starts after M + I rows' worth of projector
+                r1 = min(B * N, r0 + (cap if r0 > 0 else min(cap, edges[1])))
+                pubs = [(b_, min(N, r1 - b_ * N)) for b_ in range(r0 // N, (r1 - 1) // N + 1)]
+                launches.append((r0, r1, pubs))
+                r0 = r1
+        return launches
+
     def _select_features_persistent(self, patches, pos_enc):
         """Feature inputs, up to IPSX_PERSIST_MAX_B slides (the loop is the long pole and a slide's loop occupies ONE
         compute unit): every slide's loop is launched once, up front, as a persistent kernel that owns its compute unit and
@@ -490,25 +513,24 @@ class IPSNet(nn.Module):
         # slide, or positional encodings (a table per slide position): a slide's parts.  Several slides without them: the
         # slides are one stream of rows cut into full launches wherever a slide ends (the patch tensor is contiguous, a
         # launch may take the end of one slide and the start of the next) - 4.13 launches per 65,536-row slide instead of 5.
-        launches = []
-        if B == 1 or self.use_pos:
-            for b_ in range(B):
-                for k in range(P):
-                    launches.append((b_ * N + edges[k], b_ * N + edges[k + 1], [(b_, edges[k + 1])]))
+        # One slide, no positional encoding, fp32 logits: the projector as ONE persistent launch (ipsx_projector_stream)
+        # whose workgroups pull 64-row tiles, do moments + Linear + logits per tile and advance the slide's progress word
+        # as tiles complete - the loop starts after half a tile time and is never a whole part behind.
+        stream = (B == 1 and not self.use_pos and fused2 and os.environ.get("IPSX_CAM_STREAM", "1") != "0"
+                  and self._plan.stream_supported(N, R))
+        if stream:
+            words_ctl = self._plan.stream_ctl_words(N)
+            ctl = getattr(self, "_stream_ctl", None)
+            if ctl is None or ctl.numel() != words_ctl or ctl.device != dev:
+                ctl = self._stream_ctl = torch.zeros((words_ctl,), dtype=torch.int32, device=dev)
+            ctl.zero_()
+            self._plan.stream(patches.view(N, -1), vq, R, emb_buf.view(N, -1), logits.view(N, R), ctl, ready)
+            hip.publish_rows(ready, N)             # (whatever the last finishers left to each other; the launch is over)
+            launches = []
         else:
-            # rows of a full launch: 224 workgroups (28 per XCD).  Measured at 2 / 16 slides: 208 -> 36.3 / 43.1 M patches/s,
-            # 224 -> 36.5 / 45.9, 240 -> 30.4 / 37.8 (now and then a workgroup waits for a second round: the free units of
-            # the fullest XCD are a bound, not a promise - round 2 had found the same cliff between 224 and 232)
-            cap = max(I, min(224, 8 * (32 - -(-B // 8))) * 64 // I * I)
-            r0 = 0
-            while r0 < B * N:
-                # the first launch of the call stays short: the first loop starts after M + I rows' worth of projector
-                r1 = min(B * N, r0 + (cap if r0 > 0 else min(cap, edges[1])))
-                pubs = [(b_, min(N, r1 - b_ * N)) for b_ in range(r0 // N, (r1 - 1) // N + 1)]
-                launches.append((r0, r1, pubs))
-                r0 = r1
+            launches = self._feature_launches(B, N, P, edges)
         xf, ef, lf = patches.view(B * N, -1), emb_buf.view(B * N, -1), logits.view(1, B * N, R)
-        if fused2:
+        if fused2 and launches:
             self._plan.row_stats(xf[launches[0][0]:launches[0][1]], out=stats[launches[0][0]:launches[0][1]])
         published = None                           # (slide, rows) whose publication rides on the next GEMM launch
         for n_step, (r0, r1, pubs) in enumerate(launches):

@@ -23,6 +23,7 @@
 
 #include "ipsx_common.h"
 #include "ipsx_math.h"
+#include "ipsx_rowstats.h"
 
 namespace ipsx {
 
@@ -244,6 +245,232 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ the projector of a whole slide as ONE launch
+// IPSNet.ips on pre-extracted features (reference architecture/ips_net.py:213-241 with the LayerNorm + Linear + BatchNorm
+// + ReLU projector of :60-66): the selection loop consumes rows in order, 256 per iteration, and is as long as the
+// projector itself - so what matters is WHEN rows become available, not only how fast the GEMM runs.  Launch by launch
+// (ipsx_projector_apply_publish) a part's rows are published when the NEXT launch starts, behind a statistics kernel
+// and a logits kernel, and the loop waits for a whole part at the start and works off a whole part at the end.  Here
+// resident workgroups pull row tiles off a counter and do everything a tile needs - the LayerNorm moments of its rows
+// (row_stats_wave), the Linear on the fp32 matrix cores with the normalisation in the operand load (the stage loop of
+// conv_nhwc_kernel<1, 4, true, 4>), BatchNorm + ReLU, the tile's logits against the folded query (the MFMA sequence of
+// logits_kernel, A operand from the LDS copy of the tile) - and publish it: a flag per 32-row unit, and whoever
+// completes the lowest unpublished unit advances the loop's progress word past every completed unit behind it.
+// Same arithmetic as the three kernels it replaces: embeddings, logits and with them the selection are bit-identical
+// (tests/test_hip_kernels.py::test_projector_stream_equals_the_launch_by_launch_projector).
+// A tile is 64 rows (2 units); the FIRST pull of `short_first` workgroups is one unit, so that completions - which would
+// otherwise come in bursts of one tile per workgroup - are spread over two phases and the first rows arrive after half
+// a tile time.
+struct StreamArgs {
+    const float* x; unsigned x_bytes;
+    const float* wp; unsigned w_bytes;
+    const float* alpha; const float* shift; int relu;
+    int c_in, c_out, kgs;          // kgs = c_in / 8 packed k-groups per n-tile
+    float eps;
+    float* emb;                    // (n, c_out)
+    const float* vp; int R, vkgs;  // folded query packed for one 32-column tile (R <= 32), vkgs = c_out / 8
+    float* logits;                 // (n, R)
+    unsigned n, n_units;           // rows; units of 32 rows
+    unsigned short_first;
+    int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
+    int* ready;                    // rows published (ipsx_scan_persistent's progress word)
+};
+
+constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
+constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + 64 * 8 + 16;
+
+template <int MT>
+__device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, float* tile, float2* s_stats) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, i = lane & 31;
+    // ---- LayerNorm moments of the tile's rows: 8 MT rows per wavefront
+#pragma unroll 1
+    for (int q = 0; q < 8 * MT; ++q) {
+        const unsigned lr = wave * (8 * MT) + q, row = row0 + lr;
+        if (row < a.n) {
+            const float2 st = row_stats_wave(a.x + (size_t)row * a.c_in, a.c_in, a.eps, lane);
+            if (lane == 0) s_stats[lr] = st;
+        }
+    }
+    __syncthreads();
+
+    // ---- Linear: this wave's 128 output channels of the tile's 32 MT rows
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)a.w_bytes, 0x00020000);
+    const int nt0 = wave * 4;
+    unsigned pv[MT];
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned lr = mt * 32 + i, row = row0 + lr;
+        const bool ok = row < a.n;
+        pv[mt] = ok ? (row * (unsigned)a.c_in + 4u * half) * 4u : kOob;
+        const float2 st = ok ? s_stats[lr] : make_float2(0.0f, 1.0f);
+        mean[mt] = st.x; rstd[mt] = st.y;
+    }
+    const unsigned lb = lane * 16u;
+    unsigned wb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wb[t] = (unsigned)(nt0 + t) * (unsigned)a.kgs * 1024u;
+    f32x16 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.0f;
+    struct Stage { f32x4 a[MT], b[4]; };
+    Stage s0, s1, s2;
+    const int total = a.kgs;
+    int gp = 0;
+#define ST_ISSUE(S)                                                                        \
+    do {                                                                                   \
+        const unsigned ca = (unsigned)gp * 32u, cb = (unsigned)gp * 1024u;                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) S.a[mt] = bufload(rx, pv[mt], ca); \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) S.b[t] = bufload(rw, lb, wb[t] + cb);  \
+        if (gp + 1 < total) ++gp;                                                          \
+    } while (0)
+#define ST_STAGE(SL, SM)                                                                   \
+    ST_ISSUE(SL);                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) SM.a[mt] = norm4(SM.a[mt], mean[mt], rstd[mt]); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[mt][t] = MFMA(SM.a[mt][j], SM.b[t][j], acc[mt][t]); \
+    if (MT == 2) {                                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+    } else {                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+    }                                                                                      \
+    SB();
+    ST_ISSUE(s0);
+    ST_ISSUE(s1);
+#pragma unroll 1
+    for (int g = 0; g < total; g += 3) {
+        ST_STAGE(s2, s0)
+        if (g + 1 < total) { ST_STAGE(s0, s1) }
+        if (g + 2 < total) { ST_STAGE(s1, s2) }
+    }
+#undef ST_STAGE
+#undef ST_ISSUE
+
+    // ---- BatchNorm affine + ReLU: to HBM and to the LDS copy the logits read
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int nn = (nt0 + t) * 32 + i;
+        const float al = a.alpha ? a.alpha[nn] : 1.0f;
+        const float sh = a.shift ? a.shift[nn] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + lr;
+                float v = acc[mt][t][r];
+                if (a.alpha) v = __builtin_fmaf(v, al, sh);
+                else if (a.shift) v = v + sh;
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                tile[lr * ST_EP + nn] = v;
+                if (row < a.n) a.emb[(size_t)row * a.c_out + nn] = v;
+            }
+    }
+    __syncthreads();
+
+    // ---- logits of the tile's rows: wave mt takes rows 32 mt .. 32 mt + 31, all R logits (one 32-column tile)
+    if (wave < MT) {
+        const unsigned lr = wave * 32 + i, row = row0 + lr;
+        const bool rv = row < a.n;
+        const float* e = tile + lr * ST_EP + 4 * half;
+        const float4* vq = reinterpret_cast<const float4*>(a.vp) + lane;
+        f32x16 lacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lacc[r] = 0.0f;
+#pragma unroll 1
+        for (int k0 = 0; k0 < a.vkgs; k0 += 8) {
+            float4 ev[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ev[u] = *reinterpret_cast<const float4*>(e + (k0 + u) * 8);
+                bv[u] = vq[(size_t)(k0 + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                lacc = MFMA(rv ? ev[u].x : 0.0f, bv[u].x, lacc);
+                lacc = MFMA(rv ? ev[u].y : 0.0f, bv[u].y, lacc);
+                lacc = MFMA(rv ? ev[u].z : 0.0f, bv[u].z, lacc);
+                lacc = MFMA(rv ? ev[u].w : 0.0f, bv[u].w, lacc);
+            }
+        }
+        if (i < a.R) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned rr = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                // written THROUGH to the level the loop (another XCD) reads from: the publication below then needs no
+                // L2 write-back of its own (a buffer_wbl2 per tile costs ~30 us and serialises the XCD: 1.6 -> 5.4 ms)
+                if (rr < a.n) __hip_atomic_store(a.logits + (size_t)rr * a.R + i, lacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... and have arrived there
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];
+    float* tile = st_lds;
+    float2* s_stats = reinterpret_cast<float2*>(st_lds + 64 * ST_EP);
+    int* s_u0 = reinterpret_cast<int*>(st_lds + 64 * ST_EP + 128);
+    bool first = true;
+    for (;;) {
+        const int take = (first && blockIdx.x < a.short_first) ? 1 : 2;
+        first = false;
+        if (threadIdx.x == 0) *s_u0 = atomicAdd(&a.ctl[0], take);
+        __syncthreads();
+        const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane(*s_u0);
+        if (u0 >= a.n_units) break;                                 // workgroup-uniform
+        const int units = (take == 2 && u0 + 1 < a.n_units) ? 2 : 1;
+        if (units == 2) stream_tile<2>(a, u0 * 32u, tile, s_stats);
+        else stream_tile<1>(a, u0 * 32u, tile, s_stats);
+        // ---- publish: the tile's logits have been written through (stream_tile), so relaxed agent-scope atomics do.
+        // (The embeddings are ordinary stores: nothing reads them before the launch is over.)  The first wavefront sets
+        // the flags of this tile's units, reads the cursor - the first unpublished unit - and the 64 flags from there on
+        // in ONE load, and raises cursor and progress word past the completed units it finds (atomic maxima: both only
+        // ever grow).  Measured on the way: an agent-scope release or acquire per tile (L2 write-back / invalidate: every
+        // workgroup of the XCD re-fetches the 4 MB of weights it streams) 1.6 -> 5.4 ms; a compare-and-swap per unit
+        // (2,048 round trips to one cache line, one after the other) the same.  Without a full fence between flag and
+        // cursor, two workgroups that finish neighbouring units at the same moment may both miss the other's flag; the
+        // unit then waits for the next workgroup that finishes anything (about every microsecond) or, at the very end,
+        // for the caller's ipsx_publish_rows behind this launch.
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            if (lane < units) __hip_atomic_store(&a.ctl[2 + u0 + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (;;) {
+                const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((unsigned)p >= a.n_units) break;
+                const unsigned u = (unsigned)p + lane;
+                const int f = u < a.n_units ? __hip_atomic_load(&a.ctl[2 + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                const unsigned long long done = __ballot(f != 0);
+                const int c = done == ~0ull ? 64 : __builtin_ctzll(~done);        // completed units in a row from the cursor
+                if (c == 0) break;
+                if (lane == 0) {
+                    __hip_atomic_fetch_max(&a.ctl[1], p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_max(a.ready, (int)min((unsigned)(p + c) * 32u, a.n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (c < 64) break;
+            }
+        }
+    }
+}
+
 // nn.MaxPool2d(3, 2, 1) on channels-last activations: one thread per (output pixel, 4 channels)
 __global__ void maxpool_3x3s2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total4, int c4,
                                           int h, int w, int ho, int wo) {
@@ -383,4 +610,47 @@ IPSX_API int ipsx_avgpool_nhwc(const float* x, float* y, int64_t n, int c, int h
     if (!total) return IPSX_OK;
     avgpool_nhwc_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream)>>>(x, y, total, c, hw);
     return launched("avgpool_nhwc");
+}
+
+// The whole projector + logits of one slide as ONE persistent launch that publishes rows to a resident selection loop
+// (ipsx_scan_persistent) as it goes; see projector_stream_kernel.  ctl: ipsx_projector_stream_ctl_words(n) int32 words,
+// ZEROED by the caller before every call (the work counter, the publication cursor, a flag per 32 rows).
+IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) { return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 : 0; }
+
+IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r) {
+    if (!lin || !lin->w_packed || lin->kh != 1 || lin->kw != 1 || lin->stride != 1 || lin->pad != 0) return 0;
+    if (lin->c_out != 512 || lin->c_in % 32 != 0 || lin->c_in > 64 * ipsx::RS_MAX) return 0;
+    if (r < 1 || r > 32 || n < 64) return 0;
+    return (int64_t)n * lin->c_in * 4 < ((int64_t)1 << 31) - 65536 ? 1 : 0;
+}
+
+IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps, float* emb,
+                                   const float* v_packed, int r, float* logits, int32_t* ctl, int32_t* ready,
+                                   int workgroups, int short_first, void* stream) {
+    IPSX_REQUIRE(lin && x && emb && v_packed && logits && ctl && ready, "projector_stream: bad arguments");
+    IPSX_REQUIRE(ipsx_projector_stream_supported(lin, n, r), "projector_stream: needs a 1x1 Linear with 512 outputs, C_in %% 32 == 0, "
+                 "C_in <= %d, at most 32 logits per row and a slide below 2 GiB", 64 * ipsx::RS_MAX);
+    ipsx::StreamArgs a;
+    a.x = x; a.x_bytes = (unsigned)(n * lin->c_in * 4);
+    a.wp = lin->w_packed; a.kgs = lin->c_in / 8;
+    a.w_bytes = (unsigned)((int64_t)(lin->c_out / 32) * a.kgs * 1024);
+    a.alpha = lin->alpha; a.shift = lin->shift; a.relu = 1;
+    a.c_in = lin->c_in; a.c_out = lin->c_out; a.eps = ln_eps;
+    a.emb = emb; a.vp = v_packed; a.R = r; a.vkgs = lin->c_out / 8; a.logits = logits;
+    a.n = (unsigned)n; a.n_units = (unsigned)ipsx::cdiv(n, 32);
+    a.ctl = ctl; a.ready = ready;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // 7 of the 8 compute units of every shader engine: the resident loop's unit is then free wherever the dispatcher
+    // turns, and the LDS request keeps these workgroups one to a unit and off the loop's
+    const int wgs = workgroups > 0 ? workgroups : cus / 8 * 7;
+    a.short_first = (unsigned)(short_first >= 0 ? short_first : wgs / 2);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::projector_stream_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipsx::ST_LDS);
+        attr = true;
+    }
+    ipsx::projector_stream_kernel<<<dim3((unsigned)wgs), dim3(256), ipsx::ST_LDS, ipsx::as_stream(stream)>>>(a);
+    return ipsx::launched("projector_stream");
 }

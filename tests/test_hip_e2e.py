@@ -539,8 +539,9 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
 @pytest.mark.parametrize("B,N", [(1, 8192), (2, 8192), (9, 4096), (1, 70000)])
 def test_every_variant_of_the_feature_pipeline_selects_the_same_patches(B, N, monkeypatch):
     """The CAMELYON path has several schedules of the same arithmetic - persistent loop or per-part launches (also what
-    more than IPSX_PERSIST_MAX_B slides get), loop beside the projector or after it, equal parts or the latency-shaped
-    layout with half-tile launches: the selected indices are the same in all of them (the un-overlapped one is held
+    more than IPSX_PERSIST_MAX_B slides get), loop beside the projector or after it, the projector of one slide as ONE
+    persistent launch that publishes tile by tile (ipsx_projector_stream: the default for one slide) or launch by launch,
+    equal parts or the latency-shaped layout with half-tile launches: the selected indices are the same in all of them (the un-overlapped one is held
     against the oracle and the reference's recordings elsewhere)."""
     import os
     from ips_amd import synth
@@ -551,7 +552,8 @@ def test_every_variant_of_the_feature_pipeline_selects_the_same_patches(B, N, mo
     x = synth.make_patches(conf, B, seed=3).to(dev)
     res = {}
     for name, env in (("default", {}), ("per-part launches", {"IPSX_SCAN_PERSIST": "0"}), ("after", {"IPSX_OVERLAP_SCAN": "0"}),
-                      ("latency-shaped parts", {"IPSX_CAM_PARTS": "latency"})):
+                      ("launch by launch beside the persistent loop", {"IPSX_CAM_STREAM": "0"}),
+                      ("latency-shaped parts", {"IPSX_CAM_PARTS": "latency", "IPSX_CAM_STREAM": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         net.ips(x)

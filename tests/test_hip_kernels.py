@@ -274,6 +274,39 @@ def test_fused_trunk_remainder_rule_is_bit_neutral(n, trunk_kernel_choice):
         assert torch.equal(plan.encode_indexed(x, index), want_ix), mode
 
 
+@pytest.mark.parametrize("n,wgs,short", [(64, 0, -1), (97, 3, 1), (1000, 7, 3), (4099, 0, -1), (20000, 0, 0)])
+def test_projector_stream_equals_the_launch_by_launch_projector(n, wgs, short):
+    """ipsx_projector_stream - LayerNorm moments, Linear + BatchNorm + ReLU and the logits of every 64-row tile by resident
+    workgroups, rows published in order as they complete - leaves the bits of ipsx_projector_stats + ipsx_projector_apply
+    + ipsx_logits: embeddings, logits, and a progress word that ends on the row count (ragged last unit, fewer
+    workgroups than tiles, 32-row first tiles)."""
+    conf, _ = synth.bench_workload("cam")
+    from ips_amd.architecture.ips_net import IPSNet
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 7).to(DEV).eval()
+    plan = hip.EncoderPlan(net.encoder, False)
+    ca = net.transf.crs_attn
+    vq, R = ca.folded_query(), ca.H * ca.n_token
+    x = torch.from_numpy(rnd((n, conf.n_chan_in), n, 3.0) + 0.5).to(DEV)
+    assert plan.stream_supported(n, R)
+    want_emb = plan.encode(x)
+    want_lg = hip.logits(want_emb.view(1, n, -1), None, vq, R)[0]
+    emb = torch.full_like(want_emb, float("nan"))
+    lg = torch.full_like(want_lg, float("nan"))
+    for rep in range(2):                                   # the control words are the caller's to zero, every call
+        ctl = torch.zeros((plan.stream_ctl_words(n),), dtype=torch.int32, device=DEV)
+        ready = torch.zeros((1,), dtype=torch.int32, device=DEV)
+        plan.stream(x, vq, R, emb, lg, ctl, ready, workgroups=wgs, short_first=short)
+        torch.cuda.synchronize()
+        units = -(-n // 32)
+        assert bool((ctl[2:2 + units] == 1).all())
+        # (two workgroups that finish neighbouring units at the same moment may both leave the cursor to the next one
+        #  that finishes; at the end of a slide that is the caller's ipsx_publish_rows - never more than the tail)
+        assert int(ctl[1].item()) <= units and int(ready.item()) == min(n, 32 * int(ctl[1].item()))
+        assert int(ready.item()) >= n - 64 * max(1, min(wgs or 224, units))
+        assert torch.equal(emb, want_emb), "max abs diff %g" % float((emb - want_emb).abs().max())
+        assert torch.equal(lg, want_lg), "max abs diff %g" % float((lg - want_lg).abs().max())
+
+
 @pytest.mark.parametrize("blank_frac", [0.93, 0.0, 1.0, 0.5])
 def test_blank_patch_dedup_is_exact(monkeypatch, blank_frac):
     """IPSX_DEDUP_BLANK=1: encode non-blank patches + one blank, copy - must equal encoding every patch, bit for bit."""

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Time ipsx_projector_stream (one persistent launch: moments + Linear + logits per tile, rows published as they
+complete) against the launch-by-launch projector (row_stats + GEMM + logits) on one CAMELYON slide, both alone.
+
+    python tools/projector_stream_bench.py [rows] [workgroups ...]
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ips_amd import hip, synth   # noqa: E402
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    wgs = [int(a) for a in sys.argv[2:]] or [224, 248, 256]
+    conf, _ = synth.bench_workload("cam")
+    from ips_amd.architecture.ips_net import IPSNet
+    dev = torch.device("cuda:0")
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    plan = hip.EncoderPlan(net.encoder, False)
+    ca = net.transf.crs_attn
+    vq, R = ca.folded_query(), ca.H * ca.n_token
+    x = torch.randn((n, conf.n_chan_in), device=dev)
+    emb = torch.empty((n, conf.D), device=dev)
+    lg = torch.empty((1, n, R), device=dev)
+    flop = 2.0 * n * conf.n_chan_in * conf.D
+
+    def layered():
+        plan.encode(x, out=emb)
+        hip.logits(emb.view(1, n, -1), None, vq, R, out=lg)
+
+    ms = timed(layered)
+    print("launch by launch: %.3f ms (%.3f of the fp32 MFMA peak)" % (ms, flop / (ms * 1e-3) / 157.3e12))
+    ctl = torch.zeros((plan.stream_ctl_words(n),), dtype=torch.int32, device=dev)
+    ready = torch.zeros((1,), dtype=torch.int32, device=dev)
+    for w in wgs:
+        for short in (0, w // 2):
+            def stream():
+                ctl.zero_()
+                ready.zero_()
+                plan.stream(x, vq, R, emb, lg[0], ctl, ready, workgroups=w, short_first=short)
+            ms = timed(stream)
+            print("stream, %d workgroups, %d short first tiles: %.3f ms (%.3f of peak on %d units: %.3f)"
+                  % (w, short, ms, flop / (ms * 1e-3) / 157.3e12, w, flop / (ms * 1e-3) / 157.3e12 * 256 / w), flush=True)
+
+
+if __name__ == "__main__":
+    main()
