@@ -21,12 +21,17 @@ for c in mnist cam native50; do
   done
 done
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic_before.json"
-python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip fused_trunk_kernel 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err"
+python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip,fused_trunk_pair.h fused_trunk_kernel 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err"
 python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam 8 conv_nhwc.hip,aggregate.hip,scorer.hip > "$OUT/pmc_cam.json" 2> "$OUT/pmc_cam.err"
 python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err"
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
 python tools/scan_stamps.py cam > "$OUT/scan_stamps_cam.txt" 2>&1
 python tools/scan_stamps.py mnist >> "$OUT/scan_stamps_cam.txt" 2>&1
 python tools/scan_stamps.py large > "$OUT/scan_stamps_large.txt" 2>&1
+python tools/scan_stamps.py campipe > "$OUT/scan_stamps_campipe.txt" 2>&1
+python tools/trunk_pair_bench.py > "$OUT/trunk_pair_bench.txt" 2>&1
+python tools/projector_stream_bench.py > "$OUT/projector_stream_bench.txt" 2>&1
+python tools/loop_beside.py > "$OUT/loop_beside.txt" 2>&1
+python tools/scan_beside.py > "$OUT/scan_beside.txt" 2>&1
 python -m pytest tests/test_bench_parity.py tests/test_seed_sweep.py -q -m gpu -s 2>&1 | grep -v "amdgpu.ids" > "$OUT/parity_rates.txt"
 echo done
