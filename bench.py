@@ -244,7 +244,7 @@ def pmc_traffic(workload, kernel_name, enc_patches, n_launch):
             return None, "profiles/pmc_traffic.json[%s] was measured on another version of %s (stale)" % (workload, pmc["source"])
         if "hbm_bytes_per_step" in pmc:
             return pmc["hbm_bytes_per_step"], "bytes per step, all kernels of ips() (PMC, profiles/pmc_traffic.json)"
-        if pmc["kernel"] in (kernel_name or "") and enc_patches == pmc["patches_per_launch"] * n_launch:
+        if any(k in (kernel_name or "") for k in pmc["kernel"].split("|")) and enc_patches == pmc["patches_per_launch"] * n_launch:
             return pmc["hbm_bytes_per_launch"], "bytes per launch (PMC, profiles/pmc_traffic.json)"
         return None, "profiles/pmc_traffic.json holds %s at %d patches per launch" % (pmc["kernel"], pmc["patches_per_launch"])
     except (OSError, KeyError, ValueError):

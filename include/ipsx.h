@@ -204,14 +204,15 @@ int ipsx_projector_apply_publish(const ipsx_conv* lin, const float* x, int64_t n
  * transformer.py:71-83 for the logits).  Resident workgroups pull 64-row tiles off a counter; a tile's LayerNorm
  * moments, Linear + BatchNorm + ReLU (out: emb, (n, 512)), and logits against the folded query v_packed
  * (ipsx_fold_query; r = h * n_token <= 32; out: logits (n, r)) are computed in place, and `*ready` - the progress word
- * of the selection loop - is advanced past every completed 32-row unit in order.  Bit-identical to ipsx_projector_stats
- * + ipsx_projector_apply + ipsx_logits.  ctl: ipsx_projector_stream_ctl_words(n) int32 words ZEROED before every call.
+ * of the selection loop - is advanced past every completed 32-row unit in order.  Several slides: x holds them one
+ * after the other (n rows in all, slide_rows each, a multiple of 32), ready[s] is slide s's word, and the stream of
+ * tiles runs across the slides' ends.  Bit-identical to ipsx_projector_stats + ipsx_projector_apply + ipsx_logits.  ctl: ipsx_projector_stream_ctl_words(n) int32 words ZEROED before every call.
  * workgroups <= 0: 7 of every 8 compute units (the loop's unit stays free); short_first < 0: half of the workgroups
  * start with a 32-row tile so that completions do not come in bursts.  ipsx_projector_stream_supported: 1x1 Linear with
- * 512 outputs, c_in % 32 == 0, c_in <= 2048, 64 <= n, n * c_in * 4 < 2 GiB.                                          */
+ * 512 outputs, c_in % 32 == 0, c_in <= 2048, 64 <= n < 2^31.                                          */
 size_t ipsx_projector_stream_ctl_words(int64_t n);
 int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r);
-int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps, float* emb,
+int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t n, int64_t slide_rows, float ln_eps, float* emb,
                           const float* v_packed, int r, float* logits, int32_t* ctl, int32_t* ready,
                           int workgroups, int short_first, void* stream);
 

@@ -513,19 +513,25 @@ class IPSNet(nn.Module):
         # slide, or positional encodings (a table per slide position): a slide's parts.  Several slides without them: the
         # slides are one stream of rows cut into full launches wherever a slide ends (the patch tensor is contiguous, a
         # launch may take the end of one slide and the start of the next) - 4.13 launches per 65,536-row slide instead of 5.
-        # One slide, no positional encoding, fp32 logits: the projector as ONE persistent launch (ipsx_projector_stream)
-        # whose workgroups pull 64-row tiles, do moments + Linear + logits per tile and advance the slide's progress word
-        # as tiles complete - the loop starts after half a tile time and is never a whole part behind.
-        stream = (B == 1 and not self.use_pos and fused2 and os.environ.get("IPSX_CAM_STREAM", "1") != "0"
-                  and self._plan.stream_supported(N, R))
+        # No positional encoding, fp32 logits: the projector as ONE persistent launch (ipsx_projector_stream) whose
+        # workgroups pull 64-row tiles off the flat stream of the slides' rows, do moments + Linear + logits per tile and
+        # advance the slides' progress words as tiles complete - a slide's loop starts after half a tile time and is never
+        # a whole part behind, and with several slides the projector runs without a seam from the first row to the last.
+        stream = (not self.use_pos and fused2 and os.environ.get("IPSX_CAM_STREAM", "1") != "0"
+                  and (B == 1 or N % 32 == 0) and self._plan.stream_supported(B * N, R))
         if stream:
-            words_ctl = self._plan.stream_ctl_words(N)
+            words_ctl = self._plan.stream_ctl_words(B * N)
             ctl = getattr(self, "_stream_ctl", None)
             if ctl is None or ctl.numel() != words_ctl or ctl.device != dev:
                 ctl = self._stream_ctl = torch.zeros((words_ctl,), dtype=torch.int32, device=dev)
             ctl.zero_()
-            self._plan.stream(patches.view(N, -1), vq, R, emb_buf.view(N, -1), logits.view(N, R), ctl, ready)
-            hip.publish_rows(ready, N)             # (whatever the last finishers left to each other; the launch is over)
+            # one workgroup per compute unit the loops leave free; a slide alone: 7 of every 8 (the default), so that the
+            # loop's unit is free wherever the dispatcher turns - with several loops resident the units are simply taken
+            free = torch.cuda.get_device_properties(dev).multi_processor_count - B
+            self._plan.stream(patches.view(B * N, -1), vq, R, emb_buf.view(B * N, -1), logits.view(B * N, R), ctl, ready,
+                              workgroups=0 if B == 1 else free, slide_rows=N)
+            for b_ in range(B):                    # (whatever the last finishers left to each other; the launch is over)
+                hip.publish_rows(ready[b_:b_ + 1], N)
             launches = []
         else:
             launches = self._feature_launches(B, N, P, edges)

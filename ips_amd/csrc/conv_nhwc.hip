@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
 // otherwise come in bursts of one tile per workgroup - are spread over two phases and the first rows arrive after half
 // a tile time.
 struct StreamArgs {
-    const float* x; unsigned x_bytes;
+    const float* x;
     const float* wp; unsigned w_bytes;
     const float* alpha; const float* shift; int relu;
     int c_in, c_out, kgs;          // kgs = c_in / 8 packed k-groups per n-tile
@@ -270,10 +270,11 @@ struct StreamArgs {
     float* emb;                    // (n, c_out)
     const float* vp; int R, vkgs;  // folded query packed for one 32-column tile (R <= 32), vkgs = c_out / 8
     float* logits;                 // (n, R)
-    unsigned n, n_units;           // rows; units of 32 rows
+    unsigned n, n_units;           // rows (of all slides, one after the other); units of 32 rows
+    unsigned slide_rows;           // rows per slide: ready[s] = rows of slide s published
     unsigned short_first;
     int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
-    int* ready;                    // rows published (ipsx_scan_persistent's progress word)
+    int* ready;                    // rows published, per slide (ipsx_scan_persistent's progress words)
 };
 
 constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
@@ -294,7 +295,10 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     __syncthreads();
 
     // ---- Linear: this wave's 128 output channels of the tile's 32 MT rows
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    // (the buffer is the TILE's rows: any number of slides, one after the other, stays addressable)
+    const unsigned rows_here = min(32u * MT, a.n - row0);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)row0 * a.c_in), 0,
+                                                                        (int)(rows_here * (unsigned)a.c_in * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)a.w_bytes, 0x00020000);
     const int nt0 = wave * 4;
     unsigned pv[MT];
@@ -303,7 +307,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     for (int mt = 0; mt < MT; ++mt) {
         const unsigned lr = mt * 32 + i, row = row0 + lr;
         const bool ok = row < a.n;
-        pv[mt] = ok ? (row * (unsigned)a.c_in + 4u * half) * 4u : kOob;
+        pv[mt] = ok ? (lr * (unsigned)a.c_in + 4u * half) * 4u : kOob;
         const float2 st = ok ? s_stats[lr] : make_float2(0.0f, 1.0f);
         mean[mt] = st.x; rstd[mt] = st.y;
     }
@@ -319,8 +323,9 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.0f;
     struct Stage { f32x4 a[MT], b[4]; };
-    Stage s0, s1, s2;
-    const int total = a.kgs;
+    Stage s0, s1, s2, s3;          // ring of 4, operands requested THREE stages (3 x 2048 matrix-pipe cycles, ~2.6 us) ahead -
+                                   // a ring of 3 (two ahead): 1.246 ms per 65,536 rows on 256 units, of 4: 1.217, of 8: 1.210 -
+    const int total = a.kgs;       // with one wavefront per SIMD nothing else hides the latency of rows that come from HBM
     int gp = 0;
 #define ST_ISSUE(S)                                                                        \
     do {                                                                                   \
@@ -354,11 +359,13 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     SB();
     ST_ISSUE(s0);
     ST_ISSUE(s1);
+    ST_ISSUE(s2);
 #pragma unroll 1
-    for (int g = 0; g < total; g += 3) {
-        ST_STAGE(s2, s0)
-        if (g + 1 < total) { ST_STAGE(s0, s1) }
-        if (g + 2 < total) { ST_STAGE(s1, s2) }
+    for (int g = 0; g < total; g += 4) {           // total is a multiple of 4 (C_in % 32 == 0)
+        ST_STAGE(s3, s0)
+        ST_STAGE(s0, s1)
+        ST_STAGE(s1, s2)
+        ST_STAGE(s2, s3)
     }
 #undef ST_STAGE
 #undef ST_ISSUE
@@ -463,7 +470,11 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
                 if (c == 0) break;
                 if (lane == 0) {
                     __hip_atomic_fetch_max(&a.ctl[1], p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_max(a.ready, (int)min((unsigned)(p + c) * 32u, a.n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // rows [32 p, 32 (p + c)) of the flat row space: every slide they touch learns how far it has got
+                    const unsigned done = min((unsigned)(p + c) * 32u, a.n);
+                    for (unsigned sl = (unsigned)p * 32u / a.slide_rows; sl * a.slide_rows < done; ++sl)
+                        __hip_atomic_fetch_max(a.ready + sl, (int)min(done - sl * a.slide_rows, a.slide_rows), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (c < 64) break;
             }
@@ -621,23 +632,26 @@ IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, in
     if (!lin || !lin->w_packed || lin->kh != 1 || lin->kw != 1 || lin->stride != 1 || lin->pad != 0) return 0;
     if (lin->c_out != 512 || lin->c_in % 32 != 0 || lin->c_in > 64 * ipsx::RS_MAX) return 0;
     if (r < 1 || r > 32 || n < 64) return 0;
-    return (int64_t)n * lin->c_in * 4 < ((int64_t)1 << 31) - 65536 ? 1 : 0;
+    return n < ((int64_t)1 << 31) - 64 ? 1 : 0;
 }
 
-IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps, float* emb,
+IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t n, int64_t slide_rows, float ln_eps, float* emb,
                                    const float* v_packed, int r, float* logits, int32_t* ctl, int32_t* ready,
                                    int workgroups, int short_first, void* stream) {
     IPSX_REQUIRE(lin && x && emb && v_packed && logits && ctl && ready, "projector_stream: bad arguments");
+    IPSX_REQUIRE(slide_rows > 0 && n % slide_rows == 0 && (n == slide_rows || slide_rows % 32 == 0),
+                 "projector_stream: %lld rows are not whole slides of %lld rows (a multiple of 32 when there are several)",
+                 (long long)n, (long long)slide_rows);
     IPSX_REQUIRE(ipsx_projector_stream_supported(lin, n, r), "projector_stream: needs a 1x1 Linear with 512 outputs, C_in %% 32 == 0, "
-                 "C_in <= %d, at most 32 logits per row and a slide below 2 GiB", 64 * ipsx::RS_MAX);
+                 "C_in <= %d and at most 32 logits per row", 64 * ipsx::RS_MAX);
     ipsx::StreamArgs a;
-    a.x = x; a.x_bytes = (unsigned)(n * lin->c_in * 4);
+    a.x = x;
     a.wp = lin->w_packed; a.kgs = lin->c_in / 8;
     a.w_bytes = (unsigned)((int64_t)(lin->c_out / 32) * a.kgs * 1024);
     a.alpha = lin->alpha; a.shift = lin->shift; a.relu = 1;
     a.c_in = lin->c_in; a.c_out = lin->c_out; a.eps = ln_eps;
     a.emb = emb; a.vp = v_packed; a.R = r; a.vkgs = lin->c_out / 8; a.logits = logits;
-    a.n = (unsigned)n; a.n_units = (unsigned)ipsx::cdiv(n, 32);
+    a.n = (unsigned)n; a.n_units = (unsigned)ipsx::cdiv(n, 32); a.slide_rows = (unsigned)slide_rows;
     a.ctl = ctl; a.ready = ready;
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

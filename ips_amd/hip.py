@@ -183,7 +183,7 @@ _EXPORTS = {
                                                C.c_int32, C.c_void_p]),
     "ipsx_projector_stream_ctl_words": (C.c_size_t, [C.c_int64]),
     "ipsx_projector_stream_supported": (C.c_int, [C.POINTER(Conv), C.c_int64, C.c_int]),
-    "ipsx_projector_stream": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+    "ipsx_projector_stream": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_logits_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
@@ -521,13 +521,15 @@ class EncoderPlan:
         self._refresh()
         return bool(lib().ipsx_projector_stream_supported(C.byref(self.lin), int(n), int(R)))
 
-    def stream(self, x, vq, R, emb, logits, ctl, ready, workgroups=0, short_first=-1):
-        """Projector + logits of the feature rows ``x`` (P, F) of ONE slide as one persistent launch that advances ``ready``
-        (the progress word of ``scan_persistent``) as rows complete: ``emb`` (P, 512) and ``logits`` (P, R) are the outputs,
-        ``ctl`` = ``torch.zeros(stream_ctl_words(P), int32)`` zeroed before every call, ``vq`` the folded query."""
+    def stream(self, x, vq, R, emb, logits, ctl, ready, workgroups=0, short_first=-1, slide_rows=None):
+        """Projector + logits of the feature rows ``x`` (P, F) - one slide, or several one after the other, ``slide_rows``
+        each - as one persistent launch that advances ``ready`` (the progress word(s) of ``scan_persistent``, one per
+        slide) as rows complete: ``emb`` (P, 512) and ``logits`` (P, R) are the outputs, ``ctl`` =
+        ``torch.zeros(stream_ctl_words(P), int32)`` zeroed before every call, ``vq`` the folded query."""
         self._refresh()
         x = _f32(x)
-        _ck(lib().ipsx_projector_stream(C.byref(self.lin), _p(x), x.shape[0], C.c_float(self.ln_eps), _p(emb), _p(vq), int(R),
+        _ck(lib().ipsx_projector_stream(C.byref(self.lin), _p(x), x.shape[0], int(slide_rows or x.shape[0]),
+                                        C.c_float(self.ln_eps), _p(emb), _p(vq), int(R),
                                         _p(logits), _p(ctl), _p(ready), int(workgroups), int(short_first), _stream()),
             "ipsx_projector_stream")
         return emb

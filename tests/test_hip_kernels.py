@@ -274,12 +274,13 @@ def test_fused_trunk_remainder_rule_is_bit_neutral(n, trunk_kernel_choice):
         assert torch.equal(plan.encode_indexed(x, index), want_ix), mode
 
 
-@pytest.mark.parametrize("n,wgs,short", [(64, 0, -1), (97, 3, 1), (1000, 7, 3), (4099, 0, -1), (20000, 0, 0)])
-def test_projector_stream_equals_the_launch_by_launch_projector(n, wgs, short):
+@pytest.mark.parametrize("n,wgs,short,slides", [(64, 0, -1, 1), (97, 3, 1, 1), (1000, 7, 3, 1), (4099, 0, -1, 1), (20000, 0, 0, 1),
+                                                (3 * 1056, 5, 2, 3), (8 * 2048, 0, -1, 8)])
+def test_projector_stream_equals_the_launch_by_launch_projector(n, wgs, short, slides):
     """ipsx_projector_stream - LayerNorm moments, Linear + BatchNorm + ReLU and the logits of every 64-row tile by resident
     workgroups, rows published in order as they complete - leaves the bits of ipsx_projector_stats + ipsx_projector_apply
-    + ipsx_logits: embeddings, logits, and a progress word that ends on the row count (ragged last unit, fewer
-    workgroups than tiles, 32-row first tiles)."""
+    + ipsx_logits: embeddings, logits, and progress words that end on the row counts (ragged last unit, fewer
+    workgroups than tiles, 32-row first tiles, several slides one after the other)."""
     conf, _ = synth.bench_workload("cam")
     from ips_amd.architecture.ips_net import IPSNet
     net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 7).to(DEV).eval()
@@ -294,15 +295,17 @@ def test_projector_stream_equals_the_launch_by_launch_projector(n, wgs, short):
     lg = torch.full_like(want_lg, float("nan"))
     for rep in range(2):                                   # the control words are the caller's to zero, every call
         ctl = torch.zeros((plan.stream_ctl_words(n),), dtype=torch.int32, device=DEV)
-        ready = torch.zeros((1,), dtype=torch.int32, device=DEV)
-        plan.stream(x, vq, R, emb, lg, ctl, ready, workgroups=wgs, short_first=short)
+        ready = torch.zeros((slides,), dtype=torch.int32, device=DEV)
+        plan.stream(x, vq, R, emb, lg, ctl, ready, workgroups=wgs, short_first=short, slide_rows=n // slides)
         torch.cuda.synchronize()
         units = -(-n // 32)
         assert bool((ctl[2:2 + units] == 1).all())
         # (two workgroups that finish neighbouring units at the same moment may both leave the cursor to the next one
         #  that finishes; at the end of a slide that is the caller's ipsx_publish_rows - never more than the tail)
-        assert int(ctl[1].item()) <= units and int(ready.item()) == min(n, 32 * int(ctl[1].item()))
-        assert int(ready.item()) >= n - 64 * max(1, min(wgs or 224, units))
+        cursor, per = int(ctl[1].item()), n // slides
+        assert cursor <= units and cursor * 32 >= n - 64 * max(1, min(wgs or 224, units))
+        want_ready = [max(0, min(per, min(n, 32 * cursor) - s_ * per)) for s_ in range(slides)]
+        assert ready.tolist() == want_ready      # several slides (3 x 1,056 rows: tiles run across their ends): a word each
         assert torch.equal(emb, want_emb), "max abs diff %g" % float((emb - want_emb).abs().max())
         assert torch.equal(lg, want_lg), "max abs diff %g" % float((lg - want_lg).abs().max())
 

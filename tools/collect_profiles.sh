@@ -21,7 +21,7 @@ for c in mnist cam native50; do
   done
 done
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic_before.json"
-python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip,fused_trunk_pair.h fused_trunk_kernel 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err"
+python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip,fused_trunk_pair.h "fused_trunk_kernel|fused_trunk_pair_kernel" 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err"
 python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam 8 conv_nhwc.hip,aggregate.hip,scorer.hip > "$OUT/pmc_cam.json" 2> "$OUT/pmc_cam.err"
 python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err"
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"

@@ -4,7 +4,7 @@ record per workload): HBM bytes, corrected as /opt/skills/guides/MI355X_MICROARC
 gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> x2; WRITE_SIZE is exact; both are in KB.
 
     tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <ips() calls in the profiled run> <kernel sources, comma separated>
-                         [<dominant kernel substring> <patches per launch>]
+                         [<dominant kernel substring(s), '|' separated> <patches per launch>]
 
 With a dominant kernel (the fused trunk: the encoder IS one kernel) the record holds bytes per launch of that kernel;
 otherwise bytes per step summed over every kernel of the run (calls = 1 + warmup + 2 * steps of bench.py: the first
@@ -45,8 +45,9 @@ def main():
            "source": sources, "source_sha16": h.hexdigest()[:16],
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --config %s --steps 3 --warmup 1 --cpu-seconds 0" % workload}
     if dominant:
-        fk = [v for k, v in fetch.items() if dominant in k]
-        wk = [v for k, v in write.items() if dominant in k]
+        names = dominant.split("|")                # e.g. the fused trunk's two exact kernels (whole rounds | remainder)
+        fk = [v for k, v in fetch.items() if any(n in k for n in names)]
+        wk = [v for k, v in write.items() if any(n in k for n in names)]
         fetch_kb = sum(v[0] for v in fk) / sum(v[1] for v in fk)
         write_kb = sum(v[0] for v in wk) / sum(v[1] for v in wk)
         rec.update({"kernel": dominant, "launches_averaged": [sum(v[1] for v in fk), sum(v[1] for v in wk)],
