@@ -275,24 +275,42 @@ struct StreamArgs {
     unsigned short_first;
     int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
     int* ready;                    // rows published, per slide (ipsx_scan_persistent's progress words)
+    unsigned long long* stamps;    // diagnostic (ipsx_dbg_projector_stream_stamps): cycles per phase, summed by workgroup 0
 };
 
 constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
 constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + 64 * 8 + 16;
 
-template <int MT>
+#define ST_STAMP(k)                                                                         \
+    do {                                                                                    \
+        if (STAMP && blockIdx.x == 0 && threadIdx.x == 0) {                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
+            a.stamps[k] += t_ - a.stamps[7];                                                \
+            a.stamps[7] = t_;                                                               \
+        }                                                                                   \
+    } while (0)
+
+template <int MT, bool STAMP>
 __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, float* tile, float2* s_stats) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, i = lane & 31;
+    ST_STAMP(0);                                                   // (pull + publication of the tile before)
     // ---- LayerNorm moments of the tile's rows: 8 MT rows per wavefront
 #pragma unroll 1
-    for (int q = 0; q < 8 * MT; ++q) {
-        const unsigned lr = wave * (8 * MT) + q, row = row0 + lr;
-        if (row < a.n) {
-            const float2 st = row_stats_wave(a.x + (size_t)row * a.c_in, a.c_in, a.eps, lane);
-            if (lane == 0) s_stats[lr] = st;
+    for (int q0 = 0; q0 < 8 * MT; q0 += 4) {               // four rows at a time: their loads in flight together
+        const unsigned lr0 = wave * (8 * MT) + q0;
+        const float* xr[4];
+        float2 st[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned row = row0 + lr0 + q;
+            xr[q] = row < a.n ? a.x + (size_t)row * a.c_in : nullptr;
+            st[q] = make_float2(0.0f, 1.0f);
         }
+        row_stats_wave_n<4>(xr, a.c_in, a.eps, lane, st);
+        if (lane < 4) s_stats[lr0 + lane] = lane == 0 ? st[0] : lane == 1 ? st[1] : lane == 2 ? st[2] : st[3];
     }
     __syncthreads();
+    ST_STAMP(1);
 
     // ---- Linear: this wave's 128 output channels of the tile's 32 MT rows
     // (the buffer is the TILE's rows: any number of slides, one after the other, stays addressable)
@@ -369,6 +387,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     }
 #undef ST_STAGE
 #undef ST_ISSUE
+    ST_STAMP(2);
 
     // ---- BatchNorm affine + ReLU: to HBM and to the LDS copy the logits read
 #pragma unroll
@@ -390,6 +409,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
             }
     }
     __syncthreads();
+    ST_STAMP(3);
 
     // ---- logits of the tile's rows: wave mt takes rows 32 mt .. 32 mt + 31, all R logits (one 32-column tile)
     if (wave < MT) {
@@ -427,8 +447,10 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... and have arrived there
     }
+    ST_STAMP(4);
 }
 
+template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
     float* tile = st_lds;
@@ -443,8 +465,8 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
         const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane(*s_u0);
         if (u0 >= a.n_units) break;                                 // workgroup-uniform
         const int units = (take == 2 && u0 + 1 < a.n_units) ? 2 : 1;
-        if (units == 2) stream_tile<2>(a, u0 * 32u, tile, s_stats);
-        else stream_tile<1>(a, u0 * 32u, tile, s_stats);
+        if (units == 2) stream_tile<2, STAMP>(a, u0 * 32u, tile, s_stats);
+        else stream_tile<1, STAMP>(a, u0 * 32u, tile, s_stats);
         // ---- publish: the tile's logits have been written through (stream_tile), so relaxed agent-scope atomics do.
         // (The embeddings are ordinary stores: nothing reads them before the launch is over.)  The first wavefront sets
         // the flags of this tile's units, reads the cursor - the first unpublished unit - and the 64 flags from there on
@@ -626,6 +648,11 @@ IPSX_API int ipsx_avgpool_nhwc(const float* x, float* y, int64_t n, int c, int h
 // The whole projector + logits of one slide as ONE persistent launch that publishes rows to a resident selection loop
 // (ipsx_scan_persistent) as it goes; see projector_stream_kernel.  ctl: ipsx_projector_stream_ctl_words(n) int32 words,
 // ZEROED by the caller before every call (the work counter, the publication cursor, a flag per 32 rows).
+static unsigned long long* g_stream_stamps = nullptr;
+// Diagnostic (not part of include/ipsx.h; tools/projector_stream_bench.py): 8 zeroed uint64 on the device; workgroup 0 adds
+// the shader cycles of each phase of its tiles - [0] pull + publication, [1] moments, [2] GEMM, [3] epilogue, [4] logits.
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_projector_stream_stamps(unsigned long long* p) { g_stream_stamps = p; }
+
 IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) { return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 : 0; }
 
 IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r) {
@@ -652,7 +679,7 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     a.c_in = lin->c_in; a.c_out = lin->c_out; a.eps = ln_eps;
     a.emb = emb; a.vp = v_packed; a.R = r; a.vkgs = lin->c_out / 8; a.logits = logits;
     a.n = (unsigned)n; a.n_units = (unsigned)ipsx::cdiv(n, 32); a.slide_rows = (unsigned)slide_rows;
-    a.ctl = ctl; a.ready = ready;
+    a.ctl = ctl; a.ready = ready; a.stamps = g_stream_stamps;
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // 7 of the 8 compute units of every shader engine: the resident loop's unit is then free wherever the dispatcher
@@ -661,10 +688,15 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     a.short_first = (unsigned)(short_first >= 0 ? short_first : wgs / 2);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::projector_stream_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::projector_stream_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipsx::ST_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::projector_stream_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipsx::ST_LDS);
         attr = true;
     }
-    ipsx::projector_stream_kernel<<<dim3((unsigned)wgs), dim3(256), ipsx::ST_LDS, ipsx::as_stream(stream)>>>(a);
+    if (a.stamps)
+        ipsx::projector_stream_kernel<true><<<dim3((unsigned)wgs), dim3(256), ipsx::ST_LDS, ipsx::as_stream(stream)>>>(a);
+    else
+        ipsx::projector_stream_kernel<false><<<dim3((unsigned)wgs), dim3(256), ipsx::ST_LDS, ipsx::as_stream(stream)>>>(a);
     return ipsx::launched("projector_stream");
 }

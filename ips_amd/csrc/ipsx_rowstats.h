@@ -33,4 +33,35 @@ __device__ __forceinline__ float2 row_stats_wave(const float* __restrict__ xr, i
     return make_float2(mean, rstd);
 }
 
+// NR rows at once by one wavefront (d <= 64 * RS_MAX): the loads of all NR rows are in flight before the first add, and the
+// NR reductions run side by side - per row exactly the operations of row_stats_wave, in its order.  For a caller that has
+// nothing else in flight to hide a row's 2 us of load latency behind (projector_stream_kernel: 16 rows per wavefront
+// and tile, one after the other 32 us of a 300 us tile).  xr[q] == nullptr: no such row, st[q] is left alone.
+template <int NR>
+__device__ __forceinline__ void row_stats_wave_n(const float* const (&xr)[NR], int d, float eps, int lane, float2 (&st)[NR]) {
+    float v[NR][RS_MAX];
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+        for (int k = 0; k < RS_MAX; ++k) v[q][k] = (xr[q] && lane + 64 * k < d) ? xr[q][lane + 64 * k] : 0.0f;
+    float mean[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RS_MAX; ++k) if (lane + 64 * k < d) s = s + v[q][k];
+        mean[q] = wave_butterfly_sum(s) / (float)d;
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        float qq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RS_MAX; ++k)
+            if (lane + 64 * k < d) { const float c = v[q][k] - mean[q]; const float c2 = c * c; qq = qq + c2; }
+        const float var = wave_butterfly_sum(qq) / (float)d;
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+        if (xr[q]) st[q] = make_float2(mean[q], rstd);
+    }
+}
+
 }  // namespace ipsx

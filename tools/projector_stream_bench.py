@@ -57,6 +57,25 @@ def main():
             ms = timed(stream)
             print("stream, %d workgroups, %d short first tiles: %.3f ms (%.3f of peak on %d units: %.3f)"
                   % (w, short, ms, flop / (ms * 1e-3) / 157.3e12, w, flop / (ms * 1e-3) / 157.3e12 * 256 / w), flush=True)
+    stamps(plan, x, vq, R, emb, lg, ctl, ready, n)
+
+
+def stamps(plan, x, vq, R, emb, lg, ctl, ready, n):
+    """Shader cycles per phase of workgroup 0's tiles (ipsx_dbg_projector_stream_stamps)."""
+    import ctypes as C
+    fn = hip.lib().ipsx_dbg_projector_stream_stamps
+    fn.restype, fn.argtypes = None, [C.c_void_p]
+    st = torch.zeros((8,), dtype=torch.int64, device=x.device)
+    fn(st.data_ptr())
+    ctl.zero_(); ready.zero_()
+    plan.stream(x, vq, R, emb, lg[0], ctl, ready, workgroups=256, short_first=0)
+    torch.cuda.synchronize()
+    fn(None)
+    v = st.tolist()                                # (v[0] - pull + publication - holds the absolute time of the first stamp)
+    names = ("row moments", "GEMM", "epilogue (BatchNorm, ReLU, stores)", "logits")
+    tot = sum(v[1:5])
+    print("workgroup 0 (STAMP build), %d rows on 256 workgroups: " % n
+          + ", ".join("%s %.1f k cycles (%.0f %%)" % (nm, c / 1e3, 100.0 * c / tot) for nm, c in zip(names, v[1:5])))
 
 
 if __name__ == "__main__":
