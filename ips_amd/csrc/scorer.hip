@@ -1390,14 +1390,6 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             }
             if (pt >= 0) fold_row_max<R>(kc, ckey, lane);          // (whole waves: PF0 is a multiple of 64)
             for (int j = tid; j < cnt1; j += SCAN_NT) cnew[a.m + j] = (int)(lo1 + j);
-            const long long lo2 = lo1 + a.i;
-            const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
-            if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int e = pt + PFT * k;
-                pf[k] = (pt >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
-            }
         }
         if (STAMP && tid == 0) tacc[7] += (unsigned long long)(Lr - a.m);
         if (STAMP && PERSIST && tid == 0 && b == 0 && it < 512) stamps[8 * gridDim.x + 4 * it] = __builtin_amdgcn_s_memtime() - tlast;
@@ -1447,6 +1439,21 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         }
         if (STAMP && PERSIST && tid == 0 && b == 0 && it < 512) { stamps[8 * gridDim.x + 4 * it + 1] = __builtin_amdgcn_s_memtime() - tlast; stamps[8 * gridDim.x + 4 * it + 2] = __builtin_amdgcn_s_memrealtime(); }
         FAST_STAMP(5);
+        // the loads of the chunk after the next one, issued HERE - behind the ranking, not in the prep in front of it: the
+        // ranking's searches reload a spilled register pair, the compiler therefore drains the vector-memory counter in
+        // front of them, and loads issued before that point were waited for on the spot (1.2 k cycles per iteration by
+        // every wave, in-kernel stamps); from here they fly through the gather and the first phases of the next
+        // iteration, which touch the LDS only
+        {
+            const long long lo2 = lo + 2 * a.i;
+            const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
+            if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int e = pt + PFT * k;
+                pf[k] = (pt >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
+            }
+        }
         // P6: new memory: indices, logit rows and exponentials of the winners, into the other buffers
         for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
         {
