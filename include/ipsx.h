@@ -207,8 +207,9 @@ int ipsx_projector_apply_publish(const ipsx_conv* lin, const float* x, int64_t n
  * of the selection loop - is advanced past every completed 32-row unit in order.  Several slides: x holds them one
  * after the other (n rows in all, slide_rows each, a multiple of 32), ready[s] is slide s's word, and the stream of
  * tiles runs across the slides' ends.  Bit-identical to ipsx_projector_stats + ipsx_projector_apply + ipsx_logits.  ctl: ipsx_projector_stream_ctl_words(n) int32 words ZEROED before every call.
- * workgroups <= 0: 7 of every 8 compute units (the loop's unit stays free); short_first < 0: half of the workgroups
- * start with a 32-row tile so that completions do not come in bursts.  ipsx_projector_stream_supported: 1x1 Linear with
+ * workgroups <= 0: 7 of every 8 compute units (the loop's unit stays free); short_first >= 0: that many workgroups
+ * start with a 32-row tile, -1: half of them (completions then do not come in bursts), -2: every tile is 32 rows (a
+ * steady supply at 12 % less throughput: for ONE slide, whose loop consumes rows as fast as they are made).  ipsx_projector_stream_supported: 1x1 Linear with
  * 512 outputs, c_in % 32 == 0, c_in <= 2048, 64 <= n < 2^31.                                          */
 size_t ipsx_projector_stream_ctl_words(int64_t n);
 int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r);

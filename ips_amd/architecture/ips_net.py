@@ -525,11 +525,13 @@ class IPSNet(nn.Module):
             if ctl is None or ctl.numel() != words_ctl or ctl.device != dev:
                 ctl = self._stream_ctl = torch.zeros((words_ctl,), dtype=torch.int32, device=dev)
             ctl.zero_()
-            # one workgroup per compute unit the loops leave free; a slide alone: 7 of every 8 (the default), so that the
-            # loop's unit is free wherever the dispatcher turns - with several loops resident the units are simply taken
+            # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
+            # late).  A slide alone is as long as its loop, which consumes rows as fast as they are made: every tile 32 rows
+            # - a steady supply without bursts, first rows after half a tile time - on all but 8 units (measured, M patches/s:
+            # 64-row tiles on 224 units 35.7, 32-row tiles on 224 / 240 / 248 / 252 units 37.3 / 37.9 / 37.6-38.2 / 38.2)
             free = torch.cuda.get_device_properties(dev).multi_processor_count - B
             self._plan.stream(patches.view(B * N, -1), vq, R, emb_buf.view(B * N, -1), logits.view(B * N, R), ctl, ready,
-                              workgroups=0 if B == 1 else free, slide_rows=N)
+                              workgroups=free - 7 if B == 1 else free, slide_rows=N, short_first=-2 if B == 1 else -1)
             for b_ in range(B):                    # (whatever the last finishers left to each other; the launch is over)
                 hip.publish_rows(ready[b_:b_ + 1], N)
             launches = []

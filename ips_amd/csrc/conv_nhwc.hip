@@ -260,7 +260,9 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
 // (tests/test_hip_kernels.py::test_projector_stream_equals_the_launch_by_launch_projector).
 // A tile is 64 rows (2 units); the FIRST pull of `short_first` workgroups is one unit, so that completions - which would
 // otherwise come in bursts of one tile per workgroup - are spread over two phases and the first rows arrive after half
-// a tile time.
+// a tile time.  short_first = -2: EVERY tile is one unit - 12 % less throughput (1.46 against 1.31 ms per 65,536 rows on
+// 248 units) for a supply without bursts: what ONE slide wants, whose loop consumes rows as fast as they are made
+// (35.7 -> 38 M patches/s; the first 1 / 2 / 4 pulls short: 35.7 / 36.7 / 37.1).
 struct StreamArgs {
     const float* x;
     const float* wp; unsigned w_bytes;
@@ -273,6 +275,7 @@ struct StreamArgs {
     unsigned n, n_units;           // rows (of all slides, one after the other); units of 32 rows
     unsigned slide_rows;           // rows per slide: ready[s] = rows of slide s published
     unsigned short_first;
+    int short_pulls;               // every workgroup's first short_pulls pulls are one unit
     int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
     int* ready;                    // rows published, per slide (ipsx_scan_persistent's progress words)
     unsigned long long* stamps;    // diagnostic (ipsx_dbg_projector_stream_stamps): cycles per phase, summed by workgroup 0
@@ -457,9 +460,11 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
     float2* s_stats = reinterpret_cast<float2*>(st_lds + 64 * ST_EP);
     int* s_u0 = reinterpret_cast<int*>(st_lds + 64 * ST_EP + 128);
     bool first = true;
+    int pulls = 0;
     for (;;) {
-        const int take = (first && blockIdx.x < a.short_first) ? 1 : 2;
+        const int take = ((first && blockIdx.x < (a.short_first & 0x7fffffffu)) || pulls < a.short_pulls) ? 1 : 2;
         first = false;
+        ++pulls;
         if (threadIdx.x == 0) *s_u0 = atomicAdd(&a.ctl[0], take);
         __syncthreads();
         const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane(*s_u0);
@@ -686,6 +691,8 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     // turns, and the LDS request keeps these workgroups one to a unit and off the loop's
     const int wgs = workgroups > 0 ? workgroups : cus / 8 * 7;
     a.short_first = (unsigned)(short_first >= 0 ? short_first : wgs / 2);
+    a.short_pulls = short_first == -2 ? 0x7fffffff : 0;                            // (-2: every tile 32 rows)
+
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::projector_stream_kernel<false>),

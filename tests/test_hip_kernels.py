@@ -275,7 +275,7 @@ def test_fused_trunk_remainder_rule_is_bit_neutral(n, trunk_kernel_choice):
 
 
 @pytest.mark.parametrize("n,wgs,short,slides", [(64, 0, -1, 1), (97, 3, 1, 1), (1000, 7, 3, 1), (4099, 0, -1, 1), (20000, 0, 0, 1),
-                                                (3 * 1056, 5, 2, 3), (8 * 2048, 0, -1, 8)])
+                                                (3 * 1056, 5, 2, 3), (8 * 2048, 0, -1, 8), (5000, 9, -2, 1)])
 def test_projector_stream_equals_the_launch_by_launch_projector(n, wgs, short, slides):
     """ipsx_projector_stream - LayerNorm moments, Linear + BatchNorm + ReLU and the logits of every 64-row tile by resident
     workgroups, rows published in order as they complete - leaves the bits of ipsx_projector_stats + ipsx_projector_apply
