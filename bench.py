@@ -372,6 +372,19 @@ def main():
 
     if not args.no_kernel_events:
         net._plan.stream = timed_stream
+    plan_image_stream = net._plan.image_stream
+
+    def timed_image_stream(t, *a, **kw):                        # one image: trunk + logits as ONE persistent launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = plan_image_stream(t, *a, **kw)
+        e1.record()
+        enc_events.append((e0, e1, t.shape[0]))
+        streamed.append(2)
+        return out
+
+    if not args.no_kernel_events:
+        net._plan.image_stream = timed_image_stream
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
@@ -441,8 +454,10 @@ def main():
         recs = [None] * world
         dist.all_gather_object(recs, mine_rec)
     kernel_name = hip.encoder_kernel_name(net._plan)
-    if streamed:
-        kernel_name = "projector_stream_kernel (row moments + Linear + BatchNorm + ReLU + logits per 64-row tile, rows published as they complete)"
+    if streamed and streamed[0] == 2:
+        kernel_name = "fused_trunk_stream_kernel (the fused trunk + logits, four / two patches per pull, patches published as they complete)"
+    elif streamed:
+        kernel_name = "projector_stream_kernel (row moments + Linear + BatchNorm + ReLU + logits per tile, rows published as they complete)"
     traffic, traffic_note = pmc_traffic(name, kernel_name, enc_patches, n_launch)
     if not (args.precision == "fp32" and not args.dedup_blank and not args.lazy and world == 1 and batch == (1 if name == "b1" else B)):
         traffic = None

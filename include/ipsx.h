@@ -199,6 +199,21 @@ int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const 
 int ipsx_projector_apply_publish(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
                                  int32_t* ready, int32_t value, void* stream);
 
+/* ONE image's patches through the fused 1x32x32 trunk AND their logits as ONE persistent launch that feeds
+ * ipsx_scan_persistent patch by patch (reference: self.encoder(...) chunk by chunk in IPSNet.ips, architecture/ips_net.py:
+ * 213-241, and transformer.py:71-83 for the logits of emb + pos): resident workgroups pull two patches at a time, encode
+ * them (out: emb (n_patch, 128)), compute their logits against the folded query v_packed from emb + pos (pos: (n_patch,
+ * 128) or NULL; out: logits (n_patch, r)) and advance *ready past every completed pair in order.  Bit-identical to
+ * ipsx_trunk_encode + ipsx_logits.  ctl: ipsx_trunk_stream_ctl_words(n_patch) int32 words ZEROED before every call.
+ * workgroups <= 0: a few more than compute units (one that finds no unit at once starts late or finds nothing left);
+ * quad_pulls: a workgroup's first quad_pulls pulls are four patches (the trunk's full rate), the rest two (the finer
+ * deal); < 0: as many as leave a round of two-patch pulls.                                                              */
+size_t ipsx_trunk_stream_ctl_words(int64_t n_patch);
+int ipsx_trunk_stream_supported(const ipsx_trunk* t, int d, int r);
+int ipsx_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb, const float* pos,
+                      const float* v_packed, int r, float* logits, int32_t* ctl, int32_t* ready, int workgroups,
+                      int quad_pulls, void* stream);
+
 /* The projector AND the logits of one slide as ONE persistent launch that feeds ipsx_scan_persistent row by row
  * (reference: the projector of architecture/ips_net.py:60-66 applied chunk by chunk in IPSNet.ips :213-241, and
  * transformer.py:71-83 for the logits).  Resident workgroups pull 64-row tiles off a counter; a tile's LayerNorm

@@ -36,6 +36,8 @@
 // No global-memory round trips between layers: HBM traffic is the 4 KiB patch, the 512 B
 // embedding and the L2-resident 2.7 MB of weights.
 
+#include <algorithm>
+
 #include "ipsx_common.h"
 #include "ipsx_math.h"
 
@@ -479,14 +481,14 @@ __device__ __forceinline__ void store_l2(float* lds, const f32x16 (&v)[2], int l
         }                                                                                  \
     } while (0)
 
-template <bool STAMP>
-__global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 slabs
+// four patches p_first .. p_first + 3 by the workgroup's four wavefronts (the body of fused_trunk_kernel); KEEP: the four
+// embeddings are also left in lds[0 .. 511] (behind a barrier) for a caller that goes on with them
+// (fused_trunk_stream_kernel: the logits)
+template <bool STAMP, bool KEEP>
+__device__ __forceinline__ void trunk_quad_tile(const FusedArgs& a, long long p_first, long long n_valid, float* lds,
+                                                unsigned long long* stamps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31;
-    const long long p_first = (long long)blockIdx.x * 4;
-    const long long n_valid = a.count ? (long long)*a.count : a.n;        // compacted launches read their length on device
-    if (p_first >= n_valid) return;                                       // workgroup-uniform
     long long pi = p_first + wave;
     if (pi >= n_valid) pi = n_valid - 1;                                  // tail: recompute a valid patch, store nothing
     if (a.index) pi = a.index[pi];
@@ -613,15 +615,34 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
     }
 
     // ---- global average pool over the 16 pixels, sequential order
-    for (int o = threadIdx.x; o < 4 * 128; o += 256) {
+    float keep[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int o = threadIdx.x + 256 * h;
         const int pl = o >> 7, n = o & 127;
         const float* s = lds + pl * SLAB + n;
         float sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) sum = sum + s[k * PS2];
-        if (p_first + pl < n_valid) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
+        keep[h] = sum / 16.0f;
+        if (p_first + pl < n_valid) a.emb[(size_t)(p_first + pl) * 128 + n] = keep[h];
+    }
+    if (KEEP) {
+        __syncthreads();                                                  // every sum has been read
+        lds[threadIdx.x] = keep[0];
+        lds[threadIdx.x + 256] = keep[1];
+        __syncthreads();
     }
     IPSX_STAMP(15);
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 slabs
+    const long long p_first = (long long)blockIdx.x * 4;
+    const long long n_valid = a.count ? (long long)*a.count : a.n;        // compacted launches read their length on device
+    if (p_first >= n_valid) return;                                       // workgroup-uniform
+    trunk_quad_tile<STAMP, false>(a, p_first, n_valid, lds, stamps);
 }
 
 #include "fused_trunk_split.h"
@@ -742,6 +763,48 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
         fused_trunk_pair_kernel<<<dim3((unsigned)cdiv(rest, 2)), dim3(256), lds / 2, s>>>(a);
     }
     return launched("fused_trunk");
+}
+
+// One image through the fused trunk as ONE persistent launch that feeds a resident selection loop (fused_trunk_stream_kernel,
+// fused_trunk_pair.h).  workgroups <= 0: one per compute unit but the loop's and a few to spare.
+int fused_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, const float* pos, const float* v_packed,
+                       int r, float* logits, int32_t* ctl, int32_t* ready, int workgroups, int quad_pulls, hipStream_t s) {
+    if (t->precision != 0 || t->patch_dtype != 0) return fail(IPSX_EINVAL, "trunk_stream: the exact fp32 trunk only");
+    TrunkStreamArgs a;
+    a.f.patches = patches; a.f.emb = emb; a.f.n = n; a.f.index = nullptr; a.f.count = nullptr; a.f.in_dtype = 0;
+    a.f.w_stem = t->stem.w_packed; a.f.a_stem = t->stem.alpha; a.f.s_stem = t->stem.shift;
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 2; ++j) {
+            a.f.w[2 * k + j] = t->blocks[k].conv[j].w_packed;
+            a.f.al[2 * k + j] = t->blocks[k].conv[j].alpha;
+            a.f.sh[2 * k + j] = t->blocks[k].conv[j].shift;
+            a.f.wh[2 * k + j] = nullptr;
+        }
+    a.f.w_down = t->blocks[2].down.w_packed; a.f.a_down = t->blocks[2].down.alpha; a.f.s_down = t->blocks[2].down.shift;
+    a.f.wh_down = nullptr; a.f.wh_stem = nullptr;
+    a.pos = pos; a.vp = v_packed; a.R = r; a.logits = logits; a.ctl = ctl; a.ready = ready;
+    a.n_pairs = (unsigned)cdiv(n, 2);
+    // Four patches per pull run at the trunk's full rate (0.29 ms per pull at one workgroup per unit), two per pull at 0.84 of
+    // it (0.155 ms): as many four-patch pulls per workgroup as leave at least one round of two-patch pulls for the rest.
+    {
+        const int wgs_ = workgroups > 0 ? workgroups : device_cus() - 1;
+        const int64_t q = quad_pulls >= 0 ? quad_pulls : std::max<int64_t>(0, (n - 1) / (4 * (int64_t)wgs_));
+        a.quad_pulls = (int)std::min<int64_t>(q, 1 << 20);
+    }
+    // one workgroup per compute unit (two patches at a time, one wavefront per SIMD: the shortest time from pull to
+    // publication); the LDS request - more than half a unit's - keeps two of them off one unit and all of them off the loop's
+    const size_t lds = 96 << 10;                           // (four slabs are 69 KB)
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_stream_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    // (more workgroups than free units: one that is placed late starts late or finds nothing left - with fewer, the units
+    //  the dispatcher fails to use at once make a sixth round of 2,500 patches: 1.03 against 0.92 ms per image)
+    const int wgs = workgroups > 0 ? workgroups : device_cus() + 8;
+    fused_trunk_stream_kernel<<<dim3((unsigned)wgs), dim3(256), lds, s>>>(a);
+    return launched("fused_trunk_stream");
 }
 
 int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s) {

@@ -221,12 +221,13 @@ __device__ __forceinline__ void store_l2_pair(float* lds, const f32x16& v, int l
     }
 }
 
-__global__ __launch_bounds__(256, 2) void fused_trunk_pair_kernel(FusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // 2 slabs
+// two patches p_first, p_first + 1 by the workgroup's four wavefronts; KEEP: the two embeddings are also left in
+// lds[0 .. 255] (behind a barrier) for a caller that goes on with them (fused_trunk_stream_kernel: the logits)
+template <bool KEEP>
+__device__ __forceinline__ void trunk_pair_tile(const FusedArgs& a, long long p_first, float* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ps = wave >> 1, nh = wave & 1;                              // patch slot of the workgroup, n-tile of the pair
     const int i = lane & 31;
-    const long long p_first = (long long)blockIdx.x * 2;
     long long pi = p_first + ps;
     if (pi >= a.n) pi = a.n - 1;                                          // odd tail: recompute a valid patch, store nothing
     if (a.index) pi = a.index[pi];
@@ -334,6 +335,114 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_pair_kernel(FusedArgs a) {
         float sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) sum = sum + s[k * PS2];
-        if (p_first + pl < a.n) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
+        const float e = sum / 16.0f;
+        if (p_first + pl < a.n) a.emb[(size_t)(p_first + pl) * 128 + n] = e;
+        if (KEEP) {
+            __syncthreads();                                              // every sum has been read
+            lds[threadIdx.x] = e;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void fused_trunk_pair_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 2 slabs
+    trunk_pair_tile<false>(a, (long long)blockIdx.x * 2, lds);
+}
+
+// ------------------------------------------------------------------ one image as ONE persistent launch
+// A single image is not worth cutting into parts for the selection loop to run beside: the loop's
+// workgroup has to find a compute unit the trunk's workgroups leave free, and the last part's iterations are exposed.
+// Here the loop is resident from the start (ipsx_scan_persistent) and the trunk's workgroups - one per remaining compute
+// unit, two patches at a time (trunk_pair_tile: one wavefront per SIMD) - pull patch pairs off a counter, encode them,
+// compute their logits (the MFMA sequence of logits_kernel on emb + pos, 2 valid rows of a 32-row tile) and publish them
+// the way projector_stream_kernel does: logits written through, a flag per pair, the first wavefront raises the cursor and
+// the loop's progress word past every completed pair behind the first unpublished one.
+struct TrunkStreamArgs {
+    FusedArgs f;
+    const float* pos;          // (n, 128) positional encodings added to the embeddings for the logits, or nullptr
+    const float* vp;           // folded query, packed for one 32-column tile
+    int R;                     // logits per patch (<= 32)
+    float* logits;             // (n, R)
+    int* ctl;                  // [0] next pair, [1] first unpublished pair, [2 ...] a flag per pair; zeroed by the caller
+    int* ready;                // patches published
+    unsigned n_pairs;
+    int quad_pulls;            // a workgroup's first quad_pulls pulls are four patches, the rest two
+};
+
+__global__ __launch_bounds__(256, 1) void fused_trunk_stream_kernel(TrunkStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 slabs + the pull word behind them
+    int* s_pull = reinterpret_cast<int*>(lds + 4 * SLAB);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
+    const unsigned n = (unsigned)a.f.n;
+    int pulls = 0;
+    for (;;) {
+        // a workgroup's first quad_pulls pulls are FOUR patches (one wavefront per patch: the trunk's full rate), the
+        // rest two (trunk_pair_tile: half the time per pull - what is left of the image is dealt out finely)
+        const int take = pulls < a.quad_pulls ? 2 : 1;
+        ++pulls;
+        if (threadIdx.x == 0) *s_pull = atomicAdd(&a.ctl[0], take);
+        __syncthreads();
+        const unsigned g = (unsigned)__builtin_amdgcn_readfirstlane(*s_pull);
+        if (g >= a.n_pairs) break;                                        // workgroup-uniform
+        const unsigned p0 = 2u * g;
+        const int pairs = (take == 2 && g + 1 < a.n_pairs) ? 2 : 1;
+        if (pairs == 2) trunk_quad_tile<false, true>(a.f, (long long)p0, (long long)n, lds, nullptr);   // lds[0 .. 511] = 4 embeddings
+        else trunk_pair_tile<true>(a.f, (long long)p0, lds);                                             // lds[0 .. 255] = 2
+        // ---- logits: the first 2 * pairs rows of a 32-row tile (the others carry zeros), K = 128 in the contract's order
+        if (wave == 0) {
+            const unsigned row = p0 + (unsigned)i;
+            const bool rv = i < 2 * pairs && row < n;
+            const float* e = lds + (rv ? i : 0) * 128 + 4 * half;
+            const float* pp = a.pos ? a.pos + (size_t)(rv ? row : 0) * 128 + 4 * half : nullptr;
+            const float4* vq = reinterpret_cast<const float4*>(a.vp) + lane;
+            f32x16 lacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lacc[r] = 0.0f;
+            float4 ev[16], bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                ev[u] = *reinterpret_cast<const float4*>(e + u * 8);
+                if (pp) {
+                    const float4 pv = *reinterpret_cast<const float4*>(pp + u * 8);
+                    ev[u].x = ev[u].x + pv.x; ev[u].y = ev[u].y + pv.y; ev[u].z = ev[u].z + pv.z; ev[u].w = ev[u].w + pv.w;
+                }
+                bv[u] = vq[(size_t)u * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                lacc = MFMA(rv ? ev[u].x : 0.0f, bv[u].x, lacc);
+                lacc = MFMA(rv ? ev[u].y : 0.0f, bv[u].y, lacc);
+                lacc = MFMA(rv ? ev[u].z : 0.0f, bv[u].z, lacc);
+                lacc = MFMA(rv ? ev[u].w : 0.0f, bv[u].w, lacc);
+            }
+            // C layout: lane = logit, registers = rows; rows 0 .. 3 are registers 0 .. 3 of lane half 0
+            if (half == 0 && i < a.R) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < 2 * pairs && p0 + r < n)
+                        __hip_atomic_store(a.logits + (size_t)(p0 + r) * a.R + i, lacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- publish (see projector_stream_kernel): the flags of these pairs, then cursor and progress word past every
+            // completed pair behind the first unpublished one
+            if (lane < pairs) __hip_atomic_store(&a.ctl[2 + g + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (;;) {
+                const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((unsigned)p >= a.n_pairs) break;
+                const unsigned u = (unsigned)p + lane;
+                const int f = u < a.n_pairs ? __hip_atomic_load(&a.ctl[2 + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                const unsigned long long done = __ballot(f != 0);
+                const int c = done == ~0ull ? 64 : __builtin_ctzll(~done);
+                if (c == 0) break;
+                if (lane == 0) {
+                    __hip_atomic_fetch_max(&a.ctl[1], p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_max(a.ready, (int)min(2u * (unsigned)(p + c), n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (c < 64) break;
+            }
+        }
+        __syncthreads();                                                  // lds[0 .. 511] and the pull word are free again
     }
 }

@@ -25,6 +25,8 @@ bool fused_stem_pool100x3_covers(const ipsx_trunk* t);
 // fused_trunk.hip
 bool fused_trunk_supported(const ipsx_trunk* t);
 int fused_trunk_encode(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, hipStream_t s);
+int fused_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n, float* emb, const float* pos, const float* v_packed,
+                       int r, float* logits, int32_t* ctl, int32_t* ready, int workgroups, int quad_pulls, hipStream_t s);
 
 struct TrunkGeom {
     size_t max_elems;   // largest per-patch activation (floats) of any layer
@@ -189,4 +191,21 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
         IPSX_TRY(ipsx_avgpool_nhwc(buf[cur], emb + (size_t)p0 * g.d_out, n, c, h * w, stream));
     }
     return IPSX_OK;
+}
+
+// One image: trunk AND logits of its patches as ONE persistent launch that feeds ipsx_scan_persistent patch by patch
+// (fused_trunk_stream_kernel).  ctl: ipsx_trunk_stream_ctl_words(n) int32 words ZEROED by the caller before every call.
+IPSX_API size_t ipsx_trunk_stream_ctl_words(int64_t n_patch) { return n_patch > 0 ? (size_t)ipsx::cdiv(n_patch, 2) + 2 : 0; }
+
+IPSX_API int ipsx_trunk_stream_supported(const ipsx_trunk* t, int d, int r) {
+    return t && ipsx::fused_trunk_supported(t) && t->precision == 0 && t->patch_dtype == 0 && d == 128 && r >= 1 && r <= 32 ? 1 : 0;
+}
+
+IPSX_API int ipsx_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n_patch, float* emb, const float* pos,
+                               const float* v_packed, int r, float* logits, int32_t* ctl, int32_t* ready, int workgroups,
+                               int quad_pulls, void* stream) {
+    IPSX_REQUIRE(t && patches && emb && v_packed && logits && ctl && ready && n_patch > 0, "trunk_stream: bad arguments");
+    IPSX_REQUIRE(ipsx_trunk_stream_supported(t, 128, r), "trunk_stream: the fused fp32 1x32x32 trunk with 128 features and at most 32 logits per patch");
+    return ipsx::fused_trunk_stream(t, patches, n_patch, emb, pos, v_packed, r, logits, ctl, ready, workgroups, quad_pulls,
+                                    ipsx::as_stream(stream));
 }

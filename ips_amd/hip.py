@@ -181,6 +181,10 @@ _EXPORTS = {
     "ipsx_projector_apply": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_projector_apply_publish": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int32, C.c_void_p]),
+    "ipsx_trunk_stream_ctl_words": (C.c_size_t, [C.c_int64]),
+    "ipsx_trunk_stream_supported": (C.c_int, [C.POINTER(Trunk), C.c_int, C.c_int]),
+    "ipsx_trunk_stream": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_projector_stream_ctl_words": (C.c_size_t, [C.c_int64]),
     "ipsx_projector_stream_supported": (C.c_int, [C.POINTER(Conv), C.c_int64, C.c_int]),
     "ipsx_projector_stream": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
@@ -513,6 +517,29 @@ class EncoderPlan:
         _ck(lib().ipsx_projector_stats(_p(x), x.shape[0], x.shape[1], C.c_float(self.ln_eps), _p(out), _stream()),
             "ipsx_projector_stats")
         return out
+
+    def image_stream_supported(self, x_shape, D, R):
+        """Can ``image_stream`` encode patches of this shape (the fused fp32 1x32x32 trunk, 128 features, R <= 32)?"""
+        if not self.is_image or not self.fused(x_shape) or precision() != "fp32":
+            return False
+        return bool(lib().ipsx_trunk_stream_supported(C.byref(self.trunk), int(D), int(R)))
+
+    def image_stream(self, x, pos, vq, R, emb, logits, ctl, ready, workgroups=0, quad_pulls=-1):
+        """Trunk + logits of ONE image's patches ``x`` (P, 1, 32, 32) as one persistent launch that advances ``ready`` (the
+        progress word of ``scan_persistent``) as patches complete: ``emb`` (P, 128) and ``logits`` (P, R) are the outputs,
+        ``pos`` (P, 128) or None is added to the embeddings for the logits, ``ctl`` =
+        ``torch.zeros(image_stream_ctl_words(P), int32)`` zeroed before every call, ``vq`` the folded query."""
+        self._refresh()
+        x = _patches(x)
+        if pos is not None and (pos.stride(-1) != 1 or pos.stride(-2) != pos.shape[-1]):
+            pos = pos.contiguous()
+        _ck(lib().ipsx_trunk_stream(C.byref(self.trunk), _p(x), x.shape[0], _p(emb), _p(pos), _p(vq), int(R), _p(logits),
+                                    _p(ctl), _p(ready), int(workgroups), int(quad_pulls), _stream()), "ipsx_trunk_stream")
+        return emb
+
+    @staticmethod
+    def image_stream_ctl_words(n):
+        return int(lib().ipsx_trunk_stream_ctl_words(int(n)))
 
     def stream_supported(self, n, R):
         """Can ``stream`` run this projector on ``n`` rows with ``R`` logits per row?"""

@@ -274,6 +274,40 @@ def test_fused_trunk_remainder_rule_is_bit_neutral(n, trunk_kernel_choice):
         assert torch.equal(plan.encode_indexed(x, index), want_ix), mode
 
 
+@pytest.mark.parametrize("n,wgs,use_pos,quads", [(1, 0, True, -1), (2, 3, False, 0), (77, 5, True, 2), (79, 5, True, 100),
+                                                 (2500, 0, True, -1), (2500, 0, False, 0), (2501, 0, True, 1)])
+def test_trunk_stream_equals_encode_plus_logits(n, wgs, use_pos, quads):
+    """ipsx_trunk_stream - one image's patches through the fused trunk four or two at a time by resident workgroups, their logits
+    from emb + pos in the same workgroup, patches published in order as they complete - leaves the bits of
+    ipsx_trunk_encode + ipsx_logits and a progress word that ends on (all but the last finishers' share of) the patch count."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    plan = hip.EncoderPlan(net.encoder, True)
+    ca = net.transf.crs_attn
+    vq, R = ca.folded_query(), ca.H * ca.n_token
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn((n, 1, 32, 32), generator=gen)
+    x[torch.rand(n, generator=gen) < 0.5] = 0.0
+    x = x.to(DEV)
+    pos = torch.randn((n, 128), generator=gen).to(DEV) if use_pos else None
+    assert plan.image_stream_supported(x.shape, 128, R)
+    want_emb = plan.encode(x)
+    want_lg = hip.logits(want_emb.view(1, n, -1), pos.view(1, n, -1) if use_pos else None, vq, R)[0]
+    emb = torch.full_like(want_emb, float("nan"))
+    lg = torch.full_like(want_lg, float("nan"))
+    for rep in range(2):
+        ctl = torch.zeros((plan.image_stream_ctl_words(n),), dtype=torch.int32, device=DEV)
+        ready = torch.zeros((1,), dtype=torch.int32, device=DEV)
+        plan.image_stream(x, pos, vq, R, emb, lg, ctl, ready, workgroups=wgs, quad_pulls=quads)
+        torch.cuda.synchronize()
+        pairs = -(-n // 2)
+        assert bool((ctl[2:2 + pairs] == 1).all())
+        cursor = int(ctl[1].item())
+        assert cursor <= pairs and int(ready.item()) == min(n, 2 * cursor) and 2 * cursor >= n - 4 * max(1, wgs or 264)
+        assert torch.equal(emb, want_emb), "max abs diff %g" % float((emb - want_emb).abs().max())
+        assert torch.equal(lg, want_lg), "max abs diff %g" % float((lg - want_lg).abs().max())
+
+
 @pytest.mark.parametrize("n,wgs,short,slides", [(64, 0, -1, 1), (97, 3, 1, 1), (1000, 7, 3, 1), (4099, 0, -1, 1), (20000, 0, 0, 1),
                                                 (3 * 1056, 5, 2, 3), (8 * 2048, 0, -1, 8), (5000, 9, -2, 1)])
 def test_projector_stream_equals_the_launch_by_launch_projector(n, wgs, short, slides):
