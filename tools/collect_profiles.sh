@@ -31,6 +31,7 @@ python tools/scan_stamps.py large > "$OUT/scan_stamps_large.txt" 2>&1
 python tools/scan_stamps.py campipe > "$OUT/scan_stamps_campipe.txt" 2>&1
 python tools/trunk_pair_bench.py > "$OUT/trunk_pair_bench.txt" 2>&1
 python tools/projector_stream_bench.py > "$OUT/projector_stream_bench.txt" 2>&1
+python tools/trunk_stream_bench.py > "$OUT/trunk_stream_bench.txt" 2>&1
 python tools/loop_beside.py > "$OUT/loop_beside.txt" 2>&1
 python tools/scan_beside.py > "$OUT/scan_beside.txt" 2>&1
 python -m pytest tests/test_bench_parity.py tests/test_seed_sweep.py -q -m gpu -s 2>&1 | grep -v "amdgpu.ids" > "$OUT/parity_rates.txt"
