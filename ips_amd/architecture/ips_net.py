@@ -482,15 +482,16 @@ class IPSNet(nn.Module):
         if getattr(self, "_feat_bufs_key", None) != bkey:
             self._feat_bufs = (torch.empty((B, N, R), dtype=torch.float32, device=dev),
                                torch.empty((B, M), dtype=torch.int64, device=dev),
-                               torch.zeros((B,), dtype=torch.int32, device=dev),
-                               torch.zeros((B + 1,), dtype=torch.int32, device=dev),          # progress word per slide | status
+                               # tie flags | progress word per slide | status | control words of the projector stream: ONE fill per call
+                               torch.zeros((2 * B + 1 + self._plan.stream_ctl_words(B * N),), dtype=torch.int32, device=dev),
                                torch.empty((B * N, 2), dtype=torch.float32, device=dev),      # LayerNorm moments
                                torch.empty((B, N, self.D), dtype=torch.float32, device=dev))
             self._feat_bufs_key = bkey
             for t in self._feat_bufs:
                 t.record_stream(side)
-        logits, mem_idx_buf, tie, words, stats, emb_buf = self._feat_bufs
-        tie.zero_()
+        logits, mem_idx_buf, zeroed, stats, emb_buf = self._feat_bufs
+        tie, words, ctl = zeroed[:B], zeroed[B:2 * B + 1], zeroed[2 * B + 1:]
+        zeroed.zero_()
         # A loop that gave up waiting (bounded at ~5 s: e.g. something serialises the kernels, so that its producers
         # cannot run beside it) is REDONE in the same call by the conditional launch behind it (scan_range_if below:
         # every workgroup leaves at once unless the status word says "timed out"), so this call's results are valid
@@ -502,7 +503,6 @@ class IPSNet(nn.Module):
             warnings.warn("the persistent selection loop of an earlier ips() call timed out waiting for rows and was "
                           "redone with per-call launches (results valid; IPSX_SCAN_PERSIST=0 avoids the wait)")
             self._scan_timeout_warned = True
-        words.zero_()
         ready, status = words[:B], words[B:B + 1]
         self._scan_status = status
         side.wait_stream(main)                     # the buffers above are the main stream's; previous readers are done
@@ -522,11 +522,6 @@ class IPSNet(nn.Module):
         stream = (not self.use_pos and fused2 and os.environ.get("IPSX_CAM_STREAM", "1") != "0"
                   and (B == 1 or N % 32 == 0) and self._plan.stream_supported(B * N, R))
         if stream:
-            words_ctl = self._plan.stream_ctl_words(B * N)
-            ctl = getattr(self, "_stream_ctl", None)
-            if ctl is None or ctl.numel() != words_ctl or ctl.device != dev:
-                ctl = self._stream_ctl = torch.zeros((words_ctl,), dtype=torch.int32, device=dev)
-            ctl.zero_()
             # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
             # late).  A slide alone is as long as its loop, which consumes rows as fast as they are made: every tile 32 rows
             # - a steady supply without bursts, first rows after half a tile time - on all but 8 units (measured, M patches/s:
@@ -604,23 +599,21 @@ class IPSNet(nn.Module):
         if getattr(self, "_img_bufs_key", None) != bkey:       # (kept between calls: see _select_features_persistent)
             self._img_bufs = (torch.empty((1, N, R), dtype=torch.float32, device=dev),
                               torch.empty((1, M), dtype=torch.int64, device=dev),
-                              torch.zeros((1,), dtype=torch.int32, device=dev),
-                              torch.zeros((2,), dtype=torch.int32, device=dev),                # progress word | status
                               torch.empty((1, N, self.D), dtype=torch.float32, device=dev),
-                              torch.zeros((self._plan.image_stream_ctl_words(N),), dtype=torch.int32, device=dev))
+                              # tie flag | progress word | status | the stream's control words: ONE fill per call
+                              torch.zeros((3 + self._plan.image_stream_ctl_words(N),), dtype=torch.int32, device=dev))
             self._img_bufs_key = bkey
             for t in self._img_bufs:
                 t.record_stream(side)
-        logits, mem_idx_buf, tie, words, emb_buf, ctl = self._img_bufs
+        logits, mem_idx_buf, emb_buf, zeroed = self._img_bufs
+        tie, words, ctl = zeroed[:1], zeroed[1:3], zeroed[3:]
         mirror = getattr(self, "_scan_status_host", None)
         if mirror is not None and int(mirror.item()) & 1 and not getattr(self, "_scan_timeout_warned", False):
             import warnings
             warnings.warn("the persistent selection loop of an earlier ips() call timed out waiting for rows and was "
                           "redone with per-call launches (results valid; IPSX_SCAN_PERSIST=0 avoids the wait)")
             self._scan_timeout_warned = True
-        tie.zero_()
-        words.zero_()
-        ctl.zero_()
+        zeroed.zero_()
         ready, status = words[:1], words[1:2]
         self._scan_status = status
         side.wait_stream(main)
