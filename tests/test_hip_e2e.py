@@ -451,6 +451,34 @@ def test_scan_overlapped_with_encoder_equals_plain(monkeypatch):
     assert np.array_equal(idx_a[0].cpu().numpy(), g.mem_idx[0])
 
 
+@pytest.mark.parametrize("N", [2500, 1000, 2501])
+def test_one_image_every_schedule_selects_the_same_patches(N, monkeypatch):
+    """One image per call (the reference's eager-sequential mode): by default trunk + logits are ONE persistent launch
+    beside a resident loop (ipsx_trunk_stream); IPSX_IMAGE_STREAM=0 cuts the image into parts with the loop beside the
+    next part's trunk, IPSX_OVERLAP_SCAN=0 is encode-all-then-scan.  Same indices, patches and positions - with and
+    without positional encoding, also when the image is the shuffled one."""
+    g = Golden("mnist_full")
+    for use_pos, shuffle in ((True, False), (False, False), (True, True)):
+        conf = g.conf.clone(N=N, use_pos=use_pos, shuffle=shuffle)
+        from ips_amd.architecture import IPSNet
+        net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 7).to(DEV).eval()
+        x = synth.make_patches(conf, 1, seed=5).to(DEV)
+        assert net._can_stream_image(x)
+        res = []
+        for env in ({}, {"IPSX_IMAGE_STREAM": "0"}, {"IPSX_OVERLAP_SCAN": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            torch.manual_seed(3)                           # (shuffle draws from torch's generator)
+            mp, pos = net.ips(x)
+            mp, pos = net.ips(x) if not shuffle else (mp, pos)     # a second call: the kept buffers
+            res.append((net.last_mem_idx.clone(), mp.clone(), None if pos is None else pos.clone()))
+            for k in env:
+                monkeypatch.delenv(k)
+        for idx, mp, pos in res[1:]:
+            assert torch.equal(idx, res[0][0]) and torch.equal(mp, res[0][1])
+            assert (pos is None and res[0][2] is None) or torch.equal(pos, res[0][2])
+
+
 def test_scan_range_resumes_exactly():
     lg = torch.randn((3, 1000, 32), generator=torch.Generator().manual_seed(5)).mul(3).to(DEV)
     want = hip.scan(lg, 32, 48, 8, 4)
