@@ -9,6 +9,14 @@ One "step" = one ``IPSNet.ips(patches)`` call (no-grad, eval, eager loading: the
 tensor is resident in HBM when the timed region starts): embed every patch, score,
 run the whole selection loop, gather the M winners.
 
+``value`` follows SURVEY.md 8 d-1: each of the K timed calls is bracketed by barrier + device
+sync, a call's time is the max over ranks, ``value`` = patches per call / the MEDIAN call time
+(``ms_per_step``).  ``value_pipelined`` is the same K calls enqueued back to back between two
+fences (what a training loop sees when the host runs ahead).  The default single-GPU run also
+times every other BASELINE configuration that fits one GPU into ``also_measured`` (b1 = d-1's
+primary shape, mnist3000 = configs[2], cam / cam_x16 = configs[3], cam_native = the reference's
+shipped CAMELYON sizes), each with its own ``parity`` / ``roofline`` / ``roofline_call``.
+
 Workloads (``ips_amd.synth.BENCH_WORKLOADS``; weights seed 7, patches seed 21):
   N = 1   BASELINE.json configs[1]: Megapixel-MNIST 1500 - 2500 patches of 1x32x32 per image,
           M = I = 64, 4 query tokens, positional encoding on, at the reference's batch size
@@ -90,6 +98,10 @@ def parse():
                     help="default: mnist at --gpus 1 (the headline, BASELINE configs[1], B=16), mnist3000 at --gpus N > 1 "
                          "(configs[2], patch-sharded); the others are secondary single-GPU measurements: b1 (headline "
                          "image 0 alone), native50, traffic, cam, cam_native (the reference's shipped M = I = 5000)")
+    ap.add_argument("--also", default="all",
+                    help="default single-GPU run only: which other BASELINE configurations are timed into `also_measured` "
+                         "('all', 'none', or a comma list of b1,mnist3000,cam,cam_x16,cam_native)")
+    ap.add_argument("--also-steps", type=int, default=10, help="timed calls per `also_measured` leg (each way)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1 only. strong (default): configs[2], the same 16 x 10000 patches at every N; weak: 2500 "
                          "patches of every image per GPU (the image grows with N)")
@@ -200,10 +212,10 @@ _ALSO = {
 }
 
 
-def measure_precision(net, x, args, precision, fixture):
+def measure_precision(net, x, steps, precision, fixture):
     """The same workload with another trunk arithmetic (opt-in; never the headline `value`), reported next to the
     exact-fp32 headline together with its own parity object."""
-    for name in ("encode", "encode_indexed"):                   # drop the event-recording wrappers of the headline run
+    for name in ("encode", "encode_indexed", "stream", "image_stream"):   # drop the event-recording wrappers of the headline run
         net._plan.__dict__.pop(name, None)
     net.ips(x)
     ref_idx = net.last_mem_idx.clone()
@@ -213,7 +225,7 @@ def measure_precision(net, x, args, precision, fixture):
             net.ips(x)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             net.ips(x)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -221,7 +233,7 @@ def measure_precision(net, x, args, precision, fixture):
         par = parity(fixture, net.last_mem_idx)
     finally:
         os.environ["IPSX_PRECISION"] = "fp32"
-    return {"value": x.shape[0] * x.shape[1] * args.steps / dt, "unit": "patches/s", "ms_per_step": 1e3 * dt / args.steps,
+    return {"value": x.shape[0] * x.shape[1] * steps / dt, "unit": "patches/s", "ms_per_step": 1e3 * dt / steps,
             "same_indices_as_f32": same, "parity": par, "what": _ALSO[precision]}
 
 
@@ -251,6 +263,292 @@ def pmc_traffic(workload, kernel_name, enc_patches, n_launch):
         return None, "no PMC record"
 
 
+class Ctx:
+    """What every leg of one bench.py process shares: the process group and the device."""
+
+    def __init__(self, world, rank, dev, share):
+        self.world, self.rank, self.dev, self.share = world, rank, dev, share
+
+
+# Driver-run coverage (VERDICT r03 item 1): the default single-GPU invocation times the headline AND every other BASELINE
+# configuration that fits one GPU, each with its own parity / roofline objects, as `also_measured.<leg>`:
+#   b1          SURVEY d-1's primary shape: one ips() call on ONE image of configs[1]
+#   mnist3000   configs[2] on one GPU (16 x 10,000 patches)
+#   cam         configs[3], one slide per call (the reference's B_seq = 1)
+#   cam_x16     configs[3], 16 slides per call (the reference's B = 16 in one call)
+#   cam_native  the reference's shipped CAMELYON sizes (M = I = 5000)
+ALSO_LEGS = (("b1", "b1", None), ("mnist3000", "mnist3000", None), ("cam", "cam", None), ("cam_x16", "cam", 16),
+             ("cam_native", "cam_native", None))
+
+
+def make_input(conf, name, B, batch, dev_for_extra):
+    """The fixture's batch (host, seeded numpy stream).  More feature slides than the fixture holds (cam, --batch 16) are
+    drawn on the device - relu(N(0,1)) like the fixture's, other seeds - because 2 x 10^9 host-side normals would take longer
+    than every timed leg together; slide 0 stays the fixture's."""
+    from ips_amd import synth
+    if (not conf.is_image) and batch > B:
+        x0 = synth.make_patches(conf, B, seed=21)
+        return x0, batch - B
+    return synth.make_patches(conf, max(batch, B), seed=21), 0
+
+
+def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, headline=True):
+    """One workload: build it, warm up, time it both ways (SURVEY d-1: device sync around every call, median = `value`;
+    and the same K calls back to back between two fences = `value_pipelined`), check the selection against the
+    reference-recorded fixture, price the encoder launches.  Returns the JSON object on rank 0 (None elsewhere)."""
+    world, rank, dev, share = ctx.world, ctx.rank, ctx.dev, ctx.share
+    from ips_amd import hip, synth
+    from ips_amd import dist as ipsd
+    from ips_amd.architecture import IPSNet
+
+    weak = world > 1 and args.scaling == "weak"
+    fixture, images = name, None
+    if name == "b1":
+        conf, B = synth.bench_workload("mnist")
+        fixture, images = "mnist", slice(0, 1)
+    else:
+        conf, B = synth.bench_workload(name)
+    if weak:                                                    # the image grows with the node; 4 GPUs = configs[2]
+        conf, B = synth.bench_workload("mnist")
+        conf = conf.clone(N=PATCHES_PER_GPU_WEAK * world)
+        fixture = "mnist3000" if conf.N == 10000 else None
+    batch = 1 if name == "b1" else (batch or B)
+    n_total = conf.N
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    x, n_extra = make_input(conf, name, B, batch, dev)          # the fixture's batch; --batch may take a prefix of it
+    if name == "b1":
+        x = x[:1]
+    elif batch < x.shape[0]:
+        x, images = x[:batch], slice(0, batch)
+    if batch > B and conf.is_image:
+        fixture = None
+    x_host = x
+    if world > 1:
+        mine = ipsd.local_indices(n_total, conf.M, conf.I, rank, world)
+        x = x[:, mine].contiguous()                             # this rank's shard of every image
+    n_mine = x.shape[1]
+    if args.storage != "f32":
+        if args.precision == "fp32":
+            print("--storage %s needs --precision bf16 or fp32x3" % args.storage, file=sys.stderr)
+            sys.exit(2)
+        x = x.to({"bf16": torch.bfloat16, "f16": torch.float16}[args.storage])
+    x = x.pin_memory() if args.lazy else x.to(dev)              # headline: resident in HBM before the timed region
+    if n_extra:
+        g = torch.Generator(device=dev)
+        g.manual_seed(2100)
+        more = torch.relu(torch.randn((n_extra,) + tuple(x.shape[1:]), generator=g, device=dev, dtype=torch.float32))
+        x = torch.cat((x, more), 0)
+        del more
+
+    timings = [] if world > 1 else None
+    if world == 1:
+        def step():
+            return net.ips(x)
+    else:
+        def step():
+            return ipsd.ips_sharded(net, x, n_total, timings=timings)
+
+    step()                                                      # builds the encoder plan
+    # time the encoder launches with HIP events on the stream they run on (installed BEFORE the warm-up so that the
+    # warm-up steps run exactly what the timed steps run, event creation included)
+    enc_events = []
+    streamed = []
+
+    def timed(fn, count, tag=None):
+        def wrapper(t, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(t, *a, **kw)
+            e1.record()
+            enc_events.append((e0, e1, count(t, a)))
+            if tag:
+                streamed.append(tag)
+            return out
+        return wrapper
+
+    if not args.no_kernel_events:
+        plan = net._plan
+        plan.encode = timed(plan.encode, lambda t, a: t.shape[0])
+        plan.encode_indexed = timed(plan.encode_indexed, lambda t, a: a[0].numel())     # the overlapped path encodes in parts
+        plan.stream = timed(plan.stream, lambda t, a: t.shape[0], 1)                    # features: ONE persistent projector launch
+        plan.image_stream = timed(plan.image_stream, lambda t, a: t.shape[0], 2)        # one image: trunk + logits, ONE launch
+    for _ in range(max(warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    enc_events.clear()
+    if timings is not None:
+        timings.clear()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # the interpreter's cyclic garbage collector must not pick the timed region for a full collection: with the host
+    # several steps ahead of the GPU, a collection that ends up waiting on the device costs tens of milliseconds once
+    import gc
+    gc.collect()
+    gc.freeze()
+    fence()
+    t0 = time.perf_counter()
+    per_step = []
+    prof = None
+    if os.environ.get("IPSX_BENCH_DEBUG") == "2":
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        step()
+        per_step.append(time.perf_counter() - h0)
+    host_enqueue = time.perf_counter() - t0                     # the host's share: how long it took to ENQUEUE the steps
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
+    if os.environ.get("IPSX_BENCH_DEBUG") and rank == 0:
+        print("host ms per step:", " ".join("%.2f" % (1e3 * v) for v in per_step), file=sys.stderr)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    enc_ms = sum(a.elapsed_time(b) for a, b, _ in enc_events)
+    enc_patches = sum(n for _, _, n in enc_events)
+    n_launch = max(len(enc_events), 1)
+    achieved = enc_patches * FLOP_PER_PATCH[name] / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0       # (0: --no-kernel-events)
+    phases = ipsd.phase_ms(timings) if timings else None
+    # (more images than the fixture holds, --batch: its images are the first of the batch - the generator draws image by image)
+    par = parity(fixture, net.last_mem_idx[:B] if (world == 1 and batch > B) else net.last_mem_idx, images) if fixture else None
+
+    # SURVEY d-1's protocol - the line's `value`: every one of the K calls bracketed by a fence (barrier + device sync) in
+    # front and a device sync behind, the MAX over ranks of each call's time, the median over the K calls
+    lat = []
+    for _ in range(steps):
+        fence()
+        c0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - c0))
+    fence()
+    if world > 1:
+        t = torch.tensor(lat, dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lat = [float(v) for v in t.tolist()]
+    gc.unfreeze()
+    med_ms = statistics.median(lat)
+
+    if world > 1:                                               # every rank's verdict and phase times travel to rank 0
+        mine_rec = {"rank": rank, "patches_per_image": n_mine, "phases": phases,
+                    "indices_equal": par["indices_equal"] if par else None,
+                    "device_index": dev.index, "device": torch.cuda.get_device_name(dev)}
+        recs = [None] * world
+        dist.all_gather_object(recs, mine_rec)
+    kernel_name = hip.encoder_kernel_name(net._plan)
+    if streamed and streamed[0] == 2:
+        kernel_name = "fused_trunk_stream_kernel (the fused trunk + logits, four / two patches per pull, patches published as they complete)"
+    elif streamed:
+        kernel_name = "projector_stream_kernel (row moments + Linear + BatchNorm + ReLU + logits per tile, rows published as they complete)"
+    traffic, traffic_note = pmc_traffic(name, kernel_name, enc_patches, n_launch)
+    if not (args.precision == "fp32" and not args.dedup_blank and not args.lazy and world == 1 and batch == (1 if name == "b1" else B)):
+        traffic = None
+
+    out = None
+    if rank == 0:
+        patches_per_step = batch * n_total
+        per_patch_bytes = (conf.n_chan_in * (conf.patch_size[0] * conf.patch_size[1] if conf.is_image else 1) + conf.D) * 4
+        out = {
+            "metric": "patches scored/sec (no-grad IPS loop)",
+            "value": patches_per_step / (med_ms * 1e-3),
+            "unit": "patches/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": med_ms,
+            "higher_is_better": True,
+            "scaling": "weak" if (weak or world == 1) else "strong",
+            "vs_baseline": None,
+            "dtype": {"fp32": "f32", "fp32x3": "f32 as 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate",
+                      "bf16": "bf16 operands / f32 accumulate"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "%s, B=%d, M=%d, I=%d, n_token=%d, %s, eager%s"
+                                   % (LABEL[name] if not weak else "Megapixel-MNIST %d patches of 1x32x32 per image (2500 per GPU)" % n_total,
+                                      batch, conf.M, conf.I, conf.n_token,
+                                      "use_pos" if conf.use_pos else "no pos-enc",
+                                      "" if world == 1 else ", %d of the %d patches of every image per GPU" % (n_mine, n_total)),
+                       "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, ipsd.PARTS) if world > 1 else "single GPU",
+                       "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy),
+                       "patch_storage": args.storage},
+            "timing": "value = patches per call / median over the %d timed calls, each bracketed by barrier + device sync "
+                      "(SURVEY d-1; max over ranks per call); value_pipelined = the same %d calls enqueued back to back "
+                      "between two fences" % (steps, steps),
+            "value_pipelined": patches_per_step * steps / elapsed,
+            "ms_per_step_pipelined": 1e3 * elapsed / steps,
+            "ms_per_call_median_synced": med_ms,
+            "ms_per_call_min_synced": min(lat),
+            "host_enqueue_ms_per_step": 1e3 * host_enqueue / steps,
+            "parity": par,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": traffic_note,
+                         "algorithmic_bytes": enc_patches / n_launch * per_patch_bytes,
+                         "kernel": kernel_name,
+                         "launch_ms": enc_ms / n_launch,
+                         "patches_per_launch": enc_patches / n_launch},
+        }
+        if n_extra:
+            out["config"]["workload"] += " (slide 0 = the fixture's, the other %d drawn on the device: relu(N(0,1)))" % n_extra
+        if world > 1:
+            out["parity_all_ranks"] = all(r["indices_equal"] for r in recs) if par else None
+            out["per_rank"] = recs
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "devices": [r["device"] for r in recs], "one_gpu_per_rank": not share}
+        # the WHOLE call priced against the work it executes: encoder FLOP + the logits' folded-query contraction
+        # (2 * D * H * n_token per patch - the reference's per-iteration K projection is not executed here, DESIGN 5.3)
+        call_flop = FLOP_PER_PATCH[name] + 2 * conf.D * conf.H * conf.n_token
+        call_tflops = patches_per_step / (med_ms * 1e-3) * call_flop / 1e12
+        call_peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "fp32x3": BF16_MFMA_PEAK_TFLOPS / 6, "bf16": BF16_MFMA_PEAK_TFLOPS}[args.precision] * world
+        if args.dedup_blank:                        # the encoder skipped most patches: no meaningful FLOP rate
+            call_tflops = None
+        out["roofline_call"] = {"bound": "mfma", "achieved": call_tflops, "peak": call_peak, "unit": "TFLOP/s",
+                                "frac": call_tflops / call_peak if call_tflops is not None else None,
+                                "what": "patches/s of the whole ips() call (synced median) x executed FLOP per patch (encoder %d + logits %d)"
+                                        % (FLOP_PER_PATCH[name], 2 * conf.D * conf.H * conf.n_token),
+                                "algorithmic_bytes_per_step": patches_per_step * per_patch_bytes}
+        if args.precision == "bf16":    # priced against the dense bf16 MFMA peak
+            out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
+            out["roofline"]["frac"] = achieved / BF16_MFMA_PEAK_TFLOPS
+        if args.precision == "fp32x3":  # six bf16 products per fp32 product: the bf16 peak / 6 bounds the algorithmic rate
+            out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS / 6
+            out["roofline"]["frac"] = achieved / (BF16_MFMA_PEAK_TFLOPS / 6)
+            out["roofline"]["note"] = "algorithmic fp32 FLOP priced against dense bf16 peak / 6 (6 MFMA products per fp32 product)"
+        if args.no_kernel_events:
+            out["roofline"].update({"achieved": None, "frac": None, "traffic": None, "launch_ms": None,
+                                    "note": "--no-kernel-events: the encoder launches were not timed"})
+        elif args.dedup_blank:      # fewer patches are encoded than scored: an algorithmic FLOP rate would be wrong
+            out["roofline"].update({"achieved": None, "frac": None, "traffic": None,
+                                    "note": "blank-patch dedup: encoder ran on %d of %d patches per launch"
+                                            % (int(net._plan.n_encoded.item()), enc_patches // n_launch)})
+        if headline and world == 1 and name == "mnist" and args.precision == "fp32" and not (args.dedup_blank or args.lazy) and batch == B:
+            out["also_measured"] = {p: measure_precision(net, x, steps, p, fixture) for p in ("fp32x3", "bf16")}
+        if world == 1 and cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(conf, x_host, cpu_seconds)
+        out["host"] = host_description()
+    del net, x, x_host
+    torch.cuda.empty_cache()
+    return out
+
+
+def slim(rec):
+    """What an `also_measured` leg keeps of a full record."""
+    keep = ("value", "unit", "ms_per_step", "value_pipelined", "ms_per_step_pipelined", "steps", "warmup", "parity",
+            "roofline", "roofline_call", "host_enqueue_ms_per_step")
+    out = {k: rec[k] for k in keep if k in rec}
+    out["workload"] = rec["config"]["workload"]
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -277,9 +575,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ips_amd import hip, synth
-    from ips_amd import dist as ipsd
-    from ips_amd.architecture import IPSNet
+    from ips_amd import hip
 
     hip.lib()                                                   # fail loudly if the extension is missing
     if args.dedup_blank:
@@ -289,249 +585,17 @@ def main():
     if world > 1 and name not in ("mnist", "mnist3000"):
         print("secondary configs are single-GPU measurements", file=sys.stderr)
         sys.exit(2)
-    weak = world > 1 and args.scaling == "weak"
-    fixture, images = name, None
-    if name == "b1":
-        conf, B = synth.bench_workload("mnist")
-        fixture, images = "mnist", slice(0, 1)
-    else:
-        conf, B = synth.bench_workload(name)
-    if weak:                                                    # the image grows with the node; 4 GPUs = configs[2]
-        conf, B = synth.bench_workload("mnist")
-        conf = conf.clone(N=PATCHES_PER_GPU_WEAK * world)
-        fixture = "mnist3000" if conf.N == 10000 else None
-    batch = 1 if name == "b1" else (args.batch or B)
-    n_total = conf.N
-    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
-    x = synth.make_patches(conf, max(batch, B), seed=21)        # the fixture's batch; --batch may take a prefix of it
-    if name == "b1":
-        x = x[:1]
-    elif batch != x.shape[0]:
-        x, images = x[:batch], slice(0, batch)
-        if batch > B:
-            fixture = None
-    x_host = x
-    if world > 1:
-        mine = ipsd.local_indices(n_total, conf.M, conf.I, rank, world)
-        x = x[:, mine].contiguous()                             # this rank's shard of every image
-    n_mine = x.shape[1]
-    if args.storage != "f32":
-        if args.precision == "fp32":
-            print("--storage %s needs --precision bf16 or fp32x3" % args.storage, file=sys.stderr)
-            sys.exit(2)
-        x = x.to({"bf16": torch.bfloat16, "f16": torch.float16}[args.storage])
-    x = x.pin_memory() if args.lazy else x.to(dev)              # headline: resident in HBM before the timed region
-
-    timings = [] if world > 1 else None
-    if world == 1:
-        def step():
-            return net.ips(x)
-    else:
-        def step():
-            return ipsd.ips_sharded(net, x, n_total, timings=timings)
-
-    step()                                                      # builds the encoder plan
-    # time the encoder launches with HIP events on the stream they run on (installed BEFORE the warm-up so that the
-    # warm-up steps run exactly what the timed steps run, event creation included)
-    enc_events = []
-    plan_encode = net._plan.encode
-
-    def timed_encode(t, **kw):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = plan_encode(t, **kw)
-        b.record()
-        enc_events.append((a, b, t.shape[0]))
-        return out
-
-    if not args.no_kernel_events:
-        net._plan.encode = timed_encode
-    plan_encode_indexed = net._plan.encode_indexed
-
-    def timed_encode_indexed(flat, index):                      # the overlapped path encodes the image in parts
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = plan_encode_indexed(flat, index)
-        b.record()
-        enc_events.append((a, b, index.numel()))
-        return out
-
-    if not args.no_kernel_events:
-        net._plan.encode_indexed = timed_encode_indexed
-    plan_stream = net._plan.stream
-    streamed = []
-
-    def timed_stream(t, *a, **kw):                              # one slide of features: the projector as ONE persistent launch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = plan_stream(t, *a, **kw)
-        e1.record()
-        enc_events.append((e0, e1, t.shape[0]))
-        streamed.append(1)
-        return out
-
-    if not args.no_kernel_events:
-        net._plan.stream = timed_stream
-    plan_image_stream = net._plan.image_stream
-
-    def timed_image_stream(t, *a, **kw):                        # one image: trunk + logits as ONE persistent launch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = plan_image_stream(t, *a, **kw)
-        e1.record()
-        enc_events.append((e0, e1, t.shape[0]))
-        streamed.append(2)
-        return out
-
-    if not args.no_kernel_events:
-        net._plan.image_stream = timed_image_stream
-    for _ in range(max(args.warmup, 1)):
-        step()
-    torch.cuda.synchronize()
-    enc_events.clear()
-    if timings is not None:
-        timings.clear()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # the interpreter's cyclic garbage collector must not pick the timed region for a full collection: with the host
-    # several steps ahead of the GPU, a collection that ends up waiting on the device costs tens of milliseconds once
-    import gc
-    gc.collect()
-    gc.freeze()
-    fence()
-    t0 = time.perf_counter()
-    per_step = []
-    prof = None
-    if os.environ.get("IPSX_BENCH_DEBUG") == "2":
-        import cProfile
-        prof = cProfile.Profile()
-        prof.enable()
-    for _ in range(args.steps):
-        h0 = time.perf_counter()
-        step()
-        per_step.append(time.perf_counter() - h0)
-    host_enqueue = time.perf_counter() - t0                     # the host's share: how long it took to ENQUEUE the steps
-    if prof is not None:
-        import pstats
-        prof.disable()
-        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
-    if os.environ.get("IPSX_BENCH_DEBUG") and rank == 0:
-        print("host ms per step:", " ".join("%.2f" % (1e3 * v) for v in per_step), file=sys.stderr)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    enc_ms = sum(a.elapsed_time(b) for a, b, _ in enc_events)
-    enc_patches = sum(n for _, _, n in enc_events)
-    n_launch = max(len(enc_events), 1)
-    achieved = enc_patches * FLOP_PER_PATCH[name] / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0       # (0: --no-kernel-events)
-    phases = ipsd.phase_ms(timings) if timings else None
-    # (more images than the fixture holds, --batch: its images are the first of the batch - the generator draws image by image)
-    par = parity(fixture, net.last_mem_idx[:B] if (world == 1 and batch > B) else net.last_mem_idx, images) if fixture else None
-
-    # SURVEY d-1 protocol next to the throughput figure: device sync around every call, median
-    lat = []
-    for _ in range(args.steps):
-        fence()
-        c0 = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        lat.append(1e3 * (time.perf_counter() - c0))
-    fence()
-
-    if world > 1:                                               # every rank's verdict and phase times travel to rank 0
-        mine_rec = {"rank": rank, "patches_per_image": n_mine, "phases": phases,
-                    "indices_equal": par["indices_equal"] if par else None,
-                    "device_index": dev.index, "device": torch.cuda.get_device_name(dev)}
-        recs = [None] * world
-        dist.all_gather_object(recs, mine_rec)
-    kernel_name = hip.encoder_kernel_name(net._plan)
-    if streamed and streamed[0] == 2:
-        kernel_name = "fused_trunk_stream_kernel (the fused trunk + logits, four / two patches per pull, patches published as they complete)"
-    elif streamed:
-        kernel_name = "projector_stream_kernel (row moments + Linear + BatchNorm + ReLU + logits per tile, rows published as they complete)"
-    traffic, traffic_note = pmc_traffic(name, kernel_name, enc_patches, n_launch)
-    if not (args.precision == "fp32" and not args.dedup_blank and not args.lazy and world == 1 and batch == (1 if name == "b1" else B)):
-        traffic = None
-
+    ctx = Ctx(world, rank, dev, share)
+    out = measure(args, ctx, name, batch=args.batch, steps=args.steps, warmup=args.warmup, cpu_seconds=args.cpu_seconds, headline=True)
+    default_run = (world == 1 and args.config is None and args.batch is None and args.precision == "fp32"
+                   and args.storage == "f32" and not (args.dedup_blank or args.lazy or args.no_kernel_events))
+    if default_run and args.also != "none":
+        legs = [l for l in ALSO_LEGS if args.also == "all" or l[0] in args.also.split(",")]
+        for leg, cfg, b in legs:
+            rec = measure(args, ctx, cfg, batch=b, steps=min(args.steps, args.also_steps), warmup=min(args.warmup, 3),
+                          cpu_seconds=0.0, headline=False)
+            out.setdefault("also_measured", {})[leg] = slim(rec)
     if rank == 0:
-        patches_per_step = batch * n_total
-        per_patch_bytes = (conf.n_chan_in * (conf.patch_size[0] * conf.patch_size[1] if conf.is_image else 1) + conf.D) * 4
-        out = {
-            "metric": "patches scored/sec (no-grad IPS loop)",
-            "value": patches_per_step * args.steps / elapsed,
-            "unit": "patches/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak" if (weak or world == 1) else "strong",
-            "vs_baseline": None,
-            "dtype": {"fp32": "f32", "fp32x3": "f32 as 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate",
-                      "bf16": "bf16 operands / f32 accumulate"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": "%s, B=%d, M=%d, I=%d, n_token=%d, %s, eager%s"
-                                   % (LABEL[name] if not weak else "Megapixel-MNIST %d patches of 1x32x32 per image (2500 per GPU)" % n_total,
-                                      batch, conf.M, conf.I, conf.n_token,
-                                      "use_pos" if conf.use_pos else "no pos-enc",
-                                      "" if world == 1 else ", %d of the %d patches of every image per GPU" % (n_mine, n_total)),
-                       "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, ipsd.PARTS) if world > 1 else "single GPU",
-                       "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy),
-                       "patch_storage": args.storage},
-            "ms_per_call_median_synced": statistics.median(lat),
-            "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
-            "parity": par,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_unit": traffic_note,
-                         "algorithmic_bytes": enc_patches / n_launch * per_patch_bytes,
-                         "kernel": kernel_name,
-                         "launch_ms": enc_ms / n_launch,
-                         "patches_per_launch": enc_patches / n_launch},
-        }
-        if world > 1:
-            out["parity_all_ranks"] = all(r["indices_equal"] for r in recs) if par else None
-            out["per_rank"] = recs
-            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                                  "devices": [r["device"] for r in recs], "one_gpu_per_rank": not share}
-        # the WHOLE call priced against the work it executes: encoder FLOP + the logits' folded-query contraction
-        # (2 * D * H * n_token per patch - the reference's per-iteration K projection is not executed here)
-        call_flop = FLOP_PER_PATCH[name] + 2 * conf.D * conf.H * conf.n_token
-        call_tflops = patches_per_step * args.steps / elapsed * call_flop / 1e12
-        call_peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "fp32x3": BF16_MFMA_PEAK_TFLOPS / 6, "bf16": BF16_MFMA_PEAK_TFLOPS}[args.precision] * world
-        if args.dedup_blank:                        # the encoder skipped most patches: no meaningful FLOP rate
-            call_tflops = None
-        out["roofline_call"] = {"bound": "mfma", "achieved": call_tflops, "peak": call_peak, "unit": "TFLOP/s",
-                                "frac": call_tflops / call_peak if call_tflops is not None else None,
-                                "what": "patches/s of the whole ips() call x executed FLOP per patch (encoder %d + logits %d)"
-                                        % (FLOP_PER_PATCH[name], 2 * conf.D * conf.H * conf.n_token),
-                                "algorithmic_bytes_per_step": patches_per_step * per_patch_bytes}
-        if args.precision == "bf16":    # priced against the dense bf16 MFMA peak
-            out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
-            out["roofline"]["frac"] = achieved / BF16_MFMA_PEAK_TFLOPS
-        if args.precision == "fp32x3":  # six bf16 products per fp32 product: the bf16 peak / 6 bounds the algorithmic rate
-            out["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS / 6
-            out["roofline"]["frac"] = achieved / (BF16_MFMA_PEAK_TFLOPS / 6)
-            out["roofline"]["note"] = "algorithmic fp32 FLOP priced against dense bf16 peak / 6 (6 MFMA products per fp32 product)"
-        if args.no_kernel_events:
-            out["roofline"].update({"achieved": None, "frac": None, "traffic": None, "launch_ms": None,
-                                    "note": "--no-kernel-events: the encoder launches were not timed"})
-        elif args.dedup_blank:      # fewer patches are encoded than scored: an algorithmic FLOP rate would be wrong
-            out["roofline"].update({"achieved": None, "frac": None, "traffic": None,
-                                    "note": "blank-patch dedup: encoder ran on %d of %d patches per launch"
-                                            % (int(net._plan.n_encoded.item()), enc_patches // n_launch)})
-        if world == 1 and name == "mnist" and args.precision == "fp32" and not (args.dedup_blank or args.lazy) and batch == B:
-            out["also_measured"] = {p: measure_precision(net, x, args, p, fixture) for p in ("fp32x3", "bf16")}
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(conf, x_host, args.cpu_seconds)
-        out["host"] = host_description()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -37,7 +37,13 @@
 extern "C" {
 #endif
 
-#define IPSX_VERSION 100          /* 0.1.0 */
+/* ABI version = 100 * major + minor.  The MAJOR number changes whenever the signature or meaning of an exported
+ * function changes incompatibly or an export is removed (a caller built against another major must refuse to run:
+ * `ipsx_version() / 100 != IPSX_VERSION / 100`); the minor number counts compatible additions.
+ *   1.xx  rounds 1-2
+ *   2.00  round 3: ipsx_scan / ipsx_scan_range / ipsx_topm take (workspace, workspace_bytes) in front of `stream`,
+ *         ipsx_scan_persistent takes ready_per_image, ipsx_projector_stats_publish removed                          */
+#define IPSX_VERSION 200
 
 #define IPSX_OK            0
 #define IPSX_EINVAL       -1      /* bad argument / unsupported shape */

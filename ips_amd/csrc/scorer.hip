@@ -850,6 +850,7 @@ struct ScanArgs {
     int* status;           // persistent launch: set to 1 when the wait for `ready` timed out
     const int* cond;       // conditional launch (ipsx_scan_range_if): run only when (*cond & cond_mask) != 0, or nullptr
     int cond_mask;
+    int dbg;               // diagnostic (ipsx_dbg_scan_skip): phases of scan_r8_kernel left out, for timing only (results invalid)
 };
 
 // ipsx_scan_range_if: the recovery launch behind a persistent loop - every workgroup looks at the word the loop sets when
@@ -1492,6 +1493,417 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// scan_r8_kernel (round 4): the LDS-resident loop for R = 8 logits per candidate (8 heads, one token: the CAMELYON and
+// traffic-sign transformers), M a multiple of 64, M <= 256, I <= 256 - CAMELYON's M = I = 256 is 512 candidates.
+// Same buffers, same prologue / prefetch / gather and the SAME arithmetic as scan_fast_kernel (every sum in the contract's
+// order: bit-identical indices, scores and tie flags; tools/scan_compare.py holds the two against each other), but
+// organised around ONE THREAD PER CANDIDATE instead of one thread per (candidate, row) element:
+//   * wave w < 8 owns candidates 64 w .. 64 w + 63: a thread reads its candidate's 8 exponentials (stride 9 words: no
+//     bank conflicts), divides them by the 8 denominators, adds them in head order and forms the key - no transposition of
+//     the weights through LDS, no barrier between weights and head sums;
+//   * the row sums (contract order: lane j adds candidates j, j + 64, ..., xor butterfly) run on the helper waves 8..15,
+//     one row each, while the candidate threads' reads of their exponentials are in flight;
+//   * the memory candidates of a wave ARE a run of the ranking: wave-sorted in registers straight from the key registers
+//     (no staging of unsorted keys), while the chunk waves compact the candidates that reach the lowest memory score
+//     (typically 4-10 of 256) into an UNSORTED list S behind the runs;
+//   * ranking: a memory key's rank = its lane + 4-ary searches of the OTHER memory runs (all runs' probes of a round in
+//     flight) + the keys of S that are larger (broadcast reads); a survivor's rank = searches of all memory runs + S.
+//     Exact ties are found on the way (the key just above the insertion point of every search, the lane's run neighbour,
+//     equal scores in S) - a superset of scan_fast_kernel's "ties among the first M + 1 ranks", which is all the replay of
+//     torch.topk's order needs (it reproduces torch's result whether or not ties exist): no separate tie pass, no barrier
+//     for it.  More than R8_SMAX survivors (the first iterations of a scan): scan_fast_kernel's ranking of all keys;
+//   * the helper waves prepare the next chunk (rows, speculative exponentials, maxima) beside weights / sort / ranking.
+// Six workgroup barriers per iteration instead of nine.
+constexpr int R8_SMAX = 32;
+
+template <int NRUN>
+__device__ __forceinline__ int rank_in_runs_tie(const uint64_t* const (&base)[NRUN], uint64_t mine, bool& tie) {
+    int lo[NRUN];
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) lo[j] = 0;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 2) {
+        uint64_t p1[NRUN], p2[NRUN], p3[NRUN];
+#pragma unroll
+        for (int j = 0; j < NRUN; ++j) {
+            const uint64_t* q = base[j] + lo[j];
+            p1[j] = q[step - 1]; p2[j] = q[2 * step - 1]; p3[j] = q[3 * step - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < NRUN; ++j)
+            lo[j] += ((p1[j] > mine) ? step : 0) + ((p2[j] > mine) ? step : 0) + ((p3[j] > mine) ? step : 0);
+    }
+    // lo <= 63: the last probe decides the count; the key just above the insertion point (the last probe when it is larger,
+    // otherwise the one in front of it) is where an equal score from this run would sit
+    uint64_t last[NRUN], prev[NRUN];
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) { last[j] = base[j][lo[j]]; prev[j] = base[j][lo[j] > 0 ? lo[j] - 1 : 0]; }
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < NRUN; ++j) {
+        const bool gt = last[j] > mine;
+        const int c = lo[j] + (gt ? 1 : 0);
+        const uint64_t above = gt ? last[j] : prev[j];
+        tie = tie || (c > 0 && (uint32_t)(above >> 32) == (uint32_t)(mine >> 32));
+        rank += c;
+    }
+    return rank;
+}
+
+template <bool STAMP, bool PERSIST>
+__global__ __launch_bounds__(SCAN_NT) void scan_r8_kernel(ScanArgs a, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int R = 8, H = 8, ld = R + 1, log2R = 3, EPT = 4, LCH = 8, PF = 4;
+    constexpr int PF0 = 512, PFT = SCAN_NT - PF0;                // waves 8..15 prefetch: 512 threads x 4 >= 256 x 8 logits
+    if (!PERSIST && scan_skipped(a.cond, a.cond_mask)) return;
+    __builtin_amdgcn_s_setprio(3);
+    if (PERSIST) {
+        asm volatile("v_mov_b32 v127, 0" ::: "v127");               // (the whole register file of the compute unit: see scan_fast_kernel)
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    const int Lmax = a.m + a.i;
+    // (the LDS layout of scan_fast_kernel: scan_fast_plan sizes it)
+    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* keyB = keyA + a.n2;
+    int* candA = reinterpret_cast<int*>(keyB + a.n2);
+    int* candB = candA + Lmax;
+    uint32_t* pmax = reinterpret_cast<uint32_t*>(candB + Lmax + ((4 - ((2 * Lmax) & 3)) & 3));
+    uint32_t* wmin = pmax + 16 * R;
+    int* ccount = reinterpret_cast<int*>(wmin + 16);          // [0] survivors, [1] lowest memory score key, [2], [3] tie flag (by parity), [6] rows known
+    int* nanflag = ccount + 4;
+    uint32_t* prevk = reinterpret_cast<uint32_t*>(ccount + 8);
+    float* rden = reinterpret_cast<float*>(prevk + 2 * R);    // 16-byte aligned
+    float* xA = rden + R;
+    float* xB = xA + (size_t)Lmax * ld;
+    float* eA = xB + (size_t)Lmax * ld;
+    float* eB = eA + (size_t)Lmax * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float* lg = a.lg + (size_t)b * a.n * R;
+    const int r = tid & (R - 1), lrow0 = tid >> log2R;
+    constexpr int lstep = SCAN_NT >> log2R;
+    const int mr = a.m >> 6;                                   // memory runs = memory waves (1..4)
+
+    int* cand = candA;
+    int* cnew = candB;
+    float* xc = xA;
+    float* xn = xB;
+    float* ec = eA;
+    float* en = eB;
+    long long ready_known = 0;
+    uint32_t* const mkey = pmax;
+    uint32_t* const ckey = pmax + R;
+    if (tid < 2 * R) pmax[tid] = 0u;
+    lds_barrier();
+    SCAN_WAIT_ROWS(std::min<long long>(a.n, a.it0 * a.i + a.m + a.i));
+    {
+        uint32_t km = 0u;
+        for (int k = 0; k < EPT; ++k) {
+            const int l = lrow0 + k * lstep;
+            if (l < a.m) {
+                const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
+                const float v = scan_load<PERSIST>(lg + row * R + r);
+                xc[l * ld + r] = v;
+                km = max(km, max_key(v));
+            }
+        }
+        fold_row_max<R>(km, mkey, lane);
+    }
+    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
+    if (tid < 2) { nanflag[tid] = 0; ccount[2 + tid] = 0; }
+    const long long n_iter = a.it1 - a.it0;
+    const int pt = tid - PF0;                                  // < 0: this thread prefetches nothing
+    float pf[PF];
+    {
+        const long long lo = a.it0 * a.i + a.m;
+        const int cnt = n_iter > 0 ? (int)std::min<long long>(a.i, a.n - lo) : 0;
+        uint32_t kc = 0u;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {                    // first chunk: straight into its rows (I * R <= 2048 <= 1024 * PF)
+            const int e = tid + SCAN_NT * k;
+            if (e < cnt * R) {
+                const float v = scan_load<PERSIST>(lg + (size_t)lo * R + e);
+                xc[(a.m + (e >> log2R)) * ld + r] = v;
+                kc = max(kc, max_key(v));
+            }
+        }
+        fold_row_max<R>(kc, ckey, lane);
+        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
+        const long long lo1 = lo + a.i;
+        const int cnt1 = n_iter > 1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+        if (cnt1 > 0) SCAN_WAIT_ROWS(lo1 + cnt1);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int e = pt + PFT * k;
+            pf[k] = (pt >= 0 && e < cnt1 * R) ? scan_load<PERSIST>(lg + (size_t)lo1 * R + e) : 0.0f;
+        }
+    }
+    int tie = 0;
+    uint64_t* const sorted = keyB;
+    for (long long it = a.it0; it < a.it1; ++it) {
+        const long long lo = it * a.i + a.m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+        const int L = a.m + cnt;
+        const int par = (int)((it - a.it0) & 1);
+        // diagnostic (STAMP build): every wave's clock at 16 points of iterations 100..103 of image 0 (tools/scan_stamps.py camwaves)
+        unsigned long long* const wlog = (STAMP && b == 0 && it - a.it0 >= 100 && it - a.it0 < 104)
+                                             ? stamps + 8 * gridDim.x + 2048 + (it - a.it0 - 100) * 256 + wave * 16 : nullptr;
+#define WSTAMP(k_) do { if (STAMP && wlog != nullptr && lane == 0) wlog[k_] = __builtin_amdgcn_s_memtime(); } while (0)
+        WSTAMP(0);
+        lds_barrier();                                          // B0
+        WSTAMP(1);
+        FAST_STAMP(0);
+        // P1: row maxima from the two key words of the row (scan_fast_kernel)
+        if (tid == 0) { ccount[0] = 0; ccount[1] = -1; ccount[2 + (par ^ 1)] = 0; }
+        const uint32_t mk = max(mkey[r], ckey[r]);
+        const uint32_t mbits = as_u32(max_key_value(mk));
+        const float rowmax = as_float(mbits);
+        const bool changed = it == a.it0 || prevk[par * R + r] != mbits;
+        if (tid < R) prevk[(par ^ 1) * R + r] = mbits;
+        FAST_STAMP(1);
+        // P2: exp(x - max) of every row whose maximum moved (a column of L elements, one per thread)
+        {
+            unsigned long long moved = __ballot(changed) & ((1ull << R) - 1ull);
+            while (moved) {
+                const int rr = __ffsll((long long)moved) - 1;
+                moved &= moved - 1ull;
+                exp_column(xc + rr, ec + rr, L, ld, __shfl(rowmax, rr, 64));
+            }
+        }
+        WSTAMP(2);
+        lds_barrier();                                          // B1
+        WSTAMP(3);
+        if (tid < 2 * R) pmax[tid] = 0u;
+        FAST_STAMP(2);
+        // P3: the helper waves sum the rows (contract order) while the candidate threads fetch their 8 exponentials
+        const bool is_cand = tid < L;
+        float ev[R];
+        if (wave < 8) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) ev[q] = is_cand ? ec[tid * ld + q] : 0.0f;
+        } else if (a.dbg & 1) {
+            if (lane == 0) rden[wave - 8] = 1.0f;
+        } else {
+            const int r0 = wave - 8;
+            float v0[LCH];
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) {
+                const int i = lane + 64 * u;
+                v0[u] = i < L ? ec[i * ld + r0] : 0.0f;
+            }
+            float s0 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) s0 = s0 + v0[u];
+            s0 = wave_butterfly_sum(s0);
+            if (lane == 0) rden[r0] = s0;
+        }
+        WSTAMP(4);
+        lds_barrier();                                          // B2
+        WSTAMP(5);
+        FAST_STAMP(3);
+        uint64_t key = 0ull;
+        if (wave < 8) {
+            // weights e / den, heads added in ascending order, mean over the 8 heads (one token: the mean over tokens is the
+            // identity) - the operations of scan_fast_kernel's weight and score phases on this candidate
+            const float4 d0 = *reinterpret_cast<const float4*>(rden), d1 = *reinterpret_cast<const float4*>(rden + 4);
+            float w0 = ev[0], w1 = ev[1], w2 = ev[2], w3 = ev[3], w4 = ev[4], w5 = ev[5], w6 = ev[6], w7 = ev[7];
+            if (!(a.dbg & 2)) {
+                w0 = w0 / d0.x; w1 = w1 / d0.y; w2 = w2 / d0.z; w3 = w3 / d0.w;
+                w4 = w4 / d1.x; w5 = w5 / d1.y; w6 = w6 / d1.z; w7 = w7 / d1.w;
+            }
+            float sh = 0.0f;
+            sh = sh + w0; sh = sh + w1; sh = sh + w2; sh = sh + w3; sh = sh + w4; sh = sh + w5; sh = sh + w6; sh = sh + w7;
+            const float q = sh / (float)H;
+            if (is_cand) key = rank_key(q / 1.0f, (uint32_t)tid);
+            if (wave < mr) {                                     // lowest memory score of this wave -> the threshold
+                uint32_t lowest = (uint32_t)(key >> 32);
+                lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0xB1, 0xF, 0xF, false));
+                lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x4E, 0xF, 0xF, false));
+                lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x124, 0xF, 0xF, false));
+                lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x128, 0xF, 0xF, false));
+                lowest = min(lowest, lane_xor_u32<16>(lowest, lane));
+                lowest = min(lowest, lane_xor_u32<32>(lowest, lane));
+                if (lane == 0) atomicMin(reinterpret_cast<unsigned int*>(ccount + 1), lowest);
+            }
+        } else if (!(a.dbg & 32)) {
+            // prep of iteration it + 1 on the helper waves: its chunk into rows m.. of the SPARE buffers (dead since the last
+            // gather), exponentials under this iteration's maxima (right unless a maximum moves - checked bitwise next time)
+            const long long lo1 = lo + a.i;
+            const int cnt1 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+            uint32_t kc = 0u;
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int e = pt + PFT * k;
+                if (e < cnt1 * R) {
+                    const int row = a.m + (e >> log2R);
+                    xn[row * ld + r] = pf[k];
+                    en[row * ld + r] = det_expf_np(pf[k] - rowmax);
+                    kc = max(kc, max_key(pf[k]));
+                }
+            }
+            fold_row_max<R>(kc, ckey, lane);
+            for (int j = pt; j < cnt1; j += PFT) cnew[a.m + j] = (int)(lo1 + j);
+        }
+        WSTAMP(6);
+        lds_barrier();                                          // B4: the threshold is known
+        WSTAMP(7);
+        uint64_t mine = 0ull;
+        if (wave < mr) {
+            mine = (a.dbg & 4) ? key : wave_sort_desc(key, lane);   // this wave's memory candidates = one sorted run
+            keyA[wave * 64 + lane] = mine;
+        } else if (wave < 8) {
+            const uint32_t tau = (uint32_t)ccount[1];
+            const bool in = is_cand && (uint32_t)(key >> 32) >= tau;
+            const unsigned long long mask = __ballot(in);
+            if (mask != 0ull) {                                  // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(ccount, __popcll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (in) keyA[a.m + base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+            }
+        }
+        WSTAMP(8);
+        lds_barrier();                                          // B5: runs and survivors are in place
+        WSTAMP(9);
+        const int ks = ccount[0];
+        const int Lr = a.m + ks;
+        if (STAMP && tid == 0) tacc[7] += (unsigned long long)ks;
+        FAST_STAMP(4);
+        if (a.dbg & 8) {
+            if (wave < mr) sorted[tid] = mine;
+            lds_barrier();
+        } else if (ks <= R8_SMAX) {
+            bool hit = false, searching = false;
+            int rank = 0;
+            if (wave < mr) {
+                searching = true;
+                rank = lane;                                     // unique keys: the larger keys of the own run
+                const uint64_t below = keyA[wave * 64 + (lane < 63 ? lane + 1 : lane)];
+                int rr = 0;
+                if (mr == 4) {
+                    const uint64_t* const bs[3] = {keyA + ((wave + 1) & 3) * 64, keyA + ((wave + 2) & 3) * 64, keyA + ((wave + 3) & 3) * 64};
+                    rr = rank_in_runs_tie<3>(bs, mine, hit);
+                } else if (mr == 3) {
+                    const uint64_t* const bs[2] = {keyA + ((wave + 1) % 3) * 64, keyA + ((wave + 2) % 3) * 64};
+                    rr = rank_in_runs_tie<2>(bs, mine, hit);
+                } else if (mr == 2) {
+                    const uint64_t* const bs[1] = {keyA + (wave ^ 1) * 64};
+                    rr = rank_in_runs_tie<1>(bs, mine, hit);
+                }
+                rank += rr;
+                hit = hit || (lane < 63 && (uint32_t)(below >> 32) == (uint32_t)(mine >> 32));
+            } else if (wave == 8 && lane < ks) {
+                searching = true;
+                mine = keyA[a.m + lane];
+                if (mr == 4) {
+                    const uint64_t* const bs[4] = {keyA, keyA + 64, keyA + 128, keyA + 192};
+                    rank = rank_in_runs_tie<4>(bs, mine, hit);
+                } else if (mr == 3) {
+                    const uint64_t* const bs[3] = {keyA, keyA + 64, keyA + 128};
+                    rank = rank_in_runs_tie<3>(bs, mine, hit);
+                } else if (mr == 2) {
+                    const uint64_t* const bs[2] = {keyA, keyA + 64};
+                    rank = rank_in_runs_tie<2>(bs, mine, hit);
+                } else {
+                    const uint64_t* const bs[1] = {keyA};
+                    rank = rank_in_runs_tie<1>(bs, mine, hit);
+                }
+            }
+            if (wave < mr || wave == 8) {                        // the survivors: an unsorted list, read by everybody who ranks
+                for (int i = 0; i < ks; ++i) {                   // (workgroup-uniform trip count)
+                    const uint64_t s = keyA[a.m + i];
+                    rank += (s > mine) ? 1 : 0;
+                    hit = hit || ((uint32_t)(s >> 32) == (uint32_t)(mine >> 32) && s != mine);
+                }
+                if (searching) sorted[rank] = mine;
+                if (__ballot(searching && hit) != 0ull && lane == 0) ccount[2 + par] = 1;
+            }
+            WSTAMP(10);
+            lds_barrier();                                      // B7
+            WSTAMP(11);
+        } else {
+            // many survivors (the first iterations of a scan): the ranking of scan_fast_kernel over runs + survivors, then
+            // its pair check for ties among the first M + 1 ranks
+            rank_runs4(keyA, keyB, reinterpret_cast<uint64_t*>(en), Lr);
+            lds_barrier();
+            {
+                const int npair = a.m < Lr - 1 ? a.m : Lr - 1;
+                bool hit = false;
+                for (int j = tid; j < npair; j += SCAN_NT) hit = hit || (sorted[j] >> 32) == (sorted[j + 1] >> 32);
+                if (__ballot(hit) != 0ull && lane == 0) ccount[2 + par] = 1;
+            }
+            lds_barrier();
+        }
+        bool boundary_tie = Lr > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);
+        if (a.tie_order == 1 && ccount[2 + par] != 0) {
+            // torch.topk's order under ties depends on the WHOLE candidate array: every key back to its place, all L
+            // candidates ranked, the replay on them (rare)
+            if (is_cand) keyA[tid] = key;
+            lds_barrier();
+            if (L <= 192) {
+                int P = 1;
+                while (P < 64 && 2 * P * L <= SCAN_NT) P <<= 1;
+                rank_scatter(keyA, keyB, L, P);
+            } else {
+                rank_runs(keyA, keyB, reinterpret_cast<uint64_t*>(en), L);
+            }
+            lds_barrier();
+            boundary_tie = L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);
+            tie_order_slow(keyB, keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off));
+        }
+        FAST_STAMP(5);
+        {
+            const long long lo2 = lo + 2 * a.i;
+            const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
+            if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int e = pt + PFT * k;
+                pf[k] = (pt >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
+            }
+        }
+        WSTAMP(12);
+        // P6: new memory: indices, logit rows and exponentials of the winners, into the other buffers
+        for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j]) & 1023];
+        WSTAMP(13);
+        if (!(a.dbg & 16)) {
+            int src[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int j = lrow0 + k * lstep;
+                src[k] = j < a.m ? (int)key_pos(sorted[j]) * ld + r : 0;
+            }
+            float gx[EPT], ge[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) { gx[k] = xc[src[k]]; ge[k] = ec[src[k]]; }
+            uint32_t km = 0u;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int j = lrow0 + k * lstep;
+                if (j < a.m) { xn[j * ld + r] = gx[k]; en[j * ld + r] = ge[k]; km = max(km, max_key(gx[k])); }
+            }
+            fold_row_max<R>(km, mkey, lane);
+        }
+        if (tid == 0 && boundary_tie) tie = 1;
+        { int* t = cand; cand = cnew; cnew = t; }
+        { float* t = xc; xc = xn; xn = t; }
+        { float* t = ec; ec = en; en = t; }
+        WSTAMP(14);
+        FAST_STAMP(6);
+#undef WSTAMP
+    }
+    lds_barrier();
+    for (int j = tid; j < a.m; j += SCAN_NT) {
+        a.mem_idx[(size_t)b * a.m + j] = cand[j];
+        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
+    }
+    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
+    if (STAMP && tid == 0)
+        for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
+}
+
 // Transformer.get_scores on the logits (b, L, R) of arbitrary embeddings
 struct ScoresArgs {
     const float* lg;
@@ -2103,6 +2515,8 @@ struct FastPlan {
 };
 
 static bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
+static int g_scan_skip = 0;                // diagnostic (ipsx_dbg_scan_skip): phases of scan_r8_kernel left out (timing only)
+static bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the 8-row shapes through scan_fast_kernel
 
 static FastPlan scan_fast_plan(int m, int i, int h, int n_token) {
     FastPlan p = {false, 1, 2, 0};
@@ -2227,6 +2641,7 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     a.ready = ready; a.status = status; a.ready_stride = ready_stride;
     a.cond = cond; a.cond_mask = cond_mask;
+    a.dbg = g_scan_skip;
     a.tie_order = g_tie_order;
     a.use_lds = 1;
     a.stk_off = (int)(fp.lds - STK_BYTES);
@@ -2259,6 +2674,21 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         else if (ept == 4) IPSX_LAUNCH_FAST_C(RR, TT, 4);                                                           \
         else IPSX_LAUNCH_FAST_C(RR, TT, 8);                                                                         \
     } while (0)
+    if (g_scan_r8 && R == 8 && n_token == 1 && m % 64 == 0 && m <= 256 && i <= 256) {
+        // one thread per candidate (scan_r8_kernel): CAMELYON's M = I = 256 and every smaller shape of that transformer
+#define IPSX_LAUNCH_R8(S, P)                                                                                        \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_r8_kernel<S, P>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                           \
+        scan_r8_kernel<S, P><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st);                 \
+        return launched("scan");                                                                                    \
+    } while (0)
+        if (st && a.ready) IPSX_LAUNCH_R8(true, true);
+        if (st) IPSX_LAUNCH_R8(true, false);
+        if (a.ready) IPSX_LAUNCH_R8(false, true);
+        IPSX_LAUNCH_R8(false, false);
+#undef IPSX_LAUNCH_R8
+    }
     // the diagnostic (stamped) build exists for the two benchmark shapes
     if (st && a.ready && R == 8 && n_token == 1 && ept == 4 && lch == 8) {      // stamped persistent loop (diagnostic)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<8, 1, 4, 8, true, true>),
@@ -2352,3 +2782,12 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_stamps(unsi
 // Diagnostic entry point (not part of include/ipsx.h): nonzero sends every shape through the generic loop kernel
 // (scan_large_kernel) - tools/scan_compare.py holds the two loop kernels against each other this way.
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int on) { g_scan_generic = on != 0; }
+
+// Diagnostic entry point (not part of include/ipsx.h): 0 sends the shapes of scan_r8_kernel (8 logits per candidate, M a
+// multiple of 64, M, I <= 256) through scan_fast_kernel instead - tools/scan_compare.py and tools/scan_stamps.py use it.
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_r8(int on) { g_scan_r8 = on != 0; }
+
+// Diagnostic entry point (not part of include/ipsx.h): phases of scan_r8_kernel left out - 1 row sums, 2 divisions, 4 run
+// sort, 8 ranking, 16 gather, 32 next-chunk prep - to see what each costs inside the un-instrumented loop (the selection is
+// then meaningless; tools/scan_stamps.py cam-skip).
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_skip(int mask) { g_scan_skip = mask; }

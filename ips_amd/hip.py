@@ -21,6 +21,7 @@ _SO = os.path.join(_PKG, "lib", "libipsx.so")
 _LIB = None
 
 f32p = C.c_void_p  # device pointers travel as integers
+ABI_MAJOR = 2       # include/ipsx.h IPSX_VERSION / 100: the signatures in _EXPORTS below are those of this major version
 
 
 def backend():
@@ -264,9 +265,13 @@ def lib():
         for name, (res, args) in _EXPORTS.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        if L.ipsx_version() // 100 != 1:
-            raise RuntimeError("libipsx.so ABI version {} != 1.x".format(L.ipsx_version()))
+        if L.ipsx_version() // 100 != ABI_MAJOR:
+            raise RuntimeError("libipsx.so ABI version {} != {}.x (include/ipsx.h: the major number changes with every "
+                               "incompatible change of an exported signature)".format(L.ipsx_version(), ABI_MAJOR))
         L.ipsx_set_tie_order({"torch": 1, "canonical": 0}[tie_order()])
+        if os.environ.get("IPSX_SCAN_R8", "1") == "0":      # diagnostic: the 8-row loop shapes through scan_fast_kernel
+            L.ipsx_dbg_scan_r8.argtypes = [C.c_int]
+            L.ipsx_dbg_scan_r8(0)
         _LIB = L
     return _LIB
 

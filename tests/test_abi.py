@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.ipsx_version() // 100 == 1
+    assert lib.ipsx_version() // 100 == 2          # include/ipsx.h: major = incompatible signature changes
 
 
 def test_python_binding_covers_the_header():
@@ -60,7 +60,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
 int main(void) {
     ipsx_conv cv; ipsx_trunk tr; ipsx_transf tf;
     (void)cv; (void)tr; (void)tf;
-    if (ipsx_version() / 100 != 1) return 1;
+    if (ipsx_version() / 100 != IPSX_VERSION / 100) return 1;
     if (ipsx_packed_conv_weight_elems(64, 64, 3, 3) != (size_t)2 * 72 * 64 * 4) return 2;
     if (ipsx_patchify_count(1500, 1500, 32, 32, 32, 32) != 46 * 46) return 3;
     if (ipsx_patchify_count(10, 10, 32, 32, 32, 32) != 0) return 4;

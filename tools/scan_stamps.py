@@ -86,6 +86,62 @@ if kind == "large":
         print("  un-instrumented: %.3f ms per launch = %.1f us per iteration" % (a.elapsed_time(b) / 10, 1e2 * a.elapsed_time(b) / n_iter))
     hip.set_tie_order("torch")
     sys.exit(0)
+if kind == "camwaves":
+    # every wave's clock at the barriers of iterations 100..103 (STAMP build of scan_r8_kernel): who arrives last where
+    import numpy as np
+    dev = torch.device("cuda:0")
+    B, N, M, I, H, T = 1, 65536, 256, 256, 8, 1
+    g = torch.Generator(device="cpu").manual_seed(0)
+    lg = (torch.randn((B, N, H * T), generator=g) * 3).to(dev)
+    L = hip.lib()
+    L.ipsx_dbg_scan_stamps.argtypes = [C.c_void_p]
+    st = torch.zeros((B * 8 + 2048 + 4 * 256,), dtype=torch.int64, device=dev)
+    hip.scan(lg, M, I, H, T)
+    L.ipsx_dbg_scan_stamps(st.data_ptr())
+    hip.scan(lg, M, I, H, T)
+    torch.cuda.synchronize()
+    L.ipsx_dbg_scan_stamps(None)
+    w = st.cpu().numpy()[B * 8 + 2048:].reshape(4, 16, 16)
+    pts = ["top", "B0>", ">B1", "B1>", ">B2", "B2>", ">B4", "B4>", ">B5", "B5>", ">B7", "B7>", "loads", "cnew", "end"]
+    for it in (1, 2):
+        t0 = w[it, :, 0].min()
+        print("iteration %d: cycles since the first wave reached the top (rows: waves 0-3 memory, 4-7 chunk, 8-15 helpers)" % (100 + it))
+        print("      " + " ".join("%6s" % p for p in pts))
+        for wv in range(16):
+            print("  w%-2d " % wv + " ".join("%6d" % (w[it, wv, k] - t0) for k in range(15)))
+        nxt = w[it + 1, :, 0].min() - t0
+        print("  next iteration's first wave at the top: %d cycles" % nxt)
+    sys.exit(0)
+if kind == "camskip":
+    # what each phase of scan_r8_kernel costs INSIDE the un-instrumented loop: the kernel timed with phases left out
+    # (ipsx_dbg_scan_skip; canonical tie order so that the meaningless selections trigger no tie replay)
+    dev = torch.device("cuda:0")
+    B, N, M, I, H, T = 1, 65536, 256, 256, 8, 1
+    g = torch.Generator(device="cpu").manual_seed(0)
+    lg = (torch.randn((B, N, H * T), generator=g) * 3).to(dev)
+    L = hip.lib()
+    L.ipsx_dbg_scan_skip.argtypes = [C.c_int]
+    hip.set_tie_order("canonical")
+    n_iter = -(-(N - M) // I)
+    names = {0: "everything", 1: "- row sums", 2: "- divisions", 4: "- run sort", 8: "- ranking", 16: "- gather", 32: "- next-chunk prep",
+             12: "- sort, ranking", 28: "- sort, ranking, gather", 31: "- all but the prep", 63: "- all six"}
+    base = None
+    for mask, nme in names.items():
+        L.ipsx_dbg_scan_skip(mask)
+        for _ in range(3):
+            hip.scan(lg, M, I, H, T)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            hip.scan(lg, M, I, H, T)
+        b.record()
+        torch.cuda.synchronize()
+        us = 1e2 * a.elapsed_time(b) / n_iter
+        base = us if base is None else base
+        print("  %-28s %6.3f us per iteration  (%+.3f)" % (nme, us, us - base))
+    L.ipsx_dbg_scan_skip(0)
+    hip.set_tie_order("torch")
+    sys.exit(0)
 B, N, M, I, H, T = (16, 2500, 64, 64, 8, 4) if kind == "mnist" else (1, 65536, 256, 256, 8, 1)
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
