@@ -508,7 +508,11 @@ class IPSNet(nn.Module):
         side.wait_stream(main)                     # the buffers above are the main stream's; previous readers are done
         with torch.cuda.stream(side):
             hip.scan_persistent(logits, M, I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status)
-        hip.scan_gate(status)                      # the projector must not take the compute units before a loop has its own
+        # the projector must not take the compute units before a loop has its own.  (Also true of the persistent stream,
+        # whose workgroups sit one to a unit and leave a unit per loop free: a workgroup is dealt to an XCD before it looks
+        # for a unit there, so a loop that arrives second may be dealt to a FULL XCD and start when the stream ends - measured
+        # without the gate: 31 M patches/s with calls back to back against 43 M.)
+        hip.scan_gate(status)
         self._plan._refresh()
         fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)
         # The launches: (first row, end row) in the FLAT (B * N) row space + what each makes visible, [(slide, rows)].  One
@@ -523,12 +527,15 @@ class IPSNet(nn.Module):
                   and (B == 1 or N % 32 == 0) and self._plan.stream_supported(B * N, R))
         if stream:
             # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
-            # late).  A slide alone is as long as its loop, which consumes rows as fast as they are made: every tile 32 rows
-            # - a steady supply without bursts, first rows after half a tile time - on all but 8 units (measured, M patches/s:
-            # 64-row tiles on 224 units 35.7, 32-row tiles on 224 / 240 / 248 / 252 units 37.3 / 37.9 / 37.6-38.2 / 38.2)
+            # late).  Round 4 (the loop at 3.7 us per iteration is no longer the bound - the projector is): 64-row tiles at full
+            # rate, the first rows of a lone slide from half the workgroups' short first tiles, and the last two rounds
+            # handed out as 32-row tiles so that the launch ends evenly (short_first = -20: measured, M patches/s per
+            # slide, synced: all tiles 32 rows on 248 / 255 units 39.3 / 39.9, this on 248 / 255 units 41.1 / 41.5)
             free = torch.cuda.get_device_properties(dev).multi_processor_count - B
+            wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
+            short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-20 if B == 1 else -1)
             self._plan.stream(patches.view(B * N, -1), vq, R, emb_buf.view(B * N, -1), logits.view(B * N, R), ctl, ready,
-                              workgroups=free - 7 if B == 1 else free, slide_rows=N, short_first=-2 if B == 1 else -1)
+                              workgroups=wgs, slide_rows=N, short_first=short)
             for b_ in range(B):                    # (whatever the last finishers left to each other; the launch is over)
                 hip.publish_rows(ready[b_:b_ + 1], N)
             launches = []

@@ -276,6 +276,7 @@ struct StreamArgs {
     unsigned slide_rows;           // rows per slide: ready[s] = rows of slide s published
     unsigned short_first;
     int short_pulls;               // every workgroup's first short_pulls pulls are one unit
+    unsigned tail_start;           // units from here on are handed out one at a time (the launch ends evenly)
     int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
     int* ready;                    // rows published, per slide (ipsx_scan_persistent's progress words)
     unsigned long long* stamps;    // diagnostic (ipsx_dbg_projector_stream_stamps): cycles per phase, summed by workgroup 0
@@ -462,12 +463,18 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
     bool first = true;
     int pulls = 0;
     for (;;) {
-        const int take = ((first && blockIdx.x < (a.short_first & 0x7fffffffu)) || pulls < a.short_pulls) ? 1 : 2;
+        if (threadIdx.x == 0) {
+            // (the look at the counter may be a pull or two behind: it only decides the SIZE of this pull)
+            const bool tail = (unsigned)__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.tail_start;
+            const int take = ((first && blockIdx.x < (a.short_first & 0x7fffffffu)) || pulls < a.short_pulls || tail) ? 1 : 2;
+            s_u0[1] = take;
+            s_u0[0] = atomicAdd(&a.ctl[0], take);
+        }
         first = false;
         ++pulls;
-        if (threadIdx.x == 0) *s_u0 = atomicAdd(&a.ctl[0], take);
         __syncthreads();
-        const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane(*s_u0);
+        const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane(s_u0[0]);
+        const int take = __builtin_amdgcn_readfirstlane(s_u0[1]);
         if (u0 >= a.n_units) break;                                 // workgroup-uniform
         const int units = (take == 2 && u0 + 1 < a.n_units) ? 2 : 1;
         if (units == 2) stream_tile<2, STAMP>(a, u0 * 32u, tile, s_stats);
@@ -692,6 +699,16 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     const int wgs = workgroups > 0 ? workgroups : cus / 8 * 7;
     a.short_first = (unsigned)(short_first >= 0 ? short_first : wgs / 2);
     a.short_pulls = short_first == -2 ? 0x7fffffff : 0;                            // (-2: every tile 32 rows)
+    a.tail_start = a.n_units;
+    if (short_first <= -3) {
+        // -3 - (head + 8 tail): every workgroup's first `head` pulls and the last `tail` x workgroups units are 32-row tiles -
+        // early first rows, full-rate 64-row tiles in the middle, and an end without a last round that most units sit out
+        const int k = -short_first - 3, head = k & 7, tail = k >> 3;
+        a.short_pulls = head;
+        if (head > 0) a.short_first = 0;
+        const long long ts = (long long)a.n_units - (long long)tail * wgs;
+        a.tail_start = (unsigned)(ts > 0 ? ts : 0);
+    }
 
     static bool attr = false;
     if (!attr) {

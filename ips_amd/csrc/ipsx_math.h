@@ -78,7 +78,7 @@ __device__ __forceinline__ float det_expf_np(float x) {
 // key, every NaN -> 0xFFFFFFFF (a NaN wins, as in nanmax); 0 is below every float (the neutral element)
 __device__ __forceinline__ uint32_t max_key(float x) {
     const uint32_t u = as_u32(x);
-    const uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    const uint32_t k = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);      // negative: ~u, else u | sign bit - no compare
     return x != x ? 0xFFFFFFFFu : k;
 }
 

@@ -850,7 +850,6 @@ struct ScanArgs {
     int* status;           // persistent launch: set to 1 when the wait for `ready` timed out
     const int* cond;       // conditional launch (ipsx_scan_range_if): run only when (*cond & cond_mask) != 0, or nullptr
     int cond_mask;
-    int dbg;               // diagnostic (ipsx_dbg_scan_skip): phases of scan_r8_kernel left out, for timing only (results invalid)
 };
 
 // ipsx_scan_range_if: the recovery launch behind a persistent loop - every workgroup looks at the word the loop sets when
@@ -1093,6 +1092,11 @@ __device__ __forceinline__ void fold_row_max(uint32_t key, uint32_t* dst, int la
 // the minority of iterations, and inlined its registers are the loop's (the same lesson as tie_order_slow)
 __device__ __attribute__((noinline)) void exp_column(const float* xcol, float* ecol, int L, int ld, float mx) {
     for (int l = threadIdx.x; l < L; l += blockDim.x) ecol[l * ld] = det_expf_np(xcol[l * ld] - mx);
+}
+
+// ... by the threads t0, t0 + nt, ... of a part of the workgroup
+__device__ __attribute__((noinline)) void exp_column_part(const float* xcol, float* ecol, int L, int ld, float mx, int t0, int nt) {
+    for (int l = t0; l < L; l += nt) ecol[l * ld] = det_expf_np(xcol[l * ld] - mx);
 }
 
 template <bool PERSIST>
@@ -1494,68 +1498,112 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// scan_r8_kernel (round 4): the LDS-resident loop for R = 8 logits per candidate (8 heads, one token: the CAMELYON and
-// traffic-sign transformers), M a multiple of 64, M <= 256, I <= 256 - CAMELYON's M = I = 256 is 512 candidates.
-// Same buffers, same prologue / prefetch / gather and the SAME arithmetic as scan_fast_kernel (every sum in the contract's
-// order: bit-identical indices, scores and tie flags; tools/scan_compare.py holds the two against each other), but
-// organised around ONE THREAD PER CANDIDATE instead of one thread per (candidate, row) element:
-//   * wave w < 8 owns candidates 64 w .. 64 w + 63: a thread reads its candidate's 8 exponentials (stride 9 words: no
-//     bank conflicts), divides them by the 8 denominators, adds them in head order and forms the key - no transposition of
-//     the weights through LDS, no barrier between weights and head sums;
-//   * the row sums (contract order: lane j adds candidates j, j + 64, ..., xor butterfly) run on the helper waves 8..15,
-//     one row each, while the candidate threads' reads of their exponentials are in flight;
-//   * the memory candidates of a wave ARE a run of the ranking: wave-sorted in registers straight from the key registers
-//     (no staging of unsorted keys), while the chunk waves compact the candidates that reach the lowest memory score
-//     (typically 4-10 of 256) into an UNSORTED list S behind the runs;
-//   * ranking: a memory key's rank = its lane + 4-ary searches of the OTHER memory runs (all runs' probes of a round in
-//     flight) + the keys of S that are larger (broadcast reads); a survivor's rank = searches of all memory runs + S.
-//     Exact ties are found on the way (the key just above the insertion point of every search, the lane's run neighbour,
-//     equal scores in S) - a superset of scan_fast_kernel's "ties among the first M + 1 ranks", which is all the replay of
-//     torch.topk's order needs (it reproduces torch's result whether or not ties exist): no separate tie pass, no barrier
-//     for it.  More than R8_SMAX survivors (the first iterations of a scan): scan_fast_kernel's ranking of all keys;
-//   * the helper waves prepare the next chunk (rows, speculative exponentials, maxima) beside weights / sort / ranking.
-// Six workgroup barriers per iteration instead of nine.
-constexpr int R8_SMAX = 32;
+// scan_cam_kernel (round 4): the LDS-resident loop SPECIALISED for BASELINE configs[3] - 8 logits per candidate (8 heads, one
+// token), M = I = 256: 512 candidates.  The same arithmetic as scan_fast_kernel, every sum in the contract's order:
+// bit-identical indices, scores and tie flags (tools/scan_compare.py holds the two against each other and against the
+// generic kernel).
+//
+// What shapes it (rocprofv3 counters of the loop alone and every wave's clock at every barrier, tools/scan_stamps.py
+// camwaves / tools/pmc_scan.sh; profiles/r04_scan_*.txt): on its ONE compute unit scan_fast_kernel is bound by instruction
+// ISSUE - 11.1 k wave-instructions (6.6 k vector, 3.7 k scalar, 0.8 k LDS) in the 11.1 k cycles of an iteration, i.e. one
+// instruction per SIMD every four cycles whatever its kind; with half the waves (8) the same work is 8.3 k instructions in
+// 11.6 k cycles - then a wave's own dependent-issue and LDS latency binds.  So the loop keeps 16 waves and sheds
+// INSTRUCTIONS:
+//   * every size is a compile-time constant: LDS addresses are immediates, no loop or address arithmetic on runtime M / I,
+//     no scalar registers spilled to vector lanes (scan_fast_kernel: 135 spills, ~500 v_readlane / v_writelane);
+//   * one THREAD per candidate on waves 0..7: its 8 exponentials with two 16-byte reads (rows of 12 words: conflict-free),
+//     8 divisions, the head sum and the key - no transposition of the weights through LDS; wave w also sums row w
+//     (contract order) right in front; waves 8..15 prepare the next chunk (logits, speculative exponentials, maxima);
+//   * ranking on the 32-bit SCORE keys: without exact ties the scores alone order the candidates; a tie anywhere among the
+//     ranked candidates sends the iteration through the 64-bit ranking and the replay of torch.topk's order (a superset of
+//     "ties among the first M + 1 ranks": the replay reproduces torch's result either way);
+//   * a memory wave sorts its 64 scores WITHOUT payload - v_med3_u32 against all-ones / zero picks max or min: 3
+//     instructions and no lane-mask registers per stage - into a run that is only a search structure;
+//   * chunk candidates at or above the lowest memory score (typically 4-10 of 256) are compacted into an unsorted list S;
+//   * every (memory key, run) pair is ONE 4-ary search of 11 reads on its own thread (4 x 256 = all 1,024 threads);
+//     survivors' pairs are a second pass on the first waves; counts against S ride on the run-0 threads; the partial
+//     counts meet in LDS, the key's owner adds them and places its 64-bit key.  More than CAM_SMAX survivors (the first
+//     iterations of a scan): scan_fast_kernel's ranking of all keys;
+//   * the gather moves the exponentials 16 bytes at a time (waves 8..15) beside the logits (waves 0..7, which fold the new
+//     memory's row maxima).
+namespace cam {
+constexpr int M = 256, I = 256, L = 512, R = 8, H = 8, LD = 12, NT = 1024, SMAX = 32, PRW = M + SMAX;
+constexpr int OFF_SORTED = 0;                        // u64[L]: the ranked keys
+constexpr int OFF_KEYA = OFF_SORTED + L * 8;         // u64[L]: survivors' keys at [M..], every key by position on the tie path
+constexpr int OFF_CAND = OFF_KEYA + L * 8;           // int[2][L]: patch index of every candidate (two sets)
+constexpr int OFF_PMAX = OFF_CAND + 2 * L * 4;       // u32[2][2 R]: row-maximum keys, [memory R | chunk R], by parity
+constexpr int OFF_CNT = OFF_PMAX + 4 * R * 4;        // int[8]: see ccount below
+constexpr int OFF_DEN = OFF_CNT + 32;                // float[R], 16-byte aligned
+constexpr int OFF_PREV = OFF_DEN + R * 4;            // u32[2][R]: bits of the previous row maxima, by parity
+constexpr int OFF_RUNS = OFF_PREV + 2 * R * 4;       // u32[4][64]: the memory waves' sorted scores
+constexpr int OFF_SC = OFF_RUNS + M * 4;             // u32[M]: score key of memory candidate l
+constexpr int OFF_PR = OFF_SC + M * 4;               // int[4][PRW]: partial counts
+constexpr int OFF_X = (OFF_PR + 4 * PRW * 4 + 15) & ~15;     // float[2][L][LD]: logits
+constexpr int OFF_E = OFF_X + 2 * L * LD * 4;        // float[2][L][LD]: exponentials
+constexpr int OFF_STK = OFF_E + 2 * L * LD * 4;      // scratch of the tie replay
+constexpr int LDS_BYTES = OFF_STK + STK_BYTES;
+static_assert(OFF_DEN % 16 == 0 && OFF_X % 16 == 0 && (LD * 4) % 16 == 0, "16-byte rows");
+static_assert(M * 4 + M * 4 + 4 * PRW * 4 >= L * 8, "the ranking scratch doubles as rank_runs' run buffer");
+}  // namespace cam
 
-template <int NRUN>
-__device__ __forceinline__ int rank_in_runs_tie(const uint64_t* const (&base)[NRUN], uint64_t mine, bool& tie) {
-    int lo[NRUN];
+// descending bitonic sort of one 32-bit key per lane, the direction of every stage from one bit of `dir` (bit n set: this
+// lane keeps the LARGER key in stage n): median(s, partner, all-ones | 0) = max | min.  Duplicates are kept.
+template <int N, int J>
+__device__ __forceinline__ uint32_t cmpx32(uint32_t s, uint32_t dir, int lane) {
+    const uint32_t o = lane_xor_u32<J>(s, lane);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_sbfe((int)dir, N, 1);       // v_bfe_i32: 0 or 0xFFFFFFFF
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(s), "v"(o), "v"(c));
+    return d;
+}
+
+// bit n of the result: lane keeps the larger key in stage n of wave_sort_desc_u32 (stage (K, J): ((lane & K) == 0) == ((lane & J) == 0))
+__device__ __forceinline__ uint32_t sort_directions(int lane) {
+    constexpr int KJ[21][2] = {{2, 1}, {4, 2}, {4, 1}, {8, 4}, {8, 2}, {8, 1}, {16, 8}, {16, 4}, {16, 2}, {16, 1}, {32, 16}, {32, 8},
+                               {32, 4}, {32, 2}, {32, 1}, {64, 32}, {64, 16}, {64, 8}, {64, 4}, {64, 2}, {64, 1}};
+    uint32_t d = 0u;
 #pragma unroll
-    for (int j = 0; j < NRUN; ++j) lo[j] = 0;
+    for (int n = 0; n < 21; ++n) d |= ((((lane & KJ[n][0]) == 0) == ((lane & KJ[n][1]) == 0)) ? 1u : 0u) << n;
+    return d;
+}
+
+__device__ __forceinline__ uint32_t wave_sort_desc_u32(uint32_t s, uint32_t dir, int lane) {
+    s = cmpx32<0, 1>(s, dir, lane);
+    s = cmpx32<1, 2>(s, dir, lane); s = cmpx32<2, 1>(s, dir, lane);
+    s = cmpx32<3, 4>(s, dir, lane); s = cmpx32<4, 2>(s, dir, lane); s = cmpx32<5, 1>(s, dir, lane);
+    s = cmpx32<6, 8>(s, dir, lane); s = cmpx32<7, 4>(s, dir, lane); s = cmpx32<8, 2>(s, dir, lane); s = cmpx32<9, 1>(s, dir, lane);
+    s = cmpx32<10, 16>(s, dir, lane); s = cmpx32<11, 8>(s, dir, lane); s = cmpx32<12, 4>(s, dir, lane); s = cmpx32<13, 2>(s, dir, lane);
+    s = cmpx32<14, 1>(s, dir, lane);
+    s = cmpx32<15, 32>(s, dir, lane); s = cmpx32<16, 16>(s, dir, lane); s = cmpx32<17, 8>(s, dir, lane); s = cmpx32<18, 4>(s, dir, lane);
+    s = cmpx32<19, 2>(s, dir, lane); s = cmpx32<20, 1>(s, dir, lane);
+    return s;
+}
+
+// Score keys of this loop are images of non-negative floats or NaN (means of softmax weights): bit 31 is always set, two
+// keys differ by less than 2^31, so "p > m" is the sign bit of m - p - comparisons without the condition-code register
+// (on gfx950 a VALU write of VCC costs the next VALU reader two wait states) and without selects.
+__device__ __forceinline__ uint32_t key_gt(uint32_t p, uint32_t m) { return (m - p) >> 31; }
+
+// number of keys of a descending run of 64 that are larger than m (4-ary search: 3 + 3 + 3 + 2 reads).  `eq` collects, as a
+// running minimum of xors, whether a key EQUAL to m sits at the insertion point (0 = yes): an exact tie when the run is not
+// the key's own; `own` (all-ones for the key's own run, else 0) masks that test.
+__device__ __forceinline__ int search_run_u32(const uint32_t* run, uint32_t m, uint32_t own, uint32_t& eq) {
+    uint32_t lo = 0;
 #pragma unroll
     for (int step = 16; step >= 1; step >>= 2) {
-        uint64_t p1[NRUN], p2[NRUN], p3[NRUN];
-#pragma unroll
-        for (int j = 0; j < NRUN; ++j) {
-            const uint64_t* q = base[j] + lo[j];
-            p1[j] = q[step - 1]; p2[j] = q[2 * step - 1]; p3[j] = q[3 * step - 1];
-        }
-#pragma unroll
-        for (int j = 0; j < NRUN; ++j)
-            lo[j] += ((p1[j] > mine) ? step : 0) + ((p2[j] > mine) ? step : 0) + ((p3[j] > mine) ? step : 0);
+        const uint32_t p1 = run[lo + step - 1], p2 = run[lo + 2 * step - 1], p3 = run[lo + 3 * step - 1];
+        lo += (key_gt(p1, m) + key_gt(p2, m) + key_gt(p3, m)) * step;
     }
-    // lo <= 63: the last probe decides the count; the key just above the insertion point (the last probe when it is larger,
-    // otherwise the one in front of it) is where an equal score from this run would sit
-    uint64_t last[NRUN], prev[NRUN];
-#pragma unroll
-    for (int j = 0; j < NRUN; ++j) { last[j] = base[j][lo[j]]; prev[j] = base[j][lo[j] > 0 ? lo[j] - 1 : 0]; }
-    int rank = 0;
-#pragma unroll
-    for (int j = 0; j < NRUN; ++j) {
-        const bool gt = last[j] > mine;
-        const int c = lo[j] + (gt ? 1 : 0);
-        const uint64_t above = gt ? last[j] : prev[j];
-        tie = tie || (c > 0 && (uint32_t)(above >> 32) == (uint32_t)(mine >> 32));
-        rank += c;
-    }
-    return rank;
+    const uint32_t last = run[lo], nxt = run[lo < 63 ? lo + 1 : 63];      // lo <= 63
+    // an equal key in the run is `last` (then it is not larger) or the one behind a larger `last`
+    eq = min(eq, min((last ^ m) | own, (nxt ^ m) | own));
+    return (int)(lo + key_gt(last, m));
 }
 
 template <bool STAMP, bool PERSIST>
-__global__ __launch_bounds__(SCAN_NT) void scan_r8_kernel(ScanArgs a, unsigned long long* stamps) {
+__global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned long long* stamps) {
+    using namespace cam;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int R = 8, H = 8, ld = R + 1, log2R = 3, EPT = 4, LCH = 8, PF = 4;
-    constexpr int PF0 = 512, PFT = SCAN_NT - PF0;                // waves 8..15 prefetch: 512 threads x 4 >= 256 x 8 logits
     if (!PERSIST && scan_skipped(a.cond, a.cond_mask)) return;
     __builtin_amdgcn_s_setprio(3);
     if (PERSIST) {
@@ -1563,141 +1611,150 @@ __global__ __launch_bounds__(SCAN_NT) void scan_r8_kernel(ScanArgs a, unsigned l
         if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-    const int Lmax = a.m + a.i;
-    // (the LDS layout of scan_fast_kernel: scan_fast_plan sizes it)
-    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* keyB = keyA + a.n2;
-    int* candA = reinterpret_cast<int*>(keyB + a.n2);
-    int* candB = candA + Lmax;
-    uint32_t* pmax = reinterpret_cast<uint32_t*>(candB + Lmax + ((4 - ((2 * Lmax) & 3)) & 3));
-    uint32_t* wmin = pmax + 16 * R;
-    int* ccount = reinterpret_cast<int*>(wmin + 16);          // [0] survivors, [1] lowest memory score key, [2], [3] tie flag (by parity), [6] rows known
-    int* nanflag = ccount + 4;
-    uint32_t* prevk = reinterpret_cast<uint32_t*>(ccount + 8);
-    float* rden = reinterpret_cast<float*>(prevk + 2 * R);    // 16-byte aligned
-    float* xA = rden + R;
-    float* xB = xA + (size_t)Lmax * ld;
-    float* eA = xB + (size_t)Lmax * ld;
-    float* eB = eA + (size_t)Lmax * ld;
+    uint64_t* const sorted = reinterpret_cast<uint64_t*>(smem + OFF_SORTED);
+    uint64_t* const keyA = reinterpret_cast<uint64_t*>(smem + OFF_KEYA);
+    uint32_t* const pmax = reinterpret_cast<uint32_t*>(smem + OFF_PMAX);
+    int* const ccount = reinterpret_cast<int*>(smem + OFF_CNT);   // [0] survivors, [1] lowest memory score key, [2], [3] tie flag (by parity), [6] rows known, [7] replay
+    float* const rden = reinterpret_cast<float*>(smem + OFF_DEN);
+    uint32_t* const prevk = reinterpret_cast<uint32_t*>(smem + OFF_PREV);
+    uint32_t* const runs32 = reinterpret_cast<uint32_t*>(smem + OFF_RUNS);
+    uint32_t* const sc32 = reinterpret_cast<uint32_t*>(smem + OFF_SC);
+    int* const pr = reinterpret_cast<int*>(smem + OFF_PR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const float* lg = a.lg + (size_t)b * a.n * R;
-    const int r = tid & (R - 1), lrow0 = tid >> log2R;
-    constexpr int lstep = SCAN_NT >> log2R;
-    const int mr = a.m >> 6;                                   // memory runs = memory waves (1..4)
+    const int r = tid & (R - 1);
+    const int hid = tid - 512;                                  // helper index (waves 8..15), < 0 on the candidate waves
+    const uint32_t dir = sort_directions(lane);
 
-    int* cand = candA;
-    int* cnew = candB;
-    float* xc = xA;
-    float* xn = xB;
-    float* ec = eA;
-    float* en = eB;
-    long long ready_known = 0;
-    uint32_t* const mkey = pmax;
-    uint32_t* const ckey = pmax + R;
-    if (tid < 2 * R) pmax[tid] = 0u;
+    int ready_known = 0;
+    if (tid < 4 * R) pmax[tid] = 0u;
     lds_barrier();
-    SCAN_WAIT_ROWS(std::min<long long>(a.n, a.it0 * a.i + a.m + a.i));
+    SCAN_WAIT_ROWS(std::min<long long>(a.n, a.it0 * (long long)I + M + I));
     {
+        float* const x0 = reinterpret_cast<float*>(smem + OFF_X);
+        int* const cand0 = reinterpret_cast<int*>(smem + OFF_CAND);
         uint32_t km = 0u;
-        for (int k = 0; k < EPT; ++k) {
-            const int l = lrow0 + k * lstep;
-            if (l < a.m) {
-                const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
-                const float v = scan_load<PERSIST>(lg + row * R + r);
-                xc[l * ld + r] = v;
-                km = max(km, max_key(v));
-            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                            // memory rows: 2,048 logits, two per thread
+            const int l = (tid >> 3) + 128 * k;
+            const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * M + l];
+            const float v = scan_load<PERSIST>(lg + row * R + r);
+            x0[l * LD + r] = v;
+            km = max(km, max_key(v));
         }
-        fold_row_max<R>(km, mkey, lane);
+        fold_row_max<R>(km, pmax, lane);                        // set 0: read by the first iteration
+        if (tid < M) cand0[tid] = a.it0 == 0 ? tid : (int)a.mem_idx[(size_t)b * M + tid];
     }
-    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
-    if (tid < 2) { nanflag[tid] = 0; ccount[2 + tid] = 0; }
+    if (tid < 2) ccount[2 + tid] = 0;
     const long long n_iter = a.it1 - a.it0;
-    const int pt = tid - PF0;                                  // < 0: this thread prefetches nothing
-    float pf[PF];
+    float pf[4];
     {
-        const long long lo = a.it0 * a.i + a.m;
-        const int cnt = n_iter > 0 ? (int)std::min<long long>(a.i, a.n - lo) : 0;
+        float* const x0 = reinterpret_cast<float*>(smem + OFF_X);
+        int* const cand0 = reinterpret_cast<int*>(smem + OFF_CAND);
+        const long long lo = a.it0 * (long long)I + M;
+        const int cnt = n_iter > 0 ? (int)std::min<long long>(I, a.n - lo) : 0;
         uint32_t kc = 0u;
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {                    // first chunk: straight into its rows (I * R <= 2048 <= 1024 * PF)
-            const int e = tid + SCAN_NT * k;
+        for (int k = 0; k < 2; ++k) {                            // first chunk: straight into its rows
+            const int e = tid + NT * k;
             if (e < cnt * R) {
                 const float v = scan_load<PERSIST>(lg + (size_t)lo * R + e);
-                xc[(a.m + (e >> log2R)) * ld + r] = v;
+                x0[(M + (e >> 3)) * LD + r] = v;
                 kc = max(kc, max_key(v));
             }
         }
-        fold_row_max<R>(kc, ckey, lane);
-        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
-        const long long lo1 = lo + a.i;
-        const int cnt1 = n_iter > 1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+        fold_row_max<R>(kc, pmax + R, lane);
+        if (tid < cnt) cand0[M + tid] = (int)(lo + tid);
+        const long long lo1 = lo + I;
+        const int cnt1 = n_iter > 1 ? (int)std::max<long long>(0, std::min<long long>(I, a.n - lo1)) : 0;
         if (cnt1 > 0) SCAN_WAIT_ROWS(lo1 + cnt1);
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int e = pt + PFT * k;
-            pf[k] = (pt >= 0 && e < cnt1 * R) ? scan_load<PERSIST>(lg + (size_t)lo1 * R + e) : 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            const int e = hid + 512 * k;
+            pf[k] = (hid >= 0 && e < cnt1 * R) ? scan_load<PERSIST>(lg + (size_t)lo1 * R + e) : 0.0f;
         }
     }
     int tie = 0;
-    uint64_t* const sorted = keyB;
-    for (long long it = a.it0; it < a.it1; ++it) {
-        const long long lo = it * a.i + a.m;
-        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
-        const int L = a.m + cnt;
-        const int par = (int)((it - a.it0) & 1);
-        // diagnostic (STAMP build): every wave's clock at 16 points of iterations 100..103 of image 0 (tools/scan_stamps.py camwaves)
-        unsigned long long* const wlog = (STAMP && b == 0 && it - a.it0 >= 100 && it - a.it0 < 104)
-                                             ? stamps + 8 * gridDim.x + 2048 + (it - a.it0 - 100) * 256 + wave * 16 : nullptr;
+    const int n_it = (int)n_iter, n_rows = (int)a.n;             // (n < 2^31: 32-bit row arithmetic inside the loop)
+    for (int k_it = 0; k_it < n_it; ++k_it) {
+        const int lo = ((int)a.it0 + k_it) * I + M;
+        const int cnt = min(I, n_rows - lo);
+        const int Lc = M + cnt;                                  // candidates of this iteration (512 but for a ragged last chunk)
+        const int par = k_it & 1;
+        // current / spare buffers by parity; everything else sits at a fixed address
+        float* const xc = reinterpret_cast<float*>(smem + OFF_X) + par * (L * LD);
+        float* const xn = reinterpret_cast<float*>(smem + OFF_X) + (par ^ 1) * (L * LD);
+        float* const ec = reinterpret_cast<float*>(smem + OFF_E) + par * (L * LD);
+        float* const en = reinterpret_cast<float*>(smem + OFF_E) + (par ^ 1) * (L * LD);
+        int* const cand = reinterpret_cast<int*>(smem + OFF_CAND) + par * L;
+        int* const cnew = reinterpret_cast<int*>(smem + OFF_CAND) + (par ^ 1) * L;
+        uint32_t* const mkey = pmax + 2 * R * par;              // row-maximum keys read by this iteration: [memory | chunk]
+        uint32_t* const mkey_nx = pmax + 2 * R * (par ^ 1);     // ... and folded into by this iteration, for the next one
+        // diagnostic (STAMP build): every wave's clock at 15 points of iterations 100..103 of image 0 (tools/scan_stamps.py camwaves)
+        unsigned long long* const wlog = (STAMP && b == 0 && k_it >= 100 && k_it < 104)
+                                             ? stamps + 8 * gridDim.x + 2048 + (k_it - 100) * 256 + wave * 16 : nullptr;
 #define WSTAMP(k_) do { if (STAMP && wlog != nullptr && lane == 0) wlog[k_] = __builtin_amdgcn_s_memtime(); } while (0)
+        const int lo1 = lo + I;
+        const int cnt1 = k_it + 1 < n_it ? max(0, min(I, n_rows - lo1)) : 0;
+        uint32_t kc = 0u;
+        // one element of the next chunk into the SPARE buffers: its logit, its exponential under this iteration's maxima
+        // (right unless a maximum moves - checked bitwise by the next iteration), its share of the chunk rows' maxima
+#define CAM_PREP(k_)                                                                        \
+        do {                                                                                \
+            const int row_ = (hid >> 3) + 64 * (k_);                                        \
+            if (row_ < cnt1) {                                                              \
+                xn[(M + row_) * LD + r] = pf[k_];                                           \
+                en[(M + row_) * LD + r] = det_expf_np(pf[k_] - rowmax);                     \
+                kc = max(kc, max_key(pf[k_]));                                              \
+            }                                                                               \
+        } while (0)
         WSTAMP(0);
         lds_barrier();                                          // B0
         WSTAMP(1);
         FAST_STAMP(0);
-        // P1: row maxima from the two key words of the row (scan_fast_kernel)
-        if (tid == 0) { ccount[0] = 0; ccount[1] = -1; ccount[2 + (par ^ 1)] = 0; }
-        const uint32_t mk = max(mkey[r], ckey[r]);
-        const uint32_t mbits = as_u32(max_key_value(mk));
-        const float rowmax = as_float(mbits);
-        const bool changed = it == a.it0 || prevk[par * R + r] != mbits;
-        if (tid < R) prevk[(par ^ 1) * R + r] = mbits;
-        FAST_STAMP(1);
-        // P2: exp(x - max) of every row whose maximum moved (a column of L elements, one per thread)
-        {
+        // P1 (helper waves - the candidate waves need no maxima): row maxima from the two key words of the row
+        if (tid == 0) { ccount[0] = 0; ccount[1] = -1; ccount[2 + (par ^ 1)] = 0; ccount[7] = 0; }
+        float rowmax = 0.0f;
+        if (wave >= 8) {
+            const uint32_t mk = max(mkey[r], mkey[R + r]);
+            const uint32_t mbits = as_u32(max_key_value(mk));
+            rowmax = as_float(mbits);
+            const bool changed = k_it == 0 || prevk[par * R + r] != mbits;
+            if (hid < R) prevk[(par ^ 1) * R + r] = mbits;
+            // P2: exp(x - max) of every row whose maximum moved (a column of Lc elements, one per helper thread)
             unsigned long long moved = __ballot(changed) & ((1ull << R) - 1ull);
             while (moved) {
                 const int rr = __ffsll((long long)moved) - 1;
                 moved &= moved - 1ull;
-                exp_column(xc + rr, ec + rr, L, ld, __shfl(rowmax, rr, 64));
+                exp_column_part(xc + rr, ec + rr, Lc, LD, __shfl(rowmax, rr, 64), hid, 512);
             }
         }
+        FAST_STAMP(1);
         WSTAMP(2);
         lds_barrier();                                          // B1
         WSTAMP(3);
-        if (tid < 2 * R) pmax[tid] = 0u;
+        if (tid < 2 * R) mkey[tid] = 0u;                        // read by everybody: cleared for the folds of the NEXT iteration
         FAST_STAMP(2);
-        // P3: the helper waves sum the rows (contract order) while the candidate threads fetch their 8 exponentials
-        const bool is_cand = tid < L;
-        float ev[R];
+        // P3: the candidate waves fetch their exponentials and sum one row each (contract order: lane j adds candidates
+        // j, j + 64, ... ascending, then the xor butterfly); the helper waves start on the next chunk
+        const bool is_cand = tid < Lc;
+        float4 ev0, ev1;
         if (wave < 8) {
+            const float* const row = ec + (is_cand ? tid : 0) * LD;
+            ev0 = *reinterpret_cast<const float4*>(row);
+            ev1 = *reinterpret_cast<const float4*>(row + 4);
+            float v0[8];
 #pragma unroll
-            for (int q = 0; q < R; ++q) ev[q] = is_cand ? ec[tid * ld + q] : 0.0f;
-        } else if (a.dbg & 1) {
-            if (lane == 0) rden[wave - 8] = 1.0f;
-        } else {
-            const int r0 = wave - 8;
-            float v0[LCH];
-#pragma unroll
-            for (int u = 0; u < LCH; ++u) {
-                const int i = lane + 64 * u;
-                v0[u] = i < L ? ec[i * ld + r0] : 0.0f;
-            }
+            for (int u = 0; u < 8; ++u) v0[u] = ec[(lane + 64 * u) * LD + wave];          // (rows beyond Lc: stale, masked below)
             float s0 = 0.0f;
 #pragma unroll
-            for (int u = 0; u < LCH; ++u) s0 = s0 + v0[u];
+            for (int u = 0; u < 8; ++u) s0 = s0 + ((lane + 64 * u < Lc) ? v0[u] : 0.0f);
             s0 = wave_butterfly_sum(s0);
-            if (lane == 0) rden[r0] = s0;
+            if (lane == 0) rden[wave] = s0;
+        } else {
+            CAM_PREP(0);
+            CAM_PREP(1);
         }
         WSTAMP(4);
         lds_barrier();                                          // B2
@@ -1708,17 +1765,15 @@ __global__ __launch_bounds__(SCAN_NT) void scan_r8_kernel(ScanArgs a, unsigned l
             // weights e / den, heads added in ascending order, mean over the 8 heads (one token: the mean over tokens is the
             // identity) - the operations of scan_fast_kernel's weight and score phases on this candidate
             const float4 d0 = *reinterpret_cast<const float4*>(rden), d1 = *reinterpret_cast<const float4*>(rden + 4);
-            float w0 = ev[0], w1 = ev[1], w2 = ev[2], w3 = ev[3], w4 = ev[4], w5 = ev[5], w6 = ev[6], w7 = ev[7];
-            if (!(a.dbg & 2)) {
-                w0 = w0 / d0.x; w1 = w1 / d0.y; w2 = w2 / d0.z; w3 = w3 / d0.w;
-                w4 = w4 / d1.x; w5 = w5 / d1.y; w6 = w6 / d1.z; w7 = w7 / d1.w;
-            }
+            const float w0 = ev0.x / d0.x, w1 = ev0.y / d0.y, w2 = ev0.z / d0.z, w3 = ev0.w / d0.w;
+            const float w4 = ev1.x / d1.x, w5 = ev1.y / d1.y, w6 = ev1.z / d1.z, w7 = ev1.w / d1.w;
             float sh = 0.0f;
             sh = sh + w0; sh = sh + w1; sh = sh + w2; sh = sh + w3; sh = sh + w4; sh = sh + w5; sh = sh + w6; sh = sh + w7;
             const float q = sh / (float)H;
             if (is_cand) key = rank_key(q / 1.0f, (uint32_t)tid);
-            if (wave < mr) {                                     // lowest memory score of this wave -> the threshold
+            if (wave < 4) {                                      // lowest memory score of this wave -> the threshold
                 uint32_t lowest = (uint32_t)(key >> 32);
+                sc32[tid] = lowest;
                 lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0xB1, 0xF, 0xF, false));
                 lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x4E, 0xF, 0xF, false));
                 lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x124, 0xF, 0xF, false));
@@ -1727,32 +1782,21 @@ __global__ __launch_bounds__(SCAN_NT) void scan_r8_kernel(ScanArgs a, unsigned l
                 lowest = min(lowest, lane_xor_u32<32>(lowest, lane));
                 if (lane == 0) atomicMin(reinterpret_cast<unsigned int*>(ccount + 1), lowest);
             }
-        } else if (!(a.dbg & 32)) {
-            // prep of iteration it + 1 on the helper waves: its chunk into rows m.. of the SPARE buffers (dead since the last
-            // gather), exponentials under this iteration's maxima (right unless a maximum moves - checked bitwise next time)
-            const long long lo1 = lo + a.i;
-            const int cnt1 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
-            uint32_t kc = 0u;
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int e = pt + PFT * k;
-                if (e < cnt1 * R) {
-                    const int row = a.m + (e >> log2R);
-                    xn[row * ld + r] = pf[k];
-                    en[row * ld + r] = det_expf_np(pf[k] - rowmax);
-                    kc = max(kc, max_key(pf[k]));
-                }
-            }
-            fold_row_max<R>(kc, ckey, lane);
-            for (int j = pt; j < cnt1; j += PFT) cnew[a.m + j] = (int)(lo1 + j);
+        } else {
+            CAM_PREP(2);
+            CAM_PREP(3);
+            fold_row_max<R>(kc, mkey_nx + R, lane);
+            if (hid < cnt1) cnew[M + hid] = (int)(lo1 + hid);
         }
         WSTAMP(6);
         lds_barrier();                                          // B4: the threshold is known
         WSTAMP(7);
-        uint64_t mine = 0ull;
-        if (wave < mr) {
-            mine = (a.dbg & 4) ? key : wave_sort_desc(key, lane);   // this wave's memory candidates = one sorted run
-            keyA[wave * 64 + lane] = mine;
+        if (wave < 4) {
+            // this wave's memory scores as one sorted run (a search structure: no payload); equal neighbours = an exact tie
+            const uint32_t s = wave_sort_desc_u32((uint32_t)(key >> 32), dir, lane);
+            runs32[tid] = s;
+            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)~s, (int)s, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0: ~s)
+            if (__ballot(up == s) != 0ull && lane == 0) ccount[2 + par] = 1;
         } else if (wave < 8) {
             const uint32_t tau = (uint32_t)ccount[1];
             const bool in = is_cand && (uint32_t)(key >> 32) >= tau;
@@ -1761,143 +1805,148 @@ __global__ __launch_bounds__(SCAN_NT) void scan_r8_kernel(ScanArgs a, unsigned l
                 int base = 0;
                 if (lane == 0) base = atomicAdd(ccount, __popcll(mask));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (in) keyA[a.m + base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+                if (in) keyA[M + base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
             }
         }
         WSTAMP(8);
         lds_barrier();                                          // B5: runs and survivors are in place
         WSTAMP(9);
         const int ks = ccount[0];
-        const int Lr = a.m + ks;
+        const int Lr = M + ks;
         if (STAMP && tid == 0) tacc[7] += (unsigned long long)ks;
         FAST_STAMP(4);
-        if (a.dbg & 8) {
-            if (wave < mr) sorted[tid] = mine;
-            lds_barrier();
-        } else if (ks <= R8_SMAX) {
-            bool hit = false, searching = false;
-            int rank = 0;
-            if (wave < mr) {
-                searching = true;
-                rank = lane;                                     // unique keys: the larger keys of the own run
-                const uint64_t below = keyA[wave * 64 + (lane < 63 ? lane + 1 : lane)];
-                int rr = 0;
-                if (mr == 4) {
-                    const uint64_t* const bs[3] = {keyA + ((wave + 1) & 3) * 64, keyA + ((wave + 2) & 3) * 64, keyA + ((wave + 3) & 3) * 64};
-                    rr = rank_in_runs_tie<3>(bs, mine, hit);
-                } else if (mr == 3) {
-                    const uint64_t* const bs[2] = {keyA + ((wave + 1) % 3) * 64, keyA + ((wave + 2) % 3) * 64};
-                    rr = rank_in_runs_tie<2>(bs, mine, hit);
-                } else if (mr == 2) {
-                    const uint64_t* const bs[1] = {keyA + (wave ^ 1) * 64};
-                    rr = rank_in_runs_tie<1>(bs, mine, hit);
+        if (ks <= SMAX) {
+            const uint32_t* const skeys = reinterpret_cast<const uint32_t*>(keyA + M);       // survivor i: words 2 i (position), 2 i + 1 (score)
+            uint32_t eq = 0xFFFFFFFFu;                           // becomes 0 when this thread sees two equal scores
+            {   // pass A: memory key kk against run rb (wave-uniform: is it the key's own run?)
+                const int kk = tid & (M - 1), rb = tid >> 8;
+                const uint32_t m = sc32[kk];
+                int c = search_run_u32(runs32 + 64 * rb, m, (wave & 3) == rb ? 0xFFFFFFFFu : 0u, eq);
+                if (rb == 0) {
+                    for (int i = 0; i < ks; ++i) {               // (workgroup-uniform trip count; broadcast reads)
+                        const uint32_t sv = skeys[2 * i + 1];
+                        c += (int)key_gt(sv, m);
+                        eq = min(eq, sv ^ m);
+                    }
                 }
-                rank += rr;
-                hit = hit || (lane < 63 && (uint32_t)(below >> 32) == (uint32_t)(mine >> 32));
-            } else if (wave == 8 && lane < ks) {
-                searching = true;
-                mine = keyA[a.m + lane];
-                if (mr == 4) {
-                    const uint64_t* const bs[4] = {keyA, keyA + 64, keyA + 128, keyA + 192};
-                    rank = rank_in_runs_tie<4>(bs, mine, hit);
-                } else if (mr == 3) {
-                    const uint64_t* const bs[3] = {keyA, keyA + 64, keyA + 128};
-                    rank = rank_in_runs_tie<3>(bs, mine, hit);
-                } else if (mr == 2) {
-                    const uint64_t* const bs[2] = {keyA, keyA + 64};
-                    rank = rank_in_runs_tie<2>(bs, mine, hit);
-                } else {
-                    const uint64_t* const bs[1] = {keyA};
-                    rank = rank_in_runs_tie<1>(bs, mine, hit);
+                pr[rb * PRW + kk] = c;
+            }
+            if (ks > 0 && tid < 4 * SMAX) {                      // pass B: (survivor, run) pairs on the first waves
+                const int rb = tid >> 5, i = tid & (SMAX - 1);
+                if (i < ks) {
+                    const uint32_t m = skeys[2 * i + 1];
+                    int c = search_run_u32(runs32 + 64 * rb, m, 0u, eq);
+                    if (rb == 0) {
+                        for (int j = 0; j < ks; ++j) {
+                            const uint32_t sv = skeys[2 * j + 1];
+                            c += (int)key_gt(sv, m);
+                            eq = min(eq, (sv ^ m) | (j == i ? 0xFFFFFFFFu : 0u));
+                        }
+                    }
+                    pr[rb * PRW + M + i] = c;
                 }
             }
-            if (wave < mr || wave == 8) {                        // the survivors: an unsorted list, read by everybody who ranks
-                for (int i = 0; i < ks; ++i) {                   // (workgroup-uniform trip count)
-                    const uint64_t s = keyA[a.m + i];
-                    rank += (s > mine) ? 1 : 0;
-                    hit = hit || ((uint32_t)(s >> 32) == (uint32_t)(mine >> 32) && s != mine);
-                }
-                if (searching) sorted[rank] = mine;
-                if (__ballot(searching && hit) != 0ull && lane == 0) ccount[2 + par] = 1;
-            }
+            if (__ballot(eq == 0u) != 0ull && lane == 0) ccount[2 + par] = 1;
             WSTAMP(10);
-            lds_barrier();                                      // B7
+            lds_barrier();                                      // B6: the partial counts are in place
+            if (ccount[2 + par] == 0) {                          // (with a tie the 64-bit ranking below replaces all of this)
+                if (tid < M) {
+                    sorted[pr[tid] + pr[PRW + tid] + pr[2 * PRW + tid] + pr[3 * PRW + tid]] = key;
+                } else if (wave == 8 && lane < ks) {
+                    sorted[pr[M + lane] + pr[PRW + M + lane] + pr[2 * PRW + M + lane] + pr[3 * PRW + M + lane]] = keyA[M + lane];
+                }
+            }
             WSTAMP(11);
+            lds_barrier();                                      // B7
         } else {
-            // many survivors (the first iterations of a scan): the ranking of scan_fast_kernel over runs + survivors, then
-            // its pair check for ties among the first M + 1 ranks
-            rank_runs4(keyA, keyB, reinterpret_cast<uint64_t*>(en), Lr);
+            // many survivors (the first iterations of a scan): the ranking of scan_fast_kernel over memory keys + survivors
+            if (wave < 4) keyA[tid] = key;
+            lds_barrier();
+            rank_runs4(keyA, sorted, reinterpret_cast<uint64_t*>(smem + OFF_RUNS), Lr);
             lds_barrier();
             {
-                const int npair = a.m < Lr - 1 ? a.m : Lr - 1;
+                const int npair = M < Lr - 1 ? M : Lr - 1;
                 bool hit = false;
-                for (int j = tid; j < npair; j += SCAN_NT) hit = hit || (sorted[j] >> 32) == (sorted[j + 1] >> 32);
+                for (int j = tid; j < npair; j += NT) hit = hit || (sorted[j] >> 32) == (sorted[j + 1] >> 32);
                 if (__ballot(hit) != 0ull && lane == 0) ccount[2 + par] = 1;
             }
             lds_barrier();
         }
-        bool boundary_tie = Lr > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);
-        if (a.tie_order == 1 && ccount[2 + par] != 0) {
-            // torch.topk's order under ties depends on the WHOLE candidate array: every key back to its place, all L
-            // candidates ranked, the replay on them (rare)
+        const bool tied = ccount[2 + par] != 0;
+        if (tied) {
+            // an exact tie somewhere among the ranked candidates: the 64-bit ranking (score, then earlier position) of ALL
+            // candidates and, for the reference's order, the replay of torch.topk on them (its order depends on the whole array)
             if (is_cand) keyA[tid] = key;
             lds_barrier();
-            if (L <= 192) {
-                int P = 1;
-                while (P < 64 && 2 * P * L <= SCAN_NT) P <<= 1;
-                rank_scatter(keyA, keyB, L, P);
-            } else {
-                rank_runs(keyA, keyB, reinterpret_cast<uint64_t*>(en), L);
-            }
+            rank_runs(keyA, sorted, reinterpret_cast<uint64_t*>(smem + OFF_RUNS), Lc);
             lds_barrier();
-            boundary_tie = L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);
-            tie_order_slow(keyB, keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off));
+            if (a.tie_order == 1) {
+                // (ties among the first M + 1 ranks only: without one torch.topk's result is the canonical order)
+                const int npair = M < Lc - 1 ? M : Lc - 1;
+                bool hit = false;
+                for (int j = tid; j < npair; j += NT) hit = hit || (sorted[j] >> 32) == (sorted[j + 1] >> 32);
+                if (__ballot(hit) != 0ull && lane == 0) ccount[7] = 1;
+                lds_barrier();
+            }
         }
+        if (tid == 0) {
+            const int Lk = tied ? Lc : Lr;                       // candidates in `sorted`
+            if (Lk > M && (sorted[M - 1] >> 32) == (sorted[M] >> 32)) tie = 1;      // (before the replay reorders the first M)
+        }
+        if (tied && a.tie_order == 1 && ccount[7] != 0)
+            tie_order_slow(sorted, keyA, Lc, M, reinterpret_cast<int*>(smem + OFF_STK));
         FAST_STAMP(5);
         {
-            const long long lo2 = lo + 2 * a.i;
-            const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
+            const int lo2 = lo + 2 * I;
+            const int cnt2 = k_it + 2 < n_it ? max(0, min(I, n_rows - lo2)) : 0;
             if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
 #pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int e = pt + PFT * k;
-                pf[k] = (pt >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
+            for (int k = 0; k < 4; ++k) {
+                const int e = hid + 512 * k;
+                pf[k] = (hid >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
             }
         }
         WSTAMP(12);
-        // P6: new memory: indices, logit rows and exponentials of the winners, into the other buffers
-        for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j]) & 1023];
-        WSTAMP(13);
-        if (!(a.dbg & 16)) {
-            int src[EPT];
+        // P6: new memory into the other buffers.  Waves 0..7: the logit rows, four elements per thread (rows (tid >> 3) + 64 k,
+        // column tid & 7), and the new rows' maxima; waves 8..15: the exponentials, half a row (16 bytes) per thread, and the
+        // patch indices.  Every read of a thread is in flight before its first write.
+        {
+            const uint32_t* const spos = reinterpret_cast<const uint32_t*>(sorted);         // word 2 j: ~position of rank j
+            if (wave < 8) {
+                uint32_t p[4];
 #pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const int j = lrow0 + k * lstep;
-                src[k] = j < a.m ? (int)key_pos(sorted[j]) * ld + r : 0;
+                for (int k = 0; k < 4; ++k) p[k] = ~spos[2 * ((tid >> 3) + 64 * k)] & (L - 1);
+                float gx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gx[k] = xc[p[k] * LD + r];
+                uint32_t km = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { xn[((tid >> 3) + 64 * k) * LD + r] = gx[k]; km = max(km, max_key(gx[k])); }
+                fold_row_max<R>(km, mkey_nx, lane);                // maxima of the NEW memory rows, for the next iteration
+            } else {
+                const int j = hid >> 1, half = (hid & 1) * 4;
+                const uint32_t p = ~spos[2 * j] & (L - 1);
+                const uint32_t pc = ~spos[2 * (hid & (M - 1))] & (L - 1);
+                const float4 ge = *reinterpret_cast<const float4*>(ec + p * LD + half);
+                const int ci = cand[pc];
+                *reinterpret_cast<float4*>(en + j * LD + half) = ge;
+                if (hid < M) cnew[hid] = ci;
             }
-            float gx[EPT], ge[EPT];
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) { gx[k] = xc[src[k]]; ge[k] = ec[src[k]]; }
-            uint32_t km = 0u;
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const int j = lrow0 + k * lstep;
-                if (j < a.m) { xn[j * ld + r] = gx[k]; en[j * ld + r] = ge[k]; km = max(km, max_key(gx[k])); }
-            }
-            fold_row_max<R>(km, mkey, lane);
         }
-        if (tid == 0 && boundary_tie) tie = 1;
-        { int* t = cand; cand = cnew; cnew = t; }
-        { float* t = xc; xc = xn; xn = t; }
-        { float* t = ec; ec = en; en = t; }
+        WSTAMP(13);
         WSTAMP(14);
         FAST_STAMP(6);
 #undef WSTAMP
+#undef CAM_PREP
     }
     lds_barrier();
-    for (int j = tid; j < a.m; j += SCAN_NT) {
-        a.mem_idx[(size_t)b * a.m + j] = cand[j];
-        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
+    {
+        const int parn = (int)(n_iter & 1);                       // the set the last iteration wrote
+        const int* const cand = reinterpret_cast<const int*>(smem + OFF_CAND) + parn * L;
+        if (tid < M) {
+            a.mem_idx[(size_t)b * M + tid] = cand[tid];
+            if (a.mem_score) a.mem_score[(size_t)b * M + tid] = n_iter > 0 ? key_score(sorted[tid]) : 0.0f;
+        }
     }
     if (a.tie && tid == 0 && tie) a.tie[b] = 1;
     if (STAMP && tid == 0)
@@ -2515,8 +2564,7 @@ struct FastPlan {
 };
 
 static bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
-static int g_scan_skip = 0;                // diagnostic (ipsx_dbg_scan_skip): phases of scan_r8_kernel left out (timing only)
-static bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the 8-row shapes through scan_fast_kernel
+static bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the shape of scan_cam_kernel through scan_fast_kernel
 
 static FastPlan scan_fast_plan(int m, int i, int h, int n_token) {
     FastPlan p = {false, 1, 2, 0};
@@ -2641,7 +2689,6 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     a.ready = ready; a.status = status; a.ready_stride = ready_stride;
     a.cond = cond; a.cond_mask = cond_mask;
-    a.dbg = g_scan_skip;
     a.tie_order = g_tie_order;
     a.use_lds = 1;
     a.stk_off = (int)(fp.lds - STK_BYTES);
@@ -2674,20 +2721,22 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         else if (ept == 4) IPSX_LAUNCH_FAST_C(RR, TT, 4);                                                           \
         else IPSX_LAUNCH_FAST_C(RR, TT, 8);                                                                         \
     } while (0)
-    if (g_scan_r8 && R == 8 && n_token == 1 && m % 64 == 0 && m <= 256 && i <= 256) {
-        // one thread per candidate (scan_r8_kernel): CAMELYON's M = I = 256 and every smaller shape of that transformer
-#define IPSX_LAUNCH_R8(S, P)                                                                                        \
+    if (g_scan_r8 && R == 8 && n_token == 1 && m == cam::M && i == cam::I) {
+        // BASELINE configs[3] (8 heads, one token, M = I = 256): the specialised loop (scan_cam_kernel)
+        static_assert(cam::LDS_BYTES <= 160 * 1024, "scan_cam_kernel: LDS");
+        a.stk_off = cam::OFF_STK;
+#define IPSX_LAUNCH_CAM(S, P)                                                                                       \
     do {                                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_r8_kernel<S, P>),                              \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                           \
-        scan_r8_kernel<S, P><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st);                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_cam_kernel<S, P>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)cam::LDS_BYTES);                 \
+        scan_cam_kernel<S, P><<<dim3((unsigned)b), dim3(cam::NT), cam::LDS_BYTES, as_stream(stream)>>>(a, st);      \
         return launched("scan");                                                                                    \
     } while (0)
-        if (st && a.ready) IPSX_LAUNCH_R8(true, true);
-        if (st) IPSX_LAUNCH_R8(true, false);
-        if (a.ready) IPSX_LAUNCH_R8(false, true);
-        IPSX_LAUNCH_R8(false, false);
-#undef IPSX_LAUNCH_R8
+        if (st && a.ready) IPSX_LAUNCH_CAM(true, true);
+        if (st) IPSX_LAUNCH_CAM(true, false);
+        if (a.ready) IPSX_LAUNCH_CAM(false, true);
+        IPSX_LAUNCH_CAM(false, false);
+#undef IPSX_LAUNCH_CAM
     }
     // the diagnostic (stamped) build exists for the two benchmark shapes
     if (st && a.ready && R == 8 && n_token == 1 && ept == 4 && lch == 8) {      // stamped persistent loop (diagnostic)
@@ -2783,11 +2832,6 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_stamps(unsi
 // (scan_large_kernel) - tools/scan_compare.py holds the two loop kernels against each other this way.
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int on) { g_scan_generic = on != 0; }
 
-// Diagnostic entry point (not part of include/ipsx.h): 0 sends the shapes of scan_r8_kernel (8 logits per candidate, M a
-// multiple of 64, M, I <= 256) through scan_fast_kernel instead - tools/scan_compare.py and tools/scan_stamps.py use it.
+// Diagnostic entry point (not part of include/ipsx.h): 0 sends the shape of scan_cam_kernel (8 logits per candidate,
+// M = I = 256) through scan_fast_kernel instead - tools/scan_compare.py and tools/scan_stamps.py use it.
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_r8(int on) { g_scan_r8 = on != 0; }
-
-// Diagnostic entry point (not part of include/ipsx.h): phases of scan_r8_kernel left out - 1 row sums, 2 divisions, 4 run
-// sort, 8 ranking, 16 gather, 32 next-chunk prep - to see what each costs inside the un-instrumented loop (the selection is
-// then meaningless; tools/scan_stamps.py cam-skip).
-extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_skip(int mask) { g_scan_skip = mask; }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""The loop kernels against each other: scan_r8_kernel (one thread per candidate: 8 logits per candidate, M a multiple of
-64, M, I <= 256), scan_fast_kernel (LDS-resident, one thread per element: the shapes the reference ships; forced for the
-r8 shapes through the diagnostic switch ipsx_dbg_scan_r8) and the generic scan_large_kernel (forced through
+"""The loop kernels against each other: scan_cam_kernel (specialised: 8 logits per candidate, M = I = 256),
+scan_fast_kernel (LDS-resident, one thread per element: the shapes the reference ships; forced for the specialised
+shape through the diagnostic switch ipsx_dbg_scan_r8) and the generic scan_large_kernel (forced through
 ipsx_dbg_scan_generic) on random logits of several shapes, incl. ragged last chunks, resumed ranges, exact ties (a few, and
 in every iteration), many survivors, NaN / infinity rows: identical indices, scores and tie flags."""
 import ctypes as C
@@ -12,12 +12,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 # (B, N, M, I, H, T): every one is a shape scan_fast_kernel covers (R = H*T in {8, 32} with T in {1, 4}); the ones with
-# R = 8, M % 64 == 0, M <= 256, I <= 256 run on scan_r8_kernel by default
+# R = 8, M = I = 256 run on scan_cam_kernel by default
 SHAPES = [(2, 2500, 64, 64, 8, 4), (1, 8000, 256, 256, 8, 1), (3, 333, 16, 24, 8, 1), (2, 700, 64, 80, 8, 4), (2, 900, 100, 100, 8, 4),
           (2, 300, 16, 16, 8, 4), (1, 500, 64, 100, 8, 1), (2, 1500, 300, 300, 8, 1),
           (2, 3000, 64, 64, 8, 1), (2, 5000, 128, 200, 8, 1), (1, 4000, 192, 256, 8, 1), (3, 700, 64, 48, 8, 1),
-          (2, 6000, 256, 256, 8, 1), (2, 3000, 256, 256, 8, 1), (1, 2100, 128, 128, 8, 1), (2, 1000, 256, 100, 8, 1)]
-R8 = [k for k, s in enumerate(SHAPES) if s[4] * s[5] == 8 and s[5] == 1 and s[2] % 64 == 0 and s[2] <= 256 and s[3] <= 256]
+          (2, 6000, 256, 256, 8, 1), (2, 3000, 256, 256, 8, 1), (1, 2100, 256, 256, 8, 1), (2, 1000, 256, 100, 8, 1),
+          (3, 1900, 256, 256, 8, 1), (2, 4196, 256, 256, 8, 1)]
+R8 = [k for k, s in enumerate(SHAPES) if s[4] * s[5] == 8 and s[5] == 1 and s[2] == 256 and s[3] == 256]
 
 
 def run(only=None):
@@ -29,9 +30,9 @@ def run(only=None):
             continue
         g = torch.Generator(device="cpu").manual_seed(k)
         lg = torch.randn((B, N, H * T), generator=g) * 3
-        if k in (2, 11):
+        if k in (2, 11, 16):
             lg[0, 40, 3] = float("nan"); lg[1, 7, 0] = float("inf"); lg[2, 100:110, 5] = float("-inf")
-        if k in (4, 9):
+        if k in (4, 9, 17):
             lg[:, ::3] = lg[:, :1]                      # exact ties
         if k == 12:
             lg = torch.round(lg * 2) / 2                # quantised logits: duplicates, ties in every iteration
@@ -78,8 +79,8 @@ def main():
         for j in range(3):
             assert same(default[k][j], generic[k][j]), "output %d of shape %s: default kernel != scan_large_kernel" % (j, SHAPES[k])
             if k in fast:
-                assert same(default[k][j], fast[k][j]), "output %d of shape %s: scan_r8_kernel != scan_fast_kernel" % (j, SHAPES[k])
-    print("scan_r8_kernel == scan_fast_kernel on %d shapes, both == scan_large_kernel on %d shapes (indices, scores, tie "
+                assert same(default[k][j], fast[k][j]), "output %d of shape %s: scan_cam_kernel != scan_fast_kernel" % (j, SHAPES[k])
+    print("scan_cam_kernel == scan_fast_kernel on %d shapes, both == scan_large_kernel on %d shapes (indices, scores, tie "
           "flags; resumed ranges); tie flags raised on shapes %s"
           % (len(fast), len(default), [k for k in default if int(default[k][2].sum()) > 0]))
 

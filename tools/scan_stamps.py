@@ -87,7 +87,7 @@ if kind == "large":
     hip.set_tie_order("torch")
     sys.exit(0)
 if kind == "camwaves":
-    # every wave's clock at the barriers of iterations 100..103 (STAMP build of scan_r8_kernel): who arrives last where
+    # every wave's clock at the barriers of iterations 100..103 (STAMP build of scan_cam_kernel): who arrives last where
     import numpy as np
     dev = torch.device("cuda:0")
     B, N, M, I, H, T = 1, 65536, 256, 256, 8, 1
@@ -111,36 +111,6 @@ if kind == "camwaves":
             print("  w%-2d " % wv + " ".join("%6d" % (w[it, wv, k] - t0) for k in range(15)))
         nxt = w[it + 1, :, 0].min() - t0
         print("  next iteration's first wave at the top: %d cycles" % nxt)
-    sys.exit(0)
-if kind == "camskip":
-    # what each phase of scan_r8_kernel costs INSIDE the un-instrumented loop: the kernel timed with phases left out
-    # (ipsx_dbg_scan_skip; canonical tie order so that the meaningless selections trigger no tie replay)
-    dev = torch.device("cuda:0")
-    B, N, M, I, H, T = 1, 65536, 256, 256, 8, 1
-    g = torch.Generator(device="cpu").manual_seed(0)
-    lg = (torch.randn((B, N, H * T), generator=g) * 3).to(dev)
-    L = hip.lib()
-    L.ipsx_dbg_scan_skip.argtypes = [C.c_int]
-    hip.set_tie_order("canonical")
-    n_iter = -(-(N - M) // I)
-    names = {0: "everything", 1: "- row sums", 2: "- divisions", 4: "- run sort", 8: "- ranking", 16: "- gather", 32: "- next-chunk prep",
-             12: "- sort, ranking", 28: "- sort, ranking, gather", 31: "- all but the prep", 63: "- all six"}
-    base = None
-    for mask, nme in names.items():
-        L.ipsx_dbg_scan_skip(mask)
-        for _ in range(3):
-            hip.scan(lg, M, I, H, T)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            hip.scan(lg, M, I, H, T)
-        b.record()
-        torch.cuda.synchronize()
-        us = 1e2 * a.elapsed_time(b) / n_iter
-        base = us if base is None else base
-        print("  %-28s %6.3f us per iteration  (%+.3f)" % (nme, us, us - base))
-    L.ipsx_dbg_scan_skip(0)
-    hip.set_tie_order("torch")
     sys.exit(0)
 B, N, M, I, H, T = (16, 2500, 64, 64, 8, 4) if kind == "mnist" else (1, 65536, 256, 256, 8, 1)
 dev = torch.device("cuda:0")
