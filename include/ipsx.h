@@ -42,8 +42,10 @@ extern "C" {
  * `ipsx_version() / 100 != IPSX_VERSION / 100`); the minor number counts compatible additions.
  *   1.xx  rounds 1-2
  *   2.00  round 3: ipsx_scan / ipsx_scan_range / ipsx_topm take (workspace, workspace_bytes) in front of `stream`,
- *         ipsx_scan_persistent takes ready_per_image, ipsx_projector_stats_publish removed                          */
-#define IPSX_VERSION 200
+ *         ipsx_scan_persistent takes ready_per_image, ipsx_projector_stats_publish removed
+ *   2.01  round 4 (additions only): ipsx_aggregate_packed, ipsx_set_persistent_wait_ms; ipsx_projector_stream accepts
+ *         short_first <= -3 (guided tile sizes)                                                                     */
+#define IPSX_VERSION 201
 
 #define IPSX_OK            0
 #define IPSX_EINVAL       -1      /* bad argument / unsupported shape */
@@ -315,9 +317,10 @@ int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, 
 
 /* The whole loop as ONE launch that may start before any logits exist (overlap with the encoder without re-launching
  * per part): the kernel waits until *ready (device int32, written with ipsx_publish_rows on another stream after the
- * kernels that produced the rows) says the rows it is about to read are in memory.  The wait is bounded (~5 s); on a
- * timeout, or when *ready is set negative, the kernel ends and sets bit 0 of *status (results are then invalid; bit 1 =
- * the kernel is resident).  ready_per_image != 0: `ready` is an array of b words and image k follows ready[k] - a
+ * kernels that produced the rows) says the rows it is about to read are in memory.  The wait is bounded: 50 ms (see
+ * ipsx_set_persistent_wait_ms) WITHOUT PROGRESS of any of the call's progress words; on a timeout, or when *ready is set
+ * negative, the kernel ends and sets bit 0 of *status (results are then invalid - ipsx_scan_range_if behind it redoes the
+ * loop in the same call; bit 1 = the kernel is resident).  ready_per_image != 0: `ready` is an array of b words and image k follows ready[k] - a
  * producer that works through the images one after the other publishes each image's rows as it goes, and image k's loop
  * runs beside the production of image k + 1.
  * Shapes: ipsx_scan_persistent_supported() != 0.     */
@@ -326,6 +329,9 @@ int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, in
                          int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
                          int32_t ready_per_image, int32_t* status, void* stream);
 int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream);
+/* longest wait of a persistent loop (and of ipsx_scan_gate) without progress, in milliseconds (1 .. 20000; default 50);
+ * returns the previous value, ms <= 0 only queries */
+int ipsx_set_persistent_wait_ms(int ms);
 /* ipsx_scan_range that runs only when (*cond & cond_mask) != 0, tested ON THE DEVICE by every workgroup as it starts (no
  * host synchronisation): enqueued behind ipsx_scan_persistent with cond = its status word and mask 1, it redoes the loop
  * with plain launches in the very call whose persistent loop gave up waiting, and costs one empty launch otherwise.
@@ -381,6 +387,11 @@ size_t ipsx_aggregate_workspace_bytes(const ipsx_transf* t, int b, int m);
 /* x (b,m,d) -> out (b,T,d) */
 int ipsx_aggregate(const ipsx_transf* t, const float* x, int b, int m, float* out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* The same with operands the caller keeps between calls (they depend on the parameters only): vq_packed = ipsx_fold_query
+ * of (q, wq, wk), wv_packed = ipsx_pack_conv_weight(wv, h*dv, d, 1, 1); either may be NULL (then it is made here, in the
+ * workspace, as ipsx_aggregate does).  Saves four small launches per call in an evaluation loop. */
+int ipsx_aggregate_packed(const ipsx_transf* t, const float* vq_packed, const float* wv_packed, const float* x, int b,
+                          int m, float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* out[b][c] = act(w[c,:] . emb[b][token,:] + bias[c]); act 0 = softmax, 1 = sigmoid */
 int ipsx_head(const float* emb, int b, int n_token, int d, int token,
               const float* w, const float* bias, int n_class, int act,

@@ -117,6 +117,15 @@ class MultiHeadCrossAttention(nn.Module):
             self._folded = cached
         return cached[1]
 
+    def packed_v(self):
+        """``v_w.weight`` in the matrix cores' operand layout (``hip.pack_linear``), kept until the parameter changes."""
+        w = self.v_w.weight
+        key = (hip.weights_generation(), w.data_ptr(), w._version, w.device)
+        cached = getattr(self, "_packed_v", None)
+        if cached is None or cached[0] != key:
+            cached = self._packed_v = (key, hip.pack_linear(w))
+        return cached[1]
+
     def get_attn(self, x):
         """Attention map ``(B, H, n_token, L)`` of the queries over ``x`` (B, L, D)."""
         if _use_hip(x, self.q, self.q_w.weight, self.k_w.weight) and not self._drops():

@@ -272,6 +272,11 @@ IPSX_API size_t ipsx_aggregate_workspace_bytes(const ipsx_transf* t, int b, int 
 
 IPSX_API int ipsx_aggregate(const ipsx_transf* t, const float* x, int b, int m, float* out, void* workspace,
                             size_t workspace_bytes, void* stream) {
+    return ipsx_aggregate_packed(t, nullptr, nullptr, x, b, m, out, workspace, workspace_bytes, stream);
+}
+
+IPSX_API int ipsx_aggregate_packed(const ipsx_transf* t, const float* vq_packed, const float* wv_packed, const float* x, int b,
+                                   int m, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     IPSX_REQUIRE(t && x && out && b > 0 && m > 0, "aggregate: bad arguments");
     IPSX_REQUIRE(t->q && t->wq && t->wk && t->wv && t->fc && t->ln1_g && t->ln1_b && t->w1 && t->b1 && t->w2 &&
                      t->b2 && t->ln2_g && t->ln2_b, "aggregate: missing weights");
@@ -289,14 +294,22 @@ IPSX_API int ipsx_aggregate(const ipsx_transf* t, const float* x, int b, int m, 
     const int hdk = t->h * t->dk, hdv = t->h * t->dv, R = t->h * t->n_token;
     hipStream_t s = as_stream(stream);
 
-    IPSX_TRY(ipsx_query_proj(t->q, t->wq, t->temperature, t->n_token, t->d, hdk, qs, stream));
-    IPSX_TRY(ipsx_pack_conv_weight(t->wk, hdk, t->d, 1, 1, wkp, stream));
-    IPSX_TRY(ipsx_pack_conv_weight(t->wv, hdv, t->d, 1, 1, wvp, stream));
-    IPSX_TRY(ipsx_fold_query(qs, wkp, t->h, t->dk, t->n_token, t->d, vq, stream));
-    IPSX_TRY(ipsx_logits(x, (int64_t)m * t->d, nullptr, 0, vq, b, m, t->d, R, lg, (int64_t)m * R, stream));
+    // the folded query and the packed V weights depend on the parameters only: a caller that keeps them between calls
+    // (ipsx_fold_query / ipsx_pack_conv_weight, re-made when a parameter moves) saves four small launches per call
+    if (!vq_packed) {
+        IPSX_TRY(ipsx_query_proj(t->q, t->wq, t->temperature, t->n_token, t->d, hdk, qs, stream));
+        IPSX_TRY(ipsx_pack_conv_weight(t->wk, hdk, t->d, 1, 1, wkp, stream));
+        IPSX_TRY(ipsx_fold_query(qs, wkp, t->h, t->dk, t->n_token, t->d, vq, stream));
+        vq_packed = vq;
+    }
+    if (!wv_packed) {
+        IPSX_TRY(ipsx_pack_conv_weight(t->wv, hdv, t->d, 1, 1, wvp, stream));
+        wv_packed = wvp;
+    }
+    IPSX_TRY(ipsx_logits(x, (int64_t)m * t->d, nullptr, 0, vq_packed, b, m, t->d, R, lg, (int64_t)m * R, stream));
     ipsx_conv vproj;
     vproj.c_in = t->d; vproj.c_out = hdv; vproj.kh = vproj.kw = 1; vproj.stride = 1; vproj.pad = 0;
-    vproj.w_packed = wvp; vproj.alpha = nullptr; vproj.shift = nullptr;
+    vproj.w_packed = wv_packed; vproj.alpha = nullptr; vproj.shift = nullptr;
     IPSX_TRY(ipsx_conv2d_affine_nhwc(&vproj, x, nullptr, v, (int64_t)b * m, 1, 1, 0, stream));
 
     CtxArgs c;

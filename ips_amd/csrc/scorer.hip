@@ -847,6 +847,8 @@ struct ScanArgs {
     int* tie;
     const int* ready;      // persistent launch: number of patches whose logits are in memory (grows while we run);
     int ready_stride;      //   image b polls ready[b * ready_stride] (0: one word for all images, 1: a word per image)
+    int ready_words;       //   progress words of the call (1, or b): any of them moving restarts the wait's clock
+    unsigned long long wait_ticks;     // persistent launch: longest wait WITHOUT any progress, in 100 MHz ticks (ipsx_set_persistent_wait_ms)
     int* status;           // persistent launch: set to 1 when the wait for `ready` timed out
     const int* cond;       // conditional launch (ipsx_scan_range_if): run only when (*cond & cond_mask) != 0, or nullptr
     int cond_mask;
@@ -1155,18 +1157,27 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
     float* xn = xB;
     float* ec = eA;
     float* en = eB;
-    // persistent launch: rows below ready_known exist.  Wave 0 polls (bounded: ~5 s of the 100 MHz clock), everybody
-    // learns the result through LDS; a negative value (cancelled / timed out) ends the kernel.
+    // persistent launch: rows below ready_known exist.  Wave 0 polls, everybody learns the result through LDS; a negative
+    // value (cancelled / timed out) ends the kernel.  The wait is bounded by a.wait_ticks of the 100 MHz clock WITHOUT
+    // PROGRESS: the clock restarts whenever any progress word of the call has moved (lane k watches word k), so a slide
+    // whose turn at the projector comes late waits as long as the slides in front of it are being worked on - and a call
+    // whose producers cannot run at all (serialised kernels) gives up after wait_ticks (default 50 ms) and is redone by
+    // the conditional launch behind it.
     long long ready_known = 0;
 #define SCAN_WAIT_ROWS(need)                                                                                   \
     do {                                                                                                       \
         if (PERSIST && (long long)(need) > ready_known) {                                                      \
             if (wave == 0) {                                                                                   \
-                const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();                               \
+                unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();                                     \
                 int v_ = __hip_atomic_load(a.ready + b * a.ready_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                int seen_ = -1;                                                                                \
                 while (v_ >= 0 && v_ < (need)) {                                                               \
                     __builtin_amdgcn_s_sleep(16);                                                              \
-                    if (__builtin_amdgcn_s_memrealtime() - t0_ > 500000000ull) { v_ = -1; break; }             \
+                    int w_ = lane < a.ready_words ? __hip_atomic_load(a.ready + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; \
+                    for (int o_ = 32; o_ >= 1; o_ >>= 1) w_ += __shfl_xor(w_, o_, 64);                         \
+                    const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                          \
+                    if (w_ != seen_) { seen_ = w_; t0_ = now_; }                                               \
+                    if (now_ - t0_ > a.wait_ticks) { v_ = -1; break; }                                         \
                     v_ = __hip_atomic_load(a.ready + b * a.ready_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
                 }                                                                                              \
                 if (lane == 0) ccount[6] = v_;                                                     \
@@ -2563,6 +2574,7 @@ struct FastPlan {
     size_t lds;
 };
 
+static int g_persist_wait_ms = 50;         // ipsx_set_persistent_wait_ms: longest wait of a persistent loop / its gate without progress
 static bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
 static bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the shape of scan_cam_kernel through scan_fast_kernel
 
@@ -2613,17 +2625,17 @@ IPSX_API int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, 
 }
 
 // one thread that holds its stream until every workgroup of the persistent scan is resident (bounded: ~0.5 s)
-__global__ void scan_gate_kernel(const int* status) {
+__global__ void scan_gate_kernel(const int* status, unsigned long long wait_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while ((__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) == 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) break;
     }
 }
 
 IPSX_API int ipsx_scan_gate(const int32_t* status, void* stream) {
     IPSX_REQUIRE(status, "scan_gate: null pointer");
-    scan_gate_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(status);
+    scan_gate_kernel<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(status, (unsigned long long)g_persist_wait_ms * 100000ull);
     return launched("scan_gate");
 }
 
@@ -2688,6 +2700,8 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     a.it0 = it_begin; a.it1 = it_end;
     a.mem_idx = reinterpret_cast<long long*>(mem_idx); a.mem_score = mem_score; a.tie = tie_flag;
     a.ready = ready; a.status = status; a.ready_stride = ready_stride;
+    a.ready_words = ready ? (ready_stride ? std::min(b, 64) : 1) : 0;
+    a.wait_ticks = (unsigned long long)g_persist_wait_ms * 100000ull;
     a.cond = cond; a.cond_mask = cond_mask;
     a.tie_order = g_tie_order;
     a.use_lds = 1;
@@ -2814,6 +2828,12 @@ IPSX_API int ipsx_topm(const float* scores, int b, int l, int m, int64_t* top_id
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     topm_kernel<<<dim3((unsigned)b), dim3(256), lds, as_stream(stream)>>>(a);
     return launched("topm");
+}
+
+IPSX_API int ipsx_set_persistent_wait_ms(int ms) {
+    const int prev = g_persist_wait_ms;
+    if (ms > 0) g_persist_wait_ms = ms > 20000 ? 20000 : ms;
+    return prev;
 }
 
 IPSX_API int ipsx_set_tie_order(int mode) {

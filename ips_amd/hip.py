@@ -10,6 +10,7 @@ call returns an error code, a RuntimeError is raised.  ``IPSX_BACKEND=aten``
 ``on_device`` report False so callers keep to ATen; the default is ``hip``.
 """
 
+import collections
 import ctypes as C
 import os
 import subprocess
@@ -217,6 +218,7 @@ _EXPORTS = {
     "ipsx_scan_persistent": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ipsx_publish_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ipsx_set_persistent_wait_ms": (C.c_int, [C.c_int]),
     "ipsx_scan_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ipsx_trunk_encode_indexed": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ipsx_scores_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
@@ -229,6 +231,8 @@ _EXPORTS = {
     "ipsx_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(Transf), C.c_int, C.c_int]),
     "ipsx_aggregate": (C.c_int, [C.POINTER(Transf), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_aggregate_packed": (C.c_int, [C.POINTER(Transf), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_bn_train_supported": (C.c_int, [C.c_int64, C.c_int]),
@@ -768,14 +772,81 @@ def scan_range_if(lg, M, I, H, T, it_begin, it_end, mem_idx, tie, cond, mask=1):
     return mem_idx
 
 
-def kernels_serialised():
-    """Does the environment make kernels run one at a time?  (Counter collection and thread traces of rocprofv3, the
-    runtime's serialising debug switches.)  A persistent selection loop that waits for rows its producers publish can
-    then only time out - the producers cannot run while it waits - so callers do not use it."""
-    env = os.environ
-    on = lambda k: env.get(k, "0").strip().lower() not in ("", "0", "false", "no")
-    return (on("AMD_SERIALIZE_KERNEL") or on("HIP_LAUNCH_BLOCKING") or on("ROCPROF_COUNTER_COLLECTION") or
-            bool(env.get("ROCPROF_COUNTERS")) or on("ROCPROF_ADVANCED_THREAD_TRACE") or bool(env.get("ROCPROF_PC_SAMPLING_METHOD")))
+Geometry = collections.namedtuple("Geometry", "cus xcds cus_per_xcd")
+_GEOMETRY = {}
+
+
+def device_geometry(dev):
+    """(compute units, XCDs, compute units per XCD) of a device as this process sees it.  gfx950 / gfx942 chiplets have 32
+    units each - SPX 256 units = 8 XCDs, DPX / QPX / CPX partitions 4 / 2 / 1 - and deal workgroups to their XCDs
+    round-robin; anything else counts as one XCD.  Launch sizes of the selection pipelines are derived from this."""
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    g = _GEOMETRY.get(idx)
+    if g is None:
+        props = torch.cuda.get_device_properties(idx)
+        cus = int(props.multi_processor_count)
+        arch = str(getattr(props, "gcnArchName", ""))
+        xcds = cus // 32 if (arch.startswith("gfx95") or arch.startswith("gfx94")) and cus % 32 == 0 and cus >= 32 else 1
+        g = _GEOMETRY[idx] = Geometry(cus, xcds, cus // xcds)
+    return g
+
+
+# Persistent kernels (a selection loop that waits for rows its producers publish while both run) need kernels of
+# different streams to actually run side by side.  Under rocprofv3's counter collection, thread traces or a serialising
+# debug switch they do not - the loop could only time out.  Instead of guessing from environment variables this is
+# established ONCE per device by doing it: a four-iteration loop is launched before its rows are published.  And it is
+# revoked for the whole process when a loop ever times out in production (IPSNet mirrors the status word to the host).
+_PERSIST_OK = {}
+_PERSIST_OFF = None
+
+
+def persistent_wait_ms(ms=0):
+    """Longest wait of a persistent loop (and its gate) without any progress, in ms (default 50); ms > 0 sets it."""
+    return lib().ipsx_set_persistent_wait_ms(int(ms))
+
+
+def persistent_ok(dev):
+    if _PERSIST_OFF is not None:
+        return False
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ok = _PERSIST_OK.get(idx)
+    if ok is None:
+        ok = _PERSIST_OK[idx] = _persistent_selftest(torch.device("cuda", idx))
+    return ok
+
+
+def persistent_disable(reason):
+    """Switch the persistent pipelines off for the rest of the process (per-part launches take over) and say so once."""
+    global _PERSIST_OFF
+    if _PERSIST_OFF is None:
+        import warnings
+        _PERSIST_OFF = reason
+        warnings.warn("ips_amd: persistent selection loops are switched off for this process: " + reason +
+                      " (IPSX_SCAN_PERSIST=0 avoids the attempt)")
+
+
+def _persistent_selftest(dev):
+    M = I = 16
+    H, T = 8, 1
+    if not scan_persistent_supported(M, I, H, T):
+        return False
+    N = M + 4 * I
+    with torch.cuda.device(dev):
+        lg = torch.zeros((1, N, H * T), dtype=torch.float32, device=dev)
+        mem = torch.empty((1, M), dtype=torch.int64, device=dev)
+        words = torch.zeros((3,), dtype=torch.int32, device=dev)            # tie | progress | status
+        side, main = torch.cuda.Stream(device=dev), torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            scan_persistent(lg, M, I, H, T, mem, words[0:1], words[1:2], words[2:3])
+        scan_gate(words[2:3])
+        publish_rows(words[1:2], N)
+        main.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        status = int(words[2].item())
+    return (status & 1) == 0 and (status & 2) == 2
 
 
 def scan_persistent_supported(M, I, H, T):
@@ -913,7 +984,13 @@ def aggregate(transf, x):
     out = torch.empty((B, ca.n_token, D), dtype=torch.float32, device=x.device)
     nb = lib().ipsx_aggregate_workspace_bytes(C.byref(t), B, M)
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
-    _ck(lib().ipsx_aggregate(C.byref(t), _p(x), B, M, _p(out), _p(ws), nb, _stream()), "ipsx_aggregate")
+    # the folded query and the packed V weights depend on the parameters only: kept by the attention module between calls
+    vq = ca.folded_query() if hasattr(ca, "folded_query") else None
+    if vq is not None and vq.dtype != torch.float32:       # (bf16 logits operand: the aggregation folds its own fp32 one)
+        vq = None
+    wvp = ca.packed_v() if hasattr(ca, "packed_v") else None
+    _ck(lib().ipsx_aggregate_packed(C.byref(t), _p(vq), _p(wvp), _p(x), B, M, _p(out), _p(ws), nb, _stream()),
+        "ipsx_aggregate_packed")
     return out
 
 

@@ -5,6 +5,8 @@ must be IDENTICAL, final outputs within 1e-4 (north_star) - and (2) the CPU orac
 the same inputs - indices identical, embeddings and outputs bit for bit.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -148,7 +150,8 @@ def test_lazy_slab_pipeline(monkeypatch, pinned, keep_mb):
     monkeypatch.setenv("IPSX_LAZY_KEEP_MB", keep_mb)
     g = Golden("mnist_ragged")
     net = g.net(DEV)
-    monkeypatch.setattr(type(net), "_LAZY_SLAB_BYTES", 2 * 70 * 4096)        # 70 patches per slab -> 5 slabs
+    from ips_amd.selection import Selection
+    monkeypatch.setattr(Selection, "LAZY_SLAB_BYTES", 2 * 70 * 4096)          # 70 patches per slab -> 5 slabs
     x = g.patches()
     if pinned:
         x = x.pin_memory()
@@ -238,7 +241,7 @@ def test_configs2_size_properties(monkeypatch):
     conf = synth.mnist_conf(N=10000, M=64, I=64)
     net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 11).to(DEV).eval()
     x = synth.make_patches(conf, 2, seed=5).to(DEV)
-    assert net._can_overlap(x)
+    assert net.selection.can_overlap(x)
     net.ips(x)
     idx = net.last_mem_idx.clone()
     monkeypatch.setenv("IPSX_OVERLAP_SCAN", "0")
@@ -440,11 +443,11 @@ def test_scan_overlapped_with_encoder_equals_plain(monkeypatch):
     g = Golden("mnist_full")
     net = g.net(DEV)
     x = torch.cat([g.patches(), synth.make_patches(g.conf, 13, seed=99)], 0).to(DEV)    # 35,000 patches: overlapped
-    assert net._can_overlap(x) and not net._can_overlap(x[:4])
+    assert net.selection.can_overlap(x) and not net.selection.can_overlap(x[:4])
     mp_a, pos_a = net.ips(x)
     idx_a = net.last_mem_idx.clone()
     monkeypatch.setenv("IPSX_OVERLAP_SCAN", "0")
-    assert not net._can_overlap(x)
+    assert not net.selection.can_overlap(x)
     mp_b, pos_b = net.ips(x)
     monkeypatch.delenv("IPSX_OVERLAP_SCAN")
     assert torch.equal(idx_a, net.last_mem_idx) and torch.equal(mp_a, mp_b) and torch.equal(pos_a, pos_b)
@@ -463,7 +466,7 @@ def test_one_image_every_schedule_selects_the_same_patches(N, monkeypatch):
         from ips_amd.architecture import IPSNet
         net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 7).to(DEV).eval()
         x = synth.make_patches(conf, 1, seed=5).to(DEV)
-        assert net._can_stream_image(x)
+        assert net.selection.can_stream_image(x)
         res = []
         for env in ({}, {"IPSX_IMAGE_STREAM": "0"}, {"IPSX_OVERLAP_SCAN": "0"}):
             for k, v in env.items():
@@ -530,7 +533,7 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
     for _ in range(3):
         net.ips(x)
         assert torch.equal(net.last_mem_idx, want)
-    assert int(net._scan_status.item()) & 1 == 0 and int(net._scan_status.item()) & 2 == 2
+    assert int(net.selection.scan_status.item()) & 1 == 0 and int(net.selection.scan_status.item()) & 2 == 2
     # a loop nobody feeds: negative progress word = cancelled -> it ends at once with the failure bit set ...
     B = 3
     lg = torch.randn((B, 1024, 8), device=DEV)
@@ -550,17 +553,48 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
     words.zero_()
     hip.scan_range_if(lg, 64, 64, 8, 1, 0, n_iter, mem, tie, words[1:2], 1)        # status clear: every workgroup leaves
     assert int((mem != -7).sum().item()) == 0
-    # the host learns of a timeout from the mirrored status word, one call later, and says so once - results stay valid
-    net._scan_status_host.fill_(1)
+    # the host learns of a timeout from the mirrored status word, one call later: it says so once and switches the
+    # persistent pipelines off for the process (the per-part launches take over) - results stay valid
+    monkeypatch.setattr(hip, "_PERSIST_OFF", None)              # (restored when this test ends)
+    net.selection.scan_status_host.fill_(1)
     with pytest.warns(UserWarning, match="timed out"):
         net.ips(x)
-    assert torch.equal(net.last_mem_idx, want)
-    # kernels serialised (counter collection, debugging switches): the persistent loop is not used at all
-    monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
-    assert hip.kernels_serialised()
-    net._scan_status = None
+    assert torch.equal(net.last_mem_idx, want) and not hip.persistent_ok(DEV)
+    net.selection.scan_status = None
     net.ips(x)
-    assert net._scan_status is None and torch.equal(net.last_mem_idx, want)
+    assert net.selection.scan_status is None and torch.equal(net.last_mem_idx, want)
+    monkeypatch.setattr(hip, "_PERSIST_OFF", None)
+    assert hip.persistent_ok(DEV)
+
+
+@pytest.mark.gpu
+def test_persistent_self_test_sees_serialised_kernels():
+    """Whether a persistent loop can run beside its producers is established by doing it once per device
+    (hip.persistent_ok), not by looking for profiler / debug variables: on this box it can; with the runtime told to
+    serialise every kernel (AMD_SERIALIZE_KERNEL=3, what counter collection does too) the self-test's loop times out after
+    the bounded wait and the persistent pipelines stay off - ips() then selects the same patches with per-part launches."""
+    import subprocess
+    import sys
+    assert hip.persistent_ok(DEV)
+    code = ("import torch\n"
+            "from ips_amd import hip, synth\n"
+            "from ips_amd.architecture import IPSNet\n"
+            "dev = torch.device('cuda:0')\n"
+            "ok = hip.persistent_ok(dev)\n"
+            "conf = synth.camelyon_conf(N=4096, M=64, I=64)\n"
+            "net = synth.fill_weights(IPSNet(dev, conf), 5).to(dev).eval()\n"
+            "net.ips(synth.make_patches(conf, 1, seed=9).to(dev))\n"
+            "print('persistent_ok', ok, 'used', net.selection.scan_status is not None, 'sum', int(net.last_mem_idx.sum()))\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {"AMD_SERIALIZE_KERNEL": "3"}):
+        env = dict(os.environ, PYTHONPATH=repo, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    assert outs[0][1] == "True" and outs[0][3] == "True", outs
+    assert outs[1][1] == "False" and outs[1][3] == "False", outs
+    assert outs[0][5] == outs[1][5], outs                      # the same selection either way
 
 
 @pytest.mark.gpu

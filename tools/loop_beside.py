@@ -18,7 +18,7 @@ def main():
     net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
     x = synth.make_patches(conf, 1, seed=21).to(dev)
     net.ips(x)
-    lg = net._feat_bufs[0].clone()                        # the slide's real logits
+    lg = net.selection._bufs["features"][1][0].clone()                        # the slide's real logits
     N, M, I, H, T = conf.N, conf.M, conf.I, conf.H, conf.n_token
     mem = torch.empty((1, M), dtype=torch.int64, device=dev)
     tie = torch.zeros((1,), dtype=torch.int32, device=dev)
