@@ -43,7 +43,9 @@ extern "C" {
  *   1.xx  rounds 1-2
  *   2.00  round 3: ipsx_scan / ipsx_scan_range / ipsx_topm take (workspace, workspace_bytes) in front of `stream`,
  *         ipsx_scan_persistent takes ready_per_image, ipsx_projector_stats_publish removed
- *   2.01  round 4 (additions only): ipsx_aggregate_packed, ipsx_set_persistent_wait_ms; ipsx_projector_stream accepts
+ *   2.01  round 4 (additions only): ipsx_aggregate_packed, ipsx_set_persistent_wait_ms, ipsx_conv2d_wgrad_nhwc*,
+ *         ipsx_pack_conv_weight_strided;
+ *         ipsx_projector_stream accepts
  *         short_first <= -3 (guided tile sizes)                                                                     */
 #define IPSX_VERSION 201
 
@@ -69,6 +71,12 @@ size_t ipsx_packed_conv_weight_elems(int c_out, int c_in, int kh, int kw);
  * element j of lane l holds k = 8*group + 4*(l>>5) + j, output channel 32*tile + (l&31) */
 int ipsx_pack_conv_weight(const float* w_oihw, int c_out, int c_in, int kh, int kw,
                           float* packed, void* stream);
+/* The same from a strided view: element (n, c, ky, kx) of the convolution's weight is w[base + n*s_out + c*s_in + ky*s_ky +
+ * kx*s_kx] (element strides, any sign) - a channels-last tensor as it lies, or, with base at the last tap, negated tap
+ * strides and swapped channel strides, the weights rotated by 180 degrees and transposed that make ipsx_conv2d_affine_nhwc
+ * on dy the data gradient of the convolution. */
+int ipsx_pack_conv_weight_strided(const float* w, int64_t base, int c_out, int c_in, int kh, int kw, int64_t s_out,
+                                  int64_t s_in, int64_t s_ky, int64_t s_kx, float* packed, void* stream);
 
 /* bf16 variant for the reduced-precision trunk: [C_out/32][K/16][64 lanes][8 bf16], round to nearest even */
 size_t ipsx_packed_conv_weight_bf16_bytes(int c_out, int c_in, int kh, int kw);
@@ -135,6 +143,17 @@ int ipsx_conv2d_affine(const ipsx_conv* cv, const float* x, const float* residua
  * This is the fast layer-by-layer path (16-byte operand loads); a Linear over rows is h = w = 1. */
 int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* residual,
                             float* y, int64_t n, int h, int w, int relu, void* stream);
+/* Weight gradient of that convolution for the training step (reference: loss.backward() of training/iterative.py:157-163
+ * through the BasicBlocks of architecture/ips_net.py:264-283):
+ *   dw[co][ky][kx][ci] = sum over (img, oy, ox) of dy[img,oy,ox,co] * x[img, stride*oy + ky - pad, stride*ox + kx - pad, ci]
+ * x (n,h,w,c_in) and dy (n,ho,wo,c_out) channels-last, dw in the memory order of a channels-last weight tensor
+ * ((c_out, c_in, kh, kw) with strides (kh*kw*c_in, 1, kw*c_in, c_in)).  fp32 MFMA, reduction over the pixels split across
+ * workgroups and added in a fixed order (deterministic).  c_in and c_out multiples of 64 (ipsx_conv2d_wgrad_nhwc_supported).
+ * The data gradient is ipsx_conv2d_affine_nhwc itself: on dy with the weights rotated by 180 degrees and transposed. */
+int ipsx_conv2d_wgrad_nhwc_supported(int c_in, int c_out, int kh, int kw, int stride, int pad);
+size_t ipsx_conv2d_wgrad_nhwc_workspace_bytes(int64_t n, int c_in, int c_out, int kh, int kw);
+int ipsx_conv2d_wgrad_nhwc(const float* x, const float* dy, int64_t n, int h, int w, int c_in, int c_out, int kh, int kw,
+                           int stride, int pad, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 int ipsx_maxpool_3x3s2_nhwc(const float* x, float* y, int64_t n, int c, int h, int w, void* stream);
 /* (n,hw,c) -> (n,c) */
 int ipsx_avgpool_nhwc(const float* x, float* y, int64_t n, int c, int hw, void* stream);

@@ -63,6 +63,31 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int c_out, 
     packed[i] = v;
 }
 
+// the same from ANY strided view of the weight (element strides, possibly negative): a channels-last tensor as it lies,
+// or - base at the last tap, tap strides negated, channel strides swapped - the weights rotated by 180 degrees and
+// transposed that turn a convolution into its own data gradient (training step, csrc/conv_wgrad.hip)
+__global__ void pack_conv_weight_strided_kernel(const float* __restrict__ w, long long base, int c_out, int c_in, int kh, int kw,
+                                                long long sn, long long sc, long long sky, long long skx, int kgs, size_t total,
+                                                float* __restrict__ packed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    const size_t g = i >> 8;
+    const int kg = (int)(g % kgs);
+    const int nt = (int)(g / kgs);
+    const int n = nt * 32 + (lane & 31);
+    const int k = kg * 8 + 4 * (lane >> 5) + j;
+    const int K = kh * kw * c_in;
+    float v = 0.0f;
+    if (n < c_out && k < K) {
+        const int tap = k / c_in, c = k - tap * c_in;
+        const int ky = tap / kw, kx = tap - ky * kw;
+        v = w[base + n * sn + c * sc + ky * sky + kx * skx];
+    }
+    packed[i] = v;
+}
+
 __global__ void bn_affine_kernel(const float* gamma, const float* beta, const float* mean, const float* var,
                                  const float* lin_bias, float eps, int c, float* alpha, float* shift) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +310,16 @@ IPSX_API int ipsx_pack_conv_weight(const float* w, int c_out, int c_in, int kh, 
     pack_conv_weight_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream)>>>(
         w, c_out, c_in, kh, kw, kgs, total, packed);
     return launched("pack_conv_weight");
+}
+
+IPSX_API int ipsx_pack_conv_weight_strided(const float* w, int64_t base, int c_out, int c_in, int kh, int kw, int64_t s_out,
+                                           int64_t s_in, int64_t s_ky, int64_t s_kx, float* packed, void* stream) {
+    IPSX_REQUIRE(w && packed && c_out > 0 && c_in > 0 && kh > 0 && kw > 0, "pack_conv_weight_strided: bad arguments");
+    const size_t total = ipsx_packed_conv_weight_elems(c_out, c_in, kh, kw);
+    const int kgs = (int)cdiv((int64_t)kh * kw * c_in, 8);
+    pack_conv_weight_strided_kernel<<<dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream)>>>(
+        w, base, c_out, c_in, kh, kw, s_out, s_in, s_ky, s_kx, kgs, total, packed);
+    return launched("pack_conv_weight_strided");
 }
 
 IPSX_API int ipsx_bn_affine(const float* gamma, const float* beta, const float* mean, const float* var,

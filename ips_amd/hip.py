@@ -148,6 +148,8 @@ _EXPORTS = {
     "ipsx_device_is_gfx950": (C.c_int, [C.c_int]),
     "ipsx_packed_conv_weight_elems": (C.c_size_t, [C.c_int] * 4),
     "ipsx_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ipsx_pack_conv_weight_strided": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                                C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "ipsx_packed_conv_weight_bf16_bytes": (C.c_size_t, [C.c_int] * 4),
     "ipsx_pack_conv_weight_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_packed_conv_weight_x3_bytes": (C.c_size_t, [C.c_int] * 4),
@@ -159,6 +161,9 @@ _EXPORTS = {
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_conv2d_affine_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_conv2d_wgrad_nhwc_supported": (C.c_int, [C.c_int] * 6),
+    "ipsx_conv2d_wgrad_nhwc_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int] * 4),
+    "ipsx_conv2d_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_maxpool_3x3s2_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_avgpool_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_maxpool_3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -1006,6 +1011,80 @@ def head(emb, token, linear, act):
 
 
 # ---------------------------------------------------------------- training step (with-grad forward of the trunk)
+_CL = torch.channels_last
+
+
+def conv_train_supported(conv):
+    """Can the training step's convolutions of ``conv`` (an nn.Conv2d) run on the kernels of libipsx?  Forward and data
+    gradient: ``ipsx_conv2d_affine_nhwc`` (C_in % 32 == 0); weight gradient: ``ipsx_conv2d_wgrad_nhwc`` (channels % 64 == 0);
+    strided layers need "same" padding for the data gradient's formulation (kernel - 1 = 2 pad)."""
+    kh, kw = conv.kernel_size
+    s, p = conv.stride[0], conv.padding[0]
+    if (conv.bias is not None or conv.groups != 1 or conv.dilation != (1, 1) or conv.stride[0] != conv.stride[1]
+            or conv.padding[0] != conv.padding[1] or kh != kw or conv.weight.dtype != torch.float32):
+        return False
+    if s > 1 and kh - 1 != 2 * p:
+        return False
+    return bool(lib().ipsx_conv2d_wgrad_nhwc_supported(conv.in_channels, conv.out_channels, kh, kw, s, p))
+
+
+def _pack_conv_view(weight, dgrad=False):
+    """``_pack_conv`` of a weight tensor as it lies in memory (any strides: no contiguous copy) - or, ``dgrad``, of the
+    weights rotated by 180 degrees and transposed: -> (packed, C_out, C_in) of the convolution they describe."""
+    co, ci, kh, kw = weight.shape
+    s_co, s_ci, s_kh, s_kw = weight.stride()
+    if dgrad:
+        n_out, n_in = ci, co
+        base, sn, sc, sky, skx = (kh - 1) * s_kh + (kw - 1) * s_kw, s_ci, s_co, -s_kh, -s_kw
+    else:
+        n_out, n_in = co, ci
+        base, sn, sc, sky, skx = 0, s_co, s_ci, s_kh, s_kw
+    packed = torch.empty(lib().ipsx_packed_conv_weight_elems(n_out, n_in, kh, kw), dtype=torch.float32, device=weight.device)
+    _ck(lib().ipsx_pack_conv_weight_strided(_p(weight), base, n_out, n_in, kh, kw, sn, sc, sky, skx, _p(packed), _stream()),
+        "ipsx_pack_conv_weight_strided")
+    return packed, n_out, n_in
+
+
+def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False):
+    """Plain convolution of a channels-last (P, C_in, h, w) tensor with an OIHW ``weight`` on the fp32 matrix cores
+    (conv_nhwc_kernel): -> channels-last (P, C_out, ho, wo)."""
+    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous(memory_format=_CL):
+        raise ValueError("expected a float32 channels-last (P, C, H, W) tensor")
+    kh, kw = weight.shape[2:]
+    n, _, h, w = x.shape
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    packed, co, ci = _pack_conv_view(weight.detach(), dgrad_weights)
+    cv = Conv(ci, co, kh, kw, stride, pad, _p(packed), None, None, None)
+    y = torch.empty((n, co, ho, wo), dtype=torch.float32, device=x.device, memory_format=_CL)
+    _ck(lib().ipsx_conv2d_affine_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_nhwc")
+    return y
+
+
+def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw):
+    """Data gradient of ``conv2d_nhwc``: the same kernel on dy with the weights rotated by 180 degrees and transposed; a
+    strided layer first spreads dy over a zero map of the input's size (needs kernel - 1 = 2 pad)."""
+    co, ci, kh, kw = weight.shape
+    if stride > 1:
+        n = dy.shape[0]
+        spread = torch.empty((n, co, in_hw[0], in_hw[1]), dtype=torch.float32, device=dy.device, memory_format=_CL).zero_()
+        spread[:, :, ::stride, ::stride] = dy
+        dy = spread
+    return conv2d_nhwc(dy, weight, 1, kh - 1 - pad, dgrad_weights=True)
+
+
+def conv2d_nhwc_wgrad(x, dy, weight_shape, stride, pad):
+    """Weight gradient of ``conv2d_nhwc`` -> (C_out, C_in, kh, kw) in channels-last memory order (ipsx_conv2d_wgrad_nhwc)."""
+    co, ci, kh, kw = weight_shape
+    n, _, h, w = x.shape
+    dy = dy.contiguous(memory_format=_CL)
+    dw = torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device, memory_format=_CL)
+    nb = lib().ipsx_conv2d_wgrad_nhwc_workspace_bytes(n, ci, co, kh, kw)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
+    _ck(lib().ipsx_conv2d_wgrad_nhwc(_p(x), _p(dy), n, h, w, ci, co, kh, kw, stride, pad, _p(dw), _p(ws), nb, _stream()),
+        "ipsx_conv2d_wgrad_nhwc")
+    return dw
+
+
 def _rows_cl(t):
     """(P, C, H, W) channels-last tensor -> (rows, C) of its memory."""
     if t.dim() != 4 or t.dtype != torch.float32 or not t.is_contiguous(memory_format=torch.channels_last):

@@ -14,8 +14,11 @@ differently:
 * every ``bn -> relu`` and ``bn -> (+ identity) -> relu`` is ONE autograd node backed by ``libipsx.so``
   (``ipsx_bn_train_forward`` / ``_backward``: two memory passes each way, csrc/bn_train.hip).
 
-Convolutions (forward, data and weight gradients) and the two poolings remain stock ops.  Results equal the stock
-path to fp32 rounding (another summation order for the batch moments): tests/test_hip_train.py compares loss,
+* (round 4) the convolutions of the residual stages run on libipsx's own fp32-MFMA kernels in all three directions
+  (``_Conv``: forward / data gradient ``conv_nhwc_kernel``, weight gradient ``conv_wgrad_kernel``); ``IPSX_TRAIN_CONV=0``
+  hands them back to MIOpen.  The stem (1 or 3 input channels) and the two poolings remain stock ops.
+
+Results equal the stock path to fp32 rounding (another summation order): tests/test_hip_train.py compares loss,
 gradients, running statistics and post-step weights.  ``IPSX_TRAIN_FUSED=0`` switches it off.
 """
 import os
@@ -84,7 +87,35 @@ def bn_act(x, bn, residual=None, relu=True):
     return _BnAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
 
 
+def conv_enabled():
+    return os.environ.get("IPSX_TRAIN_CONV", "1") != "0"
+
+
+class _Conv(torch.autograd.Function):
+    """Convolution of a channels-last activation on the fp32 matrix cores, all three directions on kernels of libipsx:
+    forward and data gradient ``conv_nhwc_kernel`` (the data gradient = the same convolution of dy with the weights rotated
+    by 180 degrees and transposed), weight gradient ``conv_wgrad_kernel`` (csrc/conv_wgrad.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = x.contiguous(memory_format=_CL)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad)
+        return hip.conv2d_nhwc(x, weight.detach(), stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.geom
+        dy = dy.contiguous(memory_format=_CL)
+        dx = hip.conv2d_nhwc_dgrad(dy, weight, stride, pad, x.shape[2:]) if ctx.needs_input_grad[0] else None
+        dw = hip.conv2d_nhwc_wgrad(x, dy, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
 def _conv(conv, x):
+    if conv_enabled() and x.is_cuda and x.dtype == torch.float32 and hip.conv_train_supported(conv):
+        return _Conv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 

@@ -18,6 +18,39 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+@pytest.mark.parametrize("P,ci,co,k,s,H", [(16, 64, 64, 3, 1, 8), (33, 64, 128, 3, 2, 8), (7, 64, 128, 1, 2, 8), (40, 128, 128, 3, 1, 4),
+                                             (5, 128, 256, 3, 2, 13), (3, 256, 256, 3, 1, 7), (1024, 64, 64, 3, 1, 8), (2, 512, 512, 3, 1, 2),
+                                             (9, 64, 64, 3, 1, 13), (4, 64, 64, 1, 1, 1)])
+def test_conv_train_kernels_match_torch(P, ci, co, k, s, H):
+    """The training step's convolutions on libipsx's kernels (training/fused_encoder.py::_Conv): forward and data gradient
+    on conv_nhwc_kernel, weight gradient on conv_wgrad_kernel - against float64 autograd of F.conv2d, and bit-identical
+    from run to run (the pixel reduction of the weight gradient is split and added in a fixed order)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(P * 131 + ci + co + k)
+    pad = (k - 1) // 2
+    conv = torch.nn.Conv2d(ci, co, k, s, pad, bias=False).to(dev)
+    assert hip.conv_train_supported(conv)
+    x = torch.randn((P, ci, H, H), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((co, ci, k, k), generator=g) / (ci * k * k) ** 0.5).to(dev)
+    Ho = (H + 2 * pad - k) // s + 1
+    dy = torch.randn((P, co, Ho, Ho), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+
+    xs, ws = x.double().requires_grad_(), w.double().requires_grad_()
+    want = F.conv2d(xs, ws, None, s, pad)
+    want.backward(dy.double())
+
+    xh, wh = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = fused_encoder._Conv.apply(xh, wh, s, pad)
+    assert y.is_contiguous(memory_format=torch.channels_last) and tuple(y.shape) == tuple(want.shape)
+    y.backward(dy)
+    assert _rel(y.double(), want.detach()) < 1e-5
+    assert _rel(xh.grad.double(), xs.grad) < 1e-5
+    assert _rel(wh.grad.double(), ws.grad) < 1e-5
+    again = hip.conv2d_nhwc_wgrad(x, dy, w.shape, s, pad)
+    assert torch.equal(again, hip.conv2d_nhwc_wgrad(x, dy, w.shape, s, pad))
+    assert torch.equal(again.contiguous(), wh.grad.contiguous())
+
+
 @pytest.mark.parametrize("P,C,H,relu,res", [(8, 64, 16, True, False), (5, 64, 8, True, True), (3, 128, 4, False, False),
                                             (7, 256, 2, True, True), (16, 512, 1, True, False), (1024, 64, 16, True, False),
                                             (9, 4, 3, True, True), (33, 8, 5, False, True), (3, 1024, 2, True, False)])
