@@ -160,11 +160,133 @@ __global__ __launch_bounds__(WG_WAVES * 64) void conv_wgrad_kernel(WgradArgs a) 
     }
 }
 
+// 3x3 kernels: ONE WAVEFRONT PER TAP.  conv_wgrad_kernel gives a workgroup's wavefronts different pixels of the same tap -
+// nothing is shared between them and every MFMA needs 256 B of fresh operands from L2 (measured: 4.4 TB/s of L2 -> CU
+// traffic, matrix pipe at 0.45).  Here the wavefronts of a workgroup walk the SAME (pixel pair, image) sequence, each for
+// its own tap: the dy operand is the same line for all of them and the x operands are the taps' shifted views of one
+// neighbourhood, so all but the first request of a line is served by the compute unit's L1.  Eight wavefronts (two per
+// SIMD, evenly) take taps 0..7; the ninth tap is shared out among them by pixel pair afterwards (a second accumulator
+// block, added through LDS in wavefront order).  Partial blocks per split as before.
+__device__ __forceinline__ void wgrad_walk(const WgradArgs& a, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ry, int tap, int co0,
+                                           int ci0, int img_lo, int n_img, int slot0, int slot_step, int half, int i,
+                                           f32x16 (&acc)[2][2]) {
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    const int howo = a.ho * a.wo, npair = (howo + 1) >> 1;
+    const unsigned ystride = (unsigned)(howo * a.c_out) * 4u, xstride = (unsigned)(a.h * a.w * a.c_in) * 4u;
+    int slot = slot0, left = 0;
+    unsigned voffy = kWgOob, voffx = kWgOob, soffy = 0u, soffx = 0u;
+    auto open_slot = [&]() {
+        voffy = voffx = kWgOob;
+        left = 0;
+        if (slot < npair && n_img > 0) {
+            const int q = 2 * slot + half;
+            const int oy = q / a.wo, ox = q - oy * a.wo;
+            const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+            const bool okq = q < howo;
+            const bool okx = okq && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+            voffy = okq ? ((unsigned)q * (unsigned)a.c_out + (unsigned)(co0 + i)) * 4u : kWgOob;
+            voffx = okx ? ((unsigned)(iy * a.w + ix) * (unsigned)a.c_in + (unsigned)(ci0 + i)) * 4u : kWgOob;
+            soffy = (unsigned)img_lo * ystride;
+            soffx = (unsigned)img_lo * xstride;
+            left = n_img;
+        }
+    };
+    open_slot();
+    const int my_slots = slot0 < npair ? (npair - slot0 + slot_step - 1) / slot_step : 0;
+    const int steps = n_img > 0 ? my_slots * n_img : 0;
+    auto issue = [&](WgradStage& st) {
+        const bool live = left > 0;
+        const unsigned vy = live ? voffy : kWgOob, vx = live ? voffx : kWgOob;
+        st.a0 = wg_load(ry, vy, soffy);
+        st.a1 = wg_load(ry, vy, soffy + 128u);
+        st.b0 = wg_load(rx, vx, soffx);
+        st.b1 = wg_load(rx, vx, soffx + 128u);
+        soffy += ystride;
+        soffx += xstride;
+        if (--left <= 0) { slot += slot_step; open_slot(); }     // (wave-uniform)
+    };
+    auto mma = [&](const WgradStage& st) {
+        acc[0][0] = WG_MFMA(st.a0, st.b0, acc[0][0]);
+        acc[0][1] = WG_MFMA(st.a0, st.b1, acc[0][1]);
+        acc[1][0] = WG_MFMA(st.a1, st.b0, acc[1][0]);
+        acc[1][1] = WG_MFMA(st.a1, st.b1, acc[1][1]);
+    };
+    WgradStage s0, s1, s2, s3;
+    issue(s0);
+    issue(s1);
+    issue(s2);
+#pragma unroll 1
+    for (int t = 0; t < steps; t += 4) {
+        issue(s3); mma(s0);
+        issue(s0); mma(s1);
+        issue(s1); mma(s2);
+        issue(s2); mma(s3);
+    }
+}
+
+__global__ __launch_bounds__(WG_WAVES * 64) void conv_wgrad_taps_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];          // [WG_WAVES][64][64]: the shared ninth tap
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
+    const int g = (int)(blockIdx.x % (unsigned)a.groups), split = (int)(blockIdx.x / (unsigned)a.groups);       // groups = ci_blocks * co_blocks
+    const int cob = g % a.co_blocks, cib = g / a.co_blocks;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int img_lo = split * a.imgs_per_split, img_hi = min(a.n, img_lo + a.imgs_per_split);
+    const int n_img = img_hi > img_lo ? img_hi - img_lo : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+    float* out = a.partial + (size_t)split * a.c_out * a.K;
+    f32x16 acc[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.0f;
+    };
+    // taps 0..7: this wavefront's own tap, every pixel pair
+    zero();
+    wgrad_walk(a, rx, ry, wave, co0, ci0, img_lo, n_img, 0, 1, half, i, acc);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(size_t)(co0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half) * a.K + (size_t)wave * a.c_in + ci0 + 32 * v + i] = acc[u][v][r];
+    // tap 8: pixel pairs wave, wave + 8, ... of every image; the eight partial blocks added in wavefront order
+    zero();
+    wgrad_walk(a, rx, ry, 8, co0, ci0, img_lo, n_img, wave, WG_WAVES, half, i, acc);
+    float* mine = wg_lds + wave * 4096;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(32 * u + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 * v + i] = acc[u][v][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += WG_WAVES * 64) {
+        float s = wg_lds[e];
+#pragma unroll
+        for (int wv = 1; wv < WG_WAVES; ++wv) s = s + wg_lds[wv * 4096 + e];
+        out[(size_t)(co0 + (e >> 6)) * a.K + (size_t)8 * a.c_in + ci0 + (e & 63)] = s;
+    }
+}
+
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t total, float* __restrict__ dw) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     float s = partial[e];
-    for (int k = 1; k < splits; ++k) s = s + partial[(size_t)k * total + e];
+    int k = 1;
+    for (; k + 8 <= splits; k += 8) {              // split order kept; eight loads in flight
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(k + j) * total + e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = s + v[j];
+    }
+    for (; k < splits; ++k) s = s + partial[(size_t)k * total + e];
     dw[e] = s;
 }
 
@@ -187,7 +309,8 @@ IPSX_API int ipsx_conv2d_wgrad_nhwc_supported(int c_in, int c_out, int kh, int k
 
 IPSX_API size_t ipsx_conv2d_wgrad_nhwc_workspace_bytes(int64_t n, int c_in, int c_out, int kh, int kw) {
     if (n <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    const int groups = kh * kw * (c_in / 64) * (c_out / 64);
+    const bool by_tap = kh * kw == 9;
+    const int groups = (by_tap ? 1 : kh * kw) * (c_in / 64) * (c_out / 64);
     const int splits = wgrad_splits((int)std::min<int64_t>(n, 1 << 30), groups);
     return (size_t)splits * c_out * kh * kw * c_in * sizeof(float);
 }
@@ -212,18 +335,32 @@ IPSX_API int ipsx_conv2d_wgrad_nhwc(const float* x, const float* dy, int64_t n, 
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
     a.ci_blocks = c_in / 64; a.co_blocks = c_out / 64; a.groups = kh * kw * a.ci_blocks * a.co_blocks;
     a.K = kh * kw * c_in;
+    const bool by_tap = kh * kw == 9;                            // 3x3: one wavefront per tap (conv_wgrad_taps_kernel)
+    if (by_tap) a.groups = a.ci_blocks * a.co_blocks;
     const int splits = wgrad_splits((int)n, a.groups);
     a.imgs_per_split = ((int)n + splits - 1) / splits;
+    hipStream_t s = as_stream(stream);
+    const size_t total = (size_t)c_out * a.K;
+    if (by_tap) {
+        static bool attr_t = false;
+        const size_t lds_t = (size_t)WG_WAVES * 4096 * sizeof(float);
+        if (!attr_t) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_taps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+            attr_t = true;
+        }
+        conv_wgrad_taps_kernel<<<dim3((unsigned)(a.groups * splits)), dim3(WG_WAVES * 64), lds_t, s>>>(a);
+        IPSX_TRY(launched("conv2d_wgrad_nhwc (taps)"));
+        conv_wgrad_reduce_kernel<<<dim3((unsigned)cdiv((int64_t)total, 256)), dim3(256), 0, s>>>(a.partial, splits, total, dw);
+        return launched("conv2d_wgrad_nhwc reduce");
+    }
     const size_t lds = (size_t)WG_WAVES * 4096 * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipStream_t s = as_stream(stream);
     conv_wgrad_kernel<<<dim3((unsigned)(a.groups * splits)), dim3(WG_WAVES * 64), lds, s>>>(a);
     IPSX_TRY(launched("conv2d_wgrad_nhwc"));
-    const size_t total = (size_t)c_out * a.K;
     conv_wgrad_reduce_kernel<<<dim3((unsigned)cdiv((int64_t)total, 256)), dim3(256), 0, s>>>(a.partial, splits, total, dw);
     return launched("conv2d_wgrad_nhwc reduce");
 }

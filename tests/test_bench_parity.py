@@ -30,7 +30,7 @@ WORKLOADS = ["mnist", "mnist3000", "native50", "traffic", "cam", "cam_native"]
 GAP_FLOOR = 1e-5
 # relative score gap below which a host-made positional table that differs in the last ulp of its frequency vector (times
 # positions up to N = 10,000: entries move by ~6e-4) may legitimately change a selection
-TABLE_FLOOR = 1e-3
+TABLE_FLOOR = 1e-4
 # cam_native ranks 10,000 candidates whose scores all lie within a binade or two of 1e-4: in EVERY iteration some
 # neighbours of the reference's sorted top M + 1 are bit-equal (order_gap = 0), so the ORDER inside the memory is the
 # reference's own noise at a percent of the positions, while the SET has a clear boundary (rel_gap 2.5e-5 ... 4e-4 in

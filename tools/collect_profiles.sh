@@ -14,7 +14,11 @@ for c in mnist cam native50 cam_native; do
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -o ks -- python3 "$OLDPWD/bench.py" --config $c --steps 10 --warmup 3 --cpu-seconds 0 > "$OLDPWD/$OUT/bench_${c}_profiled.json" 2>/dev/null)
   cp $(find /tmp/ks_$c -name "*kernel_stats.csv" | head -1) "$OUT/${c}_kernel_stats.csv" 2>/dev/null
 done
-for c in mnist cam native50; do
+for ctr in FETCH_SIZE WRITE_SIZE; do            # the projector stream alone (inside ips() counter collection would serialise it away)
+  rm -rf /tmp/pmc_stream_$ctr
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_stream_$ctr -o pmc -- python3 "$OLDPWD/tools/projector_stream_bench.py" pmc > /dev/null 2>&1)
+done
+for c in mnist cam native50 traffic; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${c}_$ctr
     (cd /tmp && rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_${c}_$ctr -o pmc -- python3 "$OLDPWD/bench.py" --config $c --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1)
@@ -22,10 +26,20 @@ for c in mnist cam native50; do
 done
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic_before.json"
 python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip,fused_trunk_pair.h "fused_trunk_kernel|fused_trunk_pair_kernel" 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err"
-python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam 8 conv_nhwc.hip,aggregate.hip,scorer.hip > "$OUT/pmc_cam.json" 2> "$OUT/pmc_cam.err"
+python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam_parts 8 conv_nhwc.hip,aggregate.hip,scorer.hip > "$OUT/pmc_cam_parts.json" 2> "$OUT/pmc_cam_parts.err"
+python tools/pmc_traffic.py /tmp/pmc_stream_FETCH_SIZE /tmp/pmc_stream_WRITE_SIZE cam 5 conv_nhwc.hip,ipsx_rowstats.h "projector_stream_kernel" 65536 > "$OUT/pmc_cam.json" 2> "$OUT/pmc_cam.err"
+python tools/pmc_traffic.py /tmp/pmc_traffic_FETCH_SIZE /tmp/pmc_traffic_WRITE_SIZE traffic 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_traffic_signs.json" 2> "$OUT/pmc_traffic_signs.err"
 python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err"
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
+python tools/scan_compare.py > "$OUT/scan_compare.txt" 2>&1
+python tools/scan_stamps.py camwaves > "$OUT/scan_camwaves.txt" 2>&1
+bash tools/pmc_scan.sh "$OUT/pmc_scan" > "$OUT/scan_pmc.txt" 2>&1
+IPSX_SCAN_R8=0 bash tools/pmc_scan.sh "$OUT/pmc_scan_fast" >> "$OUT/scan_pmc.txt" 2>&1
+rm -rf "$OUT/pmc_scan" "$OUT/pmc_scan_fast"
+python tools/train_step_breakdown.py --fused --profile > "$OUT/train_step_hipconv.txt" 2>&1
+IPSX_TRAIN_CONV=0 python tools/train_step_breakdown.py --fused --profile > "$OUT/train_step_miopen.txt" 2>&1
 python tools/scan_stamps.py cam > "$OUT/scan_stamps_cam.txt" 2>&1
+IPSX_SCAN_R8=0 python tools/scan_stamps.py cam >> "$OUT/scan_stamps_cam.txt" 2>&1
 python tools/scan_stamps.py mnist >> "$OUT/scan_stamps_cam.txt" 2>&1
 python tools/scan_stamps.py large > "$OUT/scan_stamps_large.txt" 2>&1
 python tools/scan_stamps.py campipe > "$OUT/scan_stamps_campipe.txt" 2>&1

@@ -25,9 +25,36 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+def pmc_mode():
+    """The stream as ips() launches it for one slide (255 workgroups, guided tile sizes), alone, five times: what the
+    counter passes of tools/collect_profiles.sh profile - counter collection serialises kernels, so the stream cannot be
+    measured inside ips() (beside its resident loop), but alone it runs as it is."""
+    conf, _ = synth.bench_workload("cam")
+    from ips_amd.architecture.ips_net import IPSNet
+    dev = torch.device("cuda:0")
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    plan = hip.EncoderPlan(net.encoder, False)
+    ca = net.transf.crs_attn
+    vq, R = ca.folded_query(), ca.H * ca.n_token
+    n = conf.N
+    x = synth.make_patches(conf, 1, seed=21)[0].to(dev)
+    emb = torch.empty((n, conf.D), device=dev)
+    lg = torch.empty((n, R), device=dev)
+    ctl = torch.zeros((plan.stream_ctl_words(n),), dtype=torch.int32, device=dev)
+    ready = torch.zeros((1,), dtype=torch.int32, device=dev)
+    for _ in range(5):
+        ctl.zero_()
+        ready.zero_()
+        plan.stream(x, vq, R, emb, lg, ctl, ready, workgroups=hip.device_geometry(dev).cus - 1, short_first=-20)
+    torch.cuda.synchronize()
+    print("5 launches of the projector stream on %d rows" % n)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pmc":
+        return pmc_mode()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-    wgs = [int(a) for a in sys.argv[2:]] or [224, 248, 256]
+    wgs = [int(a) for a in sys.argv[2:]] or [224, 248, 255]
     conf, _ = synth.bench_workload("cam")
     from ips_amd.architecture.ips_net import IPSNet
     dev = torch.device("cuda:0")
@@ -49,13 +76,13 @@ def main():
     ctl = torch.zeros((plan.stream_ctl_words(n),), dtype=torch.int32, device=dev)
     ready = torch.zeros((1,), dtype=torch.int32, device=dev)
     for w in wgs:
-        for short in (0, w // 2, -2):
+        for short in (0, w // 2, -2, -20):
             def stream():
                 ctl.zero_()
                 ready.zero_()
                 plan.stream(x, vq, R, emb, lg[0], ctl, ready, workgroups=w, short_first=short)
             ms = timed(stream)
-            print("stream, %d workgroups, %d short first tiles (-2: every tile 32 rows): %.3f ms (%.3f of peak on %d units: %.3f)"
+            print("stream, %d workgroups, %d short first tiles (-2: every tile 32 rows, -20: guided): %.3f ms (%.3f of peak on %d units: %.3f)"
                   % (w, short, ms, flop / (ms * 1e-3) / 157.3e12, w, flop / (ms * 1e-3) / 157.3e12 * 256 / w), flush=True)
     stamps(plan, x, vq, R, emb, lg, ctl, ready, n)
 
