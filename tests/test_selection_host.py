@@ -1,0 +1,77 @@
+"""CPU: the host-side scheduling of ips_amd/selection.py - launch sizes derived from the device geometry (no GPU needed:
+the geometry is injected), parts cut at chunk boundaries, and the ABI pieces round 4 added."""
+import math
+
+import pytest
+import torch
+
+from ips_amd import hip, synth
+from ips_amd.architecture import IPSNet
+from ips_amd.selection import Selection
+
+
+class _Dev:
+    """stands in for a torch device in the geometry look-up"""
+    index = 0
+
+
+@pytest.fixture
+def geometry(monkeypatch):
+    def use(cus, xcds):
+        monkeypatch.setattr(hip, "device_geometry", lambda dev: hip.Geometry(cus, xcds, cus // xcds))
+    return use
+
+
+def _sel(conf):
+    return Selection(IPSNet(torch.device("cpu"), conf))
+
+
+def test_small_batch_split_follows_the_device(geometry):
+    sel = _sel(synth.mnist_conf(N=2500, M=64, I=64))
+    geometry(256, 8)                                   # MI355X, SPX
+    assert sel.round_patches(_Dev) == 2048 and sel.small_batch_limit(_Dev) == 32768
+    edges, its = sel.small_batch_split(1, 2500, _Dev)
+    assert edges == [0, 1024, 2016, 2500] and its == [0, 15, 30, 39]          # 1,024 + 992 + 484 patches, 15 + 15 + 9 iterations
+    assert sel.small_batch_split(16, 2500, _Dev) is None                      # 19 rounds: the four shrinking parts instead
+    geometry(128, 4)                                   # a DPX partition: half the units, the same shape of split
+    edges, its = sel.small_batch_split(1, 1250, _Dev)
+    assert edges[1] == 512 and edges[2] == 512 + 512 - 16 and edges[-1] == 1250
+    assert its[-1] == math.ceil((1250 - 64) / 64)
+
+
+def test_feature_launches_leave_a_unit_per_loop_on_the_fullest_xcd(geometry):
+    sel = _sel(synth.camelyon_conf(N=65536, M=256, I=256))
+    geometry(256, 8)
+    assert sel.free_units(_Dev, 1) == 248 and sel.free_units(_Dev, 8) == 248 and sel.free_units(_Dev, 9) == 240
+    its = sel.feature_parts(1, 65536, _Dev, True)
+    assert its[0] == 0 and its[-1] == 255 and all(b > a for a, b in zip(its, its[1:]))
+    edges = [0] + [min(65536, 256 + it * 256) for it in its[1:]]
+    edges[-1] = 65536
+    one = sel.feature_launches(1, 65536, edges, _Dev)
+    assert [r1 - r0 for r0, r1, _ in one] == [b - a for a, b in zip(edges, edges[1:])]
+    assert all(r1 - r0 <= 248 * 64 for r0, r1, _ in one)
+    # several slides: one flat stream of rows cut into full launches that may span a slide's end; every row exactly once,
+    # every slide published up to its last row
+    flat = sel.feature_launches(4, 65536, edges, _Dev)
+    assert flat[0][0] == 0 and flat[-1][1] == 4 * 65536 and all(a[1] == b[0] for a, b in zip(flat, flat[1:]))
+    assert all(r1 - r0 <= 224 * 64 for r0, r1, _ in flat)
+    last = {}
+    for _, _, pubs in flat:
+        for slide, rows in pubs:
+            assert rows >= last.get(slide, 0)
+            last[slide] = rows
+    assert last == {0: 65536, 1: 65536, 2: 65536, 3: 65536}
+    geometry(32, 1)                                    # a CPX partition: one XCD
+    assert sel.free_units(_Dev, 1) == 31
+
+
+def test_abi_major_and_the_round_4_additions_are_declared():
+    lib = hip.lib()
+    assert lib.ipsx_version() // 100 == hip.ABI_MAJOR
+    for name in ("ipsx_aggregate_packed", "ipsx_set_persistent_wait_ms", "ipsx_conv2d_wgrad_nhwc", "ipsx_pack_conv_weight_strided"):
+        assert name in hip._EXPORTS and hasattr(lib, name)
+    prev = lib.ipsx_set_persistent_wait_ms(0)          # query
+    assert prev == 50
+    assert lib.ipsx_set_persistent_wait_ms(80) == 50 and lib.ipsx_set_persistent_wait_ms(50) == 80
+    assert lib.ipsx_conv2d_wgrad_nhwc_supported(64, 128, 3, 3, 2, 1) == 1 and lib.ipsx_conv2d_wgrad_nhwc_supported(1, 64, 7, 7, 2, 3) == 0
+    assert lib.ipsx_conv2d_wgrad_nhwc_workspace_bytes(0, 64, 64, 3, 3) == 0
