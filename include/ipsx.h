@@ -44,7 +44,7 @@ extern "C" {
  *   2.00  round 3: ipsx_scan / ipsx_scan_range / ipsx_topm take (workspace, workspace_bytes) in front of `stream`,
  *         ipsx_scan_persistent takes ready_per_image, ipsx_projector_stats_publish removed
  *   2.01  round 4 (additions only): ipsx_aggregate_packed, ipsx_set_persistent_wait_ms, ipsx_conv2d_wgrad_nhwc*,
- *         ipsx_pack_conv_weight_strided;
+ *         ipsx_pack_conv_weight_strided, ipsx_conv2d_affine_to_nhwc;
  *         ipsx_projector_stream accepts
  *         short_first <= -3 (guided tile sizes)                                                                     */
 #define IPSX_VERSION 201
@@ -139,6 +139,10 @@ typedef struct ipsx_trunk {
 /* y = act(affine(conv(x)) [+ residual]); x (n,c_in,h,w), y (n,c_out,ho,wo) NCHW */
 int ipsx_conv2d_affine(const ipsx_conv* cv, const float* x, const float* residual,
                        float* y, int64_t n, int h, int w, int relu, void* stream);
+/* x NCHW as above, residual / y channels-last (n,ho,wo,c_out): the stems (1 or 3 input channels) in front of the
+ * channels-last layers */
+int ipsx_conv2d_affine_to_nhwc(const ipsx_conv* cv, const float* x, const float* residual,
+                               float* y, int64_t n, int h, int w, int relu, void* stream);
 /* the same on channels-last activations: x (n,h,w,c_in), residual / y (n,ho,wo,c_out); C_in % 32 == 0.
  * This is the fast layer-by-layer path (16-byte operand loads); a Linear over rows is h = w = 1. */
 int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* residual,
@@ -148,7 +152,8 @@ int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* re
  *   dw[co][ky][kx][ci] = sum over (img, oy, ox) of dy[img,oy,ox,co] * x[img, stride*oy + ky - pad, stride*ox + kx - pad, ci]
  * x (n,h,w,c_in) and dy (n,ho,wo,c_out) channels-last, dw in the memory order of a channels-last weight tensor
  * ((c_out, c_in, kh, kw) with strides (kh*kw*c_in, 1, kw*c_in, c_in)).  fp32 MFMA, reduction over the pixels split across
- * workgroups and added in a fixed order (deterministic).  c_in and c_out multiples of 64 (ipsx_conv2d_wgrad_nhwc_supported).
+ * workgroups and added in a fixed order (deterministic).  c_out a multiple of 64, c_in a multiple of 64 or 1 (the 7x7 stem)
+ * (ipsx_conv2d_wgrad_nhwc_supported).
  * The data gradient is ipsx_conv2d_affine_nhwc itself: on dy with the weights rotated by 180 degrees and transposed. */
 int ipsx_conv2d_wgrad_nhwc_supported(int c_in, int c_out, int kh, int kw, int stride, int pad);
 size_t ipsx_conv2d_wgrad_nhwc_workspace_bytes(int64_t n, int c_in, int c_out, int kh, int kw);

@@ -340,6 +340,11 @@ IPSX_API int ipsx_conv2d_affine(const ipsx_conv* cv, const float* x, const float
     return conv2d_affine_impl(cv, x, residual, y, n, h, w, relu, 0, stream);
 }
 
+IPSX_API int ipsx_conv2d_affine_to_nhwc(const ipsx_conv* cv, const float* x, const float* residual, float* y,
+                                        int64_t n, int h, int w, int relu, void* stream) {
+    return conv2d_affine_impl(cv, x, residual, y, n, h, w, relu, 1, stream);
+}
+
 int ipsx::conv2d_affine_impl(const ipsx_conv* cv, const float* x, const float* residual, float* y, int64_t n,
                              int h, int w, int relu, int out_nhwc, void* stream) {
     IPSX_TRY(check_conv(cv));

@@ -274,6 +274,101 @@ __global__ __launch_bounds__(WG_WAVES * 64) void conv_wgrad_taps_kernel(WgradArg
     }
 }
 
+// One input channel (the 7x7 stem of the 1-channel trunks): K = kh kw <= 64 taps are the "channels" of the B operand - lane
+// i of B-tile v reads x at the position its OWN tap 32 v + i points to (a 4-byte gather inside one small image), taps
+// beyond kh kw read nothing.  Wavefronts split the pixel pairs, blocks added through LDS as in conv_wgrad_kernel.
+__global__ __launch_bounds__(WG_WAVES * 64) void conv_wgrad_stem_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];          // [WG_WAVES][64][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
+    const int cob = (int)(blockIdx.x % (unsigned)a.groups), split = (int)(blockIdx.x / (unsigned)a.groups);     // groups = co_blocks
+    const int co0 = cob * 64;
+    const int img_lo = split * a.imgs_per_split, img_hi = min(a.n, img_lo + a.imgs_per_split);
+    const int n_img = img_hi > img_lo ? img_hi - img_lo : 0;
+    const int howo = a.ho * a.wo, npair = (howo + 1) >> 1, taps = a.kh * a.kw;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+    const unsigned ystride = (unsigned)(howo * a.c_out) * 4u, xstride = (unsigned)(a.h * a.w) * 4u;
+    const int t0 = i, t1 = 32 + i;                              // this lane's taps in the two B tiles
+    const int ky0 = t0 / a.kw, kx0 = t0 - ky0 * a.kw, ky1 = t1 / a.kw, kx1 = t1 - ky1 * a.kw;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.0f;
+    int slot = wave, left = 0;
+    unsigned voffy = kWgOob, voffx0 = kWgOob, voffx1 = kWgOob, soffy = 0u, soffx = 0u;
+    auto open_slot = [&]() {
+        voffy = voffx0 = voffx1 = kWgOob;
+        left = 0;
+        if (slot < npair && n_img > 0) {
+            const int q = 2 * slot + half;
+            const int oy = q / a.wo, ox = q - oy * a.wo;
+            const bool okq = q < howo;
+            const int iy0 = oy * a.stride + ky0 - a.pad, ix0 = ox * a.stride + kx0 - a.pad;
+            const int iy1 = oy * a.stride + ky1 - a.pad, ix1 = ox * a.stride + kx1 - a.pad;
+            const bool ok0 = okq && t0 < taps && (unsigned)iy0 < (unsigned)a.h && (unsigned)ix0 < (unsigned)a.w;
+            const bool ok1 = okq && t1 < taps && (unsigned)iy1 < (unsigned)a.h && (unsigned)ix1 < (unsigned)a.w;
+            voffy = okq ? ((unsigned)q * (unsigned)a.c_out + (unsigned)(co0 + i)) * 4u : kWgOob;
+            voffx0 = ok0 ? (unsigned)(iy0 * a.w + ix0) * 4u : kWgOob;
+            voffx1 = ok1 ? (unsigned)(iy1 * a.w + ix1) * 4u : kWgOob;
+            soffy = (unsigned)img_lo * ystride;
+            soffx = (unsigned)img_lo * xstride;
+            left = n_img;
+        }
+    };
+    open_slot();
+    const int my_slots = wave < npair ? (npair - wave + WG_WAVES - 1) / WG_WAVES : 0;
+    const int steps = my_slots * n_img;
+    auto issue = [&](WgradStage& st) {
+        const bool live = left > 0;
+        const unsigned vy = live ? voffy : kWgOob;
+        st.a0 = wg_load(ry, vy, soffy);
+        st.a1 = wg_load(ry, vy, soffy + 128u);
+        st.b0 = wg_load(rx, live ? voffx0 : kWgOob, soffx);
+        st.b1 = wg_load(rx, live ? voffx1 : kWgOob, soffx);
+        soffy += ystride;
+        soffx += xstride;
+        if (--left <= 0) { slot += WG_WAVES; open_slot(); }
+    };
+    auto mma = [&](const WgradStage& st) {
+        acc[0][0] = WG_MFMA(st.a0, st.b0, acc[0][0]);
+        acc[0][1] = WG_MFMA(st.a0, st.b1, acc[0][1]);
+        acc[1][0] = WG_MFMA(st.a1, st.b0, acc[1][0]);
+        acc[1][1] = WG_MFMA(st.a1, st.b1, acc[1][1]);
+    };
+    WgradStage s0, s1, s2, s3;
+    issue(s0);
+    issue(s1);
+    issue(s2);
+#pragma unroll 1
+    for (int t = 0; t < steps; t += 4) {
+        issue(s3); mma(s0);
+        issue(s0); mma(s1);
+        issue(s1); mma(s2);
+        issue(s2); mma(s3);
+    }
+    float* mine = wg_lds + wave * 4096;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(32 * u + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 * v + i] = acc[u][v][r];
+    __syncthreads();
+    float* out = a.partial + (size_t)split * a.c_out * a.K;
+    for (int e = threadIdx.x; e < 4096; e += WG_WAVES * 64) {
+        const int row = e >> 6, col = e & 63;
+        if (col >= taps) continue;
+        float s = wg_lds[e];
+#pragma unroll
+        for (int wv = 1; wv < WG_WAVES; ++wv) s = s + wg_lds[wv * 4096 + e];
+        out[(size_t)(co0 + row) * a.K + col] = s;
+    }
+}
+
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t total, float* __restrict__ dw) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -303,14 +398,15 @@ static int wgrad_splits(int n, int groups) {
 using namespace ipsx;
 
 IPSX_API int ipsx_conv2d_wgrad_nhwc_supported(int c_in, int c_out, int kh, int kw, int stride, int pad) {
-    return (c_in > 0 && c_in % 64 == 0 && c_out > 0 && c_out % 64 == 0 && kh > 0 && kw > 0 && kh * kw <= 49 && stride > 0 &&
-            pad >= 0) ? 1 : 0;
+    if (!(c_out > 0 && c_out % 64 == 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0)) return 0;
+    if (c_in == 1) return kh * kw <= 64 ? 1 : 0;                 // one input channel: the taps are the B operand's columns
+    return (c_in > 0 && c_in % 64 == 0 && kh * kw <= 49) ? 1 : 0;
 }
 
 IPSX_API size_t ipsx_conv2d_wgrad_nhwc_workspace_bytes(int64_t n, int c_in, int c_out, int kh, int kw) {
     if (n <= 0 || c_in <= 0 || c_out <= 0) return 0;
-    const bool by_tap = kh * kw == 9;
-    const int groups = (by_tap ? 1 : kh * kw) * (c_in / 64) * (c_out / 64);
+    const bool by_tap = kh * kw == 9 && c_in > 1;
+    const int groups = c_in == 1 ? c_out / 64 : (by_tap ? 1 : kh * kw) * (c_in / 64) * (c_out / 64);
     const int splits = wgrad_splits((int)std::min<int64_t>(n, 1 << 30), groups);
     return (size_t)splits * c_out * kh * kw * c_in * sizeof(float);
 }
@@ -319,7 +415,7 @@ IPSX_API int ipsx_conv2d_wgrad_nhwc(const float* x, const float* dy, int64_t n, 
                                     int stride, int pad, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
     IPSX_REQUIRE(x && dy && dw && n > 0 && h > 0 && w > 0, "conv2d_wgrad_nhwc: bad arguments");
     IPSX_REQUIRE(ipsx_conv2d_wgrad_nhwc_supported(c_in, c_out, kh, kw, stride, pad),
-                 "conv2d_wgrad_nhwc: C_in = %d and C_out = %d must be multiples of 64 (kernel %dx%d)", c_in, c_out, kh, kw);
+                 "conv2d_wgrad_nhwc: C_in = %d (1, or a multiple of 64) and C_out = %d (a multiple of 64), kernel %dx%d", c_in, c_out, kh, kw);
     const int ho = conv_out(h, kh, stride, pad), wo = conv_out(w, kw, stride, pad);
     IPSX_REQUIRE(ho > 0 && wo > 0, "conv2d_wgrad_nhwc: empty output");
     IPSX_REQUIRE((int64_t)n * h * w * c_in * 4 < ((int64_t)1 << 31) && (int64_t)n * ho * wo * c_out * 4 < ((int64_t)1 << 31),
@@ -335,8 +431,9 @@ IPSX_API int ipsx_conv2d_wgrad_nhwc(const float* x, const float* dy, int64_t n, 
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
     a.ci_blocks = c_in / 64; a.co_blocks = c_out / 64; a.groups = kh * kw * a.ci_blocks * a.co_blocks;
     a.K = kh * kw * c_in;
-    const bool by_tap = kh * kw == 9;                            // 3x3: one wavefront per tap (conv_wgrad_taps_kernel)
+    const bool by_tap = kh * kw == 9 && c_in > 1;                // 3x3: one wavefront per tap (conv_wgrad_taps_kernel)
     if (by_tap) a.groups = a.ci_blocks * a.co_blocks;
+    if (c_in == 1) a.groups = a.co_blocks;
     const int splits = wgrad_splits((int)n, a.groups);
     a.imgs_per_split = ((int)n + splits - 1) / splits;
     hipStream_t s = as_stream(stream);
@@ -354,6 +451,17 @@ IPSX_API int ipsx_conv2d_wgrad_nhwc(const float* x, const float* dy, int64_t n, 
         return launched("conv2d_wgrad_nhwc reduce");
     }
     const size_t lds = (size_t)WG_WAVES * 4096 * sizeof(float);
+    if (c_in == 1) {
+        static bool attr_s = false;
+        if (!attr_s) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_s = true;
+        }
+        conv_wgrad_stem_kernel<<<dim3((unsigned)(a.groups * splits)), dim3(WG_WAVES * 64), lds, s>>>(a);
+        IPSX_TRY(launched("conv2d_wgrad_nhwc (stem)"));
+        conv_wgrad_reduce_kernel<<<dim3((unsigned)cdiv((int64_t)total, 256)), dim3(256), 0, s>>>(a.partial, splits, total, dw);
+        return launched("conv2d_wgrad_nhwc reduce");
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -159,6 +159,8 @@ _EXPORTS = {
     "ipsx_bn_affine": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_affine": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_conv2d_affine_to_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_conv2d_affine_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_conv2d_wgrad_nhwc_supported": (C.c_int, [C.c_int] * 6),
@@ -1025,6 +1027,8 @@ def conv_train_supported(conv):
         return False
     if s > 1 and kh - 1 != 2 * p:
         return False
+    if conv.in_channels % 32 != 0 and conv.in_channels != 1:    # forward kernels: channels-last (C_in % 32 == 0) or the 1-channel stem
+        return False
     return bool(lib().ipsx_conv2d_wgrad_nhwc_supported(conv.in_channels, conv.out_channels, kh, kw, s, p))
 
 
@@ -1056,7 +1060,10 @@ def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False):
     packed, co, ci = _pack_conv_view(weight.detach(), dgrad_weights)
     cv = Conv(ci, co, kh, kw, stride, pad, _p(packed), None, None, None)
     y = torch.empty((n, co, ho, wo), dtype=torch.float32, device=x.device, memory_format=_CL)
-    _ck(lib().ipsx_conv2d_affine_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_nhwc")
+    if ci == 1:         # one input channel (NCHW = channels-last memory): the stem kernel, channels-last output
+        _ck(lib().ipsx_conv2d_affine_to_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_to_nhwc")
+    else:
+        _ck(lib().ipsx_conv2d_affine_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_nhwc")
     return y
 
 

@@ -14,9 +14,10 @@ differently:
 * every ``bn -> relu`` and ``bn -> (+ identity) -> relu`` is ONE autograd node backed by ``libipsx.so``
   (``ipsx_bn_train_forward`` / ``_backward``: two memory passes each way, csrc/bn_train.hip).
 
-* (round 4) the convolutions of the residual stages run on libipsx's own fp32-MFMA kernels in all three directions
-  (``_Conv``: forward / data gradient ``conv_nhwc_kernel``, weight gradient ``conv_wgrad_kernel``); ``IPSX_TRAIN_CONV=0``
-  hands them back to MIOpen.  The stem (1 or 3 input channels) and the two poolings remain stock ops.
+* (round 4) the convolutions run on libipsx's own fp32-MFMA kernels in all three directions (``_Conv``: forward / data
+  gradient ``conv_nhwc_kernel``, weight gradient ``conv_wgrad_*_kernel``; the 1-channel stem: ``conv_any_kernel`` writing
+  channels-last and ``conv_wgrad_stem_kernel``); ``IPSX_TRAIN_CONV=0`` hands them back to MIOpen.  A 3-channel stem and the
+  two poolings remain stock ops.
 
 Results equal the stock path to fp32 rounding (another summation order): tests/test_hip_train.py compares loss,
 gradients, running statistics and post-step weights.  ``IPSX_TRAIN_FUSED=0`` switches it off.

@@ -68,10 +68,12 @@ def test_feature_launches_leave_a_unit_per_loop_on_the_fullest_xcd(geometry):
 def test_abi_major_and_the_round_4_additions_are_declared():
     lib = hip.lib()
     assert lib.ipsx_version() // 100 == hip.ABI_MAJOR
-    for name in ("ipsx_aggregate_packed", "ipsx_set_persistent_wait_ms", "ipsx_conv2d_wgrad_nhwc", "ipsx_pack_conv_weight_strided"):
+    for name in ("ipsx_aggregate_packed", "ipsx_set_persistent_wait_ms", "ipsx_conv2d_wgrad_nhwc", "ipsx_pack_conv_weight_strided",
+                 "ipsx_conv2d_affine_to_nhwc"):
         assert name in hip._EXPORTS and hasattr(lib, name)
     prev = lib.ipsx_set_persistent_wait_ms(0)          # query
     assert prev == 50
     assert lib.ipsx_set_persistent_wait_ms(80) == 50 and lib.ipsx_set_persistent_wait_ms(50) == 80
-    assert lib.ipsx_conv2d_wgrad_nhwc_supported(64, 128, 3, 3, 2, 1) == 1 and lib.ipsx_conv2d_wgrad_nhwc_supported(1, 64, 7, 7, 2, 3) == 0
+    assert lib.ipsx_conv2d_wgrad_nhwc_supported(64, 128, 3, 3, 2, 1) == 1 and lib.ipsx_conv2d_wgrad_nhwc_supported(1, 64, 7, 7, 2, 3) == 1
+    assert lib.ipsx_conv2d_wgrad_nhwc_supported(3, 64, 7, 7, 2, 3) == 0 and lib.ipsx_conv2d_wgrad_nhwc_supported(64, 96, 3, 3, 1, 1) == 0
     assert lib.ipsx_conv2d_wgrad_nhwc_workspace_bytes(0, 64, 64, 3, 3) == 0
