@@ -44,7 +44,7 @@ extern "C" {
  *   2.00  round 3: ipsx_scan / ipsx_scan_range / ipsx_topm take (workspace, workspace_bytes) in front of `stream`,
  *         ipsx_scan_persistent takes ready_per_image, ipsx_projector_stats_publish removed
  *   2.01  round 4 (additions only): ipsx_aggregate_packed, ipsx_set_persistent_wait_ms, ipsx_conv2d_wgrad_nhwc*,
- *         ipsx_pack_conv_weight_strided, ipsx_conv2d_affine_to_nhwc;
+ *         ipsx_pack_conv_weight_strided, ipsx_conv2d_affine_to_nhwc, ipsx_conv2d_lds_nhwc*;
  *         ipsx_projector_stream accepts
  *         short_first <= -3 (guided tile sizes)                                                                     */
 #define IPSX_VERSION 201
@@ -147,6 +147,12 @@ int ipsx_conv2d_affine_to_nhwc(const ipsx_conv* cv, const float* x, const float*
  * This is the fast layer-by-layer path (16-byte operand loads); a Linear over rows is h = w = 1. */
 int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* residual,
                             float* y, int64_t n, int h, int w, int relu, void* stream);
+/* The fused trunk's stages as stand-alone plain convolutions of channels-last maps (training step: forward and data
+ * gradient on the maps of 32-px patches, each layer's input read once and LDS-resident for all taps): 64 -> 64 3x3 on 8x8,
+ * 128 -> 128 3x3 on 4x4, 64 -> 128 3x3 / 2 and 1x1 / 2 from 8x8 (ipsx_conv2d_lds_nhwc_supported).  cv: kernel, stride, pad and
+ * w_packed (ipsx_pack_conv_weight[_strided]); alpha / shift are ignored. */
+int ipsx_conv2d_lds_nhwc_supported(int c_in, int c_out, int k, int stride, int pad, int h, int w);
+int ipsx_conv2d_lds_nhwc(const ipsx_conv* cv, const float* x, float* y, int64_t n, int h, int w, void* stream);
 /* Weight gradient of that convolution for the training step (reference: loss.backward() of training/iterative.py:157-163
  * through the BasicBlocks of architecture/ips_net.py:264-283):
  *   dw[co][ky][kx][ci] = sum over (img, oy, ox) of dy[img,oy,ox,co] * x[img, stride*oy + ky - pad, stride*ox + kx - pad, ci]

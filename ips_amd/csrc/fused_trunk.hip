@@ -648,6 +648,75 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
 #include "fused_trunk_split.h"
 #include "fused_trunk_pair.h"
 
+// ------------------------------------------------------------------ the stages as stand-alone convolutions (training step)
+// The training step's forward and data-gradient convolutions on the maps of 32-px patches - 64 -> 64 at 8x8, 128 -> 128 at
+// 4x4, and the two strided layers between them - are the very stages of the fused trunk: a patch's map in LDS (pixel-major
+// with a zero halo row), operands by 16-byte LDS reads, weights streamed from L2 through the register ring.  Run layer
+// by layer (the backward pass needs every layer's input), each still reads its input once from HBM and has the map in LDS
+// for all nine taps, where the batch-tiled conv_nhwc_kernel fetches every activation once per tap from L2 (0.45 of the fp32
+// MFMA peak at 1,024 patches; these: see DESIGN 5.7).  Plain convolutions (BatchNorm is its own autograd node in training).
+struct LdsConvArgs {
+    const float* x;        // (n, WIN, WIN, CIN) channels-last
+    float* y;              // (n, WOUT, WOUT, COUT) channels-last
+    const float* wp;       // ipsx_pack_conv_weight layout
+    long long n;
+};
+
+// 64 -> 64, 3x3, stride 1, 8x8 maps: wave = patch (conv_l1)
+__global__ __launch_bounds__(256, 2) void conv_lds_l1_kernel(LdsConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 slabs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long p = (long long)blockIdx.x * 4 + wave;
+    if (p >= a.n) return;                                                 // (no workgroup barriers in this kernel)
+    float* S = lds + wave * SLAB;
+    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)p * 4096);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = (k * 64 + lane) * 4;                               // pixel e / 64, channel e % 64
+        *reinterpret_cast<float4*>(S + (e >> 6) * PS1 + (e & 63)) = src[k * 64 + lane];
+    }
+    for (int z = lane; z < PS1; z += 64) S[ZP1 * PS1 + z] = 0.0f;
+    wave_fence();
+    f32x16 acc[2][2];
+    conv_l1(a.wp, S, acc, lane);
+    const int i = lane & 31, half = lane >> 5;
+    float* dst = a.y + (size_t)p * 4096;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dst[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + nt * 32 + i] = acc[mt][nt][r];
+}
+
+// CIN -> 128 onto 4x4 maps (conv_l2): 4 patches per workgroup, wave w owns output channels 32 w .. 32 w + 31
+template <int CIN, int WIN, int PS, int ZP, int STRIDE, int KS>
+__global__ __launch_bounds__(256, 2) void conv_lds_l2_kernel(LdsConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 slabs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long p_first = (long long)blockIdx.x * 4;
+    constexpr int MAP = WIN * WIN * CIN;                                 // floats per patch
+    for (int q = threadIdx.x; q < 4 * MAP / 4; q += 256) {               // the four maps, 16 bytes at a time
+        const int pl = q / (MAP / 4), e = (q - pl * (MAP / 4)) * 4;      // patch, element inside its map: pixel e / CIN, channel e % CIN
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (p_first + pl < a.n) v = *reinterpret_cast<const float4*>(a.x + (size_t)(p_first + pl) * MAP + e);
+        *reinterpret_cast<float4*>(lds + pl * SLAB + (e / CIN) * PS + (e % CIN)) = v;
+    }
+    for (int z = lane; z < PS; z += 64) lds[wave * SLAB + ZP * PS + z] = 0.0f;
+    __syncthreads();
+    f32x16 acc[2];
+    conv_l2<CIN, WIN, PS, ZP, STRIDE, KS>(a.wp, lds, acc, lane, wave);
+    const int i = lane & 31, half = lane >> 5, n = 32 * wave + i;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pl = 2 * mt + (r >> 3), pix = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+            if (p_first + pl < a.n) a.y[((size_t)(p_first + pl) * 16 + pix) * 128 + n] = acc[mt][r];
+        }
+}
+
 static bool is_conv(const ipsx_conv& c, int ci, int co, int k, int s, int p) {
     return c.c_in == ci && c.c_out == co && c.kh == k && c.kw == k && c.stride == s && c.pad == p && c.w_packed &&
            c.alpha && c.shift;
@@ -817,6 +886,49 @@ int fused_trunk_encode_indexed(const ipsx_trunk* t, const float* patches, int64_
 }
 
 }  // namespace ipsx
+
+// which LDS-resident stage kernel covers this plain convolution of channels-last maps (0: none)
+static int lds_conv_kind(int c_in, int c_out, int k, int stride, int pad, int h, int w) {
+    if (h != w) return 0;
+    if (c_in == 64 && c_out == 64 && k == 3 && stride == 1 && pad == 1 && h == 8) return 1;
+    if (c_in == 128 && c_out == 128 && k == 3 && stride == 1 && pad == 1 && h == 4) return 2;
+    if (c_in == 64 && c_out == 128 && k == 3 && stride == 2 && pad == 1 && h == 8) return 3;
+    if (c_in == 64 && c_out == 128 && k == 1 && stride == 2 && pad == 0 && h == 8) return 4;
+    return 0;
+}
+
+IPSX_API int ipsx_conv2d_lds_nhwc_supported(int c_in, int c_out, int k, int stride, int pad, int h, int w) {
+    return lds_conv_kind(c_in, c_out, k, stride, pad, h, w) != 0 ? 1 : 0;
+}
+
+IPSX_API int ipsx_conv2d_lds_nhwc(const ipsx_conv* cv, const float* x, float* y, int64_t n, int h, int w, void* stream) {
+    IPSX_REQUIRE(cv && cv->w_packed && x && y && n >= 0, "conv2d_lds_nhwc: bad arguments");
+    const int kind = cv->kh == cv->kw ? lds_conv_kind(cv->c_in, cv->c_out, cv->kh, cv->stride, cv->pad, h, w) : 0;
+    IPSX_REQUIRE(kind != 0, "conv2d_lds_nhwc: %d -> %d, %dx%d / %d on %dx%d maps is not one of the fused trunk's stages", cv->c_in,
+                 cv->c_out, cv->kh, cv->kw, cv->stride, h, w);
+    if (n == 0) return IPSX_OK;
+    ipsx::LdsConvArgs a;
+    a.x = x; a.y = y; a.wp = cv->w_packed; a.n = n;
+    const size_t lds = (size_t)4 * ipsx::SLAB * sizeof(float);
+    const dim3 grid((unsigned)ipsx::cdiv(n, 4)), block(256);
+    hipStream_t s = ipsx::as_stream(stream);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::conv_lds_l1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::conv_lds_l2_kernel<128, 4, ipsx::PS2, ipsx::ZP2, 1, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::conv_lds_l2_kernel<64, 8, ipsx::PS1, ipsx::ZP1, 2, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ipsx::conv_lds_l2_kernel<64, 8, ipsx::PS1, ipsx::ZP1, 2, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (kind == 1) ipsx::conv_lds_l1_kernel<<<grid, block, lds, s>>>(a);
+    else if (kind == 2) ipsx::conv_lds_l2_kernel<128, 4, ipsx::PS2, ipsx::ZP2, 1, 3><<<grid, block, lds, s>>>(a);
+    else if (kind == 3) ipsx::conv_lds_l2_kernel<64, 8, ipsx::PS1, ipsx::ZP1, 2, 3><<<grid, block, lds, s>>>(a);
+    else ipsx::conv_lds_l2_kernel<64, 8, ipsx::PS1, ipsx::ZP1, 2, 1><<<grid, block, lds, s>>>(a);
+    return ipsx::launched("conv2d_lds_nhwc");
+}
 
 IPSX_API size_t ipsx_packed_conv_weight_bf16_bytes(int c_out, int c_in, int kh, int kw) {
     return (size_t)ipsx::cdiv(c_out, 32) * (size_t)ipsx::cdiv((int64_t)kh * kw * c_in, 16) * 1024;

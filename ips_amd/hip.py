@@ -163,6 +163,8 @@ _EXPORTS = {
                                              C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_conv2d_affine_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_conv2d_lds_nhwc_supported": (C.c_int, [C.c_int] * 7),
+    "ipsx_conv2d_lds_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_conv2d_wgrad_nhwc_supported": (C.c_int, [C.c_int] * 6),
     "ipsx_conv2d_wgrad_nhwc_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int] * 4),
     "ipsx_conv2d_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -1060,7 +1062,10 @@ def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False):
     packed, co, ci = _pack_conv_view(weight.detach(), dgrad_weights)
     cv = Conv(ci, co, kh, kw, stride, pad, _p(packed), None, None, None)
     y = torch.empty((n, co, ho, wo), dtype=torch.float32, device=x.device, memory_format=_CL)
-    if ci == 1:         # one input channel (NCHW = channels-last memory): the stem kernel, channels-last output
+    if kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0" and lib().ipsx_conv2d_lds_nhwc_supported(ci, co, kh, stride, pad, h, w):
+        # the maps of 32-px patches: the fused trunk's stage kernels, map LDS-resident for all taps
+        _ck(lib().ipsx_conv2d_lds_nhwc(C.byref(cv), _p(x), _p(y), n, h, w, _stream()), "ipsx_conv2d_lds_nhwc")
+    elif ci == 1:       # one input channel (NCHW = channels-last memory): the stem kernel, channels-last output
         _ck(lib().ipsx_conv2d_affine_to_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_to_nhwc")
     else:
         _ck(lib().ipsx_conv2d_affine_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_nhwc")

@@ -20,7 +20,8 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("P,ci,co,k,s,H", [(16, 64, 64, 3, 1, 8), (33, 64, 128, 3, 2, 8), (7, 64, 128, 1, 2, 8), (40, 128, 128, 3, 1, 4),
                                              (5, 128, 256, 3, 2, 13), (3, 256, 256, 3, 1, 7), (1024, 64, 64, 3, 1, 8), (2, 512, 512, 3, 1, 2),
-                                             (9, 64, 64, 3, 1, 13), (4, 64, 64, 1, 1, 1), (37, 1, 64, 7, 2, 32), (1024, 1, 64, 7, 2, 32), (5, 1, 64, 7, 2, 50)])
+                                             (9, 64, 64, 3, 1, 13), (4, 64, 64, 1, 1, 1), (37, 1, 64, 7, 2, 32), (1024, 1, 64, 7, 2, 32), (5, 1, 64, 7, 2, 50),
+                                             (1023, 128, 128, 3, 1, 4), (6, 64, 128, 3, 2, 8), (1, 64, 64, 3, 1, 8)])
 def test_conv_train_kernels_match_torch(P, ci, co, k, s, H):
     """The training step's convolutions on libipsx's kernels (training/fused_encoder.py::_Conv): forward and data gradient
     on conv_nhwc_kernel, weight gradient on conv_wgrad_kernel - against float64 autograd of F.conv2d, and bit-identical
