@@ -146,9 +146,12 @@ def cpu_baseline(conf, x, budget_s):
     for thr in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(thr)
         ips_torch.ips(sd, probe, x[:b_probe, :n_probe], pos)
-        t0 = time.perf_counter()
-        ips_torch.ips(sd, probe, x[:b_probe, :n_probe], pos)
-        dt = time.perf_counter() - t0
+        dt = None
+        for _ in range(2):                                      # the faster of two timed calls: one call per count was noisy
+            t0 = time.perf_counter()                            # enough to pick 8 threads on one box and 32 on the next
+            ips_torch.ips(sd, probe, x[:b_probe, :n_probe], pos)
+            d1 = time.perf_counter() - t0
+            dt = d1 if dt is None else min(dt, d1)
         if best is None or dt < best[1]:
             best = (thr, dt)
         if dt > 4 * best[1]:
