@@ -101,7 +101,12 @@ def parse():
     ap.add_argument("--also", default="all",
                     help="default single-GPU run only: which other BASELINE configurations are timed into `also_measured` "
                          "('all', 'none', or a comma list of b1,mnist3000,cam,cam_x16,cam_native)")
-    ap.add_argument("--also-steps", type=int, default=10, help="timed calls per `also_measured` leg (each way)")
+    ap.add_argument("--also-steps", type=int, default=0,
+                    help="timed calls per `also_measured` leg, each way (0 = sized per leg: ~0.3 s of calls, 10 to 40)")
+    ap.add_argument("--leg-timeout", type=int, default=120, help="seconds an `also_measured` leg may take before the line is "
+                    "printed without it")
+    ap.add_argument("--watchdog", type=int, default=600, help="seconds the headline measurement may take before every thread's "
+                    "stack is dumped to stderr and the run exits")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1 only. strong (default): configs[2], the same 16 x 10000 patches at every N; weak: 2500 "
                          "patches of every image per GPU (the image grows with N)")
@@ -154,7 +159,7 @@ def cpu_baseline(conf, x, budget_s):
             dt = d1 if dt is None else min(dt, d1)
         if best is None or dt < best[1]:
             best = (thr, dt)
-        if dt > 4 * best[1]:
+        if dt > 4 * best[1] or dt > 3.0:                       # (slower by far, or a host that chokes on this many threads)
             break
     torch.set_num_threads(best[0])
     per_patch = best[1] / (b_probe * n_probe)                   # seconds per patch at the probe's size
@@ -271,6 +276,7 @@ class Ctx:
 
     def __init__(self, world, rank, dev, share):
         self.world, self.rank, self.dev, self.share = world, rank, dev, share
+        self.cpu_job = None
 
 
 # Driver-run coverage: the default single-GPU invocation times the headline AND every other BASELINE
@@ -352,6 +358,16 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
             return ipsd.ips_sharded(net, x, n_total, timings=timings)
 
     step()                                                      # builds the encoder plan
+    if steps is None:
+        # an `also_measured` leg: enough calls for ~0.3 s of timed work each way and ~0.1 s of warm-up (short calls - one
+        # image, one slide - otherwise sit on the tail of the clock ramp and the allocator's first-use effects)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t1 = max(time.perf_counter() - c0, 1e-5)
+        steps = int(min(40, max(10, 0.3 / t1)))
+        warmup = int(min(15, max(3, 0.1 / t1)))
     # time the encoder launches with HIP events on the stream they run on (installed BEFORE the warm-up so that the
     # warm-up steps run exactly what the timed steps run, event creation included)
     enc_events = []
@@ -536,7 +552,7 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
         if headline and world == 1 and name == "mnist" and args.precision == "fp32" and not (args.dedup_blank or args.lazy) and batch == B:
             out["also_measured"] = {p: measure_precision(net, x, steps, p, fixture) for p in ("fp32x3", "bf16")}
         if world == 1 and cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(conf, x_host, cpu_seconds)
+            ctx.cpu_job = (conf, x_host, cpu_seconds)           # timed by main(), last and under a guard (see there)
         out["host"] = host_description()
     del net, x, x_host
     torch.cuda.empty_cache()
@@ -589,15 +605,50 @@ def main():
         print("secondary configs are single-GPU measurements", file=sys.stderr)
         sys.exit(2)
     ctx = Ctx(world, rank, dev, share)
+    # a run that stops making progress says where (all threads' stacks on stderr) instead of sitting there until the
+    # caller's limit: one round-4 run on a freshly leased box hung for 15 minutes without a byte of output and could not be
+    # reproduced on the next two boxes
+    import faulthandler
+    faulthandler.dump_traceback_later(args.watchdog, exit=True)
     out = measure(args, ctx, name, batch=args.batch, steps=args.steps, warmup=args.warmup, cpu_seconds=args.cpu_seconds, headline=True)
+    faulthandler.cancel_dump_traceback_later()
     default_run = (world == 1 and args.config is None and args.batch is None and args.precision == "fp32"
                    and args.storage == "f32" and not (args.dedup_blank or args.lazy or args.no_kernel_events))
     if default_run and args.also != "none":
+        import threading
         legs = [l for l in ALSO_LEGS if args.also == "all" or l[0] in args.also.split(",")]
         for leg, cfg, b in legs:
-            rec = measure(args, ctx, cfg, batch=b, steps=min(args.steps, args.also_steps), warmup=min(args.warmup, 3),
-                          cpu_seconds=0.0, headline=False)
+            # the headline is measured: a leg that does not come back must not cost it - the line goes out without the rest
+            def bail(leg=leg):
+                out["also_measured_incomplete"] = "leg %r did not finish within %d s; the line was printed without it and the legs behind it" % (leg, args.leg_timeout)
+                print(json.dumps(out), flush=True)
+                faulthandler.dump_traceback(file=sys.stderr)
+                os._exit(0)
+            guard = threading.Timer(args.leg_timeout, bail)
+            guard.daemon = True
+            guard.start()
+            rec = measure(args, ctx, cfg, batch=b, steps=None if args.also_steps <= 0 else min(args.steps, args.also_steps),
+                          warmup=min(args.warmup, 3), cpu_seconds=0.0, headline=False)
+            guard.cancel()
             out.setdefault("also_measured", {})[leg] = slim(rec)
+    if rank == 0 and getattr(ctx, "cpu_job", None) is not None:
+        # the CPU baseline comes last and under a guard: it is the one leg whose duration this script does not control (a
+        # host that throttles 64 threads down to a few cores can turn its thread probe into minutes) - the measured GPU
+        # numbers must not wait for it
+        import threading
+        conf_c, x_c, budget = ctx.cpu_job
+        limit = int(6 * budget + 60)
+
+        def bail_cpu():
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = "the CPU leg did not finish within %d s on this host; line printed without it" % limit
+            print(json.dumps(out), flush=True)
+            os._exit(0)
+        guard = threading.Timer(limit, bail_cpu)
+        guard.daemon = True
+        guard.start()
+        out["cpu_baseline"] = cpu_baseline(conf_c, x_c, budget)
+        guard.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
