@@ -46,8 +46,9 @@ extern "C" {
  *   2.01  round 4 (additions only): ipsx_aggregate_packed, ipsx_set_persistent_wait_ms, ipsx_conv2d_wgrad_nhwc*,
  *         ipsx_pack_conv_weight_strided, ipsx_conv2d_affine_to_nhwc, ipsx_conv2d_lds_nhwc*;
  *         ipsx_projector_stream accepts
- *         short_first <= -3 (guided tile sizes)                                                                     */
-#define IPSX_VERSION 201
+ *         short_first <= -3 (guided tile sizes)
+ *   2.02  round 4: ipsx_scan_persistent_on, ipsx_scan_persistent_groupable                                          */
+#define IPSX_VERSION 202
 
 #define IPSX_OK            0
 #define IPSX_EINVAL       -1      /* bad argument / unsupported shape */
@@ -358,6 +359,14 @@ int ipsx_scan_persistent_supported(int m, int i, int h, int n_token);
 int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                          int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
                          int32_t ready_per_image, int32_t* status, void* stream);
+/* ipsx_scan_persistent with FEWER resident workgroups than images (0 < workgroups < b; otherwise one per image):
+ * workgroup w runs the loops of images w, w + workgroups, ... one after the other - for a producer that works through
+ * the images in order and needs longer for an image than its loop does (the projector of 16 CAMELYON slides: two
+ * resident loops keep up, and 14 more compute units stay the projector's).  Shapes: ipsx_scan_persistent_groupable(). */
+int ipsx_scan_persistent_groupable(int m, int i, int h, int n_token);
+int ipsx_scan_persistent_on(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                            int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
+                            int32_t ready_per_image, int32_t* status, int workgroups, void* stream);
 int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream);
 /* longest wait of a persistent loop (and of ipsx_scan_gate) without progress, in milliseconds (1 .. 20000; default 50);
  * returns the previous value, ms <= 0 only queries */

@@ -852,6 +852,8 @@ struct ScanArgs {
     int* status;           // persistent launch: set to 1 when the wait for `ready` timed out
     const int* cond;       // conditional launch (ipsx_scan_range_if): run only when (*cond & cond_mask) != 0, or nullptr
     int cond_mask;
+    int slides;            // images of the call; a launch of fewer workgroups (scan_cam_kernel) gives workgroup w the
+                           // images w, w + gridDim.x, ... one after the other
 };
 
 // ipsx_scan_range_if: the recovery launch behind a persistent loop - every workgroup looks at the word the loop sets when
@@ -1621,7 +1623,7 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
         asm volatile("v_mov_b32 v127, 0" ::: "v127");               // (the whole register file of the compute unit: see scan_fast_kernel)
         if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long tacc[8], tlast = 0;
     uint64_t* const sorted = reinterpret_cast<uint64_t*>(smem + OFF_SORTED);
     uint64_t* const keyA = reinterpret_cast<uint64_t*>(smem + OFF_KEYA);
     uint32_t* const pmax = reinterpret_cast<uint32_t*>(smem + OFF_PMAX);
@@ -1632,12 +1634,17 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
     uint32_t* const sc32 = reinterpret_cast<uint32_t*>(smem + OFF_SC);
     int* const pr = reinterpret_cast<int*>(smem + OFF_PR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const float* lg = a.lg + (size_t)b * a.n * R;
     const int r = tid & (R - 1);
     const int hid = tid - 512;                                  // helper index (waves 8..15), < 0 on the candidate waves
     const uint32_t dir = sort_directions(lane);
-
+    // Fewer workgroups than slides (ipsx_scan_persistent_on): this one takes the slides blockIdx.x, + gridDim.x, ... one
+    // after the other - the producer works through the slides in that order, and a loop is faster than its slide's
+    // projector, so two resident loops follow 16 slides and the projector keeps the other 14 compute units.
+    for (int b = blockIdx.x; b < a.slides; b += (int)gridDim.x) {
+    const float* lg = a.lg + (size_t)b * a.n * R;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tacc[k] = 0;
+    if (STAMP) tlast = __builtin_amdgcn_s_memtime();
     int ready_known = 0;
     if (tid < 4 * R) pmax[tid] = 0u;
     lds_barrier();
@@ -1962,6 +1969,8 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
     if (a.tie && tid == 0 && tie) a.tie[b] = 1;
     if (STAMP && tid == 0)
         for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
+    lds_barrier();                                               // (the next slide starts on the same LDS)
+    }
 }
 
 // Transformer.get_scores on the logits (b, L, R) of arbitrary embeddings
@@ -2558,7 +2567,7 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                            int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
                            size_t workspace_bytes, void* stream, const int32_t* cond = nullptr, int32_t cond_mask = 0,
-                           int ready_stride = 0);
+                           int ready_stride = 0, int workgroups = 0);
 
 IPSX_API int ipsx_scan_range(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                              int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
@@ -2624,6 +2633,20 @@ IPSX_API int ipsx_scan_persistent(const float* logits, int b, int64_t n, int m, 
                            nullptr, 0, stream, nullptr, 0, ready_per_image ? 1 : 0);
 }
 
+IPSX_API int ipsx_scan_persistent_groupable(int m, int i, int h, int n_token) {
+    return g_scan_r8 && h * n_token == cam::R && n_token == 1 && m == cam::M && i == cam::I ? 1 : 0;
+}
+
+IPSX_API int ipsx_scan_persistent_on(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                                     int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
+                                     int32_t ready_per_image, int32_t* status, int workgroups, void* stream) {
+    IPSX_REQUIRE(ready && status, "scan_persistent: needs the progress word(s) and the status word");
+    IPSX_REQUIRE(n > m && i > 0, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
+    IPSX_REQUIRE(ipsx_scan_persistent_supported(m, i, h, n_token), "scan_persistent: shape not covered (use ipsx_scan_range)");
+    return scan_range_impl(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, ready, status,
+                           nullptr, 0, stream, nullptr, 0, ready_per_image ? 1 : 0, workgroups);
+}
+
 // one thread that holds its stream until every workgroup of the persistent scan is resident (bounded: ~0.5 s)
 __global__ void scan_gate_kernel(const int* status, unsigned long long wait_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -2657,7 +2680,8 @@ IPSX_API int ipsx_scan_range_if(const float* logits, int b, int64_t n, int m, in
 static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                            int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
                            int32_t* tie_flag, const int32_t* ready, int32_t* status, void* workspace,
-                           size_t workspace_bytes, void* stream, const int32_t* cond, int32_t cond_mask, int ready_stride) {
+                           size_t workspace_bytes, void* stream, const int32_t* cond, int32_t cond_mask, int ready_stride,
+                           int workgroups) {
     IPSX_REQUIRE(logits && mem_idx, "scan: null pointer");
     IPSX_REQUIRE(b > 0 && m > 0 && i > 0 && h > 0 && n_token > 0, "scan: bad sizes");
     IPSX_REQUIRE(n > m, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
@@ -2703,6 +2727,7 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     a.ready_words = ready ? (ready_stride ? std::min(b, 64) : 1) : 0;
     a.wait_ticks = (unsigned long long)g_persist_wait_ms * 100000ull;
     a.cond = cond; a.cond_mask = cond_mask;
+    a.slides = b;
     a.tie_order = g_tie_order;
     a.use_lds = 1;
     a.stk_off = (int)(fp.lds - STK_BYTES);
@@ -2739,11 +2764,12 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         // BASELINE configs[3] (8 heads, one token, M = I = 256): the specialised loop (scan_cam_kernel)
         static_assert(cam::LDS_BYTES <= 160 * 1024, "scan_cam_kernel: LDS");
         a.stk_off = cam::OFF_STK;
+        const int grid = workgroups > 0 && workgroups < b ? workgroups : b;
 #define IPSX_LAUNCH_CAM(S, P)                                                                                       \
     do {                                                                                                            \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_cam_kernel<S, P>),                             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cam::LDS_BYTES);                 \
-        scan_cam_kernel<S, P><<<dim3((unsigned)b), dim3(cam::NT), cam::LDS_BYTES, as_stream(stream)>>>(a, st);      \
+        scan_cam_kernel<S, P><<<dim3((unsigned)grid), dim3(cam::NT), cam::LDS_BYTES, as_stream(stream)>>>(a, st);   \
         return launched("scan");                                                                                    \
     } while (0)
         if (st && a.ready) IPSX_LAUNCH_CAM(true, true);
@@ -2752,6 +2778,8 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         IPSX_LAUNCH_CAM(false, false);
 #undef IPSX_LAUNCH_CAM
     }
+    IPSX_REQUIRE(workgroups <= 0 || workgroups >= b, "scan_persistent_on: fewer workgroups than images only for the shapes of "
+                 "ipsx_scan_persistent_groupable");
     // the diagnostic (stamped) build exists for the two benchmark shapes
     if (st && a.ready && R == 8 && n_token == 1 && ept == 4 && lch == 8) {      // stamped persistent loop (diagnostic)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<8, 1, 4, 8, true, true>),

@@ -224,6 +224,10 @@ _EXPORTS = {
     "ipsx_scan_range_if": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ipsx_scan_persistent_supported": (C.c_int, [C.c_int] * 4),
+    "ipsx_scan_persistent_groupable": (C.c_int, [C.c_int] * 4),
+    "ipsx_scan_persistent_on": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int,
+                                          C.c_void_p]),
     "ipsx_scan_persistent": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ipsx_publish_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -862,17 +866,24 @@ def scan_persistent_supported(M, I, H, T):
     return bool(lib().ipsx_scan_persistent_supported(M, I, H, T))
 
 
-def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status):
+def scan_persistent_groupable(M, I, H, T):
+    """Can fewer resident workgroups than images run this shape's persistent loops (``scan_persistent(workgroups=)``)?"""
+    return bool(lib().ipsx_scan_persistent_groupable(M, I, H, T))
+
+
+def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status, workgroups=0):
     """The whole loop as one launch on the CURRENT stream that waits for ``ready`` (int32 device scalar, advanced with
     ``publish_rows`` on the producing stream; or one word per image - ``ready.numel() == B`` > 1 - when the producer works
-    through the images one after the other) before it reads rows; see include/ipsx.h."""
+    through the images one after the other) before it reads rows; see include/ipsx.h.  ``workgroups`` in (0, B): that
+    many resident loops, each taking its images one after the other (``scan_persistent_groupable`` shapes)."""
     B, N = lg.shape[:2]
     if not lg.is_contiguous():
         raise ValueError("scan_persistent needs the full contiguous (B, N, H*T) logits buffer")
     if ready.numel() not in (1, B):
         raise ValueError("ready: one word, or one per image")
-    _ck(lib().ipsx_scan_persistent(_p(lg), B, N, M, I, H, T, _p(mem_idx), None, _p(tie), _p(ready),
-                                   1 if (ready.numel() == B and B > 1) else 0, _p(status), _stream()), "ipsx_scan_persistent")
+    _ck(lib().ipsx_scan_persistent_on(_p(lg), B, N, M, I, H, T, _p(mem_idx), None, _p(tie), _p(ready),
+                                      1 if (ready.numel() == B and B > 1) else 0, _p(status), int(workgroups), _stream()),
+        "ipsx_scan_persistent_on")
     return mem_idx
 
 

@@ -85,7 +85,7 @@ class Selection:
                 and hip.scan_persistent_supported(M, I, H, T) and hip.persistent_ok(dev))
 
     # ------------------------------------------------------------------ the persistent loop: begin / end
-    def persistent_begin(self, logits, mem_idx_buf, zeroed, B, dev):
+    def persistent_begin(self, logits, mem_idx_buf, zeroed, B, dev, loops=0):
         """Zero the call's words (tie flags | a progress word per image | status | producer control words: ONE fill), launch
         the loop on the side stream and hold the main stream until it is resident.  -> (tie, ready, status, ctl).
 
@@ -108,7 +108,7 @@ class Selection:
         self.scan_status = status
         side.wait_stream(main)                     # the buffers are the main stream's; previous readers are done
         with torch.cuda.stream(side):
-            hip.scan_persistent(logits, net.M, net.I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status)
+            hip.scan_persistent(logits, net.M, net.I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status, workgroups=loops)
         # producers must not take the compute units before a loop has its own.  (Also true of a persistent producer whose
         # workgroups sit one to a unit and leave a unit per loop free: a workgroup is dealt to an XCD before it looks for a
         # unit there, so a loop that arrives second may be dealt to a FULL XCD and start when the producer ends - measured
@@ -231,7 +231,7 @@ class Selection:
         its.append(n_iter)
         return its
 
-    def feature_launches(self, B, N, edges, dev):
+    def feature_launches(self, B, N, edges, dev, loops=None):
         """The projector launches of ``features_persistent``: (first row, end row) in the FLAT (B * N) row space + what each
         makes visible, [(slide, rows)].  One slide, or positional encodings (a table per slide position): a slide's parts.
         Several slides without them: the slides are one stream of rows cut into full launches wherever a slide ends (the
@@ -243,7 +243,7 @@ class Selection:
         if B == 1 or self.net.use_pos:
             return [(b_ * N + edges[k], b_ * N + edges[k + 1], [(b_, edges[k + 1])]) for b_ in range(B) for k in range(P)]
         g = hip.device_geometry(dev)
-        cap = max(I, min(g.cus - 4 * g.xcds, self.free_units(dev, B)) * 64 // I * I)
+        cap = max(I, min(g.cus - 4 * g.xcds, self.free_units(dev, loops or B)) * 64 // I * I)
         launches, r0 = [], 0
         while r0 < B * N:
             # the first launch of the call stays short: the first loop starts after M + I rows' worth of projector
@@ -275,7 +275,14 @@ class Selection:
                      torch.zeros((2 * B + 1 + plan.stream_ctl_words(B * N),), dtype=torch.int32, device=dev),
                      torch.empty((B * N, 2), dtype=torch.float32, device=dev),      # LayerNorm moments
                      torch.empty((B, N, net.D), dtype=torch.float32, device=dev)))
-        tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev)
+        # Resident loops: the projector goes through the slides in order and needs longer for a slide than its loop does
+        # (65,536 x 2048 rows: 1.2 ms against 0.94), so TWO loop workgroups, each taking its slides one after the other,
+        # keep up with any number of slides - and the compute units of the other loops stay the projector's
+        # (16 slides: 240 -> 254 units, 52.5 -> [DESIGN 6] M patches/s).
+        loops = B
+        if B > 2 and hip.scan_persistent_groupable(M, I, ca.H, ca.n_token):
+            loops = max(1, min(B, int(os.environ.get("IPSX_CAM_LOOPS", "2"))))
+        tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops)
         plan._refresh()
         fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)
         xf, ef, lf = patches.view(B * N, -1), emb_buf.view(B * N, -1), logits.view(1, B * N, R)
@@ -286,17 +293,17 @@ class Selection:
             # 64-row tiles at full rate, the first rows from half the workgroups' short first tiles, the last two rounds
             # handed out as 32-row tiles so that the launch ends evenly (short_first = -20; M patches/s per slide, synced:
             # all tiles 32 rows on 248 / 255 units 39.3 / 39.9, this on 248 / 255 units 41.1 / 41.5)
-            free = hip.device_geometry(dev).cus - B
+            free = hip.device_geometry(dev).cus - loops
             wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
             short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-20 if B == 1 else -1)
             plan.stream(xf, vq, R, ef, logits.view(B * N, R), ctl, ready, workgroups=wgs, slide_rows=N, short_first=short)
             for b_ in range(B):                    # (whatever the last finishers left to each other; the launch is over)
                 hip.publish_rows(ready[b_:b_ + 1], N)
         else:
-            its = self.feature_parts(B, N, dev, True)
+            its = self.feature_parts(loops, N, dev, True)
             edges = [0] + [min(N, M + it * I) for it in its[1:]]
             edges[-1] = N
-            launches = self.feature_launches(B, N, edges, dev)
+            launches = self.feature_launches(B, N, edges, dev, loops)
             if fused2:
                 plan.row_stats(xf[launches[0][0]:launches[0][1]], out=stats[launches[0][0]:launches[0][1]])
             published = None                       # (slide, rows) whose publication rides on the next GEMM launch

@@ -568,6 +568,37 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("groups", [1, 2, 3, 5])
+def test_persistent_loops_of_several_slides_on_fewer_workgroups(groups):
+    """ipsx_scan_persistent_on: the loops of 5 slides (the CAMELYON shape, M = I = 256) on 1 / 2 / 3 / 5 resident
+    workgroups, each taking its slides one after the other while the rows are published slide by slide from another
+    stream, select what the plain loop selects (ragged last chunk; a per-slide progress word)."""
+    B, N, M, I, H = 5, 256 + 7 * 256 + 100, 256, 256, 8
+    assert hip.scan_persistent_groupable(M, I, H, 1) and not hip.scan_persistent_groupable(64, 64, H, 1)
+    lg = torch.randn((B, N, H), device=DEV)
+    plain = hip.scan(lg, M, I, H, 1)
+    mem = torch.full((B, M), -7, dtype=torch.int64, device=DEV)
+    tie = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    words = torch.zeros((B + 1,), dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip.scan_persistent(lg, M, I, H, 1, mem, tie, words[:B], words[B:], workgroups=groups)
+    hip.scan_gate(words[B:])
+    for b in range(B):                              # the producer's order: slide by slide, a few steps each
+        for rows in (M + I, N // 2, N):
+            hip.publish_rows(words[b:b + 1], rows)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(words[B].item()) & 1 == 0
+    assert torch.equal(mem, plain)
+    if groups < B:                                  # shapes of the generic LDS loop: one workgroup per image only
+        lg2 = torch.randn((3, 1024, H), device=DEV)
+        with pytest.raises(RuntimeError, match="fewer workgroups"):
+            hip.scan_persistent(lg2, 64, 64, H, 1, mem[:3, :64].contiguous(), tie[:3], words[:3], words[B:], workgroups=2)
+
+
+@pytest.mark.gpu
 def test_persistent_self_test_sees_serialised_kernels():
     """Whether a persistent loop can run beside its producers is established by doing it once per device
     (hip.persistent_ok), not by looking for profiler / debug variables: on this box it can; with the runtime told to
