@@ -1,6 +1,6 @@
 // Micro-benchmark: how much of the fp32 matrix pipe do ONE and TWO wavefronts per SIMD reach - MFMAs alone, with the
 // operand loads of the projector GEMM stage (6 x b128 per 32 MFMAs) between them, and with its normalisation VALU work.
-//   hipcc --offload-arch=gfx950 -O3 tools/probe/mfma_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_waves.hip -o tools/ubench/mfma_waves && tools/ubench/mfma_waves
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
