@@ -134,9 +134,7 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
         if on_gpu:
             R = ca.H * ca.n_token
             vq = ca.folded_query()
-            if getattr(net, "_side_stream", None) is None or net._side_stream.device != dev:
-                net._side_stream = torch.cuda.Stream(device=dev, priority=-1)
-            side, main = net._side_stream, torch.cuda.current_stream(dev)
+            side, main = hip.side_stream(dev), torch.cuda.current_stream(dev)
             # Per-call device buffers are KEPT between calls of the same shape (like IPSNet._scan_bufs): a block the side
             # stream has used cannot be recycled by the allocator until that stream's work is known to be over, so
             # allocating them afresh in every call piles up one set per un-synchronised call and sends the host into

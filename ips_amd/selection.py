@@ -65,7 +65,7 @@ class Selection:
 
     def streams(self, dev):
         if self._side is None or self._side.device != torch.device(dev):
-            self._side = torch.cuda.Stream(device=dev, priority=-1)      # its few workgroups must not queue behind an encoder grid
+            self._side = hip.side_stream(dev)      # (one per device and process, high priority: hip.side_stream)
         return self._side, torch.cuda.current_stream(dev)
 
     def buffers(self, name, key, make):
