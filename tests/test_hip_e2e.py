@@ -568,6 +568,37 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
 
 
 @pytest.mark.gpu
+def test_stream_hand_over_stress(monkeypatch):
+    """The hand-over between the persistent producers and the resident loops (flags, cursor, progress words: relaxed
+    atomics behind one release fence, an acquire per wait), many times over: 40 calls with fresh slides of ragged sizes,
+    1 / 2 / 5 slides per call (5: two loop workgroups take the slides in turn), each held to the per-part launches."""
+    conf = synth.camelyon_conf(N=4096, M=256, I=256)
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 5).to(DEV).eval()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    cases = []
+    for k in range(40):
+        B = (1, 2, 5)[k % 3]
+        N = 32 * int(torch.randint(40, 400, (1,), generator=g)) if B > 1 else int(torch.randint(1300, 12000, (1,), generator=g))
+        cases.append(torch.randn((B, N, conf.n_chan_in), generator=g).to(DEV))
+    monkeypatch.setenv("IPSX_SCAN_PERSIST", "0")
+    want = []
+    for x in cases:
+        net.ips(x)
+        want.append(net.last_mem_idx.clone())
+    monkeypatch.setenv("IPSX_SCAN_PERSIST", "1")
+    used = 0
+    for rep in range(2):
+        for x, w in zip(cases, want):
+            net.selection.scan_status = None
+            net.ips(x)
+            used += net.selection.scan_status is not None
+            assert torch.equal(net.last_mem_idx, w), "slides %s, call %d" % (tuple(x.shape), rep)
+    torch.cuda.synchronize()
+    assert used == 2 * len(cases)                       # every call went through the persistent pipeline
+    assert int(net.selection.scan_status_host.item()) & 1 == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groups", [1, 2, 3, 5])
 def test_persistent_loops_of_several_slides_on_fewer_workgroups(groups):
     """ipsx_scan_persistent_on: the loops of 5 slides (the CAMELYON shape, M = I = 256) on 1 / 2 / 3 / 5 resident
