@@ -265,7 +265,8 @@ int ipsx_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n_patch
  * start with a 32-row tile, -1: half of them (completions then do not come in bursts), -2: every tile is 32 rows (a
  * steady supply at 12 % less throughput), -3 - (head + 8 tail), head < 8: every workgroup's first `head` pulls and the
  * last `tail` x workgroups units are 32-row tiles (early first rows, an even end; head = 0: half the workgroups start
- * short as with -1).  ipsx_projector_stream_supported: 1x1 Linear with
+ * short as with -1), and the few units left over when every workgroup has had its whole share go out as four column
+ * quarters each (the logits' accumulators pass from quarter to quarter: the same bits).  ipsx_projector_stream_supported: 1x1 Linear with
  * 512 outputs, c_in % 32 == 0, c_in <= 2048, 64 <= n < 2^31.                                          */
 size_t ipsx_projector_stream_ctl_words(int64_t n);
 int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r);

@@ -277,11 +277,21 @@ struct StreamArgs {
     unsigned short_first;
     int short_pulls;               // every workgroup's first short_pulls pulls are one unit
     unsigned tail_start;           // units from here on are handed out one at a time (the launch ends evenly)
+    unsigned split_start, split_units;     // the LAST split_units units are handed out as SPLIT_P column quarters each
+    unsigned split_base;           // ctl[split_base]: next quarter; then the quarters' hand-over flags and accumulators
     int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
     int* ready;                    // rows published, per slide (ipsx_scan_persistent's progress words)
     unsigned long long* stamps;    // diagnostic (ipsx_dbg_projector_stream_stamps): cycles per phase, summed by workgroup 0
 };
 
+// The last few units of a launch - what is left when every workgroup has had its whole share: 2,048 units on 255 compute
+// units are 8 each and 8 over - would be a round of their own that most of the chip sits out (a 32-row tile: 0.166 ms of
+// a 1.38 ms launch).  They are handed out as SPLIT_P column quarters to as many workgroups: every quarter computes the
+// rows' moments, its 128 columns of the Linear (a wave: 32) and its 16 k-groups of the logits' MFMA chain, whose
+// accumulators pass from quarter to quarter through memory (ctl: a flag and 1,024 floats per hand-over) - the same chain
+// in the same order, so embeddings and logits stay bit-identical.  The last quarter publishes the unit.
+constexpr int SPLIT_P = 4, SPLIT_MAX = 16;
+constexpr int SPLIT_WORDS = 1 + SPLIT_MAX * (SPLIT_P - 1) * (1 + 1024);
 constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
 constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + 64 * 8 + 16;
 
@@ -294,8 +304,11 @@ constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + 64 * 8 + 16;
         }                                                                                   \
     } while (0)
 
-template <int MT, bool STAMP>
-__device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, float* tile, float2* s_stats) {
+template <int MT, int NTW, bool STAMP>
+__device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, int part, unsigned split_unit, float* tile,
+                                            float2* s_stats) {
+    static_assert(NTW == 4 || MT == 1, "column parts are 32-row tiles");
+    constexpr int P = 4 / NTW;                                     // workgroups that share the tile's columns (NTW = 4: one)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, i = lane & 31;
     ST_STAMP(0);                                                   // (pull + publication of the tile before)
     // ---- LayerNorm moments of the tile's rows: 8 MT rows per wavefront
@@ -322,7 +335,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)row0 * a.c_in), 0,
                                                                         (int)(rows_here * (unsigned)a.c_in * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)a.w_bytes, 0x00020000);
-    const int nt0 = wave * 4;
+    const int nt0 = part * (16 / P) + wave * NTW;
     unsigned pv[MT];
     float mean[MT], rstd[MT];
 #pragma unroll
@@ -334,17 +347,17 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
         mean[mt] = st.x; rstd[mt] = st.y;
     }
     const unsigned lb = lane * 16u;
-    unsigned wb[4];
+    unsigned wb[NTW];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wb[t] = (unsigned)(nt0 + t) * (unsigned)a.kgs * 1024u;
-    f32x16 acc[MT][4];
+    for (int t = 0; t < NTW; ++t) wb[t] = (unsigned)(nt0 + t) * (unsigned)a.kgs * 1024u;
+    f32x16 acc[MT][NTW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.0f;
-    struct Stage { f32x4 a[MT], b[4]; };
+    struct Stage { f32x4 a[MT], b[NTW]; };
     Stage s0, s1, s2, s3;          // ring of 4, operands requested THREE stages (3 x 2048 matrix-pipe cycles, ~2.6 us) ahead -
                                    // a ring of 3 (two ahead): 1.246 ms per 65,536 rows on 256 units, of 4: 1.217, of 8: 1.210 -
     const int total = a.kgs;       // with one wavefront per SIMD nothing else hides the latency of rows that come from HBM
@@ -353,7 +366,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     do {                                                                                   \
         const unsigned ca = (unsigned)gp * 32u, cb = (unsigned)gp * 1024u;                 \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) S.a[mt] = bufload(rx, pv[mt], ca); \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) S.b[t] = bufload(rw, lb, wb[t] + cb);  \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) S.b[t] = bufload(rw, lb, wb[t] + cb); \
         if (gp + 1 < total) ++gp;                                                          \
     } while (0)
 #define ST_STAGE(SL, SM)                                                                   \
@@ -361,7 +374,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) SM.a[mt] = norm4(SM.a[mt], mean[mt], rstd[mt]); \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[mt][t] = MFMA(SM.a[mt][j], SM.b[t][j], acc[mt][t]); \
+            _Pragma("unroll") for (int t = 0; t < NTW; ++t) acc[mt][t] = MFMA(SM.a[mt][j], SM.b[t][j], acc[mt][t]); \
     if (MT == 2) {                                                                         \
         __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
@@ -370,13 +383,16 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
         __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
-    } else {                                                                               \
+    } else if (NTW == 4) {                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+    } else {                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
     }                                                                                      \
     SB();
     ST_ISSUE(s0);
@@ -395,7 +411,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
 
     // ---- BatchNorm affine + ReLU: to HBM and to the LDS copy the logits read
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTW; ++t) {
         const int nn = (nt0 + t) * 32 + i;
         const float al = a.alpha ? a.alpha[nn] : 1.0f;
         const float sh = a.shift ? a.shift[nn] : 0.0f;
@@ -415,17 +431,36 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     __syncthreads();
     ST_STAMP(3);
 
-    // ---- logits of the tile's rows: wave mt takes rows 32 mt .. 32 mt + 31, all R logits (one 32-column tile)
+    // ---- logits of the tile's rows: wave mt takes rows 32 mt .. 32 mt + 31, all R logits (one 32-column tile).
+    // A column part (P > 1) runs ITS k-groups of the chain: the accumulators arrive from the part before and go on to the
+    // part behind through memory (written through, one release fence before the flag; the reader: an acquire after it).
     if (wave < MT) {
         const unsigned lr = wave * 32 + i, row = row0 + lr;
         const bool rv = row < a.n;
         const float* e = tile + lr * ST_EP + 4 * half;
         const float4* vq = reinterpret_cast<const float4*>(a.vp) + lane;
+        const int kg0 = part * (64 / P), kg1 = P > 1 ? kg0 + 64 / P : a.vkgs;
+        int* const sflag = a.ctl + a.split_base + 1 + split_unit * (SPLIT_P - 1);
+        float* const sacc = reinterpret_cast<float*>(a.ctl + a.split_base + 1 + SPLIT_MAX * (SPLIT_P - 1)) +
+                            (size_t)split_unit * (SPLIT_P - 1) * 1024;
         f32x16 lacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) lacc[r] = 0.0f;
+        if (P > 1 && part > 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool ok = true;
+            while (__hip_atomic_load(sflag + part - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) { ok = false; break; }     // 50 ms: never (no hang on a bug)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lacc[r] = ok ? __hip_atomic_load(sacc + (part - 1) * 1024 + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : __builtin_nanf("");
+        }
 #pragma unroll 1
-        for (int k0 = 0; k0 < a.vkgs; k0 += 8) {
+        for (int k0 = kg0; k0 < kg1; k0 += 8) {
             float4 ev[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -440,7 +475,14 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
                 lacc = MFMA(rv ? ev[u].w : 0.0f, bv[u].w, lacc);
             }
         }
-        if (i < a.R) {
+        if (P > 1 && part < P - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __hip_atomic_store(sacc + part * 1024 + r * 64 + lane, lacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(sflag + part, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (i < a.R) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned rr = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -459,26 +501,38 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
     float* tile = st_lds;
     float2* s_stats = reinterpret_cast<float2*>(st_lds + 64 * ST_EP);
-    int* s_u0 = reinterpret_cast<int*>(st_lds + 64 * ST_EP + 128);
+    int* s_u0 = reinterpret_cast<int*>(st_lds + 64 * ST_EP + 128);         // [0] unit, [1] units taken, [2] column part or -1
     bool first = true;
     int pulls = 0;
     for (;;) {
         if (threadIdx.x == 0) {
             // (the look at the counter may be a pull or two behind: it only decides the SIZE of this pull)
             const bool tail = (unsigned)__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.tail_start;
-            const int take = ((first && blockIdx.x < (a.short_first & 0x7fffffffu)) || pulls < a.short_pulls || tail) ? 1 : 2;
+            int take = ((first && blockIdx.x < (a.short_first & 0x7fffffffu)) || pulls < a.short_pulls || tail) ? 1 : 2;
+            unsigned u = (unsigned)atomicAdd(&a.ctl[0], take);
+            int part = -1;
+            if (u >= a.split_start) {                               // the whole units are gone: a column quarter of one of the last
+                const unsigned j = (unsigned)atomicAdd(&a.ctl[a.split_base], 1);
+                if (j < a.split_units * SPLIT_P) { u = a.split_start + j / SPLIT_P; part = (int)(j % SPLIT_P); take = 1; }
+                else u = a.n_units;
+            } else if (u + take > a.split_start) {
+                take = 1;
+            }
+            s_u0[0] = (int)u;
             s_u0[1] = take;
-            s_u0[0] = atomicAdd(&a.ctl[0], take);
+            s_u0[2] = part;
         }
         first = false;
         ++pulls;
         __syncthreads();
         const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane(s_u0[0]);
         const int take = __builtin_amdgcn_readfirstlane(s_u0[1]);
+        const int part = __builtin_amdgcn_readfirstlane(s_u0[2]);
         if (u0 >= a.n_units) break;                                 // workgroup-uniform
         const int units = (take == 2 && u0 + 1 < a.n_units) ? 2 : 1;
-        if (units == 2) stream_tile<2, STAMP>(a, u0 * 32u, tile, s_stats);
-        else stream_tile<1, STAMP>(a, u0 * 32u, tile, s_stats);
+        if (part >= 0) stream_tile<1, 4 / SPLIT_P, STAMP>(a, u0 * 32u, part, u0 - a.split_start, tile, s_stats);
+        else if (units == 2) stream_tile<2, 4, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
+        else stream_tile<1, 4, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
         // ---- publish: the tile's logits have been written through (stream_tile); one release fence, then relaxed atomics.
         // (The embeddings are ordinary stores: nothing reads them before the launch is over.)  The first wavefront sets
         // the flags of this tile's units, reads the cursor - the first unpublished unit - and the 64 flags from there on
@@ -490,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
         // unit then waits for the next workgroup that finishes anything (about every microsecond) or, at the very end,
         // for the caller's ipsx_publish_rows behind this launch.
         __syncthreads();
-        if (threadIdx.x < 64) {
+        if (threadIdx.x < 64 && (part < 0 || part == SPLIT_P - 1)) {           // (a column quarter: the last one publishes)
             const int lane = threadIdx.x;
             // ONE agent-scope release per tile, in the publishing wavefront only (round 4; the advisor's form): the
             // workgroup barrier above has collected every wave's stores, so flag, cursor and progress word are ordered
@@ -670,7 +724,13 @@ static unsigned long long* g_stream_stamps = nullptr;
 // the shader cycles of each phase of its tiles - [0] pull + publication, [1] moments, [2] GEMM, [3] epilogue, [4] logits.
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_projector_stream_stamps(unsigned long long* p) { g_stream_stamps = p; }
 
-IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) { return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 : 0; }
+static int g_stream_split = 1;
+// Diagnostic: 0 = the last units of a guided launch as whole 32-row tiles (no column quarters)
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_stream_split(int on) { g_stream_split = on; }
+
+IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) {
+    return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 + ipsx::SPLIT_WORDS : 0;
+}
 
 IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r) {
     if (!lin || !lin->w_packed || lin->kh != 1 || lin->kw != 1 || lin->stride != 1 || lin->pad != 0) return 0;
@@ -705,13 +765,24 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     a.short_first = (unsigned)(short_first >= 0 ? short_first : wgs / 2);
     a.short_pulls = short_first == -2 ? 0x7fffffff : 0;                            // (-2: every tile 32 rows)
     a.tail_start = a.n_units;
+    a.split_start = a.n_units; a.split_units = 0; a.split_base = a.n_units + 2;
     if (short_first <= -3) {
         // -3 - (head + 8 tail): every workgroup's first `head` pulls and the last `tail` x workgroups units are 32-row tiles -
         // early first rows, full-rate 64-row tiles in the middle, and an end without a last round that most units sit out
         const int k = -short_first - 3, head = k & 7, tail = k >> 3;
         a.short_pulls = head;
         if (head > 0) a.short_first = 0;
-        const long long ts = (long long)a.n_units - (long long)tail * wgs;
+        // What is left over when every WORKING workgroup has had its whole share of units goes out in column quarters.
+        // Working: a launch that leaves compute units to resident loops is dealt to the XCDs round-robin whatever is
+        // free there, so each loop may keep one workgroup of its XCD waiting until the others leave - the
+        // share is computed for 2 wgs - cus workers (255 of 256: 254; too few assumed just starts the quarters early).
+        const unsigned eff = (unsigned)std::max(1, wgs < cus ? 2 * wgs - cus : wgs);
+        const unsigned per = a.n_units / eff, left = a.n_units - per * eff;
+        if (g_stream_split && per >= 2 && left > 0 && left <= (unsigned)ipsx::SPLIT_MAX && left * ipsx::SPLIT_P <= eff) {
+            a.split_units = left;
+            a.split_start = a.n_units - left;
+        }
+        const long long ts = (long long)a.split_start - (long long)tail * wgs;
         a.tail_start = (unsigned)(ts > 0 ? ts : 0);
     }
 

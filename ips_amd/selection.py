@@ -290,12 +290,13 @@ class Selection:
                 and plan.stream_supported(B * N, R)):
             # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
             # late).  Round 4: the loop (3.7 us per iteration) is no longer the bound of a lone slide, the projector is:
-            # 64-row tiles at full rate, the first rows from half the workgroups' short first tiles, the last two rounds
-            # handed out as 32-row tiles so that the launch ends evenly (short_first = -20; M patches/s per slide, synced:
-            # all tiles 32 rows on 248 / 255 units 39.3 / 39.9, this on 248 / 255 units 41.1 / 41.5)
+            # 64-row tiles at full rate, the last round handed out as 32-row tiles and what is left over then as column
+            # quarters, so that the launch ends evenly (short_first = -11: half the workgroups start with a 32-row tile, one round of single units;
+            # M patches/s per slide synced / back to back: all tiles 32 rows 39.9 / 41.1, this 41.6 / 43.4; without the
+            # quarters the leftover 8-16 units were a round of their own: stream 1.38 -> 1.30 ms)
             free = hip.device_geometry(dev).cus - loops
             wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
-            short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-20 if B == 1 else -1)
+            short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-11 if B == 1 else -1)
             plan.stream(xf, vq, R, ef, logits.view(B * N, R), ctl, ready, workgroups=wgs, slide_rows=N, short_first=short)
             for b_ in range(B):                    # (whatever the last finishers left to each other; the launch is over)
                 hip.publish_rows(ready[b_:b_ + 1], N)

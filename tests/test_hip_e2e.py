@@ -611,8 +611,8 @@ def test_persistent_loops_of_several_slides_on_fewer_workgroups(groups):
     mem = torch.full((B, M), -7, dtype=torch.int64, device=DEV)
     tie = torch.zeros((B,), dtype=torch.int32, device=DEV)
     words = torch.zeros((B + 1,), dtype=torch.int32, device=DEV)
-    side = torch.cuda.Stream(device=DEV)
-    side.wait_stream(torch.cuda.current_stream())
+    side = hip.side_stream(DEV)                     # (THE side stream: a fresh one may share the main stream's hardware queue,
+    side.wait_stream(torch.cuda.current_stream())   #  and a resident loop then keeps its own producers from running)
     with torch.cuda.stream(side):
         hip.scan_persistent(lg, M, I, H, 1, mem, tie, words[:B], words[B:], workgroups=groups)
     hip.scan_gate(words[B:])

@@ -309,7 +309,9 @@ def test_trunk_stream_equals_encode_plus_logits(n, wgs, use_pos, quads):
 
 
 @pytest.mark.parametrize("n,wgs,short,slides", [(64, 0, -1, 1), (97, 3, 1, 1), (1000, 7, 3, 1), (4099, 0, -1, 1), (20000, 0, 0, 1),
-                                                (3 * 1056, 5, 2, 3), (8 * 2048, 0, -1, 8), (5000, 9, -2, 1)])
+                                                (3 * 1056, 5, 2, 3), (8 * 2048, 0, -1, 8), (5000, 9, -2, 1),
+                                                # guided sizes; what is left over goes out in column quarters (8 / 3 / 16 units)
+                                                (65536, 255, -20, 1), (203 * 32 - 7, 40, -12, 1), (208 * 32, 64, -20, 1)])
 def test_projector_stream_equals_the_launch_by_launch_projector(n, wgs, short, slides):
     """ipsx_projector_stream - LayerNorm moments, Linear + BatchNorm + ReLU and the logits of every 64-row tile by resident
     workgroups, rows published in order as they complete - leaves the bits of ipsx_projector_stats + ipsx_projector_apply

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _rel(a, b):
+    a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 

@@ -45,7 +45,7 @@ def pmc_mode():
     for _ in range(5):
         ctl.zero_()
         ready.zero_()
-        plan.stream(x, vq, R, emb, lg, ctl, ready, workgroups=hip.device_geometry(dev).cus - 1, short_first=-20)
+        plan.stream(x, vq, R, emb, lg, ctl, ready, workgroups=hip.device_geometry(dev).cus - 1, short_first=-11)
     torch.cuda.synchronize()
     print("5 launches of the projector stream on %d rows" % n)
 
@@ -76,13 +76,13 @@ def main():
     ctl = torch.zeros((plan.stream_ctl_words(n),), dtype=torch.int32, device=dev)
     ready = torch.zeros((1,), dtype=torch.int32, device=dev)
     for w in wgs:
-        for short in (0, w // 2, -2, -20):
+        for short in (0, w // 2, -2, -20, -11):
             def stream():
                 ctl.zero_()
                 ready.zero_()
                 plan.stream(x, vq, R, emb, lg[0], ctl, ready, workgroups=w, short_first=short)
             ms = timed(stream)
-            print("stream, %d workgroups, %d short first tiles (-2: every tile 32 rows, -20: guided): %.3f ms (%.3f of peak on %d units: %.3f)"
+            print("stream, %d workgroups, %d short first tiles (-2: every tile 32 rows, -20 | -11: guided): %.3f ms (%.3f of peak on %d units: %.3f)"
                   % (w, short, ms, flop / (ms * 1e-3) / 157.3e12, w, flop / (ms * 1e-3) / 157.3e12 * 256 / w), flush=True)
     stamps(plan, x, vq, R, emb, lg, ctl, ready, n)
 
