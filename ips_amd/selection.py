@@ -80,9 +80,12 @@ class Selection:
             self._bufs[name] = held = (key, bufs)
         return held[1]
 
-    def persistent_allowed(self, dev, M, I, H, T):
+    def persistent_allowed(self, dev, M, I, H, T, loops=1):
+        """Resident loops beside their producers: switched on, the shape is covered, the device has units to spare for
+        ``loops`` of them (a small partition: the producers need the units more) and it has been SEEN to work there."""
         return (_env_on("IPSX_SCAN_PERSIST") and _env_on("IPSX_OVERLAP_SCAN") and not hip.dedup_blank()
-                and hip.scan_persistent_supported(M, I, H, T) and hip.persistent_ok(dev))
+                and hip.scan_persistent_supported(M, I, H, T) and hip.device_geometry(dev).cus >= 8 * max(1, loops)
+                and hip.persistent_ok(dev))
 
     # ------------------------------------------------------------------ the persistent loop: begin / end
     def persistent_begin(self, logits, mem_idx_buf, zeroed, B, dev, loops=0):
@@ -138,7 +141,7 @@ class Selection:
         if patches.is_cuda and self.can_overlap(patches):
             ca = net.transf.crs_attn
             if (not net.is_image and patches.is_contiguous() and patches.shape[0] <= int(os.environ.get("IPSX_PERSIST_MAX_B", "16"))
-                    and self.persistent_allowed(patches.device, net.M, net.I, ca.H, ca.n_token)):
+                    and self.persistent_allowed(patches.device, net.M, net.I, ca.H, ca.n_token, self.feature_loops(patches.shape[0]))):
                 return self.features_persistent(patches, pos_enc)
             return self.parts_with_ranges(patches, pos_enc)
         return self.slabs(patches, pos_enc)
@@ -213,6 +216,15 @@ class Selection:
             return None
         return edges + [N], its + [n_iter]
 
+    def feature_loops(self, B):
+        """Resident loop workgroups of a call of B slides: one per slide, or - shapes whose loop kernel takes its slides
+        in turn (ipsx_scan_persistent_on) - two for any number of slides."""
+        net = self.net
+        ca = net.transf.crs_attn
+        if B > 2 and hip.scan_persistent_groupable(net.M, net.I, ca.H, ca.n_token):
+            return max(1, min(B, int(os.environ.get("IPSX_CAM_LOOPS", "2"))))
+        return B
+
     def feature_parts(self, B, N, dev, persistent):
         """Iterations at which the rows of ONE slide are cut into projector launches.  Persistent loops (each owns a compute
         unit, the projector goes slide by slide): equal parts that fill the other units exactly once; otherwise every
@@ -279,9 +291,7 @@ class Selection:
         # (65,536 x 2048 rows: 1.2 ms against 0.94), so TWO loop workgroups, each taking its slides one after the other,
         # keep up with any number of slides - and the compute units of the other loops stay the projector's
         # (16 slides: 240 -> 254 units, 52.5 -> [DESIGN 6] M patches/s).
-        loops = B
-        if B > 2 and hip.scan_persistent_groupable(M, I, ca.H, ca.n_token):
-            loops = max(1, min(B, int(os.environ.get("IPSX_CAM_LOOPS", "2"))))
+        loops = self.feature_loops(B)
         tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops)
         plan._refresh()
         fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)

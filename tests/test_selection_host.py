@@ -65,6 +65,19 @@ def test_feature_launches_leave_a_unit_per_loop_on_the_fullest_xcd(geometry):
     assert sel.free_units(_Dev, 1) == 31
 
 
+def test_resident_loops_two_for_any_number_of_slides_and_none_on_a_tiny_partition(geometry, monkeypatch):
+    sel = _sel(synth.camelyon_conf(N=65536, M=256, I=256))             # the shape whose loop kernel takes slides in turn
+    assert [sel.feature_loops(b) for b in (1, 2, 3, 16)] == [1, 2, 2, 2]
+    assert [_sel(synth.camelyon_conf(N=8192, M=64, I=64)).feature_loops(b) for b in (1, 2, 3, 16)] == [1, 2, 3, 16]
+    monkeypatch.setattr(hip, "persistent_ok", lambda dev: True)        # (the self-test needs the GPU)
+    geometry(256, 8)
+    assert sel.persistent_allowed(_Dev, 256, 256, 8, 1, 2) and sel.persistent_allowed(_Dev, 64, 64, 8, 1, 16)
+    geometry(64, 2)
+    assert sel.persistent_allowed(_Dev, 64, 64, 8, 1, 8) and not sel.persistent_allowed(_Dev, 64, 64, 8, 1, 16)
+    geometry(4, 1)                                                     # no unit to spare: the per-part launches
+    assert not sel.persistent_allowed(_Dev, 256, 256, 8, 1, 1)
+
+
 def test_abi_major_and_the_round_4_additions_are_declared():
     lib = hip.lib()
     assert lib.ipsx_version() // 100 == hip.ABI_MAJOR
