@@ -827,6 +827,39 @@ def test_scan_random_shapes_with_ties_matches_oracle(seed):
         assert np.array_equal(idx.cpu().numpy(), mem)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_scan_cam_shape_with_ties_matches_oracle(seed):
+    """The specialised loop of BASELINE configs[3] (scan_cam_kernel: 8 heads, one token, M = I = 256) on QUANTISED logits
+    - equal scores in most iterations: its 32-bit ranking must notice them and hand over to the 64-bit ranking and the
+    replay of torch.topk's order - against the oracle, in both tie orders, ragged last chunk, cut into resumed ranges,
+    and with 1..4 slides per call."""
+    g = np.random.default_rng(4000 + seed)
+    M = I = 256
+    H, T = 8, 1
+    B = int(g.integers(1, 5))
+    N = M + int(g.integers(2, 9)) * I + int(g.integers(0, I))
+    levels = int(g.choice([2, 3, 5, 17, 1000]))
+    lg = (g.integers(0, levels, (B, N, H)).astype(np.float32) - 1.0) * np.float32(0.75)
+    if levels <= 5 and seed % 2 == 0:
+        lg[:, :, 1:] = lg[:, :, :1]                       # whole candidates tie
+    for mode, aten in (("torch", True), ("canonical", False)):
+        hip.set_tie_order(mode)
+        try:
+            mem = hip.scan(dev(lg), M, I, H, T).cpu().numpy()
+            n_iter = -(-(N - M) // I)
+            cut = max(1, n_iter // 2)
+            idx = torch.empty((B, M), dtype=torch.int64, device=DEV)
+            tie = torch.zeros((B,), dtype=torch.int32, device=DEV)
+            hip.scan_range(dev(lg), M, I, H, T, 0, cut, idx, tie)
+            hip.scan_range(dev(lg), M, I, H, T, cut, n_iter, idx, tie)
+        finally:
+            hip.set_tie_order("torch")
+        for b in range(B):
+            want = _oracle_scan_from_logits(lg[b], M, I, H, T, aten)
+            assert np.array_equal(mem[b], want), (mode, B, N, levels)
+        assert np.array_equal(idx.cpu().numpy(), mem)
+
+
 @pytest.mark.parametrize("N,M,I,H,T,levels", [
     (38000, 5000, 5000, 8, 1, 0),        # the reference's shipped CAMELYON sizes (config/camelyon_config.yml:35-36), ragged end
     (21000, 5000, 5000, 8, 1, 4096),     # quantised logits: equal scores in every iteration -> torch.topk's order replayed
