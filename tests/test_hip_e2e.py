@@ -623,6 +623,18 @@ def test_persistent_loops_of_several_slides_on_fewer_workgroups(groups):
     torch.cuda.synchronize()
     assert int(words[B].item()) & 1 == 0
     assert torch.equal(mem, plain)
+    # a cancelled call (negative progress words): every workgroup gives up on its FIRST slide, the slides behind it are
+    # never started - and the conditional launch behind the loop redoes all of them
+    mem.fill_(-7)
+    words.fill_(-1)
+    words[B] = 0
+    with torch.cuda.stream(side):
+        hip.scan_persistent(lg, M, I, H, 1, mem, tie, words[:B], words[B:], workgroups=groups)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(words[B].item()) & 1 == 1 and not torch.equal(mem, plain)
+    hip.scan_range_if(lg, M, I, H, 1, 0, -(-(N - M) // I), mem, tie, words[B:], 1)
+    assert torch.equal(mem, plain)
     if groups < B:                                  # shapes of the generic LDS loop: one workgroup per image only
         lg2 = torch.randn((3, 1024, H), device=DEV)
         with pytest.raises(RuntimeError, match="fewer workgroups"):
