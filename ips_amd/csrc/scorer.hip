@@ -2185,6 +2185,7 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2,
 
 struct LargeArgs {
     int tie_order;
+    int direct;            // 1: the register-resident passes for 8 heads x one token (diagnostic ipsx_dbg_scan_direct(0): off)
     const float* lg;       // (b, n, R)
     long long n;
     long long it0, it1;
@@ -2240,125 +2241,227 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         const long long lo = it * a.i + m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = m + cnt;
-        // ---- candidates' logits, memory first, transposed into the workspace: a thread takes 4 candidates at a time
-        for (int l0 = tid; l0 < L; l0 += LARGE_NT * 4) {
-            size_t row[4];
-            bool ok[4];
+        // 8 heads, one token (the reference's shipped CAMELYON configuration): a thread gathers ITS candidates' 8 logits -
+        // 32 contiguous bytes each, five candidates in flight - for the row maxima, and again (from L2) for the
+        // exponentials, which it writes transposed for the row sums and the scores.  The generic path below stages the
+        // logits transposed first: three passes over 320 KB and two writes of it where this has two gathers and one
+        // write.  Same values, same order of every sum.
+        constexpr int DG = 5;
+        const bool direct = a.direct && R == 8 && a.T == 1;        // (uniform)
+        if (direct) {
+            uint32_t km[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int l = l0 + u * LARGE_NT;
-                ok[u] = l < L;
-                row[u] = !ok[u] ? (size_t)0 : (l < m ? (size_t)mem[l] : (size_t)(lo + (l - m)));
+            for (int r = 0; r < 8; ++r) km[r] = 0u;
+            for (int r = tid; r < R; r += LARGE_NT) rmaxkey[r] = 0u;
+            for (int l0 = tid; l0 < L; l0 += DG * LARGE_NT) {
+                float4 v[DG][2];
+#pragma unroll
+                for (int c = 0; c < DG; ++c) {
+                    const int l = l0 + c * LARGE_NT;
+                    const size_t row = l >= L ? (size_t)0 : (l < m ? (size_t)mem[l] : (size_t)(lo + (l - m)));
+                    const float4* src = reinterpret_cast<const float4*>(lg + row * 8);
+                    v[c][0] = src[0];
+                    v[c][1] = src[1];
+                }
+#pragma unroll
+                for (int c = 0; c < DG; ++c)
+                    if (l0 + c * LARGE_NT < L) {
+                        km[0] = max(km[0], max_key(v[c][0].x)); km[1] = max(km[1], max_key(v[c][0].y));
+                        km[2] = max(km[2], max_key(v[c][0].z)); km[3] = max(km[3], max_key(v[c][0].w));
+                        km[4] = max(km[4], max_key(v[c][1].x)); km[5] = max(km[5], max_key(v[c][1].y));
+                        km[6] = max(km[6], max_key(v[c][1].z)); km[7] = max(km[7], max_key(v[c][1].w));
+                    }
             }
-            if ((R & 3) == 0) {
-                for (int r = 0; r < R; r += 8) {
-                    const bool two = r + 4 < R;
-                    float4 v[4][2];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4* src = reinterpret_cast<const float4*>(lg + row[u] * R + r);
-                        v[u][0] = src[0];
-                        v[u][1] = src[two ? 1 : 0];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (!ok[u]) continue;
-                        float* dst = xT + (size_t)r * Lp + (l0 + u * LARGE_NT);
-                        dst[0] = v[u][0].x; dst[Lp] = v[u][0].y; dst[2 * (size_t)Lp] = v[u][0].z; dst[3 * (size_t)Lp] = v[u][0].w;
-                        if (two) {
-                            dst += 4 * (size_t)Lp;
-                            dst[0] = v[u][1].x; dst[Lp] = v[u][1].y; dst[2 * (size_t)Lp] = v[u][1].z; dst[3 * (size_t)Lp] = v[u][1].w;
-                        }
-                    }
-                }
-            } else {
-                for (int r = 0; r < R; ++r) {
-                    float v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = lg[row[u] * R + r];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (ok[u]) xT[(size_t)r * Lp + (l0 + u * LARGE_NT)] = v[u];
-                }
-            }
-        }
-        for (int r = tid; r < R; r += LARGE_NT) rmaxkey[r] = 0u;
-        __syncthreads();
-        LARGE_STAMP(0);
-        // ---- row maxima
-        {
-            const int seg_len = ((L + seg - 1) / seg + 63) & ~63;
-            for (int unit = wave; unit < R * seg; unit += NW) {
-                const int r = unit / seg, sg = unit - r * seg;
-                const float* x = xT + (size_t)r * Lp;
-                const int l_end = std::min(L, (sg + 1) * seg_len);
-                uint32_t best = 0u;
-                for (int l0 = sg * seg_len + lane; l0 < l_end; l0 += 64 * LARGE_U) {
-                    float v[LARGE_U];
-#pragma unroll
-                    for (int u = 0; u < LARGE_U; ++u) {
-                        const int l = l0 + 64 * u;
-                        v[u] = x[l < l_end ? l : l0];
-                    }
-#pragma unroll
-                    for (int u = 0; u < LARGE_U; ++u) {
-                        const uint32_t k = max_key(v[u]);
-                        best = k > best ? k : best;
-                    }
-                }
+            for (int r = 0; r < 8; ++r) {
+                uint32_t best = km[r];
                 best = max(best, lane_xor_u32<32>(best, lane)); best = max(best, lane_xor_u32<16>(best, lane));
                 best = max(best, lane_xor_u32<8>(best, lane)); best = max(best, lane_xor_u32<4>(best, lane));
                 best = max(best, lane_xor_u32<2>(best, lane)); best = max(best, lane_xor_u32<1>(best, lane));
-                if (lane == 0) atomicMax(&rmaxkey[r], best);
+                km[r] = best;
             }
-        }
-        __syncthreads();
-        LARGE_STAMP(1);
-        // ---- exponentials, in place: blocks of 64 candidates of one row, LARGE_U blocks of a wavefront in flight
-        {
-            const int bpr = Lp >> 6;                                   // blocks per row
-            const int nblk = R * bpr;
-            for (int b0 = wave; b0 < nblk; b0 += NW * LARGE_U) {
-                float v[LARGE_U], mx[LARGE_U];
-                float* px[LARGE_U];
-                bool ok[LARGE_U];
+            __syncthreads();                                        // (rmaxkey zeroed)
+            if (lane == 0) {
 #pragma unroll
-                for (int u = 0; u < LARGE_U; ++u) {
-                    const int blk = b0 + u * NW;
-                    const int r = blk < nblk ? blk / bpr : 0;
-                    const int l = (blk - r * bpr) * 64 + lane;
-                    ok[u] = blk < nblk && l < L;
-                    px[u] = xT + (size_t)r * Lp + (ok[u] ? l : 0);
-                    mx[u] = max_key_value(rmaxkey[r]);
-                    v[u] = *px[u];
+                for (int r = 0; r < 8; ++r) atomicMax(&rmaxkey[r], km[r]);
+            }
+            __syncthreads();
+            LARGE_STAMP(0);
+            LARGE_STAMP(1);
+            {
+                float mx[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) mx[r] = max_key_value(rmaxkey[r]);
+                for (int l0 = tid; l0 < L; l0 += DG * LARGE_NT) {
+                    float4 v[DG][2];
+#pragma unroll
+                    for (int c = 0; c < DG; ++c) {
+                        const int l = l0 + c * LARGE_NT;
+                        const size_t row = l >= L ? (size_t)0 : (l < m ? (size_t)mem[l] : (size_t)(lo + (l - m)));
+                        const float4* src = reinterpret_cast<const float4*>(lg + row * 8);
+                        v[c][0] = src[0];
+                        v[c][1] = src[1];
+                    }
+#pragma unroll
+                    for (int c = 0; c < DG; ++c) {
+                        const int l = l0 + c * LARGE_NT;
+                        if (l < L) {
+                            float* dst = xT + l;
+                            dst[0] = det_expf(v[c][0].x - mx[0]);
+                            dst[Lp] = det_expf(v[c][0].y - mx[1]);
+                            dst[2 * (size_t)Lp] = det_expf(v[c][0].z - mx[2]);
+                            dst[3 * (size_t)Lp] = det_expf(v[c][0].w - mx[3]);
+                            dst[4 * (size_t)Lp] = det_expf(v[c][1].x - mx[4]);
+                            dst[5 * (size_t)Lp] = det_expf(v[c][1].y - mx[5]);
+                            dst[6 * (size_t)Lp] = det_expf(v[c][1].z - mx[6]);
+                            dst[7 * (size_t)Lp] = det_expf(v[c][1].w - mx[7]);
+                        }
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < LARGE_U; ++u)
-                    if (ok[u]) *px[u] = det_expf(v[u] - mx[u]);
             }
-        }
-        __syncthreads();
-        LARGE_STAMP(2);
-        // ---- denominators in the wavefront order of the contract: lane j adds elements j, j + 64, ... ascending
-        for (int r = wave; r < R; r += NW) {
-            const float* x = xT + (size_t)r * Lp;
-            float sum = 0.0f;
-            for (int l0 = lane; l0 < L; l0 += 64 * 2 * LARGE_U) {
-                float v[2 * LARGE_U];
+            __syncthreads();
+            LARGE_STAMP(2);
+            // ---- denominators in the wavefront order of the contract: lane j adds elements j, j + 64, ... ascending
+            for (int r = wave; r < R; r += NW) {
+                const float* x = xT + (size_t)r * Lp;
+                float sum = 0.0f;
+                for (int l0 = lane; l0 < L; l0 += 64 * 2 * LARGE_U) {
+                    float v[2 * LARGE_U];
 #pragma unroll
-                for (int u = 0; u < 2 * LARGE_U; ++u) {
-                    const int l = l0 + 64 * u;
-                    v[u] = x[l < L ? l : l0];
+                    for (int u = 0; u < 2 * LARGE_U; ++u) {
+                        const int l = l0 + 64 * u;
+                        v[u] = x[l < L ? l : l0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2 * LARGE_U; ++u)
+                        if (l0 + 64 * u < L) sum = sum + v[u];
                 }
-#pragma unroll
-                for (int u = 0; u < 2 * LARGE_U; ++u)
-                    if (l0 + 64 * u < L) sum = sum + v[u];
+                sum = wave_butterfly_sum(sum);
+                if (lane == 0) rden[r] = sum;
             }
-            sum = wave_butterfly_sum(sum);
-            if (lane == 0) rden[r] = sum;
+            __syncthreads();
+            LARGE_STAMP(3);
+        } else {
+            // ---- candidates' logits, memory first, transposed into the workspace: a thread takes 4 candidates at a time
+            for (int l0 = tid; l0 < L; l0 += LARGE_NT * 4) {
+                size_t row[4];
+                bool ok[4];
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int l = l0 + u * LARGE_NT;
+                    ok[u] = l < L;
+                    row[u] = !ok[u] ? (size_t)0 : (l < m ? (size_t)mem[l] : (size_t)(lo + (l - m)));
+                }
+                if ((R & 3) == 0) {
+                    for (int r = 0; r < R; r += 8) {
+                        const bool two = r + 4 < R;
+                        float4 v[4][2];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4* src = reinterpret_cast<const float4*>(lg + row[u] * R + r);
+                            v[u][0] = src[0];
+                            v[u][1] = src[two ? 1 : 0];
+                        }
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (!ok[u]) continue;
+                            float* dst = xT + (size_t)r * Lp + (l0 + u * LARGE_NT);
+                            dst[0] = v[u][0].x; dst[Lp] = v[u][0].y; dst[2 * (size_t)Lp] = v[u][0].z; dst[3 * (size_t)Lp] = v[u][0].w;
+                            if (two) {
+                                dst += 4 * (size_t)Lp;
+                                dst[0] = v[u][1].x; dst[Lp] = v[u][1].y; dst[2 * (size_t)Lp] = v[u][1].z; dst[3 * (size_t)Lp] = v[u][1].w;
+                            }
+                        }
+                    }
+                } else {
+                    for (int r = 0; r < R; ++r) {
+                        float v[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = lg[row[u] * R + r];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (ok[u]) xT[(size_t)r * Lp + (l0 + u * LARGE_NT)] = v[u];
+                    }
+                }
+            }
+            for (int r = tid; r < R; r += LARGE_NT) rmaxkey[r] = 0u;
+            __syncthreads();
+            LARGE_STAMP(0);
+            // ---- row maxima
+            {
+                const int seg_len = ((L + seg - 1) / seg + 63) & ~63;
+                for (int unit = wave; unit < R * seg; unit += NW) {
+                    const int r = unit / seg, sg = unit - r * seg;
+                    const float* x = xT + (size_t)r * Lp;
+                    const int l_end = std::min(L, (sg + 1) * seg_len);
+                    uint32_t best = 0u;
+                    for (int l0 = sg * seg_len + lane; l0 < l_end; l0 += 64 * LARGE_U) {
+                        float v[LARGE_U];
+    #pragma unroll
+                        for (int u = 0; u < LARGE_U; ++u) {
+                            const int l = l0 + 64 * u;
+                            v[u] = x[l < l_end ? l : l0];
+                        }
+    #pragma unroll
+                        for (int u = 0; u < LARGE_U; ++u) {
+                            const uint32_t k = max_key(v[u]);
+                            best = k > best ? k : best;
+                        }
+                    }
+                    best = max(best, lane_xor_u32<32>(best, lane)); best = max(best, lane_xor_u32<16>(best, lane));
+                    best = max(best, lane_xor_u32<8>(best, lane)); best = max(best, lane_xor_u32<4>(best, lane));
+                    best = max(best, lane_xor_u32<2>(best, lane)); best = max(best, lane_xor_u32<1>(best, lane));
+                    if (lane == 0) atomicMax(&rmaxkey[r], best);
+                }
+            }
+            __syncthreads();
+            LARGE_STAMP(1);
+            // ---- exponentials, in place: blocks of 64 candidates of one row, LARGE_U blocks of a wavefront in flight
+            {
+                const int bpr = Lp >> 6;                                   // blocks per row
+                const int nblk = R * bpr;
+                for (int b0 = wave; b0 < nblk; b0 += NW * LARGE_U) {
+                    float v[LARGE_U], mx[LARGE_U];
+                    float* px[LARGE_U];
+                    bool ok[LARGE_U];
+    #pragma unroll
+                    for (int u = 0; u < LARGE_U; ++u) {
+                        const int blk = b0 + u * NW;
+                        const int r = blk < nblk ? blk / bpr : 0;
+                        const int l = (blk - r * bpr) * 64 + lane;
+                        ok[u] = blk < nblk && l < L;
+                        px[u] = xT + (size_t)r * Lp + (ok[u] ? l : 0);
+                        mx[u] = max_key_value(rmaxkey[r]);
+                        v[u] = *px[u];
+                    }
+    #pragma unroll
+                    for (int u = 0; u < LARGE_U; ++u)
+                        if (ok[u]) *px[u] = det_expf(v[u] - mx[u]);
+                }
+            }
+            __syncthreads();
+            LARGE_STAMP(2);
+            // ---- denominators in the wavefront order of the contract: lane j adds elements j, j + 64, ... ascending
+            for (int r = wave; r < R; r += NW) {
+                const float* x = xT + (size_t)r * Lp;
+                float sum = 0.0f;
+                for (int l0 = lane; l0 < L; l0 += 64 * 2 * LARGE_U) {
+                    float v[2 * LARGE_U];
+    #pragma unroll
+                    for (int u = 0; u < 2 * LARGE_U; ++u) {
+                        const int l = l0 + 64 * u;
+                        v[u] = x[l < L ? l : l0];
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 2 * LARGE_U; ++u)
+                        if (l0 + 64 * u < L) sum = sum + v[u];
+                }
+                sum = wave_butterfly_sum(sum);
+                if (lane == 0) rden[r] = sum;
+            }
+            __syncthreads();
+            LARGE_STAMP(3);
         }
-        __syncthreads();
-        LARGE_STAMP(3);
         // ---- scores: mean over heads, then over tokens; ranking keys
         for (int l = tid; l < a.n2; l += LARGE_NT) {
             uint64_t key = 0ull;
@@ -2585,6 +2688,7 @@ struct FastPlan {
 
 static int g_persist_wait_ms = 50;         // ipsx_set_persistent_wait_ms: longest wait of a persistent loop / its gate without progress
 static bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
+static bool g_scan_direct = true;          // diagnostic (ipsx_dbg_scan_direct): 0 = scan_large_kernel's five generic passes for every shape
 static bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the shape of scan_cam_kernel through scan_fast_kernel
 
 static FastPlan scan_fast_plan(int m, int i, int h, int n_token) {
@@ -2704,6 +2808,7 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
                         m, i, h, n_token, need, workspace_bytes);
         LargeArgs la;
         la.tie_order = g_tie_order;
+        la.direct = g_scan_direct ? 1 : 0;
         la.lg = logits; la.n = n; la.it0 = it_begin; la.it1 = it_end;
         la.m = m; la.i = i; la.h = h; la.T = n_token; la.n2 = n2; la.Lp = (Lmax + 63) & ~63;
         la.mem_idx = reinterpret_cast<long long*>(mem_idx); la.mem_score = mem_score; la.tie = tie_flag;
@@ -2882,4 +2987,5 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int
 
 // Diagnostic entry point (not part of include/ipsx.h): 0 sends the shape of scan_cam_kernel (8 logits per candidate,
 // M = I = 256) through scan_fast_kernel instead - tools/scan_compare.py and tools/scan_stamps.py use it.
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_direct(int on) { g_scan_direct = on != 0; }
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_r8(int on) { g_scan_r8 = on != 0; }
