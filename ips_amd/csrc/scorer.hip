@@ -2078,14 +2078,16 @@ __device__ __forceinline__ void sort16_desc(uint64_t (&k)[16]) {
 // compare-exchange stages).  n log n comparisons instead of the bitonic network's n log^2 n: the network's cross-lane
 // stages alone were ~10 k VALU instructions per wavefront (200 k cycles for 16,384 keys; this: 3 k).  Keys are unique
 // (equal padding zeros aside).  Not inlined (see large_tie_replay); the key array is the start of the dynamic LDS.
-__device__ __attribute__((noinline)) void sort_desc_large(int n2) {
+// The real keys are keys[0, L): a thread whose 16 outputs lie behind the real keys of its pair of runs (padding zeros:
+// 6,384 of 16,384 slots at 10,000 candidates) writes zeros without searching, reading or merging.
+__device__ __attribute__((noinline)) void sort_desc_large(int n2, int L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     const int tid = threadIdx.x;
     const bool act = tid < (n2 >> 4);                                 // threads that own a run of 16
     const int o = tid * 16;                                           // first output position of this thread, every round
     uint64_t k[16];
-    if (act) {
+    if (act && o < L) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) k[c] = keys[17 * tid + c];
         sort16_desc(k);
@@ -2095,8 +2097,13 @@ __device__ __attribute__((noinline)) void sort_desc_large(int n2) {
     int steps = 5;                                                    // binary-search steps of a round: log2(len) + 1
     for (int len = 16; len < n2; len <<= 1, ++steps) {
         __syncthreads();
-        if (act) {
-            const int base = o & ~(2 * len - 1), diag = o - base;
+        const int base = o & ~(2 * len - 1), diag = o - base;
+        const bool pad = diag >= min(2 * len, max(0, L - base));      // all 16 outputs are padding zeros
+        if (act && pad) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) k[c] = 0ull;
+        }
+        if (act && !pad) {
             const int bA = base, bB = base + len;
             int lo = diag > len ? diag - len : 0, hi = diag < len ? diag : len;
             for (int it = 0; it < steps; ++it) {                      // (uniform trip count; finished lanes idle)
@@ -2481,7 +2488,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         }
         __syncthreads();
         LARGE_STAMP(4);
-        sort_desc_large(a.n2);
+        sort_desc_large(a.n2, L);
         LARGE_STAMP(5);
         if (tid == 0 && L > m && (keys[large_slot(m - 1)] >> 32) == (keys[large_slot(m)] >> 32)) tie = 1;
         const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail);
@@ -2530,7 +2537,7 @@ __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsign
     for (int l = tid; l < a.n2; l += LARGE_NT)
         keys[large_slot(l)] = l < a.L ? rank_key(a.scores[(size_t)b * a.L + l], (uint32_t)l) : 0ull;
     __syncthreads();
-    sort_desc_large(a.n2);
+    sort_desc_large(a.n2, a.L);
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (keys[large_slot(a.m - 1)] >> 32) == (keys[large_slot(a.m)] >> 32)) ? 1 : 0;
     int* lists = reinterpret_cast<int*>(ws + (size_t)b * ws_per_row);
