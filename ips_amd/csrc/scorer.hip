@@ -680,16 +680,32 @@ __device__ __forceinline__ int block_partition_pivot(stdorder::E* q, int first, 
 __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane);        // (defined with the ranking helpers below)
 
 constexpr int BLOCK_QCAP = 1024;            // ranges of more than 16 elements pending at one level: <= 16,384 / 17
+constexpr int BLOCK_RANGE = 2048;           // ranges of std::sort longer than this are partitioned by the whole workgroup
+
+// Diagnostic (ipsx_dbg_replay_stamps): shader cycles of the replay's phases, summed by thread 0 of every workgroup -
+// [0] nth_element by the workgroup, [1] its chain on one wavefront, [2 .. 5] the first four levels of std::sort's
+// partitions, [6] the deeper levels, [7] the final insertion pass; [8] = replays counted.
+__device__ unsigned long long g_replay_t[10];
+#define RSTAMP(k)                                                          \
+    do {                                                                   \
+        if (tid == 0) {                                                    \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+            g_replay_t[k] += t_ - rlast;                                   \
+            rlast = t_;                                                    \
+        }                                                                  \
+    } while (0)
 
 // la_n / lb_n: the lists of std::nth_element's chain (n ints each, GLOBAL memory); la / lb: the lists of std::sort's
 // ranges and, together, the scratch of the final pass (k - 1 ints each; GL = in global memory, else in LDS).
 template <int NT, bool GL>
 __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, int* la_n, int* lb_n, int* la, int* lb, int* stk,
                                                  unsigned long long* leaf, int leaf_words, int* queue, int* qcount,
-                                                 const unsigned long long* tiebits) {
+                                                 const unsigned long long* tiebits, const uint64_t* canon = nullptr) {
     using namespace stdorder;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k <= 0 || n <= 0) return;
+    unsigned long long rlast = tid == 0 ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (tid == 0) g_replay_t[8] += 1;
     if ((long long)k * 64 <= (long long)n || n > 64 * leaf_words || (k - 1) / 17 + 1 > BLOCK_QCAP) {
         if (tid == 0) torch_topk(q, n, k, stk);                       // heap select / sort (partial_sort), or beyond the tables
         __syncthreads();
@@ -706,6 +722,7 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
             if (cut <= nth) first = cut;
             else last = cut;
         }
+        RSTAMP(0);
         if (wave == 0) {
             while (!done && last - first > 3) {
                 if (depth == 0) {
@@ -714,7 +731,10 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
                     break;
                 }
                 --depth;
-                const int cut = wave_partition_pivot<true>(q, first, last, la_n, lb_n, lane);
+                // (the sort phase's lists are free until then: in LDS - not GL - a partition of this chain is a few LDS
+                //  round trips instead of a few L2 round trips)
+                const int cut = (!GL && last - first <= k - 1) ? wave_partition_pivot<false>(q, first, last, la, lb, lane)
+                                                               : wave_partition_pivot<true>(q, first, last, la_n, lb_n, lane);
                 if (cut <= nth) first = cut;
                 else last = cut;
             }
@@ -723,6 +743,7 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
         }
     }
     __syncthreads();
+    RSTAMP(1);
     const int last = k - 1;                                            // std::sort(q, q + k - 1)
     for (int w = tid; w < leaf_words; w += NT) leaf[w] = 0ull;
     // range lists: one word per range, first | last << 16 (both < 2^15); the depth budget of std::sort's introsort loop
@@ -737,36 +758,80 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
     __syncthreads();
     if (last <= 0) return;
     int depth = lg2(last) * 2;
-    for (int cur = 0;; cur ^= 1, --depth) {
+    int level = 0;
+    for (int cur = 0;; cur ^= 1, --depth, ++level) {
         const int ncur = qcount[cur];
         if (ncur == 0) break;
         const int* qc = queue + cur * BLOCK_QCAP;
         int* qn = queue + (cur ^ 1) * BLOCK_QCAP;
+        // tie bits j in [b0, b1] of word w (bit j: the canonical ranks j and j + 1 have equal scores)
+        auto tie_word = [&](int w, int b0, int b1) -> unsigned long long {
+            unsigned long long m = tiebits[w];
+            if (w == (b0 >> 6)) m &= ~0ull << (b0 & 63);
+            if (w == (b1 >> 6)) m &= ~0ull >> (63 - (b1 & 63));
+            return m;
+        };
+        // A range of introsort holds the elements of final ranks [rf, rl).  When no two neighbouring ranks in there AND
+        // across its two ends have equal scores, these are exactly the canonical ranks [rf, rl) and std::sort can only
+        // leave them in the one strictly descending order: they are copied from the canonical ranking (`canon`, kept
+        // in global memory by the caller) instead of being partitioned level by level - with a handful of equal pairs
+        // among thousands of candidates, only the ranges on the way to those pairs are still replayed.
+        // (1) ranges of more than BLOCK_RANGE elements: the whole workgroup, one range after the other
+        for (int r = 0; r < ncur; ++r) {
+            const int rf = qc[r] & 0xFFFF, rl = (int)((unsigned)qc[r] >> 16);
+            if (rl - rf <= BLOCK_RANGE || depth <= 0) continue;           // (workgroup-uniform)
+            if (tiebits && canon) {
+                const int b0 = rf > 0 ? rf - 1 : 0, b1 = rl - 1;
+                bool anyb = false;
+                for (int w = (b0 >> 6) + tid; w <= (b1 >> 6); w += NT) anyb |= tie_word(w, b0, b1) != 0ull;
+                if (!__syncthreads_or(anyb ? 1 : 0)) {
+                    for (int x = rf + tid; x < rl; x += NT) {
+                        const uint64_t key = canon[x];
+                        E o; o.v = key_score(key); o.i = (int)key_pos(key);
+                        q[x] = o;
+                    }
+                    continue;
+                }
+            }
+            const int cut = block_partition_pivot<NT>(q, rf, rl, la_n, lb_n, stk);
+            if (tid == 0) {
+                if (cut < last) atomicOr(&leaf[cut >> 6], 1ull << (cut & 63));
+                if (cut - rf > 16) qn[atomicAdd(&qcount[cur ^ 1], 1)] = rf | (cut << 16);
+                if (rl - cut > 16) qn[atomicAdd(&qcount[cur ^ 1], 1)] = cut | (rl << 16);
+            }
+        }
+        // (2) the others: a range per wavefront
         for (int r = wave; r < ncur; r += NT / 64) {
             const int rf = qc[r] & 0xFFFF, rl = (int)((unsigned)qc[r] >> 16);
             if (depth <= 0) {                                          // heap sort of the range: stays as it is afterwards
                 if (lane == 0) { make_heap(q, rf, rl); sort_heap(q, rf, rl); }
                 continue;
             }
+            if (rl - rf > BLOCK_RANGE) continue;                       // (done above)
             if (tiebits && rl - rf <= 64) {
-                // A range of introsort holds exactly the elements of final ranks [rf, rl) - and when no two neighbouring
-                // ranks in there have equal scores (tiebits: bit j = canonical rank j and j + 1 tie), std::sort can only
-                // leave them in the one strictly descending order: one in-register wave sort instead of replaying two
-                // more levels of partitions and the leaves.  (With ties inside, the replay goes on.)
+                // No equal neighbours INSIDE a range of at most 64: one in-register wave sort of the elements that are there
+                // instead of replaying two more levels of partitions and the leaves.  (With ties inside, the replay goes on.)
                 const int lo_w = rf >> 6, hi_w = (rl - 2) >> 6;                              // pairs (j, j + 1), j in [rf, rl - 2]
                 unsigned long long any = 0ull;
-                for (int w = lo_w; w <= hi_w; ++w) {
-                    unsigned long long m = tiebits[w];
-                    if (w == lo_w) m &= ~0ull << (rf & 63);
-                    if (w == hi_w) m &= ~0ull >> (63 - ((rl - 2) & 63));
-                    any |= m;
-                }
+                for (int w = lo_w; w <= hi_w; ++w) any |= tie_word(w, rf, rl - 2);
                 if (any == 0ull) {
                     const int x = rf + lane;
                     const E e = q[x < rl ? x : rf];
                     const uint64_t key = wave_sort_desc(x < rl ? rank_key(e.v, (uint32_t)e.i) : 0ull, lane);
                     if (x < rl) { E o; o.v = key_score(key); o.i = (int)key_pos(key); q[x] = o; }
                     continue;                                          // (a "leaf" of more than 16 elements: the last pass leaves it)
+                }
+            } else if (tiebits && canon) {
+                const int b0 = rf > 0 ? rf - 1 : 0, b1 = rl - 1;
+                bool anyb = false;
+                for (int w = (b0 >> 6) + lane; w <= (b1 >> 6); w += 64) anyb |= tie_word(w, b0, b1) != 0ull;
+                if (__ballot(anyb) == 0ull) {
+                    for (int x = rf + lane; x < rl; x += 64) {
+                        const uint64_t key = canon[x];
+                        E o; o.v = key_score(key); o.i = (int)key_pos(key);
+                        q[x] = o;
+                    }
+                    continue;
                 }
             }
             const int cut = wave_partition_pivot<GL>(q, rf, rl, la + rf, lb + rf, lane);
@@ -779,6 +844,7 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
         __syncthreads();
         if (tid == 0) qcount[cur] = 0;
         __syncthreads();
+        RSTAMP(level < 4 ? 2 + level : 6);
     }
     // the final insertion pass, leaf by leaf, an element per thread (see torch_topk_wave)
     E* tmp = reinterpret_cast<E*>(la);
@@ -786,15 +852,16 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
         const int x = base + tid;
         if (x < last) {
             const E own = q[x];
-            int w = x >> 6;
-            unsigned long long m = leaf[w] & (~0ull >> (63 - (x & 63)));
-            while (m == 0ull && w > 0) m = leaf[--w];
-            const int sfirst = m ? w * 64 + 63 - __clzll((long long)m) : 0;
-            int e = last;
-            w = x >> 6;
-            m = (x & 63) == 63 ? 0ull : (leaf[w] >> ((x & 63) + 1)) << ((x & 63) + 1);
-            while (m == 0ull && w < leaf_words - 1) m = leaf[++w];
-            if (m) e = w * 64 + __ffsll((long long)m) - 1;
+            // the leaf of x: [last cut <= x (or 0), first cut > x (or last)).  Only leaves of at most 16 elements are
+            // touched, so the cuts that matter lie in [x - 15, x + 16]: 32 bits of the bitmap, two words at most (with
+            // whole ranges copied from the canonical ranking the cuts are sparse, and a scan for the nearest one was long)
+            const int wb = x < 15 ? 0 : x - 15, wi = wb >> 6, sh = wb & 63, tx = x - wb;
+            unsigned long long bits = leaf[wi] >> sh;
+            if (sh && wi + 1 < leaf_words) bits |= leaf[wi + 1] << (64 - sh);
+            const unsigned long long back = bits & ((2ull << tx) - 1ull);          // cuts at wb .. x
+            const unsigned long long fwd = (bits >> (tx + 1)) & 0xFFFFull;           // cuts at x + 1 .. x + 16
+            const int sfirst = back ? wb + 63 - __clzll((long long)back) : (wb == 0 ? 0 : -64);   // (-64: further away than 15)
+            int e = fwd ? x + 1 + (__ffsll((long long)fwd) - 1) : last;
             if (e > last) e = last;
             int dst = x;
             if (e - sfirst <= 16) {
@@ -813,7 +880,9 @@ __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, i
     __syncthreads();
     for (int x = tid; x < last; x += NT) q[x] = tmp[x];
     __syncthreads();
+    RSTAMP(7);
 }
+#undef RSTAMP
 
 // sorted and other are the two key arrays (>= L entries each); all threads of the workgroup call this together.
 // NOTE: `sorted` serves as scratch meanwhile - on return only sorted[0, m) is defined.
@@ -2148,7 +2217,8 @@ __device__ __attribute__((noinline)) void sort_desc_large(int n2, int L) {
 // CANDIDATE order and torch.topk's routines are replayed on them (one wavefront; the index lists in the workspace); q[0, m)
 // is then the answer.  Returns whether that happened (workgroup-uniform).  All threads; contains barriers.
 // (Not inlined, like the sort; `tail` = LDS offset of the stack / leaf bitmap / range lists behind the keys.)
-__device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2, int tie_order, int* lists, int tail) {
+__device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2, int tie_order, int* lists, int tail,
+                                                           uint64_t* canon) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     int* stk = reinterpret_cast<int*>(smem + tail);
@@ -2162,6 +2232,7 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2,
     for (int s = 0; s < LARGE_KPT; ++s) {
         const int j = tid + s * LARGE_NT;
         hold[s] = j < L ? keys[large_slot(j)] : 0ull;
+        if (canon && j < L) canon[j] = hold[s];                             // the canonical ranking, for torch_topk_block's copies
         const uint64_t next = j + 1 < L ? keys[large_slot(j + 1)] : 0ull;   // (a wavefront's 64 ranks are one word of the bitmap)
         const unsigned long long word = __ballot(j + 1 < L && (hold[s] >> 32) == (next >> 32));
         if ((tid & 63) == 0) tiebits[(tid >> 6) + s * (LARGE_NT / 64)] = word;
@@ -2183,9 +2254,9 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2,
     // of a few L2 round trips, and there are hundreds of them
     if (n2 - L >= m) {
         int* ls = reinterpret_cast<int*>(keys + L);
-        torch_topk_block<LARGE_NT, false>(q, L, m, lists, lists + L, ls, ls + (m - 1), stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits);
+        torch_topk_block<LARGE_NT, false>(q, L, m, lists, lists + L, ls, ls + (m - 1), stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits, canon);
     } else {
-        torch_topk_block<LARGE_NT, true>(q, L, m, lists, lists + L, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits);
+        torch_topk_block<LARGE_NT, true>(q, L, m, lists, lists + L, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits, canon);
     }
     return true;
 }
@@ -2491,7 +2562,9 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         sort_desc_large(a.n2, L);
         LARGE_STAMP(5);
         if (tid == 0 && L > m && (keys[large_slot(m - 1)] >> 32) == (keys[large_slot(m)] >> 32)) tie = 1;
-        const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail);
+        // (the exponentials' workspace is free by now: the canonical ranking goes there when it fits - 8 B per candidate)
+        const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail,
+                                               R >= 2 ? reinterpret_cast<uint64_t*>(xT) : nullptr);
         LARGE_STAMP(6);
         const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
         const bool want_score = a.mem_score != nullptr && it + 1 == a.it1;
@@ -2541,7 +2614,7 @@ __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsign
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (keys[large_slot(a.m - 1)] >> 32) == (keys[large_slot(a.m)] >> 32)) ? 1 : 0;
     int* lists = reinterpret_cast<int*>(ws + (size_t)b * ws_per_row);
-    const bool replayed = large_tie_replay(a.L, a.m, a.n2, a.tie_order, lists, (a.n2 + (a.n2 >> 4)) * 8);
+    const bool replayed = large_tie_replay(a.L, a.m, a.n2, a.tie_order, lists, (a.n2 + (a.n2 >> 4)) * 8, nullptr);
     const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
     for (int j = tid; j < a.m; j += LARGE_NT)
         a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[large_slot(j)]);
@@ -2994,5 +3067,11 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int
 
 // Diagnostic entry point (not part of include/ipsx.h): 0 sends the shape of scan_cam_kernel (8 logits per candidate,
 // M = I = 256) through scan_fast_kernel instead - tools/scan_compare.py and tools/scan_stamps.py use it.
+// Diagnostic: read (and clear) the replay's phase stamps (g_replay_t) into out[10]
+extern "C" __attribute__((visibility("default"))) int ipsx_dbg_replay_stamps(unsigned long long* out) {
+    unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ipsx::g_replay_t), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ipsx::g_replay_t), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_direct(int on) { g_scan_direct = on != 0; }
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_r8(int on) { g_scan_r8 = on != 0; }

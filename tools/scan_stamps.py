@@ -87,6 +87,19 @@ if kind == "large":
         b.record()
         torch.cuda.synchronize()
         print("  un-instrumented: %.3f ms per launch = %.1f us per iteration" % (a.elapsed_time(b) / 10, 1e2 * a.elapsed_time(b) / n_iter))
+        if mode == "torch":
+            # the replay's own phases (thread 0's clock, product build; ipsx_dbg_replay_stamps reads and clears)
+            rs = (C.c_ulonglong * 10)()
+            L.ipsx_dbg_replay_stamps.argtypes = [C.c_void_p]
+            L.ipsx_dbg_replay_stamps(rs)
+            hip.scan(lg, M, I, H, T)
+            torch.cuda.synchronize()
+            L.ipsx_dbg_replay_stamps(rs)
+            v = [int(x) for x in rs]
+            rn = ["nth_element by the workgroup", "nth_element chain on one wavefront", "sort level 0", "sort level 1", "sort level 2",
+                  "sort level 3", "sort deeper levels", "final insertion pass"]
+            print("  the replay (%d replays), product build, k cycles each: " % v[8]
+                  + ", ".join("%s %.1f" % (nm, c / max(1, v[8]) / 1e3) for nm, c in zip(rn, v[:8])))
     hip.set_tie_order("torch")
     sys.exit(0)
 if kind == "camwaves":
