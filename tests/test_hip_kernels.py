@@ -867,19 +867,28 @@ def test_scan_cam_shape_with_ties_matches_oracle(seed):
     (40000, 8192, 8192, 2, 1, 0),        # the largest supported candidate set: 16,384
     (30000, 100, 9000, 8, 1, 64),        # 64 * M <= L: torch.topk takes partial_sort (heap select) under ties
     (9000, 4200, 300, 3, 3, 0),          # odd row count, many short chunks on a large memory
+    (24000, 5000, 5000, 8, 1, -6),       # a FEW equal pairs among 10,000 candidates (6 duplicated rows): the replay copies the
+    (26000, 3000, 7000, 8, 1, -40),      #   tie-free ranges of std::sort from the canonical ranking and follows only the
+    (20000, 6000, 4000, 8, 1, -1),       #   ranges on the way to the pairs (-n: n rows duplicated)
 ])
 def test_scan_beyond_the_lds_matches_oracle(N, M, I, H, T, levels):
     """Candidate sets that do not fit one compute unit's LDS (M + I up to 16,384: scan_large_kernel - ranking in LDS,
     the rest through the caller's workspace) against the oracle's loop, torch.topk's tie order included; a run cut into
     resumed ranges gives the same memory."""
     B, R = 2, H * T
-    if levels:
+    if levels > 0:
         g = np.random.default_rng(N + M)
         lg = (g.integers(0, levels, (B, N, R)).astype(np.float32) - np.float32(levels / 2)) * np.float32(6.0 / levels)
         if levels <= 64:
             lg[:, :, 1:] = lg[:, :, :1]
     else:
         lg = rnd((B, N, R), N + M, 3.0)
+        if levels < 0:                                    # duplicated rows: bit-equal scores for those pairs, nothing else
+            g = np.random.default_rng(N - M)
+            for b in range(B):
+                src = g.integers(0, N, -levels)
+                dst = g.integers(0, N, -levels)
+                lg[b, dst] = lg[b, src]
     assert hip.lib().ipsx_scan_workspace_bytes(B, M, I, H, T) > 0
     mem, sc = hip.scan(dev(lg), M, I, H, T, want_scores=True)
     mem, sc = mem.cpu().numpy(), sc.cpu().numpy()
