@@ -61,6 +61,18 @@ if kind == "large":
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     lg = (torch.randn((1, N, H * T), generator=g) * 1.5).to(dev)
+    if len(sys.argv) == 3 and sys.argv[2] == "bench":
+        # the logits of the bench workload itself (cam_native: the projector's embeddings of the synthetic slide)
+        from ips_amd import synth
+        from ips_amd.architecture.ips_net import IPSNet
+        conf, _ = synth.bench_workload("cam_native")
+        net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+        x = synth.make_patches(conf, 1, seed=21).to(dev)
+        plan = hip.EncoderPlan(net.encoder, False)
+        ca = net.transf.crs_attn
+        emb = plan.encode(x[0])
+        lg = hip.logits(emb.view(1, x.shape[1], -1), None, ca.folded_query(), ca.H * ca.n_token).contiguous()
+        N, M, I, H, T = x.shape[1], conf.M, conf.I, ca.H, ca.n_token
     L = hip.lib()
     L.ipsx_dbg_scan_stamps.argtypes = [C.c_void_p]
     n_iter = -(-(N - M) // I)
