@@ -2114,6 +2114,7 @@ constexpr int LARGE_LEAF_WORDS = LARGE_MAX_L / 64;
 // consecutive keys = 136 consecutive bytes, and 16 lanes at a stride of 136 B cover all 32 banks once - unpadded (128 B)
 // every lane of a wavefront would hit the same bank.
 __device__ __forceinline__ int large_slot(int i) { return i + (i >> 4); }
+__device__ __forceinline__ int next_pow2_dev(int v) { return v <= 1 ? 1 : 1 << (32 - __clz(v - 1)); }
 static size_t large_key_bytes(int n2) { return (size_t)(n2 + (n2 >> 4)) * 8; }
 
 // compare-exchange so that x >= y afterwards (descending)
@@ -2212,6 +2213,116 @@ __device__ __attribute__((noinline)) void sort_desc_large(int n2, int L) {
 }
 #undef IPSX_CE_DESC
 
+// Before the sort: only the first m + 1 ranks are ever used in order (the new memory, the tie test, the replay's copies
+// and tie bits) - the other candidates only have to EXIST for the replay to put them back into candidate order.  A
+// threshold score T is taken from a sample (every wavefront sorts 64 of its keys in registers and reports the one at the
+// target quantile; T = the median of the 16 reports), the keys at or above it are COUNTED exactly (S) and, when S lies
+// between need and half the slots, moved to the front ([0, S)), zero padding up to the power of two n2s behind them, the
+// rest behind that - and the merge sort then runs on n2s slots with S real keys instead of n2 slots with L (10,000
+// candidates, M = 5000: 8,192 slots with ~6,600 keys instead of 16,384 with 10,000).  Returns S and n2s, or false when
+// the sample missed or nothing is gained (the sort then takes everything as before: the result is the same either way).
+// All threads; contains barriers; not inlined.
+__device__ __attribute__((noinline)) bool select_top_large(int n2, int L, int need, int tail, int* S_out, int* n2s_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    int* sel = reinterpret_cast<int*>(smem + tail);                                        // (the replay's stack: 192 ints)
+    int* cnt = reinterpret_cast<int*>(smem + tail) + 3 * stdorder::STACK_RANGES;          // (its leaf bitmap: 512 ints)
+    constexpr int NW = LARGE_NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = n2 >> 1;
+    if (need >= half - (half >> 3)) return false;                         // (workgroup-uniform: not enough to gain)
+    uint32_t sk[LARGE_KPT];
+#pragma unroll
+    for (int c = 0; c < LARGE_KPT; ++c) {
+        const int l = tid + c * LARGE_NT;
+        sk[c] = l < L ? (uint32_t)(keys[large_slot(l)] >> 32) : 0u;
+    }
+    // the sample: lane's key of slot (lane + wave) mod its valid slots - spread over memory and chunk candidates alike
+    const int nvalid = (L - tid + LARGE_NT - 1) / LARGE_NT;               // >= 1 for tid < L (L >= 2048 > tid)
+    const int pick = (lane + 5 * wave) % nvalid;
+    uint32_t smp = 0u;
+#pragma unroll
+    for (int c = 0; c < LARGE_KPT; ++c) smp = c == pick ? sk[c] : smp;
+    const uint32_t dir = sort_directions(lane);
+    smp = wave_sort_desc_u32(smp, dir, lane);                             // lane j: the wavefront's j-th largest sample
+    // aim a little above what is needed: the median of 16 quantiles of 64 samples is off by ~2 % of L (one sigma); a miss
+    // on the low side falls back to the whole sort
+    const int target = min(need + L / 12, (need + half) >> 1);
+    const int qi = min(63, max(0, (int)(((long long)target * 64) / L)));
+    const uint32_t rep = (uint32_t)__shfl((int)smp, qi, 64);
+    if (lane == 0) sel[8 + wave] = (int)rep;
+    __syncthreads();
+    uint32_t T;
+    {
+        uint32_t v = lane < NW ? (uint32_t)sel[8 + lane] : 0u;           // 16 reports, the rest 0: sorted descending they lead
+        v = wave_sort_desc_u32(v, dir, lane);
+        T = (uint32_t)__shfl((int)v, NW / 2, 64);                         // the median report
+    }
+    // ---- exact count of the keys at or above T
+    int mine = 0;
+#pragma unroll
+    for (int c = 0; c < LARGE_KPT; ++c) mine += (tid + c * LARGE_NT < L && sk[c] >= T) ? 1 : 0;
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    __syncthreads();                                                      // (sel[8 ..] read by every wavefront above)
+    if (lane == 0) sel[8 + wave] = mine;
+    __syncthreads();
+    int S = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) S += sel[8 + w];
+    __syncthreads();
+    const int n2s = max(64, next_pow2_dev(S));
+    if (S < need || n2s >= n2 || n2s + (L - S) > n2) return false;
+    // ---- compaction through registers: counts per (slot c, wavefront), an exclusive scan of the 256 + 256 counts by the
+    // first wavefront, then every key to its place (the order inside the two groups is immaterial)
+    uint64_t hold[LARGE_KPT];
+    unsigned long long selm[LARGE_KPT];
+#pragma unroll
+    for (int c = 0; c < LARGE_KPT; ++c) {
+        const int l = tid + c * LARGE_NT;
+        hold[c] = l < L ? keys[large_slot(l)] : 0ull;
+        const bool is = l < L && sk[c] >= T;
+        selm[c] = __ballot(is);
+        const unsigned long long nonm = __ballot(l < L && !is);
+        if (lane == 0) { cnt[c * NW + wave] = __popcll(selm[c]); cnt[256 + c * NW + wave] = __popcll(nonm); }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            int v[4], tot = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = cnt[half * 256 + 4 * lane + k]; tot += v[k]; }
+            int incl = tot;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += u;
+            }
+            int run = incl - tot;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cnt[half * 256 + 4 * lane + k] = run; run += v[k]; }
+        }
+    }
+    for (int l = tid; l < n2; l += LARGE_NT) keys[large_slot(l)] = 0ull;   // (every key is in `hold` by now: barrier above)
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int c = 0; c < LARGE_KPT; ++c) {
+        const int l = tid + c * LARGE_NT;
+        if (l < L) {
+            const bool is = (selm[c] >> lane) & 1ull;
+            const unsigned long long valid = l - lane + 63 < L ? ~0ull : ((1ull << (L - (l - lane))) - 1ull);
+            const unsigned long long nonm = ~selm[c] & valid;
+            const int dst = is ? cnt[c * NW + wave] + __popcll(selm[c] & below)
+                               : n2s + cnt[256 + c * NW + wave] + __popcll(nonm & below);
+            keys[large_slot(dst)] = hold[c];
+        }
+    }
+    __syncthreads();
+    *S_out = S;
+    *n2s_out = n2s;
+    return true;
+}
+
 // keys = the L ranked keys (canonical order) in LDS.  When two of the first m + 1 ranked scores are equal and the tie
 // order is the reference's, the key array is turned - through registers, in place - into the (score, position) pairs in
 // CANDIDATE order and torch.topk's routines are replayed on them (one wavefront; the index lists in the workspace); q[0, m)
@@ -2231,8 +2342,8 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2,
 #pragma unroll
     for (int s = 0; s < LARGE_KPT; ++s) {
         const int j = tid + s * LARGE_NT;
-        hold[s] = j < L ? keys[large_slot(j)] : 0ull;
-        if (canon && j < L) canon[j] = hold[s];                             // the canonical ranking, for torch_topk_block's copies
+        hold[s] = j < n2 ? keys[large_slot(j)] : 0ull;                      // (after select_top_large the candidates below
+        if (canon && j < L) canon[j] = hold[s];                             //  the first m + 1 ranks sit behind a stretch of zeros)
         const uint64_t next = j + 1 < L ? keys[large_slot(j + 1)] : 0ull;   // (a wavefront's 64 ranks are one word of the bitmap)
         const unsigned long long word = __ballot(j + 1 < L && (hold[s] >> 32) == (next >> 32));
         if ((tid & 63) == 0) tiebits[(tid >> 6) + s * (LARGE_NT / 64)] = word;
@@ -2241,8 +2352,7 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2,
     stdorder::E* q = reinterpret_cast<stdorder::E*>(keys);
 #pragma unroll
     for (int s = 0; s < LARGE_KPT; ++s) {
-        const int j = tid + s * LARGE_NT;
-        if (j < L) {
+        if (hold[s] != 0ull) {                                              // (a real key is never 0: padding is)
             const int p = (int)key_pos(hold[s]);
             q[p].v = key_score(hold[s]);
             q[p].i = p;
@@ -2559,7 +2669,11 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         }
         __syncthreads();
         LARGE_STAMP(4);
-        sort_desc_large(a.n2, L);
+        {
+            int S = L, n2s = a.n2;
+            if (a.direct && L > m + 1 && L >= 2048) (void)select_top_large(a.n2, L, m + 1, tail, &S, &n2s);
+            sort_desc_large(n2s, S);
+        }
         LARGE_STAMP(5);
         if (tid == 0 && L > m && (keys[large_slot(m - 1)] >> 32) == (keys[large_slot(m)] >> 32)) tie = 1;
         // (the exponentials' workspace is free by now: the canonical ranking goes there when it fits - 8 B per candidate)
