@@ -15,7 +15,8 @@ sync, a call's time is the max over ranks, ``value`` = patches per call / the ME
 fences (what a training loop sees when the host runs ahead).  The default single-GPU run also
 times every other BASELINE configuration that fits one GPU into ``also_measured`` (b1 = d-1's
 primary shape, mnist3000 = configs[2], cam / cam_x16 = configs[3], cam_native = the reference's
-shipped CAMELYON sizes), each with its own ``parity`` / ``roofline`` / ``roofline_call``.
+shipped CAMELYON sizes, traffic = configs[0]'s model on the GPU, native50 = the reference's shipped
+50-px MNIST patches), each with its own ``parity`` / ``roofline`` / ``roofline_call``.
 
 Workloads (``ips_amd.synth.BENCH_WORKLOADS``; weights seed 7, patches seed 21):
   N = 1   BASELINE.json configs[1]: Megapixel-MNIST 1500 - 2500 patches of 1x32x32 per image,
@@ -287,7 +288,7 @@ class Ctx:
 #   cam_x16     configs[3], 16 slides per call (the reference's B = 16 in one call)
 #   cam_native  the reference's shipped CAMELYON sizes (M = I = 5000)
 ALSO_LEGS = (("b1", "b1", None), ("mnist3000", "mnist3000", None), ("cam", "cam", None), ("cam_x16", "cam", 16),
-             ("cam_native", "cam_native", None))
+             ("cam_native", "cam_native", None), ("traffic", "traffic", None), ("native50", "native50", None))
 
 
 def make_input(conf, name, B, batch, dev_for_extra):
