@@ -688,7 +688,7 @@ constexpr int BLOCK_RANGE = 2048;           // ranges of std::sort longer than t
 __device__ unsigned long long g_replay_t[10];
 #define RSTAMP(k)                                                          \
     do {                                                                   \
-        if (tid == 0) {                                                    \
+        if (rst && tid == 0) {                                             \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
             g_replay_t[k] += t_ - rlast;                                   \
             rlast = t_;                                                    \
@@ -700,12 +700,13 @@ __device__ unsigned long long g_replay_t[10];
 template <int NT, bool GL>
 __device__ __forceinline__ void torch_topk_block(stdorder::E* q, int n, int k, int* la_n, int* lb_n, int* la, int* lb, int* stk,
                                                  unsigned long long* leaf, int leaf_words, int* queue, int* qcount,
-                                                 const unsigned long long* tiebits, const uint64_t* canon = nullptr) {
+                                                 const unsigned long long* tiebits, const uint64_t* canon = nullptr,
+                                                 bool rst = false) {
     using namespace stdorder;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k <= 0 || n <= 0) return;
-    unsigned long long rlast = tid == 0 ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (tid == 0) g_replay_t[8] += 1;
+    unsigned long long rlast = rst && tid == 0 ? __builtin_amdgcn_s_memtime() : 0ull;       // (rst: diagnostic stamps on)
+    if (rst && tid == 0) g_replay_t[8] += 1;
     if ((long long)k * 64 <= (long long)n || n > 64 * leaf_words || (k - 1) / 17 + 1 > BLOCK_QCAP) {
         if (tid == 0) torch_topk(q, n, k, stk);                       // heap select / sort (partial_sort), or beyond the tables
         __syncthreads();
@@ -2329,7 +2330,7 @@ __device__ __attribute__((noinline)) bool select_top_large(int n2, int L, int ne
 // is then the answer.  Returns whether that happened (workgroup-uniform).  All threads; contains barriers.
 // (Not inlined, like the sort; `tail` = LDS offset of the stack / leaf bitmap / range lists behind the keys.)
 __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2, int tie_order, int* lists, int tail,
-                                                           uint64_t* canon) {
+                                                           uint64_t* canon, bool rst) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     int* stk = reinterpret_cast<int*>(smem + tail);
@@ -2364,15 +2365,16 @@ __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2,
     // of a few L2 round trips, and there are hundreds of them
     if (n2 - L >= m) {
         int* ls = reinterpret_cast<int*>(keys + L);
-        torch_topk_block<LARGE_NT, false>(q, L, m, lists, lists + L, ls, ls + (m - 1), stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits, canon);
+        torch_topk_block<LARGE_NT, false>(q, L, m, lists, lists + L, ls, ls + (m - 1), stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits, canon, rst);
     } else {
-        torch_topk_block<LARGE_NT, true>(q, L, m, lists, lists + L, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits, canon);
+        torch_topk_block<LARGE_NT, true>(q, L, m, lists, lists + L, lists, lists + L, stk, leaf, LARGE_LEAF_WORDS, queue + 2, queue, tiebits, canon, rst);
     }
     return true;
 }
 
 struct LargeArgs {
     int tie_order;
+    int rstamp;            // 1: the replay's phase stamps are collected (ipsx_dbg_replay_stamps)
     int direct;            // 1: the register-resident passes for 8 heads x one token (diagnostic ipsx_dbg_scan_direct(0): off)
     const float* lg;       // (b, n, R)
     long long n;
@@ -2678,7 +2680,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         if (tid == 0 && L > m && (keys[large_slot(m - 1)] >> 32) == (keys[large_slot(m)] >> 32)) tie = 1;
         // (the exponentials' workspace is free by now: the canonical ranking goes there when it fits - 8 B per candidate)
         const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail,
-                                               R >= 2 ? reinterpret_cast<uint64_t*>(xT) : nullptr);
+                                               R >= 2 ? reinterpret_cast<uint64_t*>(xT) : nullptr, a.rstamp != 0);
         LARGE_STAMP(6);
         const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
         const bool want_score = a.mem_score != nullptr && it + 1 == a.it1;
@@ -2728,7 +2730,7 @@ __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsign
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (keys[large_slot(a.m - 1)] >> 32) == (keys[large_slot(a.m)] >> 32)) ? 1 : 0;
     int* lists = reinterpret_cast<int*>(ws + (size_t)b * ws_per_row);
-    const bool replayed = large_tie_replay(a.L, a.m, a.n2, a.tie_order, lists, (a.n2 + (a.n2 >> 4)) * 8, nullptr);
+    const bool replayed = large_tie_replay(a.L, a.m, a.n2, a.tie_order, lists, (a.n2 + (a.n2 >> 4)) * 8, nullptr, false);
     const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
     for (int j = tid; j < a.m; j += LARGE_NT)
         a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[large_slot(j)]);
@@ -2882,6 +2884,7 @@ struct FastPlan {
 
 static int g_persist_wait_ms = 50;         // ipsx_set_persistent_wait_ms: longest wait of a persistent loop / its gate without progress
 static bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
+static bool g_replay_stamps_on = false;    // diagnostic (ipsx_dbg_replay_stamps): the replay's phases are stamped from the first read on
 static bool g_scan_direct = true;          // diagnostic (ipsx_dbg_scan_direct): 0 = scan_large_kernel's five generic passes for every shape
 static bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the shape of scan_cam_kernel through scan_fast_kernel
 
@@ -3003,6 +3006,7 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         LargeArgs la;
         la.tie_order = g_tie_order;
         la.direct = g_scan_direct ? 1 : 0;
+        la.rstamp = g_replay_stamps_on ? 1 : 0;
         la.lg = logits; la.n = n; la.it0 = it_begin; la.it1 = it_end;
         la.m = m; la.i = i; la.h = h; la.T = n_token; la.n2 = n2; la.Lp = (Lmax + 63) & ~63;
         la.mem_idx = reinterpret_cast<long long*>(mem_idx); la.mem_score = mem_score; la.tie = tie_flag;
@@ -3184,6 +3188,8 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int
 // Diagnostic: read (and clear) the replay's phase stamps (g_replay_t) into out[10]
 extern "C" __attribute__((visibility("default"))) int ipsx_dbg_replay_stamps(unsigned long long* out) {
     unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    g_replay_stamps_on = out != nullptr;                                   // (null: off again)
+    if (!out) return 0;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ipsx::g_replay_t), sizeof(zero)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(ipsx::g_replay_t), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }

@@ -107,6 +107,7 @@ if kind == "large":
             hip.scan(lg, M, I, H, T)
             torch.cuda.synchronize()
             L.ipsx_dbg_replay_stamps(rs)
+            L.ipsx_dbg_replay_stamps(None)                                 # (off again)
             v = [int(x) for x in rs]
             rn = ["nth_element by the workgroup", "nth_element chain on one wavefront", "sort level 0", "sort level 1", "sort level 2",
                   "sort level 3", "sort deeper levels", "final insertion pass"]
