@@ -2167,7 +2167,10 @@ __device__ __attribute__((noinline)) void sort_desc_large(int n2, int L) {
     }
     int steps = 5;                                                    // binary-search steps of a round: log2(len) + 1
     for (int len = 16; len < n2; len <<= 1, ++steps) {
-        __syncthreads();
+        // runs of up to 512 keys: a pair of runs lies inside ONE wavefront's 1,024 keys, whose lanes run in lockstep and
+        // whose LDS operations complete in order - no barrier of the workgroup (twelve of them at 16,384 slots)
+        const bool local = 2 * len <= 1024;
+        if (local) { wave_lds_fence(); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
         const int base = o & ~(2 * len - 1), diag = o - base;
         const bool pad = diag >= min(2 * len, max(0, L - base));      // all 16 outputs are padding zeros
         if (act && pad) {
@@ -2204,7 +2207,7 @@ __device__ __attribute__((noinline)) void sort_desc_large(int n2, int L) {
                 for (int c = 0; c < 16; ++c)
                     if ((c & j) == 0) IPSX_CE_DESC(k[c], k[c | j]);
         }
-        __syncthreads();                                              // every read of this round is done
+        if (local) { wave_lds_fence(); __builtin_amdgcn_wave_barrier(); } else __syncthreads();   // every read of this round is done
         if (act) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) keys[17 * tid + c] = k[c];
