@@ -241,6 +241,13 @@ class Selection:
                 break
             its.append(nxt)
         its.append(n_iter)
+        ca = self.net.transf.crs_attn
+        if not persistent and n_iter >= 3 and hip.lib().ipsx_scan_workspace_bytes(1, M, I, ca.H, ca.n_token) > 0:
+            # a candidate set beyond the LDS (the shipped CAMELYON M = I = 5000: 7 iterations of 0.2 ms): the loop is the
+            # long pole and every further launch costs it a hand-over - TWO parts: the rows of the first two iterations,
+            # then all the rest beside them (measured at 38,000 rows: parts 2+2+3 17.1 M patches/s, 2+5 17.7, 1+2+4 17.1,
+            # 1+6 16.8, 3+4 16.6)
+            its = [0, 2, n_iter]
         return its
 
     def feature_launches(self, B, N, edges, dev, loops=None):
