@@ -47,8 +47,9 @@ extern "C" {
  *         ipsx_pack_conv_weight_strided, ipsx_conv2d_affine_to_nhwc, ipsx_conv2d_lds_nhwc*;
  *         ipsx_projector_stream accepts
  *         short_first <= -3 (guided tile sizes)
- *   2.02  round 4: ipsx_scan_persistent_on, ipsx_scan_persistent_groupable                                          */
-#define IPSX_VERSION 202
+ *   2.02  round 4: ipsx_scan_persistent_on, ipsx_scan_persistent_groupable
+ *   2.03  round 4: ipsx_scan_persistent_ws, ipsx_scan_range_if_ws (persistent loops for candidate sets beyond the LDS) */
+#define IPSX_VERSION 203
 
 #define IPSX_OK            0
 #define IPSX_EINVAL       -1      /* bad argument / unsupported shape */
@@ -368,6 +369,17 @@ int ipsx_scan_persistent_groupable(int m, int i, int h, int n_token);
 int ipsx_scan_persistent_on(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
                             int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
                             int32_t ready_per_image, int32_t* status, int workgroups, void* stream);
+/* The persistent loop and its conditional recovery launch for EVERY shape ipsx_scan covers: candidate sets beyond the LDS
+ * (ipsx_scan_workspace_bytes() > 0: the reference's shipped CAMELYON M = I = 5000) take the workspace of ipsx_scan; for
+ * the other shapes these are ipsx_scan_persistent_on / ipsx_scan_range_if and the workspace is ignored (2.03). */
+int ipsx_scan_persistent_ws(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                            int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
+                            int32_t ready_per_image, int32_t* status, int workgroups, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int ipsx_scan_range_if_ws(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                          int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                          int32_t* tie_flag, const int32_t* cond, int32_t cond_mask, void* workspace,
+                          size_t workspace_bytes, void* stream);
 int ipsx_publish_rows(int32_t* ready, int32_t value, void* stream);
 /* longest wait of a persistent loop (and of ipsx_scan_gate) without progress, in milliseconds (1 .. 20000; default 50);
  * returns the previous value, ms <= 0 only queries */

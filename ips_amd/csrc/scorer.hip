@@ -2388,6 +2388,12 @@ struct LargeArgs {
     int* tie;
     unsigned char* ws;     // per image: R * Lp floats (staged logits / exponentials) + 2 * Lp ints (tie replay lists)
     size_t ws_per_image;
+    const int* ready;      // persistent launch (ipsx_scan_persistent_ws): rows whose logits are in memory, per image or one word
+    int ready_stride, ready_words;
+    unsigned long long wait_ticks;
+    int* status;           //   bit 0: gave up waiting, bit 1: resident
+    const int* cond;       // conditional launch (ipsx_scan_range_if_ws): run only when (*cond & cond_mask) != 0
+    int cond_mask;
 };
 
 // keys (padded) | row maxima, denominators | stack of the sequential fallbacks | leaf bitmap | two range lists + counters
@@ -2424,6 +2430,10 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
     int* lists = reinterpret_cast<int*>(xT + (size_t)R * Lp);
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (scan_skipped(a.cond, a.cond_mask)) return;                     // (the recovery launch behind a persistent loop)
+    if (a.ready && tid == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int* const wword = reinterpret_cast<int*>(smem + tail);           // (the replay's stack: free outside the replay)
+    long long ready_known = 0;
     if (a.it0 == 0)
         for (int j = tid; j < m; j += LARGE_NT) mem[j] = j;
     __syncthreads();
@@ -2434,6 +2444,33 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         const long long lo = it * a.i + m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = m + cnt;
+        if (a.ready && lo + cnt > ready_known) {
+            // persistent: the rows of this iteration's chunk must have been published (the wait of scan_fast_kernel:
+            // bounded, any progress word moving restarts the clock; then ONE acquire, and plain loads are good)
+            if (wave == 0) {
+                unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                int v = __hip_atomic_load(a.ready + b * a.ready_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int seen = -1;
+                while (v >= 0 && v < lo + cnt) {
+                    __builtin_amdgcn_s_sleep(16);
+                    int w = lane < a.ready_words ? __hip_atomic_load(a.ready + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    for (int o = 32; o >= 1; o >>= 1) w += __shfl_xor(w, o, 64);
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (w != seen) { seen = w; t0 = now; }
+                    if (now - t0 > a.wait_ticks) { v = -1; break; }
+                    v = __hip_atomic_load(a.ready + b * a.ready_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0) wword[0] = v;
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ready_known = wword[0];
+            __syncthreads();
+            if (ready_known < 0) {
+                if (tid == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
         // 8 heads, one token (the reference's shipped CAMELYON configuration): a thread gathers ITS candidates' 8 logits -
         // 32 contiguous bytes each, five candidates in flight - for the row maxima, and again (from L2) for the
         // exponentials, which it writes transposed for the row sums and the scores.  The generic path below stages the
@@ -2951,6 +2988,28 @@ IPSX_API int ipsx_scan_persistent_on(const float* logits, int b, int64_t n, int 
                            nullptr, 0, stream, nullptr, 0, ready_per_image ? 1 : 0, workgroups);
 }
 
+// The persistent loop for EVERY shape ipsx_scan covers - candidate sets beyond the LDS take the workspace of ipsx_scan
+// (ipsx_scan_workspace_bytes; scan_large_kernel waits for its rows like the LDS-resident loops do) - and the conditional
+// recovery launch with a workspace.
+IPSX_API int ipsx_scan_persistent_ws(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                                     int64_t* mem_idx, float* mem_score, int32_t* tie_flag, const int32_t* ready,
+                                     int32_t ready_per_image, int32_t* status, int workgroups, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    IPSX_REQUIRE(ready && status, "scan_persistent: needs the progress word(s) and the status word");
+    IPSX_REQUIRE(n > m && i > 0, "scan: needs more patches (%lld) than memory slots (%d)", (long long)n, m);
+    return scan_range_impl(logits, b, n, m, i, h, n_token, 0, (n - m + i - 1) / i, mem_idx, mem_score, tie_flag, ready, status,
+                           workspace, workspace_bytes, stream, nullptr, 0, ready_per_image ? 1 : 0, workgroups);
+}
+
+IPSX_API int ipsx_scan_range_if_ws(const float* logits, int b, int64_t n, int m, int i, int h, int n_token,
+                                   int64_t it_begin, int64_t it_end, int64_t* mem_idx, float* mem_score,
+                                   int32_t* tie_flag, const int32_t* cond, int32_t cond_mask, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    IPSX_REQUIRE(cond && cond_mask, "scan_range_if: needs the condition word and a mask");
+    return scan_range_impl(logits, b, n, m, i, h, n_token, it_begin, it_end, mem_idx, mem_score, tie_flag, nullptr, nullptr,
+                           workspace, workspace_bytes, stream, cond, cond_mask);
+}
+
 // one thread that holds its stream until every workgroup of the persistent scan is resident (bounded: ~0.5 s)
 __global__ void scan_gate_kernel(const int* status, unsigned long long wait_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -2995,11 +3054,12 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
     if (it_begin == it_end) return IPSX_OK;
     const int R = h * n_token, Lmax = m + i, n2 = std::max(64, next_pow2(Lmax));
     const FastPlan fp = scan_fast_plan(m, i, h, n_token);
-    if (!fp.ok || (g_scan_generic && !ready && !cond)) {
+    if (!fp.ok || (g_scan_generic && !ready && !cond)) {       // (forced generic: plain launches only)
         // every shape the LDS-resident loop does not cover - other head / token counts, candidate sets beyond the LDS (the
         // reference's shipped CAMELYON configuration: M = I = 5000): ranking in LDS, everything else through the
         // caller's workspace (scan_large_kernel)
-        IPSX_REQUIRE(!ready && !cond, "scan_persistent / scan_range_if: shape not covered");
+        IPSX_REQUIRE(!(ready && cond), "scan: a persistent launch is not conditional");
+        IPSX_REQUIRE(!ready || status, "scan_persistent: needs the status word");
         IPSX_REQUIRE(Lmax <= LARGE_MAX_L, "scan: M+I = %d candidates - at most %d are supported", Lmax, LARGE_MAX_L);
         IPSX_REQUIRE(R <= 256, "scan: H * n_token = %d > 256 not supported", R);
         const size_t need = (size_t)b * scan_large_ws_per_image(m, i, h, n_token);
@@ -3014,6 +3074,10 @@ static int scan_range_impl(const float* logits, int b, int64_t n, int m, int i, 
         la.m = m; la.i = i; la.h = h; la.T = n_token; la.n2 = n2; la.Lp = (Lmax + 63) & ~63;
         la.mem_idx = reinterpret_cast<long long*>(mem_idx); la.mem_score = mem_score; la.tie = tie_flag;
         la.ws = static_cast<unsigned char*>(workspace); la.ws_per_image = scan_large_ws_per_image(m, i, h, n_token);
+        la.ready = ready; la.status = status; la.ready_stride = ready_stride;
+        la.ready_words = ready ? (ready_stride ? std::min(b, 64) : 1) : 0;
+        la.wait_ticks = (unsigned long long)g_persist_wait_ms * 100000ull;
+        la.cond = cond; la.cond_mask = cond_mask;
         const size_t lds = large_lds_bytes(n2, R);
         IPSX_REQUIRE(lds <= kLdsLimit, "scan: internal - %zu B of LDS", lds);
         if (g_scan_stamps) {                                           // diagnostic build (tools/scan_stamps.py large)

@@ -228,6 +228,12 @@ _EXPORTS = {
     "ipsx_scan_persistent_on": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int,
                                           C.c_void_p]),
+    "ipsx_scan_persistent_ws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ipsx_scan_range_if_ws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
     "ipsx_scan_persistent": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ipsx_publish_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -776,10 +782,14 @@ def scan_range(lg, M, I, H, T, it_begin, it_end, mem_idx, tie, workspace=None):
     return mem_idx
 
 
-def scan_range_if(lg, M, I, H, T, it_begin, it_end, mem_idx, tie, cond, mask=1):
+def scan_range_if(lg, M, I, H, T, it_begin, it_end, mem_idx, tie, cond, mask=1, workspace=None):
     """``scan_range`` that every workgroup abandons at once unless ``cond`` (int32 device scalar) has a bit of ``mask``
     set: the in-call recovery of a persistent loop that gave up waiting (its status word, bit 0)."""
     B, N = lg.shape[:2]
+    if workspace is not None:
+        _ck(lib().ipsx_scan_range_if_ws(_p(lg), B, N, M, I, H, T, it_begin, it_end, _p(mem_idx), None, _p(tie), _p(cond), mask,
+                                        _p(workspace), workspace.numel(), _stream()), "ipsx_scan_range_if_ws")
+        return mem_idx
     _ck(lib().ipsx_scan_range_if(_p(lg), B, N, M, I, H, T, it_begin, it_end, _p(mem_idx), None, _p(tie), _p(cond), mask,
                                  _stream()), "ipsx_scan_range_if")
     return mem_idx
@@ -882,12 +892,19 @@ def scan_persistent_supported(M, I, H, T):
     return bool(lib().ipsx_scan_persistent_supported(M, I, H, T))
 
 
+def scan_persistent_large(M, I, H, T):
+    """Does this shape run its persistent loop on ``scan_large_kernel`` (a candidate set beyond the LDS: the caller hands
+    ``scan_workspace`` to ``scan_persistent`` / ``scan_range_if``)?"""
+    return (not scan_persistent_supported(M, I, H, T) and lib().ipsx_scan_workspace_bytes(1, M, I, H, T) > 0
+            and M + I <= 16384 and H * T <= 256)
+
+
 def scan_persistent_groupable(M, I, H, T):
     """Can fewer resident workgroups than images run this shape's persistent loops (``scan_persistent(workgroups=)``)?"""
     return bool(lib().ipsx_scan_persistent_groupable(M, I, H, T))
 
 
-def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status, workgroups=0):
+def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status, workgroups=0, workspace=None):
     """The whole loop as one launch on the CURRENT stream that waits for ``ready`` (int32 device scalar, advanced with
     ``publish_rows`` on the producing stream; or one word per image - ``ready.numel() == B`` > 1 - when the producer works
     through the images one after the other) before it reads rows; see include/ipsx.h.  ``workgroups`` in (0, B): that
@@ -897,6 +914,11 @@ def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status, workgroups=0):
         raise ValueError("scan_persistent needs the full contiguous (B, N, H*T) logits buffer")
     if ready.numel() not in (1, B):
         raise ValueError("ready: one word, or one per image")
+    if workspace is not None:          # a candidate set beyond the LDS (scan_workspace): scan_large_kernel waits for its rows
+        _ck(lib().ipsx_scan_persistent_ws(_p(lg), B, N, M, I, H, T, _p(mem_idx), None, _p(tie), _p(ready),
+                                          1 if (ready.numel() == B and B > 1) else 0, _p(status), int(workgroups),
+                                          _p(workspace), workspace.numel(), _stream()), "ipsx_scan_persistent_ws")
+        return mem_idx
     _ck(lib().ipsx_scan_persistent_on(_p(lg), B, N, M, I, H, T, _p(mem_idx), None, _p(tie), _p(ready),
                                       1 if (ready.numel() == B and B > 1) else 0, _p(status), int(workgroups), _stream()),
         "ipsx_scan_persistent_on")

@@ -80,15 +80,16 @@ class Selection:
             self._bufs[name] = held = (key, bufs)
         return held[1]
 
-    def persistent_allowed(self, dev, M, I, H, T, loops=1):
+    def persistent_allowed(self, dev, M, I, H, T, loops=1, large=False):
         """Resident loops beside their producers: switched on, the shape is covered, the device has units to spare for
         ``loops`` of them (a small partition: the producers need the units more) and it has been SEEN to work there."""
         return (_env_on("IPSX_SCAN_PERSIST") and _env_on("IPSX_OVERLAP_SCAN") and not hip.dedup_blank()
-                and hip.scan_persistent_supported(M, I, H, T) and hip.device_geometry(dev).cus >= 8 * max(1, loops)
+                and (hip.scan_persistent_supported(M, I, H, T) or (large and hip.scan_persistent_large(M, I, H, T)))
+                and hip.device_geometry(dev).cus >= 8 * max(1, loops)
                 and hip.persistent_ok(dev))
 
     # ------------------------------------------------------------------ the persistent loop: begin / end
-    def persistent_begin(self, logits, mem_idx_buf, zeroed, B, dev, loops=0):
+    def persistent_begin(self, logits, mem_idx_buf, zeroed, B, dev, loops=0, scan_ws=None):
         """Zero the call's words (tie flags | a progress word per image | status | producer control words: ONE fill), launch
         the loop on the side stream and hold the main stream until it is resident.  -> (tie, ready, status, ctl).
 
@@ -111,7 +112,8 @@ class Selection:
         self.scan_status = status
         side.wait_stream(main)                     # the buffers are the main stream's; previous readers are done
         with torch.cuda.stream(side):
-            hip.scan_persistent(logits, net.M, net.I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status, workgroups=loops)
+            hip.scan_persistent(logits, net.M, net.I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status, workgroups=loops,
+                                workspace=scan_ws)
         # producers must not take the compute units before a loop has its own.  (Also true of a persistent producer whose
         # workgroups sit one to a unit and leave a unit per loop free: a workgroup is dealt to an XCD before it looks for a
         # unit there, so a loop that arrives second may be dealt to a FULL XCD and start when the producer ends - measured
@@ -119,12 +121,13 @@ class Selection:
         hip.scan_gate(status)
         return tie, ready, status, ctl
 
-    def persistent_end(self, logits, mem_idx_buf, tie, status, n_iter, dev):
+    def persistent_end(self, logits, mem_idx_buf, tie, status, n_iter, dev, scan_ws=None):
         net = self.net
         ca = net.transf.crs_attn
         side, main = self.streams(dev)
         main.wait_stream(side)
-        hip.scan_range_if(logits, net.M, net.I, ca.H, ca.n_token, 0, n_iter, mem_idx_buf, tie, status, 1)   # no-op unless timed out
+        hip.scan_range_if(logits, net.M, net.I, ca.H, ca.n_token, 0, n_iter, mem_idx_buf, tie, status, 1,
+                          workspace=scan_ws)                                                           # no-op unless timed out
         if self.scan_status_host is None:
             self.scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self.scan_status_host.copy_(status, non_blocking=True)
@@ -141,7 +144,8 @@ class Selection:
         if patches.is_cuda and self.can_overlap(patches):
             ca = net.transf.crs_attn
             if (not net.is_image and patches.is_contiguous() and patches.shape[0] <= int(os.environ.get("IPSX_PERSIST_MAX_B", "16"))
-                    and self.persistent_allowed(patches.device, net.M, net.I, ca.H, ca.n_token, self.feature_loops(patches.shape[0]))):
+                    and self.persistent_allowed(patches.device, net.M, net.I, ca.H, ca.n_token, self.feature_loops(patches.shape[0]),
+                                                large=_env_on("IPSX_LARGE_PERSIST"))):
                 return self.features_persistent(patches, pos_enc)
             return self.parts_with_ranges(patches, pos_enc)
         return self.slabs(patches, pos_enc)
@@ -287,19 +291,20 @@ class Selection:
         vq, R = ca.folded_query(), ca.H * ca.n_token
         n_iter = self.n_iter(N)
         self.streams(dev)
-        logits, mem_idx_buf, zeroed, stats, emb_buf = self.buffers(
+        logits, mem_idx_buf, zeroed, stats, emb_buf, scan_ws = self.buffers(
             "features", (B, N, M, I, R, net.D, str(dev)),
             lambda: (torch.empty((B, N, R), dtype=torch.float32, device=dev),
                      torch.empty((B, M), dtype=torch.int64, device=dev),
                      torch.zeros((2 * B + 1 + plan.stream_ctl_words(B * N),), dtype=torch.int32, device=dev),
                      torch.empty((B * N, 2), dtype=torch.float32, device=dev),      # LayerNorm moments
-                     torch.empty((B, N, net.D), dtype=torch.float32, device=dev)))
+                     torch.empty((B, N, net.D), dtype=torch.float32, device=dev),
+                     hip.scan_workspace(B, M, I, ca.H, ca.n_token, dev)))            # (candidate sets beyond the LDS; else None)
         # Resident loops: the projector goes through the slides in order and needs longer for a slide than its loop does
         # (65,536 x 2048 rows: 1.2 ms against 0.94), so TWO loop workgroups, each taking its slides one after the other,
         # keep up with any number of slides - and the compute units of the other loops stay the projector's
         # (16 slides: 240 -> 254 units, 52.5 -> [DESIGN 6] M patches/s).
         loops = self.feature_loops(B)
-        tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops)
+        tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops, scan_ws)
         plan._refresh()
         fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)
         xf, ef, lf = patches.view(B * N, -1), emb_buf.view(B * N, -1), logits.view(1, B * N, R)
@@ -344,7 +349,7 @@ class Selection:
                     for b_, rows in pubs:          # after the kernels that wrote those rows
                         hip.publish_rows(ready[b_:b_ + 1], rows)
         net._emb_parts = [emb_buf]
-        return self.persistent_end(logits, mem_idx_buf, tie, status, n_iter, dev)
+        return self.persistent_end(logits, mem_idx_buf, tie, status, n_iter, dev, scan_ws)
 
     # ------------------------------------------------------------------ pipeline: one image, persistent trunk stream
     def image_stream(self, patches, pos_enc):

@@ -568,6 +568,50 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
 
 
 @pytest.mark.gpu
+def test_persistent_loop_for_candidate_sets_beyond_the_lds(monkeypatch):
+    """ipsx_scan_persistent_ws / ipsx_scan_range_if_ws: the loop of a candidate set beyond the LDS (scan_large_kernel, the
+    reference's shipped CAMELYON shape in small) follows the projector stream as one resident launch and selects what the
+    per-part launches select; a cancelled loop sets its status word and the conditional launch with the workspace redoes it."""
+    conf = synth.camelyon_conf(N=11000, M=2100, I=2100)
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 5).to(DEV).eval()
+    x = synth.make_patches(conf, 2, seed=9).to(DEV)
+    ca = net.transf.crs_attn
+    assert hip.scan_persistent_large(conf.M, conf.I, ca.H, ca.n_token) and not hip.scan_persistent_supported(conf.M, conf.I, ca.H, ca.n_token)
+    monkeypatch.setenv("IPSX_LARGE_PERSIST", "0")
+    want = []
+    for xb in (x[:1], x):
+        net.selection.scan_status = None
+        net.ips(xb)
+        assert net.selection.scan_status is None
+        want.append(net.last_mem_idx.clone())
+    monkeypatch.setenv("IPSX_LARGE_PERSIST", "1")
+    for xb, w in zip((x[:1], x), want):
+        for _ in range(2):
+            net.selection.scan_status = None
+            net.ips(xb)
+            assert net.selection.scan_status is not None and torch.equal(net.last_mem_idx, w)
+    assert int(net.selection.scan_status.item()) & 3 == 2
+    # a loop nobody feeds (negative progress words) gives up at once; the conditional launch repairs the result
+    B, N, M, I, H = 2, 9000, 2100, 2100, 8
+    lg = torch.randn((B, N, H), device=DEV)
+    plain = hip.scan(lg, M, I, H, 1)
+    ws = hip.scan_workspace(B, M, I, H, 1, lg.device)
+    mem = torch.full((B, M), -7, dtype=torch.int64, device=DEV)
+    tie = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    words = torch.tensor([-1, -1, 0], dtype=torch.int32, device=DEV)
+    hip.scan_persistent(lg, M, I, H, 1, mem, tie, words[:2], words[2:], workspace=ws)
+    torch.cuda.synchronize()
+    assert int(words[2].item()) & 1 == 1 and not torch.equal(mem, plain)
+    n_iter = -(-(N - M) // I)
+    hip.scan_range_if(lg, M, I, H, 1, 0, n_iter, mem, tie, words[2:], 1, workspace=ws)
+    assert torch.equal(mem, plain)
+    mem.fill_(-7)
+    words.zero_()
+    hip.scan_range_if(lg, M, I, H, 1, 0, n_iter, mem, tie, words[2:], 1, workspace=ws)      # status clear: nothing runs
+    assert int((mem != -7).sum().item()) == 0
+
+
+@pytest.mark.gpu
 def test_stream_hand_over_stress(monkeypatch):
     """The hand-over between the persistent producers and the resident loops (flags, cursor, progress words: relaxed
     atomics behind one release fence, an acquire per wait), many times over: 40 calls with fresh slides of ragged sizes,

@@ -82,7 +82,8 @@ def test_abi_major_and_the_round_4_additions_are_declared():
     lib = hip.lib()
     assert lib.ipsx_version() // 100 == hip.ABI_MAJOR
     for name in ("ipsx_aggregate_packed", "ipsx_set_persistent_wait_ms", "ipsx_conv2d_wgrad_nhwc", "ipsx_pack_conv_weight_strided",
-                 "ipsx_conv2d_affine_to_nhwc", "ipsx_scan_persistent_on", "ipsx_scan_persistent_groupable"):
+                 "ipsx_conv2d_affine_to_nhwc", "ipsx_scan_persistent_on", "ipsx_scan_persistent_groupable",
+                 "ipsx_scan_persistent_ws", "ipsx_scan_range_if_ws"):
         assert name in hip._EXPORTS and hasattr(lib, name)
     assert lib.ipsx_scan_persistent_groupable(256, 256, 8, 1) == 1 and lib.ipsx_scan_persistent_groupable(64, 64, 8, 4) == 0
     prev = lib.ipsx_set_persistent_wait_ms(0)          # query
