@@ -591,6 +591,26 @@ def test_persistent_loop_for_candidate_sets_beyond_the_lds(monkeypatch):
             net.ips(xb)
             assert net.selection.scan_status is not None and torch.equal(net.last_mem_idx, w)
     assert int(net.selection.scan_status.item()) & 3 == 2
+    # many calls on fresh slides of ragged sizes (the hand-over between the stream's tiles and the loop's waits)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    cases = []
+    for k in range(10):
+        B = 1 + k % 2
+        N = 32 * int(torch.randint(140, 420, (1,), generator=g)) if B > 1 else int(torch.randint(4300, 14000, (1,), generator=g))
+        cases.append(torch.randn((B, N, conf.n_chan_in), generator=g).to(DEV))
+    monkeypatch.setenv("IPSX_LARGE_PERSIST", "0")
+    wants = []
+    for xc in cases:
+        net.ips(xc)
+        wants.append(net.last_mem_idx.clone())
+    monkeypatch.setenv("IPSX_LARGE_PERSIST", "1")
+    for xc, w in zip(cases, wants):
+        net.selection.scan_status = None
+        net.ips(xc)
+        assert torch.equal(net.last_mem_idx, w), tuple(xc.shape)
+        assert (net.selection.scan_status is not None) == (net.selection.n_iter(xc.shape[1]) >= 3)   # (short loops: one scan)
+    torch.cuda.synchronize()
+    assert int(net.selection.scan_status_host.item()) & 1 == 0
     # a loop nobody feeds (negative progress words) gives up at once; the conditional launch repairs the result
     B, N, M, I, H = 2, 9000, 2100, 2100, 8
     lg = torch.randn((B, N, H), device=DEV)
