@@ -363,14 +363,27 @@ class EncoderPlan:
     def __init__(self, encoder, is_image):
         self.encoder, self.is_image = encoder, is_image
         self._sig = None
+        self._holders = None
         self._keep = []
         self._ws = None
         self._ws_small = 0
         self._held = 0
 
     def _signature(self):
+        """(storage pointer, version counter) of every parameter and buffer.  The walk over the module tree (~100 us for a
+        ResNet trunk: it sits in front of the first launch of EVERY ips() call) is done once: what is kept are the modules'
+        own parameter / buffer dictionaries, read afresh in every call - a tensor that is replaced, moved or written in
+        place is seen; a CHILD MODULE exchanged below the top level of the encoder is not (the top level is checked)."""
+        top = tuple(id(m) for m in self.encoder._modules.values())
+        if self._holders is None or self._holders[0] != top:
+            slots = []
+            for mod in self.encoder.modules():
+                slots += [(mod._parameters, k) for k, t in mod._parameters.items() if t is not None]
+                slots += [(mod._buffers, k) for k, t in mod._buffers.items() if t is not None]
+            self._holders = (top, slots)
         sig = [precision(), weights_generation()]
-        for t in list(self.encoder.parameters()) + list(self.encoder.buffers()):
+        for d, k in self._holders[1]:
+            t = d[k]
             sig.append((t.data_ptr(), t._version))
         return tuple(sig)
 
