@@ -305,7 +305,16 @@ def _ck(rc, what):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current stream's handle.  (The raw getter: ``torch.cuda.current_stream()`` builds a Stream object through three
+    Python layers - ~4 us, ten times per ips() call, most of them between the first and the last launch of the call.)"""
+    return C.c_void_p(_raw_stream(_cur_device()))
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+if _raw_stream is None or _cur_device is None:          # (another torch build: the documented way)
+    def _stream():                                      # noqa: F811
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _p(t):
@@ -350,6 +359,21 @@ def _pack_conv(weight):
     _ck(lib().ipsx_pack_conv_weight(_p(_f32(weight.detach())), co, ci, kh, kw, _p(packed), _stream()),
         "ipsx_pack_conv_weight")
     return packed
+
+
+class _PlanHold:
+    """``EncoderPlan.hold()``: the plan's weight check runs on entry and is skipped until exit."""
+    __slots__ = ("plan",)
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        self.plan._refresh()
+        self.plan._held += 1
+
+    def __exit__(self, *exc):
+        self.plan._held -= 1
 
 
 class EncoderPlan:
@@ -472,16 +496,7 @@ class EncoderPlan:
     def hold(self):
         """Context manager: check the weights once, then skip the check until the block ends - for a caller that makes
         several encode calls while the weights cannot change (one no-grad ``ips()`` call; the check walks ~80 tensors)."""
-        plan = self
-
-        class _Hold:
-            def __enter__(self):
-                plan._refresh()
-                plan._held += 1
-
-            def __exit__(self, *exc):
-                plan._held -= 1
-        return _Hold()
+        return _PlanHold(self)
 
     def fused(self, x_shape):
         """True when encode_indexed is available for patches of this (C, h, w)."""

@@ -98,6 +98,7 @@ class Selection:
         call's results are valid either way and no host synchronisation is added.  The status word is mirrored into pinned
         host memory, asynchronously, and looked at in the NEXT call - by then it has long arrived: a timeout switches the
         persistent pipelines off for the rest of the process (the per-part launches take over) and says so once."""
+        zeroed.zero_()                             # (first: everything below is host work in front of the call's second launch)
         net = self.net
         ca = net.transf.crs_attn
         mirror = self.scan_status_host
@@ -107,7 +108,6 @@ class Selection:
                                    "per-part launches: results valid)")
         side, main = self.streams(dev)
         tie, words, ctl = zeroed[:B], zeroed[B:2 * B + 1], zeroed[2 * B + 1:]
-        zeroed.zero_()
         ready, status = words[:B], words[B:B + 1]
         self.scan_status = status
         side.wait_stream(main)                     # the buffers are the main stream's; previous readers are done
