@@ -932,7 +932,7 @@ def scan_persistent_groupable(M, I, H, T):
     return bool(lib().ipsx_scan_persistent_groupable(M, I, H, T))
 
 
-def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status, workgroups=0, workspace=None):
+def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status, workgroups=0, workspace=None, stream=None):
     """The whole loop as one launch on the CURRENT stream that waits for ``ready`` (int32 device scalar, advanced with
     ``publish_rows`` on the producing stream; or one word per image - ``ready.numel() == B`` > 1 - when the producer works
     through the images one after the other) before it reads rows; see include/ipsx.h.  ``workgroups`` in (0, B): that
@@ -942,13 +942,14 @@ def scan_persistent(lg, M, I, H, T, mem_idx, tie, ready, status, workgroups=0, w
         raise ValueError("scan_persistent needs the full contiguous (B, N, H*T) logits buffer")
     if ready.numel() not in (1, B):
         raise ValueError("ready: one word, or one per image")
-    if workspace is not None:          # a candidate set beyond the LDS (scan_workspace): scan_large_kernel waits for its rows
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()     # (``stream``: launch there without
+    if workspace is not None:          # a candidate set beyond the LDS             #  making it the current stream)
         _ck(lib().ipsx_scan_persistent_ws(_p(lg), B, N, M, I, H, T, _p(mem_idx), None, _p(tie), _p(ready),
                                           1 if (ready.numel() == B and B > 1) else 0, _p(status), int(workgroups),
-                                          _p(workspace), workspace.numel(), _stream()), "ipsx_scan_persistent_ws")
+                                          _p(workspace), workspace.numel(), st), "ipsx_scan_persistent_ws")
         return mem_idx
     _ck(lib().ipsx_scan_persistent_on(_p(lg), B, N, M, I, H, T, _p(mem_idx), None, _p(tie), _p(ready),
-                                      1 if (ready.numel() == B and B > 1) else 0, _p(status), int(workgroups), _stream()),
+                                      1 if (ready.numel() == B and B > 1) else 0, _p(status), int(workgroups), st),
         "ipsx_scan_persistent_on")
     return mem_idx
 

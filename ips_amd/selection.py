@@ -111,9 +111,8 @@ class Selection:
         ready, status = words[:B], words[B:B + 1]
         self.scan_status = status
         side.wait_stream(main)                     # the buffers are the main stream's; previous readers are done
-        with torch.cuda.stream(side):
-            hip.scan_persistent(logits, net.M, net.I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status, workgroups=loops,
-                                workspace=scan_ws)
+        hip.scan_persistent(logits, net.M, net.I, ca.H, ca.n_token, mem_idx_buf, tie, ready, status, workgroups=loops,
+                            workspace=scan_ws, stream=side)
         # producers must not take the compute units before a loop has its own.  (Also true of a persistent producer whose
         # workgroups sit one to a unit and leave a unit per loop free: a workgroup is dealt to an XCD before it looks for a
         # unit there, so a loop that arrives second may be dealt to a FULL XCD and start when the producer ends - measured
