@@ -221,6 +221,8 @@ class IPSNet(nn.Module):
             mem_patch = self._take(src, mem_idx).to(device)
             self._device_patches = None
             mem_pos = self._take(pos_enc, mem_idx) if self.use_pos else None
+            if self._selection is not None:
+                self._selection.after_call()
         finally:
             if was_training:
                 self.encoder.train()

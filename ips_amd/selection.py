@@ -51,6 +51,7 @@ class Selection:
         self._copy = None
         self.scan_status = None          # status word of the last persistent loop (device), its host mirror
         self.scan_status_host = None
+        self._mirror_pending = None
         self._part_index = None
 
     # ------------------------------------------------------------------ small helpers
@@ -127,11 +128,19 @@ class Selection:
         main.wait_stream(side)
         hip.scan_range_if(logits, net.M, net.I, ca.H, ca.n_token, 0, n_iter, mem_idx_buf, tie, status, 1,
                           workspace=scan_ws)                                                           # no-op unless timed out
-        if self.scan_status_host is None:
-            self.scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        self.scan_status_host.copy_(status, non_blocking=True)
+        self._mirror_pending = status              # (copied to the host by after_call: behind the call's gathers)
         hip.scan.last_tie = tie
         return mem_idx_buf.clone()                 # the buffer is overwritten by the next call
+
+    def after_call(self):
+        """The last thing an ``ips()`` call enqueues: the status word of its persistent loop goes to its pinned host mirror
+        (looked at in the NEXT call) - behind the gathers of the selected patches, not in front of them."""
+        status = self._mirror_pending
+        if status is not None:
+            self._mirror_pending = None
+            if self.scan_status_host is None:
+                self.scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            self.scan_status_host.copy_(status, non_blocking=True)
 
     # ------------------------------------------------------------------ which pipeline
     def select(self, patches, pos_enc):
