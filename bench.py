@@ -2,6 +2,7 @@
 """bench.py - patches scored / second of the IPS no-grad hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5          (starts its own 8 ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -19,13 +20,15 @@ shipped CAMELYON sizes, traffic = configs[0]'s model on the GPU, native50 = the 
 50-px MNIST patches), each with its own ``parity`` / ``roofline`` / ``roofline_call``.
 
 Workloads (``ips_amd.synth.BENCH_WORKLOADS``; weights seed 7, patches seed 21):
-  N = 1   BASELINE.json configs[1]: Megapixel-MNIST 1500 - 2500 patches of 1x32x32 per image,
-          M = I = 64, 4 query tokens, positional encoding on, at the reference's batch size
-          B = 16 (config/mnist_config.yml B_seq).
-  N > 1   BASELINE.json configs[2]: Megapixel-MNIST 3000 - 10,000 patches per image, B = 16, the patch
-          axis sharded over the N ranks (ips_amd/dist.py; strong scaling: the job is the same at
-          every N).  ``--scaling weak`` instead gives every GPU 2500 patches of each image (the
-          image grows with the node).  value counts the patches all ranks scored.
+  every N BASELINE.json configs[1] ("MegaMNIST-1500 @ 1/2/4/8 GPU"): Megapixel-MNIST 1500 - 2500 patches
+          of 1x32x32 per image, M = I = 64, 4 query tokens, positional encoding on, at the reference's
+          batch size B = 16 (config/mnist_config.yml B_seq).  The SAME 16 x 2500 patches at every N
+          (``"scaling": "strong"``): at N > 1 the patch axis is sharded over the N ranks (ips_amd/dist.py),
+          value counts the patches all ranks scored, and the line carries ``n1_value_same_workload`` (rank 0
+          alone, same process, same inputs) and ``also_measured.mnist3000`` (configs[2], sharded the same way).
+          ``--scaling weak`` instead gives every GPU 2500 patches of each image (the image grows with N).
+  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+  (a child ``python -m torch.distributed.run``; the parent never touches the GPU) and relays rank 0's line.
 
 Every line carries
   parity        ``net.last_mem_idx`` after the timed loop against the REFERENCE's selection on the same
@@ -96,12 +99,13 @@ def parse():
                     help="do not bracket the encoder launches with HIP events (no `roofline.achieved`): what the events themselves "
                          "cost - at one image per call they move the dispatcher's placement of the loop's workgroup, DESIGN 6")
     ap.add_argument("--config", default=None, choices=sorted(FLOP_PER_PATCH),
-                    help="default: mnist at --gpus 1 (the headline, BASELINE configs[1], B=16), mnist3000 at --gpus N > 1 "
-                         "(configs[2], patch-sharded); the others are secondary single-GPU measurements: b1 (headline "
-                         "image 0 alone), native50, traffic, cam, cam_native (the reference's shipped M = I = 5000)")
+                    help="default: mnist at every --gpus N (the headline, BASELINE configs[1], B=16; patch-sharded at N > 1, "
+                         "where mnist3000 = configs[2] is also allowed); the others are secondary single-GPU measurements: b1 "
+                         "(headline image 0 alone), native50, traffic, cam, cam_native (the reference's shipped M = I = 5000)")
     ap.add_argument("--also", default="all",
-                    help="default single-GPU run only: which other BASELINE configurations are timed into `also_measured` "
-                         "('all', 'none', or a comma list of b1,mnist3000,cam,cam_x16,cam_native)")
+                    help="default run only: which other BASELINE configurations are timed into `also_measured` ('all', 'none', "
+                         "or a comma list of b1,mnist3000,cam,cam_x16,cam_native,traffic,native50; at N > 1 only mnist3000 - "
+                         "configs[2], sharded - and the single-rank time of the headline, `n1_value_same_workload`)")
     ap.add_argument("--also-steps", type=int, default=0,
                     help="timed calls per `also_measured` leg, each way (0 = sized per leg: ~0.3 s of calls, 10 to 40)")
     ap.add_argument("--leg-timeout", type=int, default=120, help="seconds an `also_measured` leg may take before the line is "
@@ -109,8 +113,8 @@ def parse():
     ap.add_argument("--watchdog", type=int, default=600, help="seconds the headline measurement may take before every thread's "
                     "stack is dumped to stderr and the run exits")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="N > 1 only. strong (default): configs[2], the same 16 x 10000 patches at every N; weak: 2500 "
-                         "patches of every image per GPU (the image grows with N)")
+                    help="strong (default): BASELINE configs[1], the same 16 x 2500 patches at every N, patch axis sharded over "
+                         "the ranks; weak: 2500 patches of every image per GPU (the image grows with N; N = 4 is configs[2])")
     return ap.parse_args()
 
 
@@ -129,10 +133,15 @@ def host_description():
 
 
 def cpu_baseline(conf, x, budget_s):
-    """The reference's CPU path (ATen restatement, oracle/ips_torch.py) on a BOUNDED sample of the same workload: whole
-    ``ips()`` calls on the batch itself when one call fits the budget, otherwise on a prefix of it - fewer images first,
-    then a shorter patch axis cut at a chunk boundary (the per-patch cost of the loop does not depend on N: every
-    iteration embeds I patches and scores M + I) - repeated until the budget is used."""
+    """The reference's CPU path (ATen restatement, oracle/ips_torch.py) on a BOUNDED sample of the same workload.
+
+    Thread count (round 5: the probe on a 2 x 320-patch prefix did not predict the batch - 5.6 k at 64 threads on one
+    box, 9.3 k at 32 on the next of the same CPU model): FIXED counts 16 / 32 / 64 (capped by the CPUs this process may
+    use), each timed on whole ``ips()`` calls over at least ONE FULL image of the workload (the faster of two calls
+    after a warm-up call), the table goes into the record and the best count runs the sample.  The sample: whole
+    calls on the batch itself when one call fits the budget, otherwise on a prefix of it - fewer images first, then a
+    shorter patch axis cut at a chunk boundary (only where one image alone exceeds the budget: the per-patch cost of
+    the loop does not depend on N) - repeated until the budget is used."""
     from ips_amd import synth
     from ips_amd.architecture import IPSNet
     from oracle import ips_torch
@@ -142,35 +151,43 @@ def cpu_baseline(conf, x, budget_s):
     B, N = x.shape[:2]
     host = host_description()
     avail = host["cpus_available"]
-    # The reference loop feeds the encoder I patches per image per call: too little work for every core of a big
-    # host (256 threads measured 14 patches/s).  Probe a few thread counts on a short prefix of the same batch and keep
-    # the fastest - that is the reference's best case on this host.
-    n_probe = min(N, conf.M + 4 * conf.I)
-    b_probe = min(B, 2)
-    best, probe = None, conf.clone(N=n_probe)
-    pos = net.pos_enc[:, :n_probe] if conf.use_pos else None
-    for thr in sorted({min(avail, c) for c in (4, 8, 16, 32, 64)}):
+    pos_full = net.pos_enc[:, :N] if conf.use_pos else None
+    # one image must be affordable three times per thread count: otherwise (traffic signs / 10,000-candidate CAMELYON on
+    # a small host) the table is taken on a chunk-aligned prefix of the image and says so
+    torch.set_num_threads(min(avail, 32))
+    n_quick = min(N, conf.M + 2 * conf.I)
+    ips_torch.ips(sd, conf.clone(N=n_quick), x[:1, :n_quick], net.pos_enc[:, :n_quick] if conf.use_pos else None)
+    t0 = time.perf_counter()
+    ips_torch.ips(sd, conf.clone(N=n_quick), x[:1, :n_quick], net.pos_enc[:, :n_quick] if conf.use_pos else None)
+    est_image = (time.perf_counter() - t0) / n_quick * N
+    n_tab = N
+    if 9 * est_image > max(budget_s, 1.0) * 2:
+        room = max(conf.M + conf.I, int(N * (2 * budget_s / 9) / est_image))
+        n_tab = max(conf.M + conf.I, min(N, conf.M + (room - conf.M) // conf.I * conf.I))
+    tab_conf = conf if n_tab == N else conf.clone(N=n_tab)
+    pos_tab = net.pos_enc[:, :n_tab] if conf.use_pos else None
+    table, best = [], None
+    for thr in sorted({min(avail, c) for c in (16, 32, 64)}):
         torch.set_num_threads(thr)
-        ips_torch.ips(sd, probe, x[:b_probe, :n_probe], pos)
+        ips_torch.ips(sd, tab_conf, x[:1, :n_tab], pos_tab)       # warm-up at this count (thread pool, oneDNN primitives)
         dt = None
-        for _ in range(2):                                      # the faster of two timed calls: one call per count was noisy
-            t0 = time.perf_counter()                            # enough to pick 8 threads on one box and 32 on the next
-            ips_torch.ips(sd, probe, x[:b_probe, :n_probe], pos)
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ips_torch.ips(sd, tab_conf, x[:1, :n_tab], pos_tab)
             d1 = time.perf_counter() - t0
             dt = d1 if dt is None else min(dt, d1)
+        table.append({"threads": thr, "patches_per_s": n_tab / dt, "ms_per_image": 1e3 * dt})
         if best is None or dt < best[1]:
             best = (thr, dt)
-        if dt > 4 * best[1] or dt > 3.0:                       # (slower by far, or a host that chokes on this many threads)
-            break
     torch.set_num_threads(best[0])
-    per_patch = best[1] / (b_probe * n_probe)                   # seconds per patch at the probe's size
+    per_patch = best[1] / n_tab                                 # seconds per patch at the best count
     # the sample: as much of the batch as one call can take in about a third of the budget
     room = max(1, int(budget_s / 3 / per_patch))                # patches
     b_s = max(1, min(B, room // N))
     n_s = N if b_s * N <= room else max(conf.M + conf.I, min(N, conf.M + (room - conf.M) // conf.I * conf.I))
     sample_conf = conf if n_s == N else conf.clone(N=n_s)
     xs = x[:b_s, :n_s]
-    pos_s = net.pos_enc[:, :n_s] if conf.use_pos else None
+    pos_s = pos_full[:, :n_s] if conf.use_pos else None
     reps, t0 = 0, time.perf_counter()
     while True:
         ips_torch.ips(sd, sample_conf, xs, pos_s)
@@ -182,10 +199,12 @@ def cpu_baseline(conf, x, budget_s):
     return {"value": b_s * n_s * reps / dt, "unit": "patches/s", "cores": torch.get_num_threads(),
             "threads": torch.get_num_threads(), "nproc": host["nproc"], "cpus_available": avail, "cpu_model": host["cpu_model"],
             "kind": "port",
+            "thread_table": table,
+            "thread_table_on": "one image x %d patches%s, faster of two ips() calls per count" % (n_tab, "" if n_tab == N else " (a chunk-aligned prefix: a full image does not fit the budget)"),
             "sample": "%d x ips() on %s, %d image(s) x %d patches (oracle/ips_torch.py: the reference's ATen/oneDNN CPU path "
-                      "restated, %.1f s; thread count = fastest of 4..64 on a %d x %d-patch prefix)"
+                      "restated, %.1f s; thread count = best of the fixed counts in thread_table)"
                       % (reps, "the bench batch itself" if whole else "a prefix of the bench batch (first images, patch axis cut at a chunk boundary)",
-                         b_s, n_s, dt, b_probe, n_probe)}
+                         b_s, n_s, dt)}
 
 
 def parity(name, mem_idx, images=None):
@@ -263,10 +282,11 @@ def pmc_traffic(workload, kernel_name, enc_patches, n_launch):
             h.update(open(os.path.join(REPO, "ips_amd", "csrc", src), "rb").read())
         if h.hexdigest()[:16] != pmc["source_sha16"]:
             return None, "profiles/pmc_traffic.json[%s] was measured on another version of %s (stale)" % (workload, pmc["source"])
+        stamp = "; builder-run rocprofv3 passes on kernel sources %s sha16 %s = the sources of this run" % (pmc["source"], pmc["source_sha16"])
         if "hbm_bytes_per_step" in pmc:
-            return pmc["hbm_bytes_per_step"], "bytes per step, all kernels of ips() (PMC, profiles/pmc_traffic.json)"
+            return pmc["hbm_bytes_per_step"], "bytes per step, all kernels of ips() (PMC, profiles/pmc_traffic.json%s)" % stamp
         if any(k in (kernel_name or "") for k in pmc["kernel"].split("|")) and enc_patches == pmc["patches_per_launch"] * n_launch:
-            return pmc["hbm_bytes_per_launch"], "bytes per launch (PMC, profiles/pmc_traffic.json)"
+            return pmc["hbm_bytes_per_launch"], "bytes per launch (PMC, profiles/pmc_traffic.json%s)" % stamp
         return None, "profiles/pmc_traffic.json holds %s at %d patches per launch" % (pmc["kernel"], pmc["patches_per_launch"])
     except (OSError, KeyError, ValueError):
         return None, "no PMC record"
@@ -487,7 +507,9 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": med_ms,
             "higher_is_better": True,
-            "scaling": "weak" if (weak or world == 1) else "strong",
+            # the SAME 16 x 2500 patches at every N (BASELINE "MegaMNIST-1500 @ 1/2/4/8 GPU"): the N = 1 line is the first
+            # point of a strong-scaling curve; --scaling weak (2500 patches of every image per GPU) says so at every N
+            "scaling": "weak" if args.scaling == "weak" else "strong",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "fp32x3": "f32 as 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate",
                       "bf16": "bf16 operands / f32 accumulate"}[args.precision],
@@ -569,14 +591,49 @@ def slim(rec):
     return out
 
 
+EXIT_WATCHDOG = 3        # a leg (or the CPU baseline) did not come back: the partial line is printed, the exit code says so
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` (N > 1) without a launcher's environment: start the N ranks as a CHILD
+    ``python -m torch.distributed.run`` of this very command and hand its exit code on.  The parent has not touched the GPU
+    (no HIP call, no ``torch.cuda.is_available()``) and never does - it only waits; rank 0 of the child prints the JSON
+    line on the stdout they share.  (Never an exec: a process that has initialised the GPU must not be replaced, and the
+    parent may have been started under a profiler that has.)"""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL between processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = proc.wait()
+    if rc != 0:
+        print("bench.py: the %d-rank child run exited with code %d" % (args.gpus, rc), file=sys.stderr)
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                       # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world),
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's --nproc-per-node must equal --gpus)" % (args.gpus, world),
                   file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
@@ -601,7 +658,7 @@ def main():
     if args.dedup_blank:
         os.environ["IPSX_DEDUP_BLANK"] = "1"
     os.environ["IPSX_PRECISION"] = args.precision
-    name = args.config or ("mnist" if world == 1 else "mnist3000")
+    name = args.config or "mnist"                               # ONE workload at every N: BASELINE configs[1]
     if world > 1 and name not in ("mnist", "mnist3000"):
         print("secondary configs are single-GPU measurements", file=sys.stderr)
         sys.exit(2)
@@ -613,18 +670,40 @@ def main():
     faulthandler.dump_traceback_later(args.watchdog, exit=True)
     out = measure(args, ctx, name, batch=args.batch, steps=args.steps, warmup=args.warmup, cpu_seconds=args.cpu_seconds, headline=True)
     faulthandler.cancel_dump_traceback_later()
-    default_run = (world == 1 and args.config is None and args.batch is None and args.precision == "fp32"
-                   and args.storage == "f32" and not (args.dedup_blank or args.lazy or args.no_kernel_events))
+    plain = (args.config is None and args.batch is None and args.precision == "fp32"
+             and args.storage == "f32" and not (args.dedup_blank or args.lazy or args.no_kernel_events))
+    default_run = world == 1 and plain
+    if world > 1 and plain and args.scaling == "strong":
+        # the first point of the curve, measured in THIS run on THIS box: rank 0 alone, the same 16 x 2500 patches, the
+        # single-GPU path (the other ranks wait at the barrier); then configs[2] sharded the same way
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
+        if rank == 0:
+            solo = measure(args, Ctx(1, 0, dev, share), name, batch=None, steps=min(args.steps, 10), warmup=min(args.warmup, 3),
+                           cpu_seconds=0.0, headline=False)
+            out["n1_value_same_workload"] = solo["value"]
+            out["n1_ms_per_step_same_workload"] = solo["ms_per_step"]
+            out["speedup_over_n1_same_run"] = out["value"] / solo["value"]
+        dist.barrier()
+        if args.also != "none":
+            rec = measure(args, ctx, "mnist3000", batch=None, steps=min(args.steps, 10), warmup=min(args.warmup, 3),
+                          cpu_seconds=0.0, headline=False)
+            if rank == 0:
+                leg = slim(rec)
+                leg["parity_all_ranks"] = rec.get("parity_all_ranks")
+                leg["per_rank"] = rec.get("per_rank")
+                out.setdefault("also_measured", {})["mnist3000"] = leg
+        faulthandler.cancel_dump_traceback_later()
     if default_run and args.also != "none":
         import threading
         legs = [l for l in ALSO_LEGS if args.also == "all" or l[0] in args.also.split(",")]
         for leg, cfg, b in legs:
-            # the headline is measured: a leg that does not come back must not cost it - the line goes out without the rest
+            # the headline is measured: a leg that does not come back must not cost it - the line goes out without the rest,
+            # and the exit code (EXIT_WATCHDOG) tells the caller that a GPU leg hung
             def bail(leg=leg):
                 out["also_measured_incomplete"] = "leg %r did not finish within %d s; the line was printed without it and the legs behind it" % (leg, args.leg_timeout)
                 print(json.dumps(out), flush=True)
                 faulthandler.dump_traceback(file=sys.stderr)
-                os._exit(0)
+                os._exit(EXIT_WATCHDOG)
             guard = threading.Timer(args.leg_timeout, bail)
             guard.daemon = True
             guard.start()
@@ -634,7 +713,7 @@ def main():
             out.setdefault("also_measured", {})[leg] = slim(rec)
     if rank == 0 and getattr(ctx, "cpu_job", None) is not None:
         # the CPU baseline comes last and under a guard: it is the one leg whose duration this script does not control (a
-        # host that throttles 64 threads down to a few cores can turn its thread probe into minutes) - the measured GPU
+        # host that throttles 64 threads down to a few cores can turn its thread table into minutes) - the measured GPU
         # numbers must not wait for it
         import threading
         conf_c, x_c, budget = ctx.cpu_job
@@ -644,7 +723,7 @@ def main():
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = "the CPU leg did not finish within %d s on this host; line printed without it" % limit
             print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(EXIT_WATCHDOG)
         guard = threading.Timer(limit, bail_cpu)
         guard.daemon = True
         guard.start()

@@ -393,23 +393,47 @@ class EncoderPlan:
         self._ws_small = 0
         self._held = 0
 
+    def _walk(self):
+        """The module tree, flattened ONCE: every module's child dictionary (the structural fingerprint is the ids of their
+        values, re-read in every call - plain dictionary reads, ~5 us for a ResNet trunk, where ``encoder.modules()`` costs
+        ~100 us in front of the first launch of EVERY ips() call), the (dictionary, key) slot of every parameter / buffer
+        that exists, and the slots that are None today (a bias or a running statistic that appears later is seen)."""
+        kids, slots, empty = [], [], []
+        for mod in self.encoder.modules():
+            kids.append(mod._modules)
+            for d in (mod._parameters, mod._buffers):
+                for k, t in d.items():
+                    (slots if t is not None else empty).append((d, k))
+        return kids, slots, empty
+
+    @staticmethod
+    def _structure(kids):
+        return tuple(id(c) for d in kids for c in d.values())
+
     def _signature(self):
-        """(storage pointer, version counter) of every parameter and buffer.  The walk over the module tree (~100 us for a
-        ResNet trunk: it sits in front of the first launch of EVERY ips() call) is done once: what is kept are the modules'
-        own parameter / buffer dictionaries, read afresh in every call - a tensor that is replaced, moved or written in
-        place is seen; a CHILD MODULE exchanged below the top level of the encoder is not (the top level is checked)."""
-        top = tuple(id(m) for m in self.encoder._modules.values())
-        if self._holders is None or self._holders[0] != top:
-            slots = []
-            for mod in self.encoder.modules():
-                slots += [(mod._parameters, k) for k, t in mod._parameters.items() if t is not None]
-                slots += [(mod._buffers, k) for k, t in mod._buffers.items() if t is not None]
-            self._holders = (top, slots)
-        sig = [precision(), weights_generation()]
-        for d, k in self._holders[1]:
-            t = d[k]
-            sig.append((t.data_ptr(), t._version))
-        return tuple(sig)
+        """(storage pointer, version counter) of every parameter and buffer + the ids of every child module: a tensor that
+        is replaced, moved or written in place, a child module exchanged at ANY depth (``layer2[0].bn1 = ...``,
+        ``convert_sync_batchnorm``), an entry that appears, disappears or stops being None - each re-packs the plan."""
+        h = self._holders
+        if h is not None:
+            try:
+                if self._structure(h[1]) != h[0] or any(d[k] is not None for d, k in h[3]):
+                    h = None
+            except KeyError:
+                h = None
+        for _ in range(2):
+            if h is None:
+                kids, slots, empty = self._walk()
+                h = self._holders = (self._structure(kids), kids, slots, empty)
+            sig = [precision(), weights_generation(), h[0]]
+            try:
+                for d, k in h[2]:
+                    t = d[k]
+                    sig.append((t.data_ptr(), t._version))
+                return tuple(sig)
+            except (KeyError, AttributeError):         # an entry was removed / set to None since the walk: walk again
+                h = None
+        raise RuntimeError("EncoderPlan: the encoder's parameters changed while they were being read")
 
     def _conv(self, conv, bn, prec=0, stem=False):
         packed = _pack_conv(conv.weight)
@@ -853,13 +877,24 @@ _PERSIST_OFF = None
 
 
 def persistent_wait_ms(ms=0):
-    """Longest wait of a persistent loop (and its gate) without any progress, in ms (default 50); ms > 0 sets it."""
+    """Longest wait of a persistent loop (and its gate) without any progress, in ms (default 50); ms > 0 sets it.
+    ``IPSX_PERSIST_WAIT_MS`` sets it once per process, when the first device is asked about (``persistent_ok``)."""
     return lib().ipsx_set_persistent_wait_ms(int(ms))
 
 
+_PERSIST_STRIKES = 0
+_PERSIST_WAIT_SET = False
+
+
 def persistent_ok(dev):
+    global _PERSIST_WAIT_SET
     if _PERSIST_OFF is not None:
         return False
+    if not _PERSIST_WAIT_SET:
+        _PERSIST_WAIT_SET = True
+        ms = int(os.environ.get("IPSX_PERSIST_WAIT_MS", "0") or 0)
+        if ms > 0:
+            persistent_wait_ms(ms)
     dev = torch.device(dev)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     ok = _PERSIST_OK.get(idx)
@@ -876,6 +911,32 @@ def persistent_disable(reason):
         _PERSIST_OFF = reason
         warnings.warn("ips_amd: persistent selection loops are switched off for this process: " + reason +
                       " (IPSX_SCAN_PERSIST=0 avoids the attempt)")
+
+
+def persistent_timed_out(dev):
+    """A persistent loop gave up waiting (its call was redone by the conditional launch: results valid).  ONE such event
+    on healthy hardware is a stalled host - the garbage collector, the allocator synchronising for a hipFree, a main
+    stream sharing the side stream's hardware queue for a moment - between the loop's launch and its producer's; it does
+    not cost a long-running job its pipelines: the device's self-test is run again (a device synchronisation, once per
+    event), and the pipelines stay on while it passes and fewer than ``IPSX_PERSIST_STRIKES`` (default 3) loops have
+    timed out in this process.  -> True when they stay on."""
+    global _PERSIST_STRIKES
+    import warnings
+    _PERSIST_STRIKES += 1
+    limit = max(1, int(os.environ.get("IPSX_PERSIST_STRIKES", "3") or 3))
+    what = "a persistent selection loop timed out waiting for rows (its call was redone with per-part launches: results valid)"
+    if _PERSIST_STRIKES >= limit:
+        persistent_disable("%s - %d such events in this process" % (what, _PERSIST_STRIKES))
+        return False
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ok = _PERSIST_OK[idx] = _persistent_selftest(torch.device("cuda", idx))
+    if not ok:
+        persistent_disable(what + "; a loop beside its producer no longer passes the device's self-test")
+        return False
+    warnings.warn("ips_amd: %s; the device's self-test passes, the persistent pipelines stay on (event %d of %d allowed; "
+                  "IPSX_PERSIST_WAIT_MS raises the wait, IPSX_PERSIST_STRIKES the allowance)" % (what, _PERSIST_STRIKES, limit))
+    return True
 
 
 def _persistent_selftest(dev):
@@ -1162,16 +1223,33 @@ def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw):
     return conv2d_nhwc(dy, weight, 1, kh - 1 - pad, dgrad_weights=True)
 
 
+# ipsx_conv2d_wgrad_nhwc addresses x and dy through 32-bit buffer offsets: either activation of ONE call stays below this
+# many bytes (csrc/conv_wgrad.hip: "call per slice and add"); conv2d_nhwc_wgrad slices the image axis accordingly
+_WGRAD_MAX_BYTES = (1 << 31) - (1 << 20)
+
+
 def conv2d_nhwc_wgrad(x, dy, weight_shape, stride, pad):
-    """Weight gradient of ``conv2d_nhwc`` -> (C_out, C_in, kh, kw) in channels-last memory order (ipsx_conv2d_wgrad_nhwc)."""
+    """Weight gradient of ``conv2d_nhwc`` -> (C_out, C_in, kh, kw) in channels-last memory order (ipsx_conv2d_wgrad_nhwc).
+    Activations of 2 GiB and more (the kernel's buffer range) are taken in slices of whole images, the slices' gradients
+    added in slice order (deterministic; the forward kernel slices per launch in the same way)."""
     co, ci, kh, kw = weight_shape
     n, _, h, w = x.shape
     dy = dy.contiguous(memory_format=_CL)
+    ho, wo = dy.shape[2:]
+    per_image = 4 * max(h * w * ci, ho * wo * co)
+    step = max(1, min(n, _WGRAD_MAX_BYTES // per_image))
     dw = torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device, memory_format=_CL)
-    nb = lib().ipsx_conv2d_wgrad_nhwc_workspace_bytes(n, ci, co, kh, kw)
+    nb = max(lib().ipsx_conv2d_wgrad_nhwc_workspace_bytes(c, ci, co, kh, kw) for c in {step, n - (n - 1) // step * step})
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
-    _ck(lib().ipsx_conv2d_wgrad_nhwc(_p(x), _p(dy), n, h, w, ci, co, kh, kw, stride, pad, _p(dw), _p(ws), nb, _stream()),
-        "ipsx_conv2d_wgrad_nhwc")
+    part = dw
+    for i0 in range(0, max(n, 1), step):
+        cnt = min(step, n - i0)
+        if i0 > 0 and part is dw:
+            part = torch.empty_like(dw)
+        _ck(lib().ipsx_conv2d_wgrad_nhwc(_p(x[i0:i0 + cnt]), _p(dy[i0:i0 + cnt]), cnt, h, w, ci, co, kh, kw, stride, pad,
+                                         _p(part), _p(ws), nb, _stream()), "ipsx_conv2d_wgrad_nhwc")
+        if part is not dw:
+            dw += part
     return dw
 
 

@@ -21,7 +21,8 @@ Launch sizes come from the device (``hip.device_geometry``): a producer that run
 compute units they leave free on the FULLEST XCD (workgroups are dealt to XCDs round-robin), the fused trunk's
 "round" is 8 patches per compute unit.  Whether persistent kernels can run beside their producers at all is established
 ONCE per device by a self-test (``hip.persistent_ok``: under counter collection or a serialising debug switch they
-cannot) and revoked for the process when a loop ever times out (``hip.persistent_disable``).
+cannot), checked again when a loop times out, and revoked for the process when that check fails or loops keep timing out
+(``hip.persistent_timed_out``).
 """
 
 import math
@@ -97,16 +98,16 @@ class Selection:
         A loop that gave up waiting (no progress for hip.persistent_wait_ms: something serialises the kernels, so that its
         producers cannot run beside it) is REDONE in the same call by the conditional launch of ``persistent_end``, so a
         call's results are valid either way and no host synchronisation is added.  The status word is mirrored into pinned
-        host memory, asynchronously, and looked at in the NEXT call - by then it has long arrived: a timeout switches the
-        persistent pipelines off for the rest of the process (the per-part launches take over) and says so once."""
+        host memory, asynchronously, and looked at in the NEXT call - by then it has long arrived: a timeout re-runs the
+        device's self-test, and repeated timeouts (``hip.persistent_timed_out``: IPSX_PERSIST_STRIKES, default 3) or a failing
+        self-test switch the persistent pipelines off for the rest of the process (the per-part launches take over)."""
         zeroed.zero_()                             # (first: everything below is host work in front of the call's second launch)
         net = self.net
         ca = net.transf.crs_attn
         mirror = self.scan_status_host
         if mirror is not None and int(mirror.item()) & 1:
             mirror.zero_()
-            hip.persistent_disable("a persistent selection loop timed out waiting for rows (its call was redone with "
-                                   "per-part launches: results valid)")
+            hip.persistent_timed_out(dev)          # (self-test again; off for the process only after repeated events)
         side, main = self.streams(dev)
         tie, words, ctl = zeroed[:B], zeroed[B:2 * B + 1], zeroed[2 * B + 1:]
         ready, status = words[:B], words[B:B + 1]

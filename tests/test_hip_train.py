@@ -22,7 +22,8 @@ def _rel(a, b):
 @pytest.mark.parametrize("P,ci,co,k,s,H", [(16, 64, 64, 3, 1, 8), (33, 64, 128, 3, 2, 8), (7, 64, 128, 1, 2, 8), (40, 128, 128, 3, 1, 4),
                                              (5, 128, 256, 3, 2, 13), (3, 256, 256, 3, 1, 7), (1024, 64, 64, 3, 1, 8), (2, 512, 512, 3, 1, 2),
                                              (9, 64, 64, 3, 1, 13), (4, 64, 64, 1, 1, 1), (37, 1, 64, 7, 2, 32), (1024, 1, 64, 7, 2, 32), (5, 1, 64, 7, 2, 50),
-                                             (1023, 128, 128, 3, 1, 4), (6, 64, 128, 3, 2, 8), (1, 64, 64, 3, 1, 8)])
+                                             (1023, 128, 128, 3, 1, 4), (6, 64, 128, 3, 2, 8), (1, 64, 64, 3, 1, 8),
+                                             (4, 256, 512, 3, 2, 7), (6, 128, 256, 1, 2, 13), (4, 256, 512, 1, 2, 7), (3, 256, 512, 3, 2, 4)])
 def test_conv_train_kernels_match_torch(P, ci, co, k, s, H):
     """The training step's convolutions on libipsx's kernels (training/fused_encoder.py::_Conv): forward and data gradient
     on conv_nhwc_kernel, weight gradient on conv_wgrad_kernel - against float64 autograd of F.conv2d, and bit-identical
@@ -52,6 +53,45 @@ def test_conv_train_kernels_match_torch(P, ci, co, k, s, H):
     again = hip.conv2d_nhwc_wgrad(x, dy, w.shape, s, pad)
     assert torch.equal(again, hip.conv2d_nhwc_wgrad(x, dy, w.shape, s, pad))
     assert torch.equal(again.contiguous(), wh.grad.contiguous())
+
+
+def test_weight_gradient_of_activations_beyond_one_buffer_is_sliced(monkeypatch):
+    """conv2d_nhwc_wgrad on activations of 2 GiB and more (ipsx_conv2d_wgrad_nhwc addresses one 2 GiB buffer per call):
+    whole-image slices, added in slice order.  First with the limit lowered so that a small case is cut into four slices
+    (against float64 autograd and against the slices added by hand, bit for bit), then at a real size - 2,700 maps of
+    56 x 56 x 64 are 2.17 GB each way -, where the stock path and the forward kernel work and this used to raise."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    P, ci, co, H = 33, 64, 128, 8
+    x = torch.randn((P, ci, H, H), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((P, co, 4, 4), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    whole = hip.conv2d_nhwc_wgrad(x, dy, (co, ci, 3, 3), 2, 1)
+    monkeypatch.setattr(hip, "_WGRAD_MAX_BYTES", 9 * 4 * ci * H * H)          # nine images per call: 9 + 9 + 9 + 6
+    sliced = hip.conv2d_nhwc_wgrad(x, dy, (co, ci, 3, 3), 2, 1)
+    monkeypatch.undo()
+    by_hand = None
+    for i0 in range(0, P, 9):
+        part = hip.conv2d_nhwc_wgrad(x[i0:i0 + 9], dy[i0:i0 + 9], (co, ci, 3, 3), 2, 1)
+        by_hand = part if by_hand is None else by_hand + part
+    assert torch.equal(sliced, by_hand)
+    xs, ws = x.double(), torch.zeros((co, ci, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(xs, ws, None, 2, 1).backward(dy.double())
+    assert _rel(sliced.double(), ws.grad) < 1e-5 and _rel(whole.double(), ws.grad) < 1e-5
+
+    P, C, H = 2700, 64, 56
+    x = torch.empty((P, C, H, H), device=dev).contiguous(memory_format=torch.channels_last).normal_(generator=torch.Generator(device=dev).manual_seed(1))
+    dy = torch.empty((P, C, H, H), device=dev).contiguous(memory_format=torch.channels_last).normal_(generator=torch.Generator(device=dev).manual_seed(2))
+    assert x.numel() * 4 >= 1 << 31
+    dw = hip.conv2d_nhwc_wgrad(x, dy, (C, C, 3, 3), 1, 1)
+    step = hip._WGRAD_MAX_BYTES // (4 * C * H * H)
+    assert 0 < step < P
+    by_hand = hip.conv2d_nhwc_wgrad(x[:step], dy[:step], (C, C, 3, 3), 1, 1) + hip.conv2d_nhwc_wgrad(x[step:], dy[step:], (C, C, 3, 3), 1, 1)
+    assert torch.equal(dw, by_hand) and bool(torch.isfinite(dw).all())
+    # a sample of the entries against float64 on a slice of the images (the full float64 convolution would need 20 GB)
+    probe = hip.conv2d_nhwc_wgrad(x[:64], dy[:64], (C, C, 3, 3), 1, 1)
+    ws = torch.zeros((C, C, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(x[:64].double(), ws, None, 1, 1).backward(dy[:64].double())
+    assert _rel(probe.double(), ws.grad) < 1e-5
 
 
 @pytest.mark.parametrize("P,C,H,relu,res", [(8, 64, 16, True, False), (5, 64, 8, True, True), (3, 128, 4, False, False),
@@ -130,29 +170,26 @@ def _stock_taps(encoder, x):
     return mods[-1](h).flatten(1), taps
 
 
-@pytest.mark.parametrize("conf_fn,patch,min_clean", [(synth.mnist_conf, 32, 1), (synth.traffic_conf, 64, 0)])
-def test_fused_encoder_matches_stock_autograd(conf_fn, patch, min_clean):
+@pytest.mark.parametrize("conf_fn,patch", [(synth.mnist_conf, 32), (synth.traffic_conf, 64)])
+def test_fused_encoder_matches_float64_autograd(conf_fn, patch):
     """Same modules, same input: embeddings, loss, every parameter gradient and the BatchNorm running statistics of the
-    fused path equal those of the stock ops to fp32 rounding.
+    fused path against the SAME modules evaluated by stock autograd in float64 (round 5; rounds 2-4 compared with the
+    stock float32 path, whose convolution algorithm MIOpen picks per process - the set of usable seeds moved from run to
+    run and the bound had to be loosened until a real bug could have passed).
 
     One caveat is inherent to ReLU networks, not to this path: an activation that is zero to rounding (|y| ~ 1e-7) can
-    come out as +1 ulp on one path and as 0 on the other, which switches that element's gradient on or off (observed:
-    1 element of 98,304 for one seed, moving the smallest gradient sums by ~2 %).  So the ReLU masks of both paths are
-    compared first; seeds without such a flip (most of them for the 2-stage MNIST trunk with its 0.4 M activations, at
-    least one of four for the 4-stage trunk on 64-px patches with 3 M) are held to the tight bound, the others to a
-    loose one."""
+    come out as +1 ulp in float32 and as -1e-9 in float64, which switches that element's gradient on or off.  The ReLU
+    masks of both evaluations are compared first; a seed with such a flip (rare: ~0.4 M activations in the 2-stage
+    trunk, 3 M in the 4-stage trunk on 64-px patches) is held to a loose bound only, and at least TWO seeds of at most
+    ten must be free of flips and pass the tight bound on every parameter gradient."""
     dev = torch.device("cuda:0")
     conf = conf_fn(N=64, M=8, I=8, patch=patch)
     clean = 0
     for seed in range(10):
-        # (whether a seed is free of ReLU flips depends on the stock path's convolution algorithm, which MIOpen picks per
-        #  PROCESS - in about one run of seven every seed of the 4-stage trunk has a flip: four seeds, then more until
-        #  enough clean ones have been held to the tight bound; the kernels themselves are held to float64 in
-        #  test_conv_train_kernels_match_torch)
-        if seed >= 4 and clean >= min_clean:
+        if seed >= 3 and clean >= 2:
             break
         net_a = synth.fill_weights(IPSNet(dev, conf), 5 + seed).to(dev).train()
-        net_b = copy.deepcopy(net_a)
+        enc_b = copy.deepcopy(net_a.encoder).double()
         assert fused_encoder.supported(net_a.encoder)
         g = torch.Generator(device="cpu").manual_seed(seed)
         P = 24
@@ -163,25 +200,25 @@ def test_fused_encoder_matches_stock_autograd(conf_fn, patch, min_clean):
         emb_a = fused_encoder.encode(net_a.encoder, x, taps_a)
         loss_a = ((emb_a - t) ** 2).mean()
         loss_a.backward()
-        emb_b, taps_b = _stock_taps(net_b.encoder, x)
-        loss_b = ((emb_b - t) ** 2).mean()
+        emb_b, taps_b = _stock_taps(enc_b, x.double())
+        loss_b = ((emb_b - t.double()) ** 2).mean()
         loss_b.backward()
 
-        assert _rel(emb_a.detach(), emb_b.detach()) < 1e-5
+        assert _rel(emb_a.detach().double(), emb_b.detach()) < 1e-5
         assert abs(float(loss_a.detach()) - float(loss_b.detach())) <= 1e-5 * abs(float(loss_b.detach()))
         flips = sum(int(((ha > 0) != (hb > 0)).sum()) for ha, hb in zip(taps_a, taps_b))
         assert flips <= 8
         clean += flips == 0
         tol = 5e-5 if flips == 0 else 0.2
-        for (na, pa), (nb, pb) in zip(net_a.encoder.named_parameters(), net_b.encoder.named_parameters()):
+        for (na, pa), (nb, pb) in zip(net_a.encoder.named_parameters(), enc_b.named_parameters()):
             assert na == nb and pa.grad is not None
-            assert _rel(pa.grad, pb.grad) < tol, (seed, na, flips)
-        for (na, ba), (nb, bb) in zip(net_a.encoder.named_buffers(), net_b.encoder.named_buffers()):
+            assert _rel(pa.grad.double(), pb.grad) < tol, (seed, na, flips)
+        for (na, ba), (nb, bb) in zip(net_a.encoder.named_buffers(), enc_b.named_buffers()):
             if na.endswith("num_batches_tracked"):
                 assert int(ba) == int(bb) == 1
             else:
-                assert _rel(ba, bb) < 1e-5, na
-    assert clean >= min_clean
+                assert _rel(ba.double(), bb) < 1e-5, na
+    assert clean >= 2
 
 
 def test_training_forward_uses_the_fused_path_and_env_switches_it_off(monkeypatch):

@@ -92,3 +92,47 @@ def test_abi_major_and_the_round_4_additions_are_declared():
     assert lib.ipsx_conv2d_wgrad_nhwc_supported(64, 128, 3, 3, 2, 1) == 1 and lib.ipsx_conv2d_wgrad_nhwc_supported(1, 64, 7, 7, 2, 3) == 1
     assert lib.ipsx_conv2d_wgrad_nhwc_supported(3, 64, 7, 7, 2, 3) == 0 and lib.ipsx_conv2d_wgrad_nhwc_supported(64, 96, 3, 3, 1, 1) == 0
     assert lib.ipsx_conv2d_wgrad_nhwc_workspace_bytes(0, 64, 64, 3, 3) == 0
+
+
+def test_plan_signature_sees_nested_module_swaps_and_new_entries():
+    """EncoderPlan._signature (CPU: it only reads pointers and version counters): in-place writes, replaced tensors, a child
+    module exchanged BELOW the top level, a buffer that was None and appears, an entry that is removed - each changes the
+    signature (the advisor's round-4 finding: a nested swap after the first ips() kept stale packed weights)."""
+    net = IPSNet(torch.device("cpu"), synth.mnist_conf(N=200, M=16, I=16)).eval()
+    plan = hip.EncoderPlan(net.encoder, True)
+    s0 = plan._signature()
+    assert plan._signature() == s0
+    with torch.no_grad():
+        net.encoder[4][0].conv1.weight.mul_(2.0)                   # in place: the version counter moves
+    s1 = plan._signature()
+    assert s1 != s0
+    old_bn = net.encoder[5][1].bn2
+    net.encoder[5][1].bn2 = torch.nn.BatchNorm2d(old_bn.num_features)   # a nested child replaced
+    s2 = plan._signature()
+    assert s2 != s1 and plan._signature() == s2
+    bn = net.encoder[1]
+    keep = bn.running_mean
+    bn.running_mean = None                                          # an entry goes away (stays in the dict as None) ...
+    s3 = plan._signature()
+    assert s3 != s2
+    bn.running_mean = keep                                          # ... and one that was None appears
+    s4 = plan._signature()
+    assert s4 != s3
+    del net.encoder[4][1].bn1._buffers["num_batches_tracked"]       # a key removed outright: no KeyError, a new signature
+    assert plan._signature() != s4
+
+
+def test_bench_py_parent_starts_the_ranks_and_hands_their_failure_on():
+    """``python bench.py --gpus 2`` with no launcher environment starts its own ranks as a child process; here (no GPU) the
+    ranks refuse to run, and the parent's exit code says so.  (The same command on a GPU: tests/test_hip_e2e.py.)"""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("the GPU variant of this test runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs a GPU") == 2 and "2-rank child run exited" in out.stderr
