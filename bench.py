@@ -136,12 +136,14 @@ def cpu_baseline(conf, x, budget_s):
     """The reference's CPU path (ATen restatement, oracle/ips_torch.py) on a BOUNDED sample of the same workload.
 
     Thread count (round 5: the probe on a 2 x 320-patch prefix did not predict the batch - 5.6 k at 64 threads on one
-    box, 9.3 k at 32 on the next of the same CPU model): FIXED counts 16 / 32 / 64 (capped by the CPUs this process may
-    use), each timed on whole ``ips()`` calls over at least ONE FULL image of the workload (the faster of two calls
-    after a warm-up call), the table goes into the record and the best count runs the sample.  The sample: whole
-    calls on the batch itself when one call fits the budget, otherwise on a prefix of it - fewer images first, then a
-    shorter patch axis cut at a chunk boundary (only where one image alone exceeds the budget: the per-patch cost of
-    the loop does not depend on N) - repeated until the budget is used."""
+    box, 9.3 k at 32 on the next of the same CPU model; and ONE image alone does not either: 21 k patches/s at 16 threads
+    where the batch of 16 reaches 10.6 k): FIXED counts 16 / 32 / 64 (capped by the CPUs this process may use), each timed
+    on whole ``ips()`` calls over the WHOLE BATCH with the patch axis cut at a chunk boundary - every iteration then has
+    the sample's own shape (B x I patches through the encoder, M + I candidates per image), and a call covers at least
+    one full image's worth of patches -, the faster of two calls after a warm-up call; the table goes into the record
+    and the best count runs the sample.  The sample: whole calls on the batch itself when one call fits the budget,
+    otherwise on a prefix of it - fewer images first, then a shorter patch axis cut at a chunk boundary - repeated until
+    the budget is used."""
     from ips_amd import synth
     from ips_amd.architecture import IPSNet
     from oracle import ips_torch
@@ -152,35 +154,28 @@ def cpu_baseline(conf, x, budget_s):
     host = host_description()
     avail = host["cpus_available"]
     pos_full = net.pos_enc[:, :N] if conf.use_pos else None
-    # one image must be affordable three times per thread count: otherwise (traffic signs / 10,000-candidate CAMELYON on
-    # a small host) the table is taken on a chunk-aligned prefix of the image and says so
-    torch.set_num_threads(min(avail, 32))
-    n_quick = min(N, conf.M + 2 * conf.I)
-    ips_torch.ips(sd, conf.clone(N=n_quick), x[:1, :n_quick], net.pos_enc[:, :n_quick] if conf.use_pos else None)
-    t0 = time.perf_counter()
-    ips_torch.ips(sd, conf.clone(N=n_quick), x[:1, :n_quick], net.pos_enc[:, :n_quick] if conf.use_pos else None)
-    est_image = (time.perf_counter() - t0) / n_quick * N
-    n_tab = N
-    if 9 * est_image > max(budget_s, 1.0) * 2:
-        room = max(conf.M + conf.I, int(N * (2 * budget_s / 9) / est_image))
-        n_tab = max(conf.M + conf.I, min(N, conf.M + (room - conf.M) // conf.I * conf.I))
+    # the table's shape: all B images, M + k I patches each with B (M + k I) >= N (one image's worth) and k >= 8
+    k_tab = max(8, -(-(max(N // B, conf.M) - conf.M) // conf.I))
+    n_tab = min(N, conf.M + k_tab * conf.I)
     tab_conf = conf if n_tab == N else conf.clone(N=n_tab)
     pos_tab = net.pos_enc[:, :n_tab] if conf.use_pos else None
     table, best = [], None
     for thr in sorted({min(avail, c) for c in (16, 32, 64)}):
         torch.set_num_threads(thr)
-        ips_torch.ips(sd, tab_conf, x[:1, :n_tab], pos_tab)       # warm-up at this count (thread pool, oneDNN primitives)
+        ips_torch.ips(sd, tab_conf, x[:, :n_tab], pos_tab)        # warm-up at this count (thread pool, oneDNN primitives)
         dt = None
         for _ in range(2):
             t0 = time.perf_counter()
-            ips_torch.ips(sd, tab_conf, x[:1, :n_tab], pos_tab)
+            ips_torch.ips(sd, tab_conf, x[:, :n_tab], pos_tab)
             d1 = time.perf_counter() - t0
             dt = d1 if dt is None else min(dt, d1)
-        table.append({"threads": thr, "patches_per_s": n_tab / dt, "ms_per_image": 1e3 * dt})
+        table.append({"threads": thr, "patches_per_s": B * n_tab / dt, "ms_per_call": 1e3 * dt})
         if best is None or dt < best[1]:
             best = (thr, dt)
+        if dt > max(budget_s, 1.0):                              # (a host on which this count chokes: no larger ones)
+            break
     torch.set_num_threads(best[0])
-    per_patch = best[1] / n_tab                                 # seconds per patch at the best count
+    per_patch = best[1] / (B * n_tab)                           # seconds per patch at the best count
     # the sample: as much of the batch as one call can take in about a third of the budget
     room = max(1, int(budget_s / 3 / per_patch))                # patches
     b_s = max(1, min(B, room // N))
@@ -200,7 +195,8 @@ def cpu_baseline(conf, x, budget_s):
             "threads": torch.get_num_threads(), "nproc": host["nproc"], "cpus_available": avail, "cpu_model": host["cpu_model"],
             "kind": "port",
             "thread_table": table,
-            "thread_table_on": "one image x %d patches%s, faster of two ips() calls per count" % (n_tab, "" if n_tab == N else " (a chunk-aligned prefix: a full image does not fit the budget)"),
+            "thread_table_on": "%d image(s) x %d patches (the whole batch, patch axis cut at a chunk boundary: the sample's own "
+                               "per-iteration shape), faster of two ips() calls per count" % (B, n_tab),
             "sample": "%d x ips() on %s, %d image(s) x %d patches (oracle/ips_torch.py: the reference's ATen/oneDNN CPU path "
                       "restated, %.1f s; thread count = best of the fixed counts in thread_table)"
                       % (reps, "the bench batch itself" if whole else "a prefix of the bench batch (first images, patch axis cut at a chunk boundary)",

