@@ -24,8 +24,14 @@
  *   - eval BatchNorm is the affine y = fma(acc, alpha, shift) with
  *     alpha = gamma * (1/sqrt(var+eps)), shift = beta - mean*alpha;
  *   - exp() is ipsx's own fma polynomial (identical bits on host and device);
- *   - row sums (softmax denominators, LayerNorm moments) are 64 strided partial
- *     sums combined by an xor butterfly (the wavefront reduction order).
+ *   - row sums (softmax denominators, the transformer's LayerNorm moments) are 64 strided
+ *     partial sums combined by an xor butterfly (the wavefront reduction order);
+ *   - the projector (ipsx_projector*) evaluates Linear(LayerNorm(x)) with the LayerNorm FOLDED
+ *     into the epilogue: acc = the fma chain of the RAW row, t = fma(-mean, colsum[o], acc),
+ *     u = t * rstd, y = relu(fma(u, alpha, shift')); the row's moments are eight chains - chain
+ *     (h, j) over x[8g + 4h + j], g ascending: exactly what lane (row, half h) of the GEMM's
+ *     operand stream holds - folded ((c0+c1)+(c2+c3)) per half, half 0 + half 1;
+ *     mean = sum / F, var = fma(-mean, mean, sumsq / F) clamped at 0, rstd = 1 / sqrt(var + eps).
  */
 #ifndef IPSX_H
 #define IPSX_H
@@ -48,8 +54,11 @@ extern "C" {
  *         ipsx_projector_stream accepts
  *         short_first <= -3 (guided tile sizes)
  *   2.02  round 4: ipsx_scan_persistent_on, ipsx_scan_persistent_groupable
- *   2.03  round 4: ipsx_scan_persistent_ws, ipsx_scan_range_if_ws (persistent loops for candidate sets beyond the LDS) */
-#define IPSX_VERSION 203
+ *   2.03  round 4: ipsx_scan_persistent_ws, ipsx_scan_range_if_ws (persistent loops for candidate sets beyond the LDS)
+ *   3.00  round 5: struct ipsx_conv grew by `colsum` (every struct that embeds it moved) and the projector's arithmetic
+ *         contract changed (LayerNorm folded into the epilogue: ipsx_projector* need lin->colsum, ipsx_projector_stats
+ *         returns the moments in the operand-stream order); ipsx_weight_colsum added */
+#define IPSX_VERSION 300
 
 #define IPSX_OK            0
 #define IPSX_EINVAL       -1      /* bad argument / unsupported shape */
@@ -111,6 +120,8 @@ typedef struct ipsx_conv {
     const float* shift;           /* c_out, BatchNorm shift / bias (or NULL) */
     const void* w_packed_bf16;    /* bf16 operand stream for ipsx_trunk.precision: ipsx_pack_conv_weight_bf16
                                      (precision 1) or ipsx_pack_conv_weight_x3 (precision 2); NULL = fp32 only */
+    const float* colsum;          /* c_out, sum over c_in of the weights (ipsx_weight_colsum): the projector's Linear
+                                     only (ipsx_projector*: the folded LayerNorm's mean term); NULL elsewhere      */
 } ipsx_conv;
 
 /* one residual block: BasicBlock (n_conv = 2) or Bottleneck (n_conv = 3)     */
@@ -222,10 +233,13 @@ int ipsx_patchify_sparse(const int64_t* index, const float* value, const int64_t
 
 /* Replaces IPSNet.encoder as built by get_projector (ips_net.py:54-60):
  * ReLU(BN1d(Linear(LayerNorm_noaffine(x)))); x (n,f) -> out (n,d).
- * `lin` is the Linear packed as a 1x1 conv (c_in=f, c_out=d) whose alpha/shift
+ * `lin` is the Linear packed as a 1x1 conv (c_in=f, c_out=d; f % 32 == 0) whose alpha/shift
  * hold the BatchNorm affine with the Linear bias folded into shift
- * (shift' = fma(bias, alpha, shift)).  LayerNorm is applied to the GEMM's A operand in
- * registers from a (mean, rstd) pass; workspace: ipsx_projector_workspace_bytes(n).                */
+ * (shift' = fma(bias, alpha, shift)) and whose colsum holds ipsx_weight_colsum of the weights.
+ * The LayerNorm is folded into the GEMM's epilogue (see "Arithmetic contract") from a (mean, rstd)
+ * pass; workspace: ipsx_projector_workspace_bytes(n).                                              */
+/* cs[o] = sum over c of w[o][c] of a Linear's (c_out, c_in) fp32 weights: ascending in float64, rounded once */
+int ipsx_weight_colsum(const float* w, int c_out, int c_in, float* colsum, void* stream);
 int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps,
                    float* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t ipsx_projector_workspace_bytes(int64_t n);      /* 8 bytes per row: (mean, rstd) */
@@ -256,8 +270,9 @@ int ipsx_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n_patch
 
 /* The projector AND the logits of one slide as ONE persistent launch that feeds ipsx_scan_persistent row by row
  * (reference: the projector of architecture/ips_net.py:60-66 applied chunk by chunk in IPSNet.ips :213-241, and
- * transformer.py:71-83 for the logits).  Resident workgroups pull 64-row tiles off a counter; a tile's LayerNorm
- * moments, Linear + BatchNorm + ReLU (out: emb, (n, 512)), and logits against the folded query v_packed
+ * transformer.py:71-83 for the logits).  Resident workgroups pull 64-row tiles off a counter; a tile's Linear (its rows'
+ * LayerNorm moments come off the GEMM's own operand registers: every row is read once) + folded LayerNorm + BatchNorm +
+ * ReLU (out: emb, (n, 512)), and logits against the folded query v_packed
  * (ipsx_fold_query; r = h * n_token <= 32; out: logits (n, r)) are computed in place, and `*ready` - the progress word
  * of the selection loop - is advanced past every completed 32-row unit in order.  Several slides: x holds them one
  * after the other (n rows in all, slide_rows each, a multiple of 32), ready[s] is slide s's word, and the stream of
@@ -268,7 +283,7 @@ int ipsx_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n_patch
  * last `tail` x workgroups units are 32-row tiles (early first rows, an even end; head = 0: half the workgroups start
  * short as with -1), and the few units left over when every workgroup has had its whole share go out as four column
  * quarters each (the logits' accumulators pass from quarter to quarter: the same bits).  ipsx_projector_stream_supported: 1x1 Linear with
- * 512 outputs, c_in % 32 == 0, c_in <= 2048, 64 <= n < 2^31.                                          */
+ * 512 outputs and its column sums (lin->colsum), c_in % 32 == 0, 64 <= n < 2^31.                    */
 size_t ipsx_projector_stream_ctl_words(int64_t n);
 int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r);
 int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t n, int64_t slide_rows, float ln_eps, float* emb,

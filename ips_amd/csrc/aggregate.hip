@@ -41,20 +41,30 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     }
 }
 
-// (mean, rstd) of every row - the moments of layernorm_rows_kernel, same arithmetic (64 strided partial sums in
-// ascending order + xor butterfly; centred second moment) - for consumers that normalise on the fly
-// (conv_nhwc_kernel<.., NORM>).  One wavefront per row; a row of up to 64 * RS_MAX floats stays in registers between
-// the two passes (every element is read ONCE, 256 B per wave-instruction), longer rows are re-read.
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, long long n, int d, float eps,
-                                                        float2* __restrict__ stats, int* ready, int value) {
+// (mean, rstd) of every feature row for the projector's GEMM, which folds the LayerNorm into its epilogue
+// (conv_nhwc_kernel<.., NORM>): the moments in the order the GEMM's own operand stream would give them
+// (ipsx_rowstats.h row_moments_wave32 - projector_stream_kernel takes them off its operand registers instead).
+// One wavefront per 32 rows.
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ x, long long n, int d, float eps,
+                                                          float2* __restrict__ stats, int* ready, int value) {
     // (ipsx_projector_stats_publish: everything enqueued before this launch has completed and is visible - that is what
     //  the stream order of two kernels means - so the first thread can say so on behalf of a launch of its own)
     if (ready && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ready, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float2 st = row_stats_wave(x + (size_t)row * d, d, eps, lane);
-    if (lane == 0) stats[row] = st;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (row0 >= n) return;
+    const float2 st = row_moments_wave32(x, row0, n, d, eps, lane);
+    if (lane < 32 && row0 + lane < n) stats[row0 + lane] = st;
+}
+
+// cs[o] = sum_c w[o][c] of a Linear's (c_out, c_in) weights: ascending in float64, rounded once (oracle orc_weight_colsum)
+__global__ void weight_colsum_kernel(const float* __restrict__ w, int c_out, int c_in, float* __restrict__ cs) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= c_out) return;
+    const float* wr = w + (size_t)o * c_in;
+    double s = 0.0;
+    for (int c = 0; c < c_in; ++c) s = s + (double)wr[c];
+    cs[o] = (float)s;
 }
 
 // LayerNorm of a row held in LDS by ONE wavefront (all 64 lanes call it)
@@ -228,16 +238,23 @@ static AggLayout agg_layout(const ipsx_transf* t, int b, int m) {
 using namespace ipsx;
 
 IPSX_API int ipsx_projector_stats(const float* x, int64_t n, int f, float ln_eps, float* stats, void* stream) {
-    IPSX_REQUIRE(x && stats && n >= 0 && f > 0, "projector_stats: bad arguments");
+    IPSX_REQUIRE(x && stats && n >= 0 && f > 0 && f % 8 == 0, "projector_stats: bad arguments (the row length is a multiple of 8)");
     if (n == 0) return IPSX_OK;
-    row_stats_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(x, n, f, ln_eps, reinterpret_cast<float2*>(stats),
-                                                                                     nullptr, 0);
-    return launched("projector row statistics");
+    row_moments_kernel<<<dim3((unsigned)cdiv(n, 128)), dim3(256), 0, as_stream(stream)>>>(x, n, f, ln_eps, reinterpret_cast<float2*>(stats),
+                                                                                        nullptr, 0);
+    return launched("projector row moments");
+}
+
+IPSX_API int ipsx_weight_colsum(const float* w, int c_out, int c_in, float* colsum, void* stream) {
+    IPSX_REQUIRE(w && colsum && c_out > 0 && c_in > 0, "weight_colsum: bad arguments");
+    weight_colsum_kernel<<<dim3((unsigned)cdiv(c_out, 64)), dim3(64), 0, as_stream(stream)>>>(w, c_out, c_in, colsum);
+    return launched("weight_colsum");
 }
 
 IPSX_API int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
                                   void* stream) {
     IPSX_REQUIRE(lin && x && out && stats && n >= 0, "projector_apply: bad arguments");
+    IPSX_REQUIRE(lin->colsum, "projector_apply: lin->colsum (ipsx_weight_colsum) is needed: the LayerNorm is folded into the epilogue");
     IPSX_REQUIRE(lin->kh == 1 && lin->kw == 1 && lin->stride == 1 && lin->pad == 0, "projector: lin must be 1x1");
     if (n == 0) return IPSX_OK;
     return conv_nhwc_impl(lin, x, nullptr, stats, out, n, 1, 1, 1, stream);
@@ -245,7 +262,7 @@ IPSX_API int ipsx_projector_apply(const ipsx_conv* lin, const float* x, int64_t 
 
 IPSX_API int ipsx_projector_apply_publish(const ipsx_conv* lin, const float* x, int64_t n, const float* stats, float* out,
                                           int32_t* ready, int32_t value, void* stream) {
-    IPSX_REQUIRE(lin && x && out && stats && ready && n > 0, "projector_apply_publish: bad arguments");
+    IPSX_REQUIRE(lin && x && out && stats && ready && n > 0 && lin->colsum, "projector_apply_publish: bad arguments");
     IPSX_REQUIRE(lin->kh == 1 && lin->kw == 1 && lin->stride == 1 && lin->pad == 0, "projector: lin must be 1x1");
     return conv_nhwc_impl(lin, x, nullptr, stats, out, n, 1, 1, 1, stream, ready, value);
 }
@@ -254,8 +271,9 @@ IPSX_API int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, flo
                             void* workspace, size_t workspace_bytes, void* stream) {
     IPSX_REQUIRE(lin && x && out && n >= 0, "projector: bad arguments");
     if (n == 0) return IPSX_OK;
-    // LayerNorm is fused into the Linear: a statistics pass leaves (mean, rstd) per row (8 B per row - the only
-    // workspace) and the GEMM normalises its A operand in registers; the normalised rows never exist in memory
+    // LayerNorm is folded into the Linear: a statistics pass leaves (mean, rstd) per row (8 B per row - the only
+    // workspace) and the GEMM applies them in its epilogue, rstd * (x W^T - mean * colsum(W)); the normalised rows
+    // never exist
     const size_t need = (size_t)n * 2 * sizeof(float);
     if (!workspace || workspace_bytes < need)
         return fail(IPSX_EWORKSPACE, "projector: workspace %zu B < %zu B", workspace_bytes, need);

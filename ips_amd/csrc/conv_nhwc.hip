@@ -48,6 +48,7 @@ struct NhwcArgs {
     int spt;               // stages (k-groups) per tap = c_in / 8
     int kgs;               // packed k-groups per n-tile = kh*kw*c_in / 8
     const float* stats;    // NORM kernels: (mean, rstd) per input row (1x1 convolutions = Linear layers only)
+    const float* colsum;   // NORM kernels: column sums of the weights, one per output channel (ipsx_weight_colsum)
     int* ready;            // NORM kernels, optional: *ready = ready_value by the first thread (see ipsx_projector_apply_publish)
     int ready_value;
 };
@@ -59,17 +60,6 @@ struct NhwcStage {
 
 __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-
-// (x - mean) * rstd on four operand values as two packed fp32 pairs (v_pk_add_f32 / v_pk_mul_f32: the same two roundings
-// per element, half the instructions - with one wave per SIMD every VALU instruction is matrix-pipe time)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 norm4(f32x4 v, float mean, float rstd) {
-    const f32x2 m = {mean, mean}, r = {rstd, rstd};
-    f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-    lo = (lo - m) * r;
-    hi = (hi - m) * r;
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 template <int NTW>
@@ -110,10 +100,11 @@ __device__ __forceinline__ unsigned nhwc_voff(const NhwcArgs& a, const NhwcPixel
     return ok ? ((p.img_pix + (unsigned)(iy * a.w + ix)) * (unsigned)a.c_in + 4u * half) * 4u : kOob;
 }
 
-// NORM: the A operand is LayerNorm'ed on its way into the matrix pipe - (x - mean) * rstd with the row moments of
-// row_stats_kernel (aggregate.hip), the very expression layernorm_rows_kernel evaluates, so the normalised row never
-// exists in memory (projector: 8 KB per row written and read back otherwise).  1x1 convolutions only (no padding
-// lanes: a zero from the bounds check must stay a zero).
+// NORM: a Linear behind a LayerNorm without affine (the projector, reference architecture/ips_net.py:54-60) with the
+// LayerNorm FOLDED into the epilogue - Linear(LN(x)) = rstd * (x W^T - mean * colsum(W)) + b, exact algebra (round 5; the
+// contract: oracle/ips_oracle.cpp orc_projector): the RAW rows run through the matrix pipe, the epilogue applies
+// t = fma(-mean, cs[n], acc), u = t * rstd with the row moments of row_moments_kernel (aggregate.hip) - no arithmetic on
+// the operands between load and MFMA, and the normalised row never exists.  1x1 convolutions only.
 // NTW: n-tiles (32 output channels each) per wave - 2 (wave tile 64 x 64) or 4 (64 x 128: half the activation loads
 // and half the NORM arithmetic per MFMA, and with 4 waves along N a workgroup covers 512 output channels, so very
 // wide layers read every activation row once); 8 * NTW MFMAs and 2 + NTW loads per stage.
@@ -136,12 +127,6 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
     for (int t = 0; t < NTW; ++t)                                   //  its accumulators are never stored)
         wb[t] = (unsigned)min(nt0 + t, (a.c_out + 31) / 32 - 1) * (unsigned)a.kgs * 1024u;
     const int taps = a.kh * a.kw, total = taps * a.spt;
-    float mean0 = 0.0f, rstd0 = 1.0f, mean1 = 0.0f, rstd1 = 1.0f;
-    if (NORM) {
-        const unsigned r0 = min(m_base + (lane & 31), a.m_total - 1), r1 = min(m_base + 32 + (lane & 31), a.m_total - 1);
-        const float2 st0 = reinterpret_cast<const float2*>(a.stats)[r0], st1 = reinterpret_cast<const float2*>(a.stats)[r1];
-        mean0 = st0.x; rstd0 = st0.y; mean1 = st1.x; rstd1 = st1.y;
-    }
 
     f32x16 acc[2][NTW];
 #pragma unroll
@@ -179,7 +164,6 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
 #define SGB_LOAD() __builtin_amdgcn_sched_group_barrier(0x020, 1, 0)
 #define NHWC_STAGE(SL, SM)                                                                  \
     NHWC_ISSUE(SL);                                                                         \
-    if (NORM) { SM.a0 = norm4(SM.a0, mean0, rstd0); SM.a1 = norm4(SM.a1, mean1, rstd1); }   \
     nhwc_mma<NTW>(SM, acc);                                                                 \
     if (NTW == 2) {                                                                         \
         SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(3); SGB_LOAD(); SGB_MFMA(4); \
@@ -220,14 +204,27 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
 #undef NHWC_ADVANCE
 #undef NHWC_ISSUE
 
-    // epilogue: BatchNorm affine, residual, ReLU; lanes of a store are 32 consecutive channels
+    // epilogue: (the folded LayerNorm,) BatchNorm affine, residual, ReLU; lanes of a store are 32 consecutive channels
     const int i = lane & 31;
+    float nmean[NORM ? 2 : 1][NORM ? 16 : 1], rstd[NORM ? 2 : 1][NORM ? 16 : 1];
+    if (NORM) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned m = min(m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.m_total - 1);
+                const float2 st = reinterpret_cast<const float2*>(a.stats)[m];
+                nmean[NORM ? mt : 0][NORM ? r : 0] = -st.x;
+                rstd[NORM ? mt : 0][NORM ? r : 0] = st.y;
+            }
+    }
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = (nt0 + nt) * 32 + i;
         if (n >= a.c_out) continue;
         const float al = a.alpha ? a.alpha[n] : 1.0f;
         const float sh = a.shift ? a.shift[n] : 0.0f;
+        const float cs = NORM ? a.colsum[n] : 0.0f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -236,6 +233,10 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
                 if (m >= a.m_total) continue;
                 const size_t idx = (size_t)m * a.c_out + n;
                 float v = acc[mt][nt][r];
+                if (NORM) {
+                    v = __builtin_fmaf(nmean[NORM ? mt : 0][NORM ? r : 0], cs, v);
+                    v = v * rstd[NORM ? mt : 0][NORM ? r : 0];
+                }
                 if (a.alpha) v = __builtin_fmaf(v, al, sh);
                 else if (a.shift) v = v + sh;
                 if (a.res) v = v + a.res[idx];
@@ -251,11 +252,13 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
 // projector itself - so what matters is WHEN rows become available, not only how fast the GEMM runs.  Launch by launch
 // (ipsx_projector_apply_publish) a part's rows are published when the NEXT launch starts, behind a statistics kernel
 // and a logits kernel, and the loop waits for a whole part at the start and works off a whole part at the end.  Here
-// resident workgroups pull row tiles off a counter and do everything a tile needs - the LayerNorm moments of its rows
-// (row_stats_wave), the Linear on the fp32 matrix cores with the normalisation in the operand load (the stage loop of
-// conv_nhwc_kernel<1, 4, true, 4>), BatchNorm + ReLU, the tile's logits against the folded query (the MFMA sequence of
-// logits_kernel, A operand from the LDS copy of the tile) - and publish it: a flag per 32-row unit, and whoever
-// completes the lowest unpublished unit advances the loop's progress word past every completed unit behind it.
+// resident workgroups pull row tiles off a counter and do everything a tile needs - the Linear on the fp32 matrix cores
+// on the RAW rows (the stage loop of conv_nhwc_kernel<1, 4, true, 4>), the LayerNorm moments of the tile's rows taken off
+// the very operand registers that feed the MFMAs (round 5: every feature row is read ONCE - rounds 3-4 read it in a
+// moments pass first, 10 % of a tile with the matrix pipe idle and twice the HBM traffic), the folded LayerNorm +
+// BatchNorm + ReLU in the epilogue, the tile's logits against the folded query (the MFMA sequence of logits_kernel, A
+// operand from the LDS copy of the tile) - and publish it: a flag per 32-row unit, and whoever completes the lowest
+// unpublished unit advances the loop's progress word past every completed unit behind it.
 // Same arithmetic as the three kernels it replaces: embeddings, logits and with them the selection are bit-identical
 // (tests/test_hip_kernels.py::test_projector_stream_equals_the_launch_by_launch_projector).
 // A tile is 64 rows (2 units); the FIRST pull of `short_first` workgroups is one unit, so that completions - which would
@@ -267,6 +270,7 @@ struct StreamArgs {
     const float* x;
     const float* wp; unsigned w_bytes;
     const float* alpha; const float* shift; int relu;
+    const float* colsum;           // column sums of the weights (the folded LayerNorm's mean term)
     int c_in, c_out, kgs;          // kgs = c_in / 8 packed k-groups per n-tile
     float eps;
     float* emb;                    // (n, c_out)
@@ -287,13 +291,14 @@ struct StreamArgs {
 // The last few units of a launch - what is left when every workgroup has had its whole share: 2,048 units on 255 compute
 // units are 8 each and 8 over - would be a round of their own that most of the chip sits out (a 32-row tile: 0.166 ms of
 // a 1.38 ms launch).  They are handed out as SPLIT_P column quarters to as many workgroups: every quarter computes the
-// rows' moments, its 128 columns of the Linear (a wave: 32) and its 16 k-groups of the logits' MFMA chain, whose
+// rows' moments (off its own operand stream), its 128 columns of the Linear (a wave: 32) and its 16 k-groups of the logits' MFMA chain, whose
 // accumulators pass from quarter to quarter through memory (ctl: a flag and 1,024 floats per hand-over) - the same chain
 // in the same order, so embeddings and logits stay bit-identical.  The last quarter publishes the unit.
 constexpr int SPLIT_P = 4, SPLIT_MAX = 16;
 constexpr int SPLIT_WORDS = 1 + SPLIT_MAX * (SPLIT_P - 1) * (1 + 1024);
 constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
-constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + 64 * 8 + 16;
+constexpr int ST_STATS = 4 * 64 * 2;                // floats: (mean, rstd) of the tile's rows, a copy per wavefront
+constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + ST_STATS * 4 + 16;
 
 #define ST_STAMP(k)                                                                         \
     do {                                                                                    \
@@ -311,23 +316,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     constexpr int P = 4 / NTW;                                     // workgroups that share the tile's columns (NTW = 4: one)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, i = lane & 31;
     ST_STAMP(0);                                                   // (pull + publication of the tile before)
-    // ---- LayerNorm moments of the tile's rows: 8 MT rows per wavefront
-#pragma unroll 1
-    for (int q0 = 0; q0 < 8 * MT; q0 += 4) {               // four rows at a time: their loads in flight together
-        const unsigned lr0 = wave * (8 * MT) + q0;
-        const float* xr[4];
-        float2 st[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned row = row0 + lr0 + q;
-            xr[q] = row < a.n ? a.x + (size_t)row * a.c_in : nullptr;
-            st[q] = make_float2(0.0f, 1.0f);
-        }
-        row_stats_wave_n<4>(xr, a.c_in, a.eps, lane, st);
-        if (lane < 4) s_stats[lr0 + lane] = lane == 0 ? st[0] : lane == 1 ? st[1] : lane == 2 ? st[2] : st[3];
-    }
-    __syncthreads();
-    ST_STAMP(1);
+    ST_STAMP(1);                                                   // (rounds 3-4: the row-moment pass; gone)
 
     // ---- Linear: this wave's 128 output channels of the tile's 32 MT rows
     // (the buffer is the TILE's rows: any number of slides, one after the other, stays addressable)
@@ -337,14 +326,12 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)a.w_bytes, 0x00020000);
     const int nt0 = part * (16 / P) + wave * NTW;
     unsigned pv[MT];
-    float mean[MT], rstd[MT];
+    RowMoments mom[MT];                                            // of row 32 mt + i, this lane's half of every k-group
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const unsigned lr = mt * 32 + i, row = row0 + lr;
-        const bool ok = row < a.n;
-        pv[mt] = ok ? (lr * (unsigned)a.c_in + 4u * half) * 4u : kOob;
-        const float2 st = ok ? s_stats[lr] : make_float2(0.0f, 1.0f);
-        mean[mt] = st.x; rstd[mt] = st.y;
+        pv[mt] = row < a.n ? (lr * (unsigned)a.c_in + 4u * half) * 4u : kOob;      // (no such row: zeros, never stored)
+        rm_zero(mom[mt]);
     }
     const unsigned lb = lane * 16u;
     unsigned wb[NTW];
@@ -371,7 +358,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     } while (0)
 #define ST_STAGE(SL, SM)                                                                   \
     ST_ISSUE(SL);                                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) SM.a[mt] = norm4(SM.a[mt], mean[mt], rstd[mt]); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) rm_add(mom[mt], SM.a[mt]);           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
             _Pragma("unroll") for (int t = 0; t < NTW; ++t) acc[mt][t] = MFMA(SM.a[mt][j], SM.b[t][j], acc[mt][t]); \
@@ -409,18 +396,42 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
 #undef ST_ISSUE
     ST_STAMP(2);
 
-    // ---- BatchNorm affine + ReLU: to HBM and to the LDS copy the logits read
+    // ---- the rows' moments: every wavefront has summed the same operand stream and keeps its own copy (no workgroup
+    // barrier: the copy is written and read by this wavefront only)
+    float2* const wst = s_stats + wave * 64;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float2 st = rm_finish(mom[mt], a.c_in, a.eps, lane);
+        if (lane < 32) wst[mt * 32 + i] = st;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float nmean[MT][16], rstd[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 st = wst[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+            nmean[mt][r] = -st.x;
+            rstd[mt][r] = st.y;
+        }
+
+    // ---- folded LayerNorm, BatchNorm affine, ReLU: to HBM and to the LDS copy the logits read
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int nn = (nt0 + t) * 32 + i;
         const float al = a.alpha ? a.alpha[nn] : 1.0f;
         const float sh = a.shift ? a.shift[nn] : 0.0f;
+        const float cs = a.colsum[nn];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + lr;
                 float v = acc[mt][t][r];
+                v = __builtin_fmaf(nmean[mt][r], cs, v);
+                v = v * rstd[mt][r];
                 if (a.alpha) v = __builtin_fmaf(v, al, sh);
                 else if (a.shift) v = v + sh;
                 if (a.relu) v = v > 0.0f ? v : 0.0f;
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
     extern __shared__ __attribute__((aligned(16))) float st_lds[];
     float* tile = st_lds;
     float2* s_stats = reinterpret_cast<float2*>(st_lds + 64 * ST_EP);
-    int* s_u0 = reinterpret_cast<int*>(st_lds + 64 * ST_EP + 128);         // [0] unit, [1] units taken, [2] column part or -1
+    int* s_u0 = reinterpret_cast<int*>(st_lds + 64 * ST_EP + ST_STATS);    // [0] unit, [1] units taken, [2] column part or -1
     bool first = true;
     int pulls = 0;
     for (;;) {
@@ -625,12 +636,12 @@ IPSX_API int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const 
     return conv_nhwc_impl(cv, x, residual, nullptr, y, n, h, w, relu, stream);
 }
 
-// row_stats != null: x rows are LayerNorm'ed on the fly ((mean, rstd) per row; 1x1 convolution on 1x1 maps)
+// row_stats != null: the LayerNorm of the x rows is folded into the epilogue ((mean, rstd) per row; 1x1 convolution on 1x1 maps)
 int ipsx::conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* residual, const float* row_stats, float* y,
                          int64_t n, int h, int w, int relu, void* stream, int* ready, int ready_value) {
     IPSX_REQUIRE(cv && cv->w_packed && x && y && n >= 0 && h > 0 && w > 0, "conv2d_affine_nhwc: bad arguments");
-    IPSX_REQUIRE(!row_stats || (cv->kh == 1 && cv->kw == 1 && cv->pad == 0 && cv->stride == 1 && h == 1 && w == 1),
-                 "conv2d_affine_nhwc: row statistics go with a Linear layer (1x1 convolution on rows)");
+    IPSX_REQUIRE(!row_stats || (cv->kh == 1 && cv->kw == 1 && cv->pad == 0 && cv->stride == 1 && h == 1 && w == 1 && cv->colsum),
+                 "conv2d_affine_nhwc: row statistics go with a Linear layer (1x1 convolution on rows) that carries its column sums");
     IPSX_REQUIRE(cv->c_in % 32 == 0, "conv2d_affine_nhwc: C_in = %d is not a multiple of 32", cv->c_in);
     if (n == 0) return IPSX_OK;
     const int ho = conv_out(h, cv->kh, cv->stride, cv->pad), wo = conv_out(w, cv->kw, cv->stride, cv->pad);
@@ -657,6 +668,7 @@ int ipsx::conv_nhwc_impl(const ipsx_conv* cv, const float* x, const float* resid
         a.kh = cv->kh; a.kw = cv->kw; a.stride = cv->stride; a.pad = cv->pad; a.relu = relu;
         a.spt = cv->c_in / 8; a.kgs = kgs;
         a.stats = row_stats ? row_stats + (size_t)i0 * 2 : nullptr;
+        a.colsum = cv->colsum;
         a.ready = (row_stats && i0 == 0) ? ready : nullptr;      // (the first launch of the call follows what was enqueued before)
         a.ready_value = ready_value;
         const unsigned mt64 = (unsigned)cdiv(a.m_total, 64), nt64 = (unsigned)cdiv(cv->c_out, 64);
@@ -734,7 +746,7 @@ IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) {
 
 IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r) {
     if (!lin || !lin->w_packed || lin->kh != 1 || lin->kw != 1 || lin->stride != 1 || lin->pad != 0) return 0;
-    if (lin->c_out != 512 || lin->c_in % 32 != 0 || lin->c_in > 64 * ipsx::RS_MAX) return 0;
+    if (lin->c_out != 512 || lin->c_in % 32 != 0 || !lin->colsum) return 0;
     if (r < 1 || r > 32 || n < 64) return 0;
     return n < ((int64_t)1 << 31) - 64 ? 1 : 0;
 }
@@ -747,12 +759,12 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
                  "projector_stream: %lld rows are not whole slides of %lld rows (a multiple of 32 when there are several)",
                  (long long)n, (long long)slide_rows);
     IPSX_REQUIRE(ipsx_projector_stream_supported(lin, n, r), "projector_stream: needs a 1x1 Linear with 512 outputs, C_in %% 32 == 0, "
-                 "C_in <= %d and at most 32 logits per row", 64 * ipsx::RS_MAX);
+                 "its column sums (ipsx_conv.colsum) and at most 32 logits per row");
     ipsx::StreamArgs a;
     a.x = x;
     a.wp = lin->w_packed; a.kgs = lin->c_in / 8;
     a.w_bytes = (unsigned)((int64_t)(lin->c_out / 32) * a.kgs * 1024);
-    a.alpha = lin->alpha; a.shift = lin->shift; a.relu = 1;
+    a.alpha = lin->alpha; a.shift = lin->shift; a.relu = 1; a.colsum = lin->colsum;
     a.c_in = lin->c_in; a.c_out = lin->c_out; a.eps = ln_eps;
     a.emb = emb; a.vp = v_packed; a.R = r; a.vkgs = lin->c_out / 8; a.logits = logits;
     a.n = (unsigned)n; a.n_units = (unsigned)ipsx::cdiv(n, 32); a.slide_rows = (unsigned)slide_rows;

@@ -1,6 +1,11 @@
-// ipsx_rowstats.h - the LayerNorm row moments (mean, rstd) of one feature row by ONE wavefront, in the contract's order:
-// 64 strided partial sums in ascending order + xor butterfly, centred second moment (oracle/ips_oracle.cpp orc_projector).
-// Shared by row_stats_kernel (aggregate.hip) and the logits + statistics launch (scorer.hip).
+// ipsx_rowstats.h - LayerNorm row moments (mean, rstd).
+//  * row_stats_wave: one feature row by ONE wavefront - 64 strided partial sums in ascending order + xor butterfly,
+//    centred second moment (the transformer's LayerNorms, oracle layernorm_row);
+//  * RowMoments / row_moments_wave32 (round 5): the PROJECTOR's moments, taken off the operand stream of its GEMM - lane
+//    (row, half h) holds the four consecutive k = 8g + 4h + j of k-group g, so a row's sums run as eight chains (h, j)
+//    over g ascending, folded ((c0 + c1) + (c2 + c3)) per half and half 0 + half 1; var = E[x^2] - mean^2
+//    (oracle/ips_oracle.cpp projector_moments).  Shared by projector_stream_kernel / conv_nhwc_kernel<NORM>
+//    (conv_nhwc.hip), row_moments_kernel (aggregate.hip) and the logits + statistics launch (scorer.hip).
 #pragma once
 
 #include "ipsx_math.h"
@@ -33,35 +38,59 @@ __device__ __forceinline__ float2 row_stats_wave(const float* __restrict__ xr, i
     return make_float2(mean, rstd);
 }
 
-// NR rows at once by one wavefront (d <= 64 * RS_MAX): the loads of all NR rows are in flight before the first add, and the
-// NR reductions run side by side - per row exactly the operations of row_stats_wave, in its order.  For a caller that has
-// nothing else in flight to hide a row's 2 us of load latency behind (projector_stream_kernel: 16 rows per wavefront
-// and tile, one after the other 32 us of a 300 us tile).  xr[q] == nullptr: no such row, st[q] is left alone.
-template <int NR>
-__device__ __forceinline__ void row_stats_wave_n(const float* const (&xr)[NR], int d, float eps, int lane, float2 (&st)[NR]) {
-    float v[NR][RS_MAX];
+// ---- the projector's moments (see the header comment): per lane the four j-chains of its half of the row
+typedef float rm_f32x2 __attribute__((ext_vector_type(2)));
+typedef float rm_f32x4 __attribute__((ext_vector_type(4)));
+
+struct RowMoments {
+    rm_f32x2 s01, s23, q01, q23;
+};
+
+__device__ __forceinline__ void rm_zero(RowMoments& m) {
+    m.s01 = rm_f32x2{0.0f, 0.0f}; m.s23 = m.s01; m.q01 = m.s01; m.q23 = m.s01;
+}
+
+// one k-group's four values of this lane: two packed adds, two packed fmas (v_pk_add_f32 / v_pk_fma_f32 - the roundings
+// of the scalar operations, half the instructions)
+__device__ __forceinline__ void rm_add(RowMoments& m, rm_f32x4 v) {
+    const rm_f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    m.s01 = m.s01 + lo;
+    m.s23 = m.s23 + hi;
+    m.q01 = __builtin_elementwise_fma(lo, lo, m.q01);
+    m.q23 = __builtin_elementwise_fma(hi, hi, m.q23);
+}
+
+// (mean, rstd) of the row whose halves lanes i and i + 32 hold - the same bits in both (a + b == b + a)
+__device__ __forceinline__ float2 rm_finish(const RowMoments& m, int d, float eps, int lane) {
+    float t = (m.s01[0] + m.s01[1]) + (m.s23[0] + m.s23[1]);
+    float u = (m.q01[0] + m.q01[1]) + (m.q23[0] + m.q23[1]);
+    t = t + lane_xor_f32<32>(t, lane);
+    u = u + lane_xor_f32<32>(u, lane);
+    const float mean = t / (float)d, ex2 = u / (float)d;
+    float var = __builtin_fmaf(-mean, mean, ex2);
+    var = var > 0.0f ? var : 0.0f;
+    return make_float2(mean, 1.0f / __builtin_sqrtf(var + eps));
+}
+
+// the moments of rows row0 .. row0 + 31 (those below n) by one wavefront: lane l -> row row0 + (l & 31), half l >> 5;
+// d % 8 == 0.  Eight 16-byte loads in flight per lane.
+__device__ __forceinline__ float2 row_moments_wave32(const float* __restrict__ x, long long row0, long long n, int d, float eps,
+                                                     int lane) {
+    const long long row = row0 + (lane & 31);
+    const rm_f32x4* p = reinterpret_cast<const rm_f32x4*>(x + (size_t)(row < n ? row : n - 1) * d + 4 * (lane >> 5));
+    RowMoments m;
+    rm_zero(m);
+    const int kgs = d >> 3;
+    int g = 0;
+    for (; g + 8 <= kgs; g += 8) {
+        rm_f32x4 v[8];
 #pragma unroll
-    for (int q = 0; q < NR; ++q)
+        for (int u = 0; u < 8; ++u) v[u] = p[2 * (g + u)];
 #pragma unroll
-        for (int k = 0; k < RS_MAX; ++k) v[q][k] = (xr[q] && lane + 64 * k < d) ? xr[q][lane + 64 * k] : 0.0f;
-    float mean[NR];
-#pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < RS_MAX; ++k) if (lane + 64 * k < d) s = s + v[q][k];
-        mean[q] = wave_butterfly_sum(s) / (float)d;
+        for (int u = 0; u < 8; ++u) rm_add(m, v[u]);
     }
-#pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        float qq = 0.0f;
-#pragma unroll
-        for (int k = 0; k < RS_MAX; ++k)
-            if (lane + 64 * k < d) { const float c = v[q][k] - mean[q]; const float c2 = c * c; qq = qq + c2; }
-        const float var = wave_butterfly_sum(qq) / (float)d;
-        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
-        if (xr[q]) st[q] = make_float2(mean[q], rstd);
-    }
+    for (; g < kgs; ++g) rm_add(m, p[2 * g]);
+    return rm_finish(m, d, eps, lane);
 }
 
 }  // namespace ipsx

@@ -199,10 +199,11 @@ __global__ __launch_bounds__(256) void logits_stats_kernel(LogitsArgs a, unsigne
                                                            long long sn, int sf, float eps, float2* __restrict__ sout) {
     if (blockIdx.x < n_logits_x) { logits_wave<NT>(a, blockIdx.x, (int)blockIdx.y); return; }
     if (blockIdx.y != 0) return;
-    const long long row = (long long)(blockIdx.x - n_logits_x) * 4 + (threadIdx.x >> 6);
-    if (row >= sn) return;
-    const float2 st = row_stats_wave(sx + (size_t)row * sf, sf, eps, threadIdx.x & 63);
-    if ((threadIdx.x & 63) == 0) sout[row] = st;
+    const int lane = threadIdx.x & 63;                               // one wavefront per 32 rows (row_moments_kernel's arithmetic)
+    const long long row0 = ((long long)(blockIdx.x - n_logits_x) * 4 + (threadIdx.x >> 6)) * 32;
+    if (row0 >= sn) return;
+    const float2 st = row_moments_wave32(sx, row0, sn, sf, eps, lane);
+    if (lane < 32 && row0 + lane < sn) sout[row0 + lane] = st;
 }
 
 // ---- the same logits on the bf16 matrix pipe (BASELINE configs[4]: "MFMA bf16/fp16 QK^T path").  x = emb (+ pos)
@@ -2848,7 +2849,8 @@ IPSX_API int ipsx_logits_stats(const float* emb, int64_t emb_bstride, const floa
     const unsigned nlx = (unsigned)cdiv(n, 128);
     const int nt = (r + 31) / 32;
     IPSX_REQUIRE(nt <= 8, "logits_stats: H * n_token = %d > 256 not supported", r);
-    dim3 grid(nlx + (unsigned)cdiv(stats_n, 4), (unsigned)b);
+    IPSX_REQUIRE(stats_f % 8 == 0, "logits_stats: the feature rows' length is a multiple of 8");
+    dim3 grid(nlx + (unsigned)cdiv(stats_n, 128), (unsigned)b);
     hipStream_t s = as_stream(stream);
     float2* so = reinterpret_cast<float2*>(stats_out);
     if (nt == 1) logits_stats_kernel<1><<<grid, dim3(256), 0, s>>>(a, nlx, stats_x, stats_n, stats_f, ln_eps, so);

@@ -22,7 +22,7 @@ _SO = os.path.join(_PKG, "lib", "libipsx.so")
 _LIB = None
 
 f32p = C.c_void_p  # device pointers travel as integers
-ABI_MAJOR = 2       # include/ipsx.h IPSX_VERSION / 100: the signatures in _EXPORTS below are those of this major version
+ABI_MAJOR = 3       # include/ipsx.h IPSX_VERSION / 100: the signatures in _EXPORTS below are those of this major version
 
 
 def backend():
@@ -120,7 +120,7 @@ class Conv(C.Structure):
     _fields_ = [("c_in", C.c_int), ("c_out", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
                 ("stride", C.c_int), ("pad", C.c_int),
                 ("w_packed", C.c_void_p), ("alpha", C.c_void_p), ("shift", C.c_void_p),
-                ("w_packed_bf16", C.c_void_p)]
+                ("w_packed_bf16", C.c_void_p), ("colsum", C.c_void_p)]
 
 
 class Block(C.Structure):
@@ -188,6 +188,7 @@ _EXPORTS = {
     "ipsx_projector": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_projector_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "ipsx_weight_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_projector_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "ipsx_projector_apply": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_projector_apply_publish": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -492,8 +493,12 @@ class EncoderPlan:
             w = lin.weight.detach()
             packed = _pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1))
             aff = _bn_affine(bn, bias=lin.bias)
-            self._keep += [packed, aff]
-            self.lin = Conv(w.shape[1], w.shape[0], 1, 1, 1, 0, _p(packed), _p(aff[0]), _p(aff[1]))
+            # the LayerNorm in front of the Linear is folded into the GEMM's epilogue: rstd * (x W^T - mean * colsum(W))
+            colsum = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+            wf = _f32(w)
+            _ck(lib().ipsx_weight_colsum(_p(wf), w.shape[0], w.shape[1], _p(colsum), _stream()), "ipsx_weight_colsum")
+            self._keep += [packed, aff, colsum, wf]
+            self.lin = Conv(w.shape[1], w.shape[0], 1, 1, 1, 0, _p(packed), _p(aff[0]), _p(aff[1]), None, _p(colsum))
             self.ln_eps = float(ln.eps)
             self.d_out = w.shape[0]
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.ipsx_version() // 100 == 2          # include/ipsx.h: major = incompatible signature changes
+    assert lib.ipsx_version() // 100 == 3          # include/ipsx.h: major = incompatible signature changes
 
 
 def test_python_binding_covers_the_header():

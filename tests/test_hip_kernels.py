@@ -308,6 +308,35 @@ def test_trunk_stream_equals_encode_plus_logits(n, wgs, use_pos, quads):
         assert torch.equal(lg, want_lg), "max abs diff %g" % float((lg - want_lg).abs().max())
 
 
+@pytest.mark.parametrize("n,f", [(1, 2048), (31, 2048), (33, 64), (130, 1024), (4097, 2048), (257, 8), (64, 2056)])
+def test_projector_moments_and_column_sums_are_the_oracles(n, f):
+    """ipsx_projector_stats (row_moments_kernel: the moments in the order the GEMM's operand stream gives them, round 5)
+    and ipsx_weight_colsum against the oracle's restatement, bit for bit: ragged row counts, rows of 8 ... 2,056 floats,
+    post-ReLU-like rows with a large mean (where E[x^2] - mean^2 cancels most) and constant rows (variance clamped at 0)."""
+    x = np.abs(rnd((n, f), 100 + n + f)) * 3.0 + 5.0
+    x[0, :] = 2.5                                                 # a constant row: var = 0 exactly or clamped
+    if n > 2:
+        x[2, :] = 0.0
+    want = np.empty((n, 2), dtype=np.float32)
+    orc.lib().orc_projector_moments(orc._f(x)[1], C.c_int64(n), f, C.c_float(1e-5), want.ctypes.data_as(orc.f32p))
+    got = torch.full((n, 2), float("nan"), device=DEV)
+    hip._ck(hip.lib().ipsx_projector_stats(hip._p(dev(x)), n, f, C.c_float(1e-5), hip._p(got), None), "ipsx_projector_stats")
+    assert ulp_diff(got.cpu().numpy(), want) == 0
+    # float64 truth: the single-pass variance is good to ~1e-5 relative even at mean / std = 8
+    mean64, var64 = x.astype(np.float64).mean(1), x.astype(np.float64).var(1)
+    assert np.abs(want[:, 0] - mean64).max() <= 2e-6 * np.abs(mean64).max()
+    rstd64 = 1.0 / np.sqrt(var64 + 1e-5)
+    ok = var64 > 1e-3                                             # (a constant row's variance is rounding noise against eps)
+    assert not ok.any() or (np.abs(want[:, 1] - rstd64) / rstd64)[ok].max() <= 5e-4
+    w = rnd((96, f), 7 + f, 0.3)
+    cs = np.empty((96,), dtype=np.float32)
+    orc.lib().orc_weight_colsum(orc._f(w)[1], 96, f, cs.ctypes.data_as(orc.f32p))
+    got_cs = torch.empty((96,), device=DEV)
+    hip._ck(hip.lib().ipsx_weight_colsum(hip._p(dev(w)), 96, f, hip._p(got_cs), None), "ipsx_weight_colsum")
+    assert ulp_diff(got_cs.cpu().numpy(), cs) == 0
+    assert np.array_equal(cs, w.astype(np.float64).sum(1).astype(np.float32)) or np.abs(cs - w.astype(np.float64).sum(1)).max() < 1e-5
+
+
 @pytest.mark.parametrize("n,wgs,short,slides", [(64, 0, -1, 1), (97, 3, 1, 1), (1000, 7, 3, 1), (4099, 0, -1, 1), (20000, 0, 0, 1),
                                                 (3 * 1056, 5, 2, 3), (8 * 2048, 0, -1, 8), (5000, 9, -2, 1),
                                                 # guided sizes; what is left over goes out in column quarters (8 / 3 / 16 units)
