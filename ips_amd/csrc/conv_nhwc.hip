@@ -29,6 +29,7 @@ namespace ipsx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
@@ -297,7 +298,7 @@ struct StreamArgs {
 constexpr int SPLIT_P = 4, SPLIT_MAX = 16;
 constexpr int SPLIT_WORDS = 1 + SPLIT_MAX * (SPLIT_P - 1) * (1 + 1024);
 constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
-constexpr int ST_STATS = 4 * 64 * 2;                // floats: (mean, rstd) of the tile's rows, a copy per wavefront
+constexpr int ST_STATS = 64 * 2;                    // floats: (mean, rstd) of the tile's rows
 constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + ST_STATS * 4 + 16;
 
 #define ST_STAMP(k)                                                                         \
@@ -309,10 +310,20 @@ constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + ST_STATS * 4 + 16;
         }                                                                                   \
     } while (0)
 
-template <int MT, int NTW, bool STAMP>
+__device__ __forceinline__ void bufstore(__amdgpu_buffer_rsrc_t r, f32x4 v, unsigned voff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, 0, 0);
+}
+
+// MB: the row block (32 rows) whose moments THIS wavefront sums - every wavefront of a workgroup streams the same rows
+// through its MFMAs, so the 64-row tile's two blocks are shared out by wavefront parity (4 instead of 8 packed VALU
+// instructions per stage: each costs matrix-pipe time) and meet in the LDS; every row's sums are still ONE wavefront's
+// chains in the contract's order.
+template <int MT, int NTW, int MB, bool STAMP>
 __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, int part, unsigned split_unit, float* tile,
                                             float2* s_stats) {
     static_assert(NTW == 4 || MT == 1, "column parts are 32-row tiles");
+    static_assert(MB < MT, "row block");
     constexpr int P = 4 / NTW;                                     // workgroups that share the tile's columns (NTW = 4: one)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, i = lane & 31;
     ST_STAMP(0);                                                   // (pull + publication of the tile before)
@@ -326,12 +337,12 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)a.w_bytes, 0x00020000);
     const int nt0 = part * (16 / P) + wave * NTW;
     unsigned pv[MT];
-    RowMoments mom[MT];                                            // of row 32 mt + i, this lane's half of every k-group
+    RowMoments mom;                                                // of row 32 MB + i, this lane's half of every k-group
+    rm_zero(mom);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const unsigned lr = mt * 32 + i, row = row0 + lr;
         pv[mt] = row < a.n ? (lr * (unsigned)a.c_in + 4u * half) * 4u : kOob;      // (no such row: zeros, never stored)
-        rm_zero(mom[mt]);
     }
     const unsigned lb = lane * 16u;
     unsigned wb[NTW];
@@ -358,7 +369,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     } while (0)
 #define ST_STAGE(SL, SM)                                                                   \
     ST_ISSUE(SL);                                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) rm_add(mom[mt], SM.a[mt]);           \
+    rm_add(mom, SM.a[MB]);                                                                 \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
             _Pragma("unroll") for (int t = 0; t < NTW; ++t) acc[mt][t] = MFMA(SM.a[mt][j], SM.b[t][j], acc[mt][t]); \
@@ -396,51 +407,63 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
 #undef ST_ISSUE
     ST_STAMP(2);
 
-    // ---- the rows' moments: every wavefront has summed the same operand stream and keeps its own copy (no workgroup
-    // barrier: the copy is written and read by this wavefront only)
-    float2* const wst = s_stats + wave * 64;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float2 st = rm_finish(mom[mt], a.c_in, a.eps, lane);
-        if (lane < 32) wst[mt * 32 + i] = st;
+    // ---- the rows' moments meet in the LDS (two wavefronts hold each block's: the same bits)
+    {
+        const float2 st = rm_finish(mom, a.c_in, a.eps, lane);
+        if (lane < 32) s_stats[MB * 32 + i] = st;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float nmean[MT][16], rstd[MT][16];
+    __syncthreads();
+    f32x2 nmean[MT][8], rstd[MT][8];                               // of accumulator registers (r, r + 1): rows lr, lr + 1
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float2 st = wst[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-            nmean[mt][r] = -st.x;
-            rstd[mt][r] = st.y;
+        for (int r = 0; r < 16; r += 2) {
+            const float4 st = *reinterpret_cast<const float4*>(s_stats + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            nmean[mt][r >> 1] = f32x2{-st.x, -st.z};
+            rstd[mt][r >> 1] = f32x2{st.y, st.w};
         }
 
-    // ---- folded LayerNorm, BatchNorm affine, ReLU: to HBM and to the LDS copy the logits read
+    // ---- folded LayerNorm, BatchNorm affine, ReLU: into the LDS copy of the tile (the logits read it; the wavefronts
+    // that have no logits to do carry it to HBM meanwhile, 16 bytes per lane - rounds 3-4 stored 4 bytes per lane from here)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int nn = (nt0 + t) * 32 + i;
         const float al = a.alpha ? a.alpha[nn] : 1.0f;
         const float sh = a.shift ? a.shift[nn] : 0.0f;
         const float cs = a.colsum[nn];
+        const f32x2 al2 = {al, al}, sh2 = {sh, sh}, cs2 = {cs, cs};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + lr;
-                float v = acc[mt][t][r];
-                v = __builtin_fmaf(nmean[mt][r], cs, v);
-                v = v * rstd[mt][r];
-                if (a.alpha) v = __builtin_fmaf(v, al, sh);
-                else if (a.shift) v = v + sh;
-                if (a.relu) v = v > 0.0f ? v : 0.0f;
-                tile[lr * ST_EP + nn] = v;
-                if (row < a.n) a.emb[(size_t)row * a.c_out + nn] = v;
+            for (int r = 0; r < 16; r += 2) {
+                const unsigned lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                f32x2 v = {acc[mt][t][r], acc[mt][t][r + 1]};
+                v = __builtin_elementwise_fma(nmean[mt][r >> 1], cs2, v);
+                v = v * rstd[mt][r >> 1];
+                if (a.alpha) v = __builtin_elementwise_fma(v, al2, sh2);
+                else if (a.shift) v = v + sh2;
+                if (a.relu) { v[0] = v[0] > 0.0f ? v[0] : 0.0f; v[1] = v[1] > 0.0f ? v[1] : 0.0f; }
+                tile[lr * ST_EP + nn] = v[0];
+                tile[(lr + 1) * ST_EP + nn] = v[1];
             }
     }
     __syncthreads();
     ST_STAMP(3);
+
+    // ---- the tile's embeddings to HBM, by the wavefronts the logits leave idle (rows beyond the end: the buffer's bounds
+    // check drops the store)
+    if (wave >= MT) {
+        constexpr int COLS4 = 32 * NTW;                            // float4 per row of this workgroup's columns
+        constexpr int NCOPY = 4 - MT;
+        const unsigned col0 = (unsigned)part * (16 / P) * 32u;
+        const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(a.emb + (size_t)row0 * a.c_out, 0,
+                                                                            (int)(rows_here * (unsigned)a.c_out * 4u), 0x00020000);
+#pragma unroll 8
+        for (int e = (wave - MT) * 64 + lane; e < 32 * MT * COLS4; e += NCOPY * 64) {
+            const unsigned r = (unsigned)e / COLS4, c = col0 + 4u * ((unsigned)e % COLS4);
+            bufstore(re, *reinterpret_cast<const f32x4*>(tile + r * ST_EP + c), (r * (unsigned)a.c_out + c) * 4u);
+        }
+    }
 
     // ---- logits of the tile's rows: wave mt takes rows 32 mt .. 32 mt + 31, all R logits (one 32-column tile).
     // A column part (P > 1) runs ITS k-groups of the chain: the accumulators arrive from the part before and go on to the
@@ -541,9 +564,11 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
         const int part = __builtin_amdgcn_readfirstlane(s_u0[2]);
         if (u0 >= a.n_units) break;                                 // workgroup-uniform
         const int units = (take == 2 && u0 + 1 < a.n_units) ? 2 : 1;
-        if (part >= 0) stream_tile<1, 4 / SPLIT_P, STAMP>(a, u0 * 32u, part, u0 - a.split_start, tile, s_stats);
-        else if (units == 2) stream_tile<2, 4, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
-        else stream_tile<1, 4, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
+        if (part >= 0) stream_tile<1, 4 / SPLIT_P, 0, STAMP>(a, u0 * 32u, part, u0 - a.split_start, tile, s_stats);
+        else if (units == 2) {
+            if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) stream_tile<2, 4, 1, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
+            else stream_tile<2, 4, 0, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
+        } else stream_tile<1, 4, 0, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
         // ---- publish: the tile's logits have been written through (stream_tile); one release fence, then relaxed atomics.
         // (The embeddings are ordinary stores: nothing reads them before the launch is over.)  The first wavefront sets
         // the flags of this tile's units, reads the cursor - the first unpublished unit - and the 64 flags from there on

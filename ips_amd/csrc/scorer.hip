@@ -1986,6 +1986,8 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
             tie_order_slow(sorted, keyA, Lc, M, reinterpret_cast<int*>(smem + OFF_STK));
         FAST_STAMP(5);
         {
+            // (round 5: a SECOND chunk in flight - requested three iterations ahead - changed nothing, 5.18 against 5.16 us per
+            //  iteration beside the projector stream: the loop is not waiting for these loads)
             const int lo2 = lo + 2 * I;
             const int cnt2 = k_it + 2 < n_it ? max(0, min(I, n_rows - lo2)) : 0;
             if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
@@ -2025,6 +2027,12 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
         WSTAMP(13);
         WSTAMP(14);
         FAST_STAMP(6);
+        // diagnostic (STAMP build; tools/scan_stamps.py campipe): when this iteration ended (100 MHz clock) and how many rows
+        // the loop knew to be published then - the timeline of a call, loop against producer
+        if (STAMP && b == 0 && tid == 0 && k_it < 512) {
+            stamps[8 * gridDim.x + 4 * k_it + 2] = __builtin_amdgcn_s_memrealtime();
+            stamps[8 * gridDim.x + 4 * k_it + 3] = (unsigned long long)ready_known;
+        }
 #undef WSTAMP
 #undef CAM_PREP
     }

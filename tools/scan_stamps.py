@@ -24,7 +24,7 @@ if kind == "campipe":
     x = synth.make_patches(conf, B, seed=21).to(dev)
     L = hip.lib()
     L.ipsx_dbg_scan_stamps.argtypes = [C.c_void_p]
-    st = torch.zeros((B * 8 + 2048,), dtype=torch.int64, device=dev)
+    st = torch.zeros((B * 8 + 2048 + 4 * 256,), dtype=torch.int64, device=dev)     # (+ scan_cam_kernel's per-wave log of iterations 100-103)
     for _ in range(3):
         net.ips(x)
     torch.cuda.synchronize()
@@ -35,7 +35,20 @@ if kind == "campipe":
     n_iter = 255
     log = st.cpu().numpy()[B * 8:B * 8 + 4 * n_iter].reshape(n_iter, 4)
     s = st.cpu().numpy()[:8]
-    if not log.any():        # (scan_cam_kernel keeps no per-iteration log: the phase totals below are what there is)
+    if log[:, 2].any() and not log[:, 0].any():
+        # scan_cam_kernel: end of every iteration on the 100 MHz clock + the rows it knew to be published by then
+        t = (log[:, 2] - log[0, 2]) / 100.0
+        rows = log[:, 3]
+        print("cam loop inside ips(): iteration ends, us since the end of iteration 0 | rows known published | us for the last 16 iterations")
+        for it in range(0, n_iter, 16):
+            print("   it %3d   %8.1f us   %6d rows   %6.1f us / 16 it" % (it, t[it], rows[it], t[it] - t[max(it - 16, 0)]))
+        print("   it %3d   %8.1f us   %6d rows" % (n_iter - 1, t[-1], rows[-1]))
+        d = t[1:] - t[:-1]
+        import numpy as np
+        print("   per iteration: median %.2f us, mean %.2f us, 90th percentile %.2f us, longest %.1f us (it %d); iterations over 8 us: %d, their sum %.1f us"
+              % (np.median(d), d.mean(), np.percentile(d, 90), d.max(), int(d.argmax()) + 1, int((d > 8).sum()), float(d[d > 8].sum())))
+        log = None
+    elif not log.any():        # (no per-iteration log from this kernel: the phase totals below are what there is)
         log = None
     print("per iteration (phase 4 incl. waits, phase 5 rank), every 8th:" if log is not None else "(no per-iteration log from this kernel)")
     if log is not None:
