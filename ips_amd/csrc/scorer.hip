@@ -1894,7 +1894,9 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
                 int base = 0;
                 if (lane == 0) base = atomicAdd(ccount, __popcll(mask));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (in) keyA[M + base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+                // (v_mbcnt: survivors on the lanes below this one - no per-lane mask constant, which the compiler kept in two
+                //  registers across the loop and SPILLED: a scratch reload in the hot loop, round 5)
+                if (in) keyA[M + base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = key;
             }
         }
         WSTAMP(8);
@@ -1942,7 +1944,13 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
                 if (tid < M) {
                     sorted[pr[tid] + pr[PRW + tid] + pr[2 * PRW + tid] + pr[3 * PRW + tid]] = key;
                 } else if (wave == 8 && lane < ks) {
-                    sorted[pr[M + lane] + pr[PRW + M + lane] + pr[2 * PRW + M + lane] + pr[3 * PRW + M + lane]] = keyA[M + lane];
+                    // (addresses from a copy of the lane index the compiler cannot see through: hoisted out of the loop they
+                    //  were four registers it spilled - four scratch reloads per iteration, in front of a barrier everybody
+                    //  waits at, that went to HBM whenever a producer beside the loop streamed through the L2; round 5)
+                    int ll = lane;
+                    asm volatile("" : "+v"(ll));
+                    const int* const prs = pr + M + ll;
+                    sorted[prs[0] + prs[PRW] + prs[2 * PRW] + prs[3 * PRW]] = keyA[M + ll];
                 }
             }
             WSTAMP(11);
@@ -2004,9 +2012,15 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
         {
             const uint32_t* const spos = reinterpret_cast<const uint32_t*>(sorted);         // word 2 j: ~position of rank j
             if (wave < 8) {
+                // (addresses from a copy of the thread index the compiler cannot see through: hoisted out of the loop they
+                //  were four registers it spilled - four scratch reloads per iteration that went to HBM whenever a producer
+                //  beside the loop streamed through the L2, round 5)
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
+                const uint32_t* const sp = spos + 2 * (tl >> 3);
                 uint32_t p[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) p[k] = ~spos[2 * ((tid >> 3) + 64 * k)] & (L - 1);
+                for (int k = 0; k < 4; ++k) p[k] = ~sp[128 * k] & (L - 1);
                 float gx[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) gx[k] = xc[p[k] * LD + r];
