@@ -57,7 +57,8 @@ extern "C" {
  *   2.03  round 4: ipsx_scan_persistent_ws, ipsx_scan_range_if_ws (persistent loops for candidate sets beyond the LDS)
  *   3.00  round 5: struct ipsx_conv grew by `colsum` (every struct that embeds it moved) and the projector's arithmetic
  *         contract changed (LayerNorm folded into the epilogue: ipsx_projector* need lin->colsum, ipsx_projector_stats
- *         returns the moments in the operand-stream order); ipsx_weight_colsum added */
+ *         returns the moments in the operand-stream order); ipsx_weight_colsum added; the two stream kernels publish their
+ *         last rows themselves (one more control word each: ipsx_*_stream_ctl_words), ipsx_ips_finish added */
 #define IPSX_VERSION 300
 
 #define IPSX_OK            0
@@ -437,6 +438,15 @@ size_t ipsx_topm_workspace_bytes(int b, int l, int m);
 int ipsx_gather_rows(const void* src, const int64_t* idx, void* dst,
                      int b, int64_t n_rows, int m, int64_t row_bytes,
                      int64_t src_bstride_rows, void* stream);
+
+/* The end of IPSNet.ips (architecture/ips_net.py:243-250: mem_patch = patches[mem_idx], mem_pos = pos_enc[mem_idx]) in ONE
+ * launch for calls whose selection ran as a resident loop: both gathers (rows of 16-byte units; pos may be NULL;
+ * *_bstride_rows = rows per image, 0 = one table for every image), a fresh copy of the loop's (b, m) index buffer, and -
+ * status_host != NULL - the loop's status word stored to its pinned host mirror (read by the caller one call later). */
+int ipsx_ips_finish(const void* patches, int64_t patch_row_bytes, int64_t patch_bstride_rows, int64_t n_rows,
+                    const void* pos, int64_t pos_row_bytes, int64_t pos_bstride_rows, const int64_t* mem_idx, int b, int m,
+                    void* mem_patch, void* mem_pos, int64_t* mem_idx_out, const int32_t* status, int32_t* status_host,
+                    void* stream);
 
 /* --------------------------------------------------------------- aggregation
  * Replaces Transformer.forward (transformer.py:85-109,122-132,150-152) and the

@@ -218,11 +218,18 @@ class IPSNet(nn.Module):
                 mem_idx = self._select_aten(patches, pos_enc)
 
             src = self._device_patches if self._device_patches is not None else patches
-            mem_patch = self._take(src, mem_idx).to(device)
             self._device_patches = None
-            mem_pos = self._take(pos_enc, mem_idx) if self.use_pos else None
-            if self._selection is not None:
-                self._selection.after_call()
+            sel = self._selection
+            done = sel.finish(src, pos_enc if self.use_pos else None) if sel is not None else None
+            if done is not None:       # a resident loop's call ends in ONE launch: gathers, indices, status word (round 5)
+                mem_idx, mem_patch, mem_pos = done
+            else:
+                if sel is not None:
+                    mem_idx = sel.take_unfinished(mem_idx)
+                mem_patch = self._take(src, mem_idx).to(device)
+                mem_pos = self._take(pos_enc, mem_idx) if self.use_pos else None
+                if sel is not None:
+                    sel.after_call()
         finally:
             if was_training:
                 self.encoder.train()

@@ -284,6 +284,7 @@ struct StreamArgs {
     unsigned tail_start;           // units from here on are handed out one at a time (the launch ends evenly)
     unsigned split_start, split_units;     // the LAST split_units units are handed out as SPLIT_P column quarters each
     unsigned split_base;           // ctl[split_base]: next quarter; then the quarters' hand-over flags and accumulators
+    unsigned exit_word;            // ctl[exit_word]: workgroups that have left (the last one out publishes every row)
     int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
     int* ready;                    // rows published, per slide (ipsx_scan_persistent's progress words)
     unsigned long long* stamps;    // diagnostic (ipsx_dbg_projector_stream_stamps): cycles per phase, summed by workgroup 0
@@ -609,6 +610,17 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
             }
         }
     }
+    // The last workgroup out publishes whatever two simultaneous finishers left to each other (round 5; the caller's
+    // ipsx_publish_rows launches behind this one did that): every workgroup has fenced its tiles before it counts itself out.
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (__hip_atomic_fetch_add(&a.ctl[a.exit_word], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            __hip_atomic_fetch_max(&a.ctl[1], (int)a.n_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (unsigned sl = 0; sl * a.slide_rows < a.n; ++sl)
+                __hip_atomic_fetch_max(a.ready + sl, (int)a.slide_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // nn.MaxPool2d(3, 2, 1) on channels-last activations: one thread per (output pixel, 4 channels)
@@ -766,7 +778,7 @@ static int g_stream_split = 1;
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_stream_split(int on) { g_stream_split = on; }
 
 IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) {
-    return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 + ipsx::SPLIT_WORDS : 0;
+    return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 + ipsx::SPLIT_WORDS + 1 : 0;
 }
 
 IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r) {
@@ -803,6 +815,7 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     a.short_pulls = short_first == -2 ? 0x7fffffff : 0;                            // (-2: every tile 32 rows)
     a.tail_start = a.n_units;
     a.split_start = a.n_units; a.split_units = 0; a.split_base = a.n_units + 2;
+    a.exit_word = a.n_units + 2 + (unsigned)ipsx::SPLIT_WORDS;
     if (short_first <= -3) {
         // -3 - (head + 8 tail): every workgroup's first `head` pulls and the last `tail` x workgroups units are 32-row tiles -
         // early first rows, full-rate 64-row tiles in the middle, and an end without a last round that most units sit out

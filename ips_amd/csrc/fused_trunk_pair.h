@@ -448,4 +448,14 @@ __global__ __launch_bounds__(256, 1) void fused_trunk_stream_kernel(TrunkStreamA
         }
         __syncthreads();                                                  // lds[0 .. 511] and the pull word are free again
     }
+    // The last workgroup out publishes whatever two simultaneous finishers left to each other (round 5; the caller's
+    // ipsx_publish_rows launch behind this one did that): every workgroup has fenced its tiles before it counts itself out.
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (__hip_atomic_fetch_add(&a.ctl[2 + a.n_pairs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            __hip_atomic_fetch_max(&a.ctl[1], (int)a.n_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(a.ready, (int)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }

@@ -683,6 +683,12 @@ __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane);     
 constexpr int BLOCK_QCAP = 1024;            // ranges of more than 16 elements pending at one level: <= 16,384 / 17
 constexpr int BLOCK_RANGE = 2048;           // ranges of std::sort longer than this are partitioned by the whole workgroup
 
+// Diagnostic (ipsx_dbg_persist_log; tools/soak.py): what the gate and the resident loops saw, on the 100 MHz clock -
+// [0] gate launches, [1] longest gate wait (ticks), [2] gate waits that ran into their bound, [3] start of the last gate,
+// [4] the moment the last loop became resident, [5] loops that gave up waiting for rows, [6] start of the slowest gate,
+// [7] the moment the loop it waited for became resident (0: not before the gate gave up)
+__device__ unsigned long long g_persist_log[8];
+
 // Diagnostic (ipsx_dbg_replay_stamps): shader cycles of the replay's phases, summed by thread 0 of every workgroup -
 // [0] nth_element by the workgroup, [1] its chain on one wavefront, [2 .. 5] the first four levels of std::sort's
 // partitions, [6] the deeper levels, [7] the final insertion pass; [8] = replays counted.
@@ -1195,7 +1201,10 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         // size the producers' launches for the remaining compute units)
         asm volatile("v_mov_b32 v127, 0" ::: "v127");
         // resident: tell the gate on the producing stream (ipsx_scan_gate) that the encoder may start
-        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g_persist_log[4], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     constexpr int H = R / T, ld = R + 1;
@@ -1261,7 +1270,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                                 \
             ready_known = ccount[6];                                                               \
             if (ready_known < 0) {                                                                             \
-                if (tid == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
+                if (tid == 0) { __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); g_persist_log[5] += 1; } \
                 return;                                                                                        \
             }                                                                                                  \
         }                                                                                                      \
@@ -1692,7 +1701,10 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
     __builtin_amdgcn_s_setprio(3);
     if (PERSIST) {
         asm volatile("v_mov_b32 v127, 0" ::: "v127");               // (the whole register file of the compute unit: see scan_fast_kernel)
-        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g_persist_log[4], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     unsigned long long tacc[8], tlast = 0;
     uint64_t* const sorted = reinterpret_cast<uint64_t*>(smem + OFF_SORTED);
@@ -2454,7 +2466,10 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
     if (scan_skipped(a.cond, a.cond_mask)) return;                     // (the recovery launch behind a persistent loop)
-    if (a.ready && tid == 0) __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.ready && tid == 0) {
+        __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g_persist_log[4], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     int* const wword = reinterpret_cast<int*>(smem + tail);           // (the replay's stack: free outside the replay)
     long long ready_known = 0;
     if (a.it0 == 0)
@@ -3037,9 +3052,19 @@ IPSX_API int ipsx_scan_range_if_ws(const float* logits, int b, int64_t n, int m,
 // one thread that holds its stream until every workgroup of the persistent scan is resident (bounded: ~0.5 s)
 __global__ void scan_gate_kernel(const int* status, unsigned long long wait_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool gave_up = false;
     while ((__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) == 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) { gave_up = true; break; }
+    }
+    const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t0;
+    g_persist_log[0] += 1;
+    g_persist_log[3] = t0;
+    if (gave_up) g_persist_log[2] += 1;
+    if (waited > g_persist_log[1]) {
+        g_persist_log[1] = waited;
+        g_persist_log[6] = t0;
+        g_persist_log[7] = gave_up ? 0ull : __hip_atomic_load(&g_persist_log[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -3266,6 +3291,13 @@ IPSX_API int ipsx_set_tie_order(int mode) {
 
 // Diagnostic entry point (not part of include/ipsx.h): when set to a device buffer of b*8 uint64, the next
 // resident scans accumulate per-phase s_memtime cycles there (tools/scan_stamps.py); NULL switches it off.
+// Diagnostic (not part of include/ipsx.h): copies g_persist_log to out8 (host memory) and clears it; synchronises the device
+extern "C" __attribute__((visibility("default"))) int ipsx_dbg_persist_log(unsigned long long* out8) {
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(ipsx::g_persist_log), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ipsx::g_persist_log), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_stamps(unsigned long long* buf) {
     ipsx::g_scan_stamps = buf;
 }

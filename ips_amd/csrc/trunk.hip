@@ -195,7 +195,7 @@ IPSX_API int ipsx_trunk_encode(const ipsx_trunk* t, const float* patches, int64_
 
 // One image: trunk AND logits of its patches as ONE persistent launch that feeds ipsx_scan_persistent patch by patch
 // (fused_trunk_stream_kernel).  ctl: ipsx_trunk_stream_ctl_words(n) int32 words ZEROED by the caller before every call.
-IPSX_API size_t ipsx_trunk_stream_ctl_words(int64_t n_patch) { return n_patch > 0 ? (size_t)ipsx::cdiv(n_patch, 2) + 2 : 0; }
+IPSX_API size_t ipsx_trunk_stream_ctl_words(int64_t n_patch) { return n_patch > 0 ? (size_t)ipsx::cdiv(n_patch, 2) + 3 : 0; }   // (+ the exit counter)
 
 IPSX_API int ipsx_trunk_stream_supported(const ipsx_trunk* t, int d, int r) {
     return t && ipsx::fused_trunk_supported(t) && t->precision == 0 && t->patch_dtype == 0 && d == 128 && r >= 1 && r <= 32 ? 1 : 0;

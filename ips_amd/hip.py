@@ -248,6 +248,8 @@ _EXPORTS = {
     "ipsx_topm_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "ipsx_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                    C.c_int64, C.c_int64, C.c_void_p]),
+    "ipsx_ips_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(Transf), C.c_int, C.c_int]),
     "ipsx_aggregate": (C.c_int, [C.POINTER(Transf), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -918,20 +920,27 @@ def persistent_disable(reason):
                       " (IPSX_SCAN_PERSIST=0 avoids the attempt)")
 
 
+_PERSIST_CALLS = 0            # calls that launched a resident loop (Selection.persistent_begin counts them)
+_PERSIST_RECENT = []          # _PERSIST_CALLS at the time of every recent timeout
+
+
 def persistent_timed_out(dev):
     """A persistent loop gave up waiting (its call was redone by the conditional launch: results valid).  ONE such event
-    on healthy hardware is a stalled host - the garbage collector, the allocator synchronising for a hipFree, a main
-    stream sharing the side stream's hardware queue for a moment - between the loop's launch and its producer's; it does
-    not cost a long-running job its pipelines: the device's self-test is run again (a device synchronisation, once per
-    event), and the pipelines stay on while it passes and fewer than ``IPSX_PERSIST_STRIKES`` (default 3) loops have
-    timed out in this process.  -> True when they stay on."""
+    on healthy hardware is a stalled host between the loop's launch and its producer's - the soak run
+    (tools/soak.py, profiles/r05_soak.txt) saw one in ~5,000 calls while the cyclic garbage collector could land there
+    (40-60 ms per full collection; it is held off across those lines now) and one in ~19,000 since: it does not cost a
+    long-running job its pipelines.  The device's self-test is run again (a device synchronisation, once per event), and
+    the pipelines stay on while it passes and fewer than ``IPSX_PERSIST_STRIKES`` (default 3) loops have timed out within
+    the last ``IPSX_PERSIST_WINDOW`` (default 1,000) calls that launched one.  -> True when they stay on."""
     global _PERSIST_STRIKES
     import warnings
     _PERSIST_STRIKES += 1
     limit = max(1, int(os.environ.get("IPSX_PERSIST_STRIKES", "3") or 3))
+    window = max(1, int(os.environ.get("IPSX_PERSIST_WINDOW", "1000") or 1000))
+    _PERSIST_RECENT[:] = [c for c in _PERSIST_RECENT if _PERSIST_CALLS - c < window] + [_PERSIST_CALLS]
     what = "a persistent selection loop timed out waiting for rows (its call was redone with per-part launches: results valid)"
-    if _PERSIST_STRIKES >= limit:
-        persistent_disable("%s - %d such events in this process" % (what, _PERSIST_STRIKES))
+    if len(_PERSIST_RECENT) >= limit:
+        persistent_disable("%s - %d such events within %d calls" % (what, len(_PERSIST_RECENT), window))
         return False
     dev = torch.device(dev)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -939,8 +948,9 @@ def persistent_timed_out(dev):
     if not ok:
         persistent_disable(what + "; a loop beside its producer no longer passes the device's self-test")
         return False
-    warnings.warn("ips_amd: %s; the device's self-test passes, the persistent pipelines stay on (event %d of %d allowed; "
-                  "IPSX_PERSIST_WAIT_MS raises the wait, IPSX_PERSIST_STRIKES the allowance)" % (what, _PERSIST_STRIKES, limit))
+    warnings.warn("ips_amd: %s; the device's self-test passes, the persistent pipelines stay on (event %d of %d allowed within "
+                  "%d calls; IPSX_PERSIST_WAIT_MS raises the wait, IPSX_PERSIST_STRIKES the allowance)"
+                  % (what, len(_PERSIST_RECENT), limit, window))
     return True
 
 
@@ -1077,6 +1087,40 @@ def gather_rows(src, idx):
     _ck(lib().ipsx_gather_rows(_p(src), _p(idx), _p(out), B, N, M, row_bytes, bstride, _stream()),
         "ipsx_gather_rows")
     return out
+
+
+def ips_finish_supported(src, pos):
+    """Can ``ips_finish`` end the call: device tensors whose rows are whole 16-byte units at 16-byte addresses?"""
+    if not (on_device(src) and src.is_contiguous() and src.dim() >= 3):
+        return False
+    if (src[0, 0].numel() * src.element_size()) % 16 or src.data_ptr() % 16:
+        return False
+    if pos is None:
+        return True
+    if not on_device(pos) or pos.dim() != 3:
+        return False
+    p1 = pos[:1] if pos.stride(0) == 0 else pos
+    return p1.is_contiguous() and (pos.shape[2] * pos.element_size()) % 16 == 0 and pos.data_ptr() % 16 == 0
+
+
+def ips_finish(src, pos, idx_buf, status, status_host):
+    """The end of an ``ips()`` call whose loop ran resident, ONE launch: ``src[b, idx[b, m]]``, ``pos[b, idx[b, m]]`` (or None),
+    a fresh copy of the loop's index buffer, the loop's status word to its pinned host mirror (``ipsx_ips_finish``).
+    -> (mem_idx, mem_patch, mem_pos)"""
+    B, M = idx_buf.shape
+    N = src.shape[1]
+    row_bytes = src[0, 0].numel() * src.element_size()
+    out = torch.empty((B, M) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    idx = torch.empty_like(idx_buf)
+    out_pos = None
+    pos_bytes = pos_bs = 0
+    if pos is not None:
+        pos_bs = 0 if (pos.stride(0) == 0 or pos.shape[0] == 1) else pos.shape[1]
+        pos_bytes = pos.shape[2] * pos.element_size()
+        out_pos = torch.empty((B, M, pos.shape[2]), dtype=pos.dtype, device=pos.device)
+    _ck(lib().ipsx_ips_finish(_p(src), row_bytes, N if src.shape[0] > 1 else 0, N, _p(pos), pos_bytes, pos_bs, _p(idx_buf), B, M,
+                              _p(out), _p(out_pos), _p(idx), _p(status), _p(status_host), _stream()), "ipsx_ips_finish")
+    return idx, out, out_pos
 
 
 # ------------------------------------------------------------------ image -> patches

@@ -25,12 +25,31 @@ cannot), checked again when a loop times out, and revoked for the process when t
 (``hip.persistent_timed_out``).
 """
 
+import contextlib
+import gc
 import math
 import os
 
 import torch
 
 from . import hip
+
+
+@contextlib.contextmanager
+def _no_gc_pause():
+    """Between the launch of a resident loop and the launch of its producers the host must not stall: the loop gives up
+    after 50 ms without progress (the call is then redone, results valid - but it costs 50 ms and counts as a strike).
+    What did stall it, once in ~5,000 calls of a soak run (tools/soak.py, profiles/r05_soak.txt): a full collection of the
+    interpreter's cyclic garbage collector, 40-60 ms in a process that has torch loaded, landing between the two launches.
+    The collector is held off for those few lines (an allocation-count trigger is only postponed)."""
+    was = gc.isenabled()
+    if was:
+        gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _env_on(name):
@@ -53,6 +72,7 @@ class Selection:
         self.scan_status = None          # status word of the last persistent loop (device), its host mirror
         self.scan_status_host = None
         self._mirror_pending = None
+        self._unfinished = None
         self._part_index = None
 
     # ------------------------------------------------------------------ small helpers
@@ -102,6 +122,7 @@ class Selection:
         device's self-test, and repeated timeouts (``hip.persistent_timed_out``: IPSX_PERSIST_STRIKES, default 3) or a failing
         self-test switch the persistent pipelines off for the rest of the process (the per-part launches take over)."""
         zeroed.zero_()                             # (first: everything below is host work in front of the call's second launch)
+        hip._PERSIST_CALLS += 1
         net = self.net
         ca = net.transf.crs_attn
         mirror = self.scan_status_host
@@ -131,7 +152,32 @@ class Selection:
                           workspace=scan_ws)                                                           # no-op unless timed out
         self._mirror_pending = status              # (copied to the host by after_call: behind the call's gathers)
         hip.scan.last_tie = tie
-        return mem_idx_buf.clone()                 # the buffer is overwritten by the next call
+        # the loop's own buffer - overwritten by the next call: ``finish`` (one launch: both gathers, a fresh copy of these
+        # indices, the status word to the host) or ``take_unfinished`` + a copy is the caller's next step
+        self._unfinished = mem_idx_buf
+        return mem_idx_buf
+
+    def finish(self, src, pos):
+        """The end of an ``ips()`` call whose loop ran resident, as ONE launch (``hip.ips_finish``: both gathers, a fresh copy
+        of the selected indices, the loop's status word to its pinned host mirror) -> (mem_idx, mem_patch, mem_pos), or None
+        when this call has nothing of the kind pending or the tensors' rows are not whole 16-byte units (the caller then
+        gathers itself and ``after_call`` mirrors the status word)."""
+        buf, self._unfinished = self._unfinished, None
+        if buf is None:
+            return None
+        status = self._mirror_pending
+        if status is None or not hip.ips_finish_supported(src, pos):
+            self._unfinished = buf
+            return None
+        if self.scan_status_host is None:
+            self.scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self._mirror_pending = None
+        return hip.ips_finish(src, pos, buf, status, self.scan_status_host)
+
+    def take_unfinished(self, mem_idx):
+        """``mem_idx`` as a tensor of the caller's own (the loop's buffer is overwritten by the next call)."""
+        buf, self._unfinished = self._unfinished, None
+        return mem_idx.clone() if buf is not None and mem_idx is buf else mem_idx
 
     def after_call(self):
         """The last thing an ``ips()`` call enqueues: the status word of its persistent loop goes to its pinned host mirror
@@ -313,50 +359,51 @@ class Selection:
         # keep up with any number of slides - and the compute units of the other loops stay the projector's
         # (16 slides: 240 -> 254 units, 52.5 -> [DESIGN 6] M patches/s).
         loops = self.feature_loops(B)
-        tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops, scan_ws)
         plan._refresh()
         fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)
         xf, ef, lf = patches.view(B * N, -1), emb_buf.view(B * N, -1), logits.view(1, B * N, R)
-        if (not net.use_pos and fused2 and _env_on("IPSX_CAM_STREAM") and (B == 1 or N % 32 == 0)
-                and plan.stream_supported(B * N, R)):
-            # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
-            # late).  Round 4: the loop (3.7 us per iteration) is no longer the bound of a lone slide, the projector is:
-            # 64-row tiles at full rate, the last round handed out as 32-row tiles and what is left over then as column
-            # quarters, so that the launch ends evenly (short_first = -11: half the workgroups start with a 32-row tile, one round of single units;
-            # M patches/s per slide synced / back to back: all tiles 32 rows 39.9 / 41.1, this 41.6 / 43.4; without the
-            # quarters the leftover 8-16 units were a round of their own: stream 1.38 -> 1.30 ms)
-            free = hip.device_geometry(dev).cus - loops
-            wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
-            short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-11 if B == 1 else -1)
-            plan.stream(xf, vq, R, ef, logits.view(B * N, R), ctl, ready, workgroups=wgs, slide_rows=N, short_first=short)
-            for b_ in range(B):                    # (whatever the last finishers left to each other; the launch is over)
-                hip.publish_rows(ready[b_:b_ + 1], N)
-        else:
-            its = self.feature_parts(loops, N, dev, True)
-            edges = [0] + [min(N, M + it * I) for it in its[1:]]
-            edges[-1] = N
-            launches = self.feature_launches(B, N, edges, dev, loops)
-            if fused2:
-                plan.row_stats(xf[launches[0][0]:launches[0][1]], out=stats[launches[0][0]:launches[0][1]])
-            published = None                       # (slide, rows) whose publication rides on the next GEMM launch
-            for n_step, (r0, r1, pubs) in enumerate(launches):
-                if not fused2:
-                    plan.row_stats(xf[r0:r1], out=stats[r0:r1])
-                emb = plan.encode(xf[r0:r1], stats=stats[r0:r1], out=ef[r0:r1],
-                                  publish=(ready[published[0]:published[0] + 1], published[1]) if published else None)
-                published = None
-                emb = emb.view(1, r1 - r0, -1)
-                pos = pos_enc[r0 // N:r0 // N + 1, r0 % N:r0 % N + (r1 - r0)] if net.use_pos else None
-                nxt = launches[n_step + 1] if n_step + 1 < len(launches) else None
-                if fused2 and nxt is not None:
-                    hip.logits_stats(emb, pos, vq, R, lf[:, r0:r1], xf[nxt[0]:nxt[1]], stats[nxt[0]:nxt[1]], plan.ln_eps)
-                    for b_, rows in pubs[:-1]:     # (a launch across a slide's end: the finished slide is published at once)
-                        hip.publish_rows(ready[b_:b_ + 1], rows)
-                    published = pubs[-1]
-                else:
-                    hip.logits(emb, pos, vq, R, out=lf[:, r0:r1])
-                    for b_, rows in pubs:          # after the kernels that wrote those rows
-                        hip.publish_rows(ready[b_:b_ + 1], rows)
+        with _no_gc_pause():                       # from the loop's launch to its producers': no host stall
+            tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops, scan_ws)
+            if (not net.use_pos and fused2 and _env_on("IPSX_CAM_STREAM") and (B == 1 or N % 32 == 0)
+                    and plan.stream_supported(B * N, R)):
+                # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
+                # late).  Round 4: the loop (3.7 us per iteration) is no longer the bound of a lone slide, the projector is:
+                # 64-row tiles at full rate, the last round handed out as 32-row tiles and what is left over then as column
+                # quarters, so that the launch ends evenly (short_first = -11: half the workgroups start with a 32-row tile, one round of single units;
+                # M patches/s per slide synced / back to back: all tiles 32 rows 39.9 / 41.1, this 41.6 / 43.4; without the
+                # quarters the leftover 8-16 units were a round of their own: stream 1.38 -> 1.30 ms)
+                free = hip.device_geometry(dev).cus - loops
+                wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
+                short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-11 if B == 1 else -1)
+                plan.stream(xf, vq, R, ef, logits.view(B * N, R), ctl, ready, workgroups=wgs, slide_rows=N, short_first=short)
+                # (whatever two simultaneous finishers leave to each other is published by the last workgroup out: round 5 -
+                #  it was one publish_rows launch per slide behind the stream)
+            else:
+                its = self.feature_parts(loops, N, dev, True)
+                edges = [0] + [min(N, M + it * I) for it in its[1:]]
+                edges[-1] = N
+                launches = self.feature_launches(B, N, edges, dev, loops)
+                if fused2:
+                    plan.row_stats(xf[launches[0][0]:launches[0][1]], out=stats[launches[0][0]:launches[0][1]])
+                published = None                       # (slide, rows) whose publication rides on the next GEMM launch
+                for n_step, (r0, r1, pubs) in enumerate(launches):
+                    if not fused2:
+                        plan.row_stats(xf[r0:r1], out=stats[r0:r1])
+                    emb = plan.encode(xf[r0:r1], stats=stats[r0:r1], out=ef[r0:r1],
+                                      publish=(ready[published[0]:published[0] + 1], published[1]) if published else None)
+                    published = None
+                    emb = emb.view(1, r1 - r0, -1)
+                    pos = pos_enc[r0 // N:r0 // N + 1, r0 % N:r0 % N + (r1 - r0)] if net.use_pos else None
+                    nxt = launches[n_step + 1] if n_step + 1 < len(launches) else None
+                    if fused2 and nxt is not None:
+                        hip.logits_stats(emb, pos, vq, R, lf[:, r0:r1], xf[nxt[0]:nxt[1]], stats[nxt[0]:nxt[1]], plan.ln_eps)
+                        for b_, rows in pubs[:-1]:     # (a launch across a slide's end: the finished slide is published at once)
+                            hip.publish_rows(ready[b_:b_ + 1], rows)
+                        published = pubs[-1]
+                    else:
+                        hip.logits(emb, pos, vq, R, out=lf[:, r0:r1])
+                        for b_, rows in pubs:          # after the kernels that wrote those rows
+                            hip.publish_rows(ready[b_:b_ + 1], rows)
         net._emb_parts = [emb_buf]
         return self.persistent_end(logits, mem_idx_buf, tie, status, n_iter, dev, scan_ws)
 
@@ -378,9 +425,10 @@ class Selection:
                      torch.empty((1, M), dtype=torch.int64, device=dev),
                      torch.empty((1, N, net.D), dtype=torch.float32, device=dev),
                      torch.zeros((3 + plan.image_stream_ctl_words(N),), dtype=torch.int32, device=dev)))
-        tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, 1, dev)
-        plan.image_stream(patches[0], pos_enc[0] if net.use_pos else None, vq, R, emb_buf[0], logits[0], ctl, ready)
-        hip.publish_rows(ready, N)                 # (whatever the last finishers left to each other; the launch is over)
+        with _no_gc_pause():                       # from the loop's launch to its producer's: no host stall
+            tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, 1, dev)
+            plan.image_stream(patches[0], pos_enc[0] if net.use_pos else None, vq, R, emb_buf[0], logits[0], ctl, ready)
+        # (whatever two simultaneous finishers leave to each other is published by the last workgroup out: no launch for it)
         net._emb_parts = [emb_buf]
         return self.persistent_end(logits, mem_idx_buf, tie, status, self.n_iter(N), dev)
 

@@ -594,6 +594,7 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
     # the process (IPSX_PERSIST_STRIKES) switches them off (the per-part launches take over) - results valid throughout
     monkeypatch.setattr(hip, "_PERSIST_OFF", None)              # (restored when this test ends)
     monkeypatch.setattr(hip, "_PERSIST_STRIKES", 0)
+    monkeypatch.setattr(hip, "_PERSIST_RECENT", [])
     for event in (1, 2):
         net.selection.scan_status_host.fill_(1)
         with pytest.warns(UserWarning, match="self-test passes"):
@@ -609,7 +610,18 @@ def test_persistent_loop_equals_per_part_launches_and_recovers_from_a_timeout(mo
     assert net.selection.scan_status is None and torch.equal(net.last_mem_idx, want)
     monkeypatch.setattr(hip, "_PERSIST_OFF", None)
     monkeypatch.setattr(hip, "_PERSIST_STRIKES", 0)
+    monkeypatch.setattr(hip, "_PERSIST_RECENT", [])
     assert hip.persistent_ok(DEV)
+    # ... and events further apart than IPSX_PERSIST_WINDOW calls do not add up
+    monkeypatch.setenv("IPSX_PERSIST_WINDOW", "2")
+    for _ in range(4):
+        net.selection.scan_status_host.fill_(1)
+        with pytest.warns(UserWarning, match="self-test passes"):
+            net.ips(x)
+        net.ips(x)
+        net.ips(x)
+        assert hip.persistent_ok(DEV) and torch.equal(net.last_mem_idx, want)
+    monkeypatch.setattr(hip, "_PERSIST_RECENT", [])
 
 
 @pytest.mark.gpu

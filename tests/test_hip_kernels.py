@@ -308,6 +308,33 @@ def test_trunk_stream_equals_encode_plus_logits(n, wgs, use_pos, quads):
         assert torch.equal(lg, want_lg), "max abs diff %g" % float((lg - want_lg).abs().max())
 
 
+def test_ips_finish_is_the_two_gathers_the_index_copy_and_the_status_mirror():
+    """ipsx_ips_finish - the end of an ips() call with a resident loop as ONE launch - against ipsx_gather_rows on the same
+    indices: image patches with a per-image positional table, feature rows with ONE table expanded over the batch, no
+    table at all; the index buffer comes back as a fresh tensor and the status word lands in the pinned host mirror."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for shape, pos_mode in (((3, 50, 1, 32, 32), "per_image"), ((2, 300, 2048), "expanded"), ((1, 70, 3, 8, 8), None)):
+        src = torch.randn(shape, generator=g).to(DEV)
+        B, N = shape[:2]
+        M = 17
+        idx = torch.randint(0, N, (B, M), generator=g).to(DEV)
+        pos = None
+        if pos_mode == "per_image":
+            pos = torch.randn((B, N, 128), generator=g).to(DEV)
+        elif pos_mode == "expanded":
+            pos = torch.randn((1, N, 512), generator=g).to(DEV).expand(B, -1, -1)
+        status = torch.tensor([2], dtype=torch.int32, device=DEV)
+        mirror = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        assert hip.ips_finish_supported(src, pos)
+        got_idx, got_patch, got_pos = hip.ips_finish(src, pos, idx, status, mirror)
+        torch.cuda.synchronize()
+        assert got_idx.data_ptr() != idx.data_ptr() and torch.equal(got_idx, idx)
+        assert torch.equal(got_patch, hip.gather_rows(src, idx))
+        assert (got_pos is None) == (pos is None) and (pos is None or torch.equal(got_pos, hip.gather_rows(pos, idx)))
+        assert int(mirror.item()) == 2
+    assert not hip.ips_finish_supported(torch.zeros((1, 4, 3), device=DEV), None)          # rows of 12 bytes: the gathers take over
+
+
 @pytest.mark.parametrize("n,f", [(1, 2048), (31, 2048), (33, 64), (130, 1024), (4097, 2048), (257, 8), (64, 2056)])
 def test_projector_moments_and_column_sums_are_the_oracles(n, f):
     """ipsx_projector_stats (row_moments_kernel: the moments in the order the GEMM's operand stream gives them, round 5)
