@@ -58,7 +58,8 @@ extern "C" {
  *   3.00  round 5: struct ipsx_conv grew by `colsum` (every struct that embeds it moved) and the projector's arithmetic
  *         contract changed (LayerNorm folded into the epilogue: ipsx_projector* need lin->colsum, ipsx_projector_stats
  *         returns the moments in the operand-stream order); ipsx_weight_colsum added; the two stream kernels publish their
- *         last rows themselves (one more control word each: ipsx_*_stream_ctl_words), ipsx_ips_finish added */
+ *         last rows themselves (one more control word each: ipsx_*_stream_ctl_words), ipsx_ips_finish, ipsx_ips_call_run /
+ *         ipsx_ips_call_elapsed added */
 #define IPSX_VERSION 300
 
 #define IPSX_OK            0
@@ -447,6 +448,33 @@ int ipsx_ips_finish(const void* patches, int64_t patch_row_bytes, int64_t patch_
                     const void* pos, int64_t pos_row_bytes, int64_t pos_bstride_rows, const int64_t* mem_idx, int b, int m,
                     void* mem_patch, void* mem_pos, int64_t* mem_idx_out, const int32_t* status, int32_t* status_host,
                     void* stream);
+
+/* ONE IPSNet.ips call whose selection loop is resident (architecture/ips_net.py:169-262 for one image on the fused trunk,
+ * or for feature slides through the projector), enqueued by ONE library call: fill of the control words, the loop on
+ * `side_stream` (ipsx_scan_persistent_ws), the gate, the producer on `stream` (ipsx_trunk_stream when `trunk` is set -
+ * b == 1 -, ipsx_projector_stream when `lin` is set), the conditional recovery launch (ipsx_scan_range_if_ws) and the end
+ * of the call (ipsx_ips_finish), with the two cross-stream hand-overs between them.  Same kernels, same results as the
+ * entry points called one by one; the host's share of a call drops from ~12 calls to one, and nothing can stall the host
+ * between the launch of the loop and the launch of the producer it waits for.
+ *   words: words_total int32 = tie flags [b] | progress words [b] | status | the producer's control words
+ *          (ipsx_trunk_stream_ctl_words / ipsx_projector_stream_ctl_words); zeroed by the call.
+ *   timing_slot in [0, 64): the producer's launch is bracketed by a library-owned HIP event pair; ipsx_ips_call_elapsed
+ *          (slot, &ms) reads it once the stream has been synchronised.  -1: no events.                                */
+typedef struct ipsx_ips_call {
+    int b; int64_t n; int m, i, h, n_token;
+    float* logits; int64_t* mem_idx; int32_t* words; int64_t words_total;
+    int loops; void* scan_workspace; size_t scan_workspace_bytes;
+    const ipsx_trunk* trunk; const float* pos; int quad_pulls;
+    const ipsx_conv* lin; float ln_eps; int short_first;
+    const void* x; float* emb; const float* v_packed; int r; int workgroups;
+    const void* src; int64_t src_row_bytes, src_bstride_rows;
+    const void* pos_table; int64_t pos_row_bytes, pos_bstride_rows;
+    void* mem_patch; void* mem_pos; int64_t* mem_idx_out; int32_t* status_host;
+    int timing_slot;
+    void* stream; void* side_stream;
+} ipsx_ips_call;
+int ipsx_ips_call_run(const ipsx_ips_call* c);
+int ipsx_ips_call_elapsed(int slot, float* ms);
 
 /* --------------------------------------------------------------- aggregation
  * Replaces Transformer.forward (transformer.py:85-109,122-132,150-152) and the

@@ -1,0 +1,100 @@
+// call.hip - one IPSNet.ips call whose selection loop is resident, enqueued by ONE library call (round 5).
+//
+// Reference: IPSNet.ips, architecture/ips_net.py:169-262, for ONE image (B_seq = 1, config/mnist_config.yml:4-5) or for
+// feature slides (config/camelyon_config.yml).  The pieces are the library's own entry points - fill, the resident loop on
+// the side stream (ipsx_scan_persistent_ws), the gate, the producer (ipsx_trunk_stream | ipsx_projector_stream), the
+// conditional recovery launch (ipsx_scan_range_if_ws), the end of the call (ipsx_ips_finish) - and the two cross-stream
+// hand-overs between them.  Enqueued from Python they cost ~12 ctypes calls, two torch event objects and ~170 us of host
+// time per call, of which ~100 us sit IN FRONT of the producer's launch: a synchronised call of one image was 0.92 ms
+// around a 0.77 ms kernel.  Enqueued here the host's share is one call; and nothing of the interpreter - the
+// garbage collector, the allocator, another thread holding the GIL - can stall the host between the launch of the loop
+// and the launch of the producer it waits for (tools/soak.py: what a loop's rare timeouts were made of).
+//
+// Timing: slots of HIP event pairs owned by the library bracket the PRODUCER's launch on request (bench.py's roofline
+// figure: torch's own event objects cannot be recorded from here).
+
+#include "ipsx_common.h"
+
+namespace {
+
+constexpr int kSlots = 64, kDevices = 16;
+
+struct DeviceEvents {
+    hipEvent_t fork = nullptr, join = nullptr;          // main -> side (the loop follows the fill), side -> main (the end follows the loop)
+    hipEvent_t t0[kSlots] = {}, t1[kSlots] = {};
+    bool ok = false;
+};
+
+DeviceEvents* device_events() {
+    static DeviceEvents ev[kDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevices) return nullptr;
+    DeviceEvents& e = ev[dev];
+    if (!e.ok) {
+        if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        e.ok = true;
+    }
+    return &e;
+}
+
+}  // namespace
+
+using namespace ipsx;
+
+IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
+    IPSX_REQUIRE(c && c->logits && c->mem_idx && c->words && c->x && c->emb && c->v_packed && c->src && c->mem_patch && c->mem_idx_out,
+                 "ips_call: null pointer");
+    IPSX_REQUIRE(c->b > 0 && c->n > c->m && c->m > 0 && c->i > 0 && c->h > 0 && c->n_token > 0, "ips_call: bad sizes");
+    IPSX_REQUIRE((c->trunk != nullptr) != (c->lin != nullptr), "ips_call: exactly one producer (trunk for one image, lin for feature slides)");
+    IPSX_REQUIRE(!c->trunk || c->b == 1, "ips_call: the trunk stream takes ONE image");
+    IPSX_REQUIRE(c->side_stream && c->side_stream != c->stream, "ips_call: the loop needs a stream of its own");
+    IPSX_REQUIRE(c->words_total >= 2 * (int64_t)c->b + 1, "ips_call: control words");
+    DeviceEvents* ev = device_events();
+    if (!ev) return fail(IPSX_EHIP, "ips_call: no events on this device");
+    hipStream_t main = as_stream(c->stream), side = as_stream(c->side_stream);
+    int32_t* const tie = c->words;
+    int32_t* const ready = c->words + c->b;
+    int32_t* const status = c->words + 2 * c->b;
+    int32_t* const ctl = status + 1;
+    const int64_t n_iter = cdiv(c->n - c->m, c->i);
+    auto hip_ok = [](hipError_t e, const char* what) { return e == hipSuccess ? IPSX_OK : fail(IPSX_EHIP, "ips_call: %s: %s", what, hipGetErrorString(e)); };
+
+    IPSX_TRY(hip_ok(hipMemsetAsync(c->words, 0, (size_t)c->words_total * sizeof(int32_t), main), "fill"));
+    IPSX_TRY(hip_ok(hipEventRecord(ev->fork, main), "event"));
+    IPSX_TRY(hip_ok(hipStreamWaitEvent(side, ev->fork, 0), "wait"));
+    IPSX_TRY(ipsx_scan_persistent_ws(c->logits, c->b, c->n, c->m, c->i, c->h, c->n_token, c->mem_idx, nullptr, tie, ready,
+                                     c->b > 1 ? 1 : 0, status, c->loops, c->scan_workspace, c->scan_workspace_bytes, side));
+    // producers must not take the compute units before a loop has its own (see ipsx_scan_gate)
+    IPSX_TRY(ipsx_scan_gate(status, main));
+    const int slot = c->timing_slot;
+    if (slot >= 0 && slot < kSlots) {
+        if (!ev->t0[slot]) {
+            IPSX_TRY(hip_ok(hipEventCreate(&ev->t0[slot]), "timing event"));
+            IPSX_TRY(hip_ok(hipEventCreate(&ev->t1[slot]), "timing event"));
+        }
+        IPSX_TRY(hip_ok(hipEventRecord(ev->t0[slot], main), "timing event"));
+    }
+    if (c->trunk)
+        IPSX_TRY(ipsx_trunk_stream(c->trunk, static_cast<const float*>(c->x), c->n, c->emb, c->pos, c->v_packed, c->r, c->logits, ctl,
+                                   ready, c->workgroups, c->quad_pulls, main));
+    else
+        IPSX_TRY(ipsx_projector_stream(c->lin, static_cast<const float*>(c->x), (int64_t)c->b * c->n, c->n, c->ln_eps, c->emb, c->v_packed,
+                                       c->r, c->logits, ctl, ready, c->workgroups, c->short_first, main));
+    if (slot >= 0 && slot < kSlots) IPSX_TRY(hip_ok(hipEventRecord(ev->t1[slot], main), "timing event"));
+    IPSX_TRY(hip_ok(hipEventRecord(ev->join, side), "event"));
+    IPSX_TRY(hip_ok(hipStreamWaitEvent(main, ev->join, 0), "wait"));
+    // a loop that gave up waiting is redone here, in the same call (a no-op otherwise)
+    IPSX_TRY(ipsx_scan_range_if_ws(c->logits, c->b, c->n, c->m, c->i, c->h, c->n_token, 0, n_iter, c->mem_idx, nullptr, tie, status, 1,
+                                   c->scan_workspace, c->scan_workspace_bytes, main));
+    return ipsx_ips_finish(c->src, c->src_row_bytes, c->src_bstride_rows, c->n, c->pos_table, c->pos_row_bytes, c->pos_bstride_rows,
+                           c->mem_idx, c->b, c->m, c->mem_patch, c->mem_pos, c->mem_idx_out, status, c->status_host, main);
+}
+
+IPSX_API int ipsx_ips_call_elapsed(int slot, float* ms) {
+    IPSX_REQUIRE(ms && slot >= 0 && slot < kSlots, "ips_call_elapsed: bad arguments");
+    DeviceEvents* ev = device_events();
+    if (!ev || !ev->t0[slot]) return fail(IPSX_EINVAL, "ips_call_elapsed: slot %d was never recorded on this device", slot);
+    const hipError_t e = hipEventElapsedTime(ms, ev->t0[slot], ev->t1[slot]);
+    return e == hipSuccess ? IPSX_OK : fail(IPSX_EHIP, "ips_call_elapsed: %s", hipGetErrorString(e));
+}

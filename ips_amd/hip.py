@@ -132,6 +132,20 @@ class Trunk(C.Structure):
                 ("n_block", C.c_int), ("blocks", C.POINTER(Block)), ("precision", C.c_int), ("patch_dtype", C.c_int)]
 
 
+class IpsCall(C.Structure):
+    """include/ipsx.h ``ipsx_ips_call``: one ips() call with a resident loop, enqueued by ONE library call."""
+    _fields_ = [("b", C.c_int), ("n", C.c_int64), ("m", C.c_int), ("i", C.c_int), ("h", C.c_int), ("n_token", C.c_int),
+                ("logits", C.c_void_p), ("mem_idx", C.c_void_p), ("words", C.c_void_p), ("words_total", C.c_int64),
+                ("loops", C.c_int), ("scan_workspace", C.c_void_p), ("scan_workspace_bytes", C.c_size_t),
+                ("trunk", C.POINTER(Trunk)), ("pos", C.c_void_p), ("quad_pulls", C.c_int),
+                ("lin", C.POINTER(Conv)), ("ln_eps", C.c_float), ("short_first", C.c_int),
+                ("x", C.c_void_p), ("emb", C.c_void_p), ("v_packed", C.c_void_p), ("r", C.c_int), ("workgroups", C.c_int),
+                ("src", C.c_void_p), ("src_row_bytes", C.c_int64), ("src_bstride_rows", C.c_int64),
+                ("pos_table", C.c_void_p), ("pos_row_bytes", C.c_int64), ("pos_bstride_rows", C.c_int64),
+                ("mem_patch", C.c_void_p), ("mem_pos", C.c_void_p), ("mem_idx_out", C.c_void_p), ("status_host", C.c_void_p),
+                ("timing_slot", C.c_int), ("stream", C.c_void_p), ("side_stream", C.c_void_p)]
+
+
 class Transf(C.Structure):
     _fields_ = [("n_token", C.c_int), ("h", C.c_int), ("d", C.c_int), ("dk", C.c_int),
                 ("dv", C.c_int), ("d_inner", C.c_int)] + \
@@ -248,6 +262,8 @@ _EXPORTS = {
     "ipsx_topm_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "ipsx_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                    C.c_int64, C.c_int64, C.c_void_p]),
+    "ipsx_ips_call_run": (C.c_int, [C.POINTER(IpsCall)]),
+    "ipsx_ips_call_elapsed": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "ipsx_ips_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(Transf), C.c_int, C.c_int]),

@@ -26,6 +26,7 @@ cannot), checked again when a loop times out, and revoked for the process when t
 """
 
 import contextlib
+import ctypes as C
 import gc
 import math
 import os
@@ -73,6 +74,9 @@ class Selection:
         self.scan_status_host = None
         self._mirror_pending = None
         self._unfinished = None
+        self._done = None                          # (mem_idx, mem_patch, mem_pos) of a call the library enqueued whole
+        self._calls = {}                           # hip.IpsCall structures, per pipeline
+        self.timing_hook = None                    # callable(rows) -> slot of a library-owned event pair around the producer, or None
         self._part_index = None
 
     # ------------------------------------------------------------------ small helpers
@@ -162,6 +166,9 @@ class Selection:
         of the selected indices, the loop's status word to its pinned host mirror) -> (mem_idx, mem_patch, mem_pos), or None
         when this call has nothing of the kind pending or the tensors' rows are not whole 16-byte units (the caller then
         gathers itself and ``after_call`` mirrors the status word)."""
+        done, self._done = self._done, None
+        if done is not None:
+            return done
         buf, self._unfinished = self._unfinished, None
         if buf is None:
             return None
@@ -178,6 +185,79 @@ class Selection:
         """``mem_idx`` as a tensor of the caller's own (the loop's buffer is overwritten by the next call)."""
         buf, self._unfinished = self._unfinished, None
         return mem_idx.clone() if buf is not None and mem_idx is buf else mem_idx
+
+    def native_ok(self, src, pos):
+        """Can the library enqueue this call whole (``ipsx_ips_call_run``)?  Needs what ``ips_finish`` needs of the tensors."""
+        return _env_on("IPSX_NATIVE_CALL") and hip.ips_finish_supported(src, pos)
+
+    def native_call(self, name, patches, pos_enc, logits, mem_idx_buf, zeroed, emb_buf, scan_ws, loops, wgs, trunk_pos=None,
+                    quad_pulls=-1, short_first=-1):
+        """One ips() call with a resident loop, enqueued by ONE library call (csrc/call.hip): fill, loop on the side stream,
+        gate, producer (the fused trunk for one image / the projector for feature slides), conditional recovery, and the end
+        of the call (both gathers, indices, status word to the host).  Same kernels and results as the launches one by one
+        (``IPSX_NATIVE_CALL=0``); the host's share of a call is one ctypes call, and nothing of the interpreter sits between
+        the loop's launch and its producer's.  -> mem_idx (fresh); ``finish`` hands out (mem_idx, mem_patch, mem_pos)."""
+        net, plan = self.net, self.plan()
+        B, N = patches.shape[:2]
+        dev = patches.device
+        ca = net.transf.crs_attn
+        vq, R = ca.folded_query(), ca.H * ca.n_token
+        mirror = self.scan_status_host
+        if mirror is None:
+            mirror = self.scan_status_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        elif int(mirror.item()) & 1:
+            mirror.zero_()
+            hip.persistent_timed_out(dev)          # (self-test again; off for the process only after repeated events)
+        hip._PERSIST_CALLS += 1
+        side, _ = self.streams(dev)
+        plan._refresh()
+        c = self._calls.get(name)
+        if c is None or c[0] is not logits:
+            call = hip.IpsCall()
+            call.b, call.n, call.m, call.i, call.h, call.n_token = B, N, net.M, net.I, ca.H, ca.n_token
+            call.logits, call.mem_idx = logits.data_ptr(), mem_idx_buf.data_ptr()
+            call.words, call.words_total = zeroed.data_ptr(), zeroed.numel()
+            call.loops = loops
+            call.scan_workspace = scan_ws.data_ptr() if scan_ws is not None else None
+            call.scan_workspace_bytes = scan_ws.numel() if scan_ws is not None else 0
+            call.emb, call.r, call.workgroups = emb_buf.data_ptr(), R, wgs
+            call.quad_pulls, call.short_first = quad_pulls, short_first
+            call.status_host = mirror.data_ptr()
+            call.side_stream = side.cuda_stream
+            c = self._calls[name] = (logits, call, (mem_idx_buf, zeroed, emb_buf, scan_ws, mirror))
+        call = c[1]
+        if net.is_image:
+            call.trunk, call.lin = C.pointer(plan.trunk), None
+            call.pos = trunk_pos.data_ptr() if trunk_pos is not None else None
+        else:
+            call.trunk, call.lin, call.ln_eps = None, C.pointer(plan.lin), plan.ln_eps
+        call.x = patches.data_ptr()
+        call.v_packed = vq.data_ptr()
+        M = net.M
+        mem_patch = torch.empty((B, M) + tuple(patches.shape[2:]), dtype=patches.dtype, device=dev)
+        mem_idx = torch.empty((B, M), dtype=torch.int64, device=dev)
+        mem_pos = None
+        call.src = patches.data_ptr()
+        call.src_row_bytes = patches[0, 0].numel() * patches.element_size()
+        call.src_bstride_rows = N if B > 1 else 0
+        if pos_enc is not None:
+            mem_pos = torch.empty((B, M, pos_enc.shape[2]), dtype=pos_enc.dtype, device=dev)
+            call.pos_table = pos_enc.data_ptr()
+            call.pos_row_bytes = pos_enc.shape[2] * pos_enc.element_size()
+            call.pos_bstride_rows = 0 if (pos_enc.stride(0) == 0 or B == 1) else N
+            call.mem_pos = mem_pos.data_ptr()
+        else:
+            call.pos_table, call.pos_row_bytes, call.pos_bstride_rows, call.mem_pos = None, 0, 0, None
+        call.mem_patch, call.mem_idx_out = mem_patch.data_ptr(), mem_idx.data_ptr()
+        call.timing_slot = self.timing_hook(B * N) if self.timing_hook is not None else -1
+        call.stream = hip._stream().value
+        hip._ck(hip.lib().ipsx_ips_call_run(C.byref(call)), "ipsx_ips_call_run")
+        tie, status = zeroed[:B], zeroed[2 * B:2 * B + 1]
+        self.scan_status = status
+        hip.scan.last_tie = tie
+        net._emb_parts = [emb_buf]
+        self._done = (mem_idx, mem_patch, mem_pos)
+        return mem_idx
 
     def after_call(self):
         """The last thing an ``ips()`` call enqueues: the status word of its persistent loop goes to its pinned host mirror
@@ -362,10 +442,17 @@ class Selection:
         plan._refresh()
         fused2 = vq.dtype == torch.float32         # (bf16 logits: a launch of their own, plain statistics and publication)
         xf, ef, lf = patches.view(B * N, -1), emb_buf.view(B * N, -1), logits.view(1, B * N, R)
+        streamed = (not net.use_pos and fused2 and _env_on("IPSX_CAM_STREAM") and (B == 1 or N % 32 == 0)
+                    and plan.stream_supported(B * N, R))
+        if streamed and patches.dtype == torch.float32 and self.native_ok(patches, None):
+            free = hip.device_geometry(dev).cus - loops
+            wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
+            short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-11 if B == 1 else -1)
+            return self.native_call("features", patches, None, logits, mem_idx_buf, zeroed, emb_buf, scan_ws, loops, wgs,
+                                    short_first=short)
         with _no_gc_pause():                       # from the loop's launch to its producers': no host stall
             tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops, scan_ws)
-            if (not net.use_pos and fused2 and _env_on("IPSX_CAM_STREAM") and (B == 1 or N % 32 == 0)
-                    and plan.stream_supported(B * N, R)):
+            if streamed:
                 # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
                 # late).  Round 4: the loop (3.7 us per iteration) is no longer the bound of a lone slide, the projector is:
                 # 64-row tiles at full rate, the last round handed out as 32-row tiles and what is left over then as column
@@ -425,6 +512,10 @@ class Selection:
                      torch.empty((1, M), dtype=torch.int64, device=dev),
                      torch.empty((1, N, net.D), dtype=torch.float32, device=dev),
                      torch.zeros((3 + plan.image_stream_ctl_words(N),), dtype=torch.int32, device=dev)))
+        if patches.dtype == torch.float32 and self.native_ok(patches, pos_enc if net.use_pos else None):
+            tp = (pos_enc[0] if pos_enc[0].is_contiguous() else pos_enc[0].contiguous()) if net.use_pos else None
+            return self.native_call("image", patches, pos_enc if net.use_pos else None, logits, mem_idx_buf, zeroed, emb_buf, None, 0, 0,
+                                    trunk_pos=tp, quad_pulls=-1)
         with _no_gc_pause():                       # from the loop's launch to its producer's: no host stall
             tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, 1, dev)
             plan.image_stream(patches[0], pos_enc[0] if net.use_pos else None, vq, R, emb_buf[0], logits[0], ctl, ready)
