@@ -333,8 +333,12 @@ int ipsx_logits_bf16(const float* emb, int64_t emb_bstride, const float* pos, in
 /* Order of equal scores in the top-M steps of ipsx_scan / ipsx_scan_range / ipsx_topm (process-wide).
  * 1 (default) = the reference's: torch.topk on CPU returns what libstdc++'s nth_element + sort (or
  * partial_sort when 64*M <= L) leave behind (ATen/native/TopKImpl.h:45-68, reference call site
- * ips_net.py:148); those routines are replayed on the device whenever two of the first M+1 ranked
- * scores are equal, so the selected indices match the reference's CPU path under ties as well.
+ * ips_net.py:148); those routines are replayed on the device - by ipsx_topm whenever two of the first M+1
+ * ranked scores are equal; by the selection loops (ipsx_scan*, round 5) when two NEIGHBOURS among the first
+ * M+1 canonical ranks have equal scores AND bit-identical logit rows (duplicated patches: they tie in the
+ * reference's arithmetic as well, so its order there is torch's) - two different rows whose scores collide in
+ * the last bit of THIS arithmetic keep the canonical order (in the reference's arithmetic they are an ulp apart).
+ * 2 = the loops replay on every tie too (rounds 1-4).
  * 0 = canonical: score descending, earlier candidate position first (no sequential step).
  * Returns the previous mode; any other argument only queries.                                       */
 int ipsx_set_tie_order(int mode);

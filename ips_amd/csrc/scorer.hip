@@ -366,7 +366,7 @@ __device__ __forceinline__ uint64_t* sort_desc(uint64_t* src, uint64_t* tmp, int
 // position first).  When two of the first m+1 ranked scores are equal the reference returns whatever libstdc++'s
 // nth_element / sort / partial_sort leave behind, and that order feeds the next iteration; with tie order 1
 // ("torch", the default) one lane replays those routines on the candidate array and rewrites sorted[0..m).
-static int g_tie_order = 1;
+static int g_tie_order = 1;     // 0 canonical; 1 (default) torch.topk's order where bit-identical candidates tie; 2 wherever scores tie
 constexpr int STK_BYTES = 3 * stdorder::STACK_RANGES * 4;
 
 // every wave evaluates this on the same data: the result is uniform over the workgroup without a barrier
@@ -382,12 +382,28 @@ __device__ __forceinline__ bool ranked_ties(const uint64_t* sorted, int L, int m
 }
 
 // the same test on the padded key array of the large kernels (key j at slot j + (j >> 4))
-__device__ __forceinline__ bool ranked_ties_padded(const uint64_t* sorted, int L, int m, int lane) {
+// where the logit rows of a loop's candidates live (scan_large_kernel): candidate p < m is memory slot p = patch mem[p],
+// candidate p >= m is patch lo + (p - m); R floats per patch.  lg == nullptr: no rows (ipsx_topm: scores only)
+struct TieRows { const float* lg; const long long* mem; long long lo; int m, R; };
+
+// ties among the first m + 1 canonical ranks that call for torch.topk's order: tie_order 2 (and callers without rows) any
+// two neighbours of equal score; tie_order 1, the loop's rule (oracle orc_topm_loop): neighbours of equal score whose logit
+// rows are bit-identical
+__device__ __forceinline__ bool ranked_ties_padded(const uint64_t* sorted, int L, int m, int lane, int tie_order = 2,
+                                                   const TieRows* rows = nullptr) {
     const int n = m < L - 1 ? m : L - 1;
+    const bool by_rows = tie_order == 1 && rows != nullptr && rows->lg != nullptr;
     bool any = false;
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
-        const bool e = j < n && (sorted[j + (j >> 4)] >> 32) == (sorted[j + 1 + ((j + 1) >> 4)] >> 32);
+        const uint64_t ka = j < n ? sorted[j + (j >> 4)] : 0ull, kb = j < n ? sorted[j + 1 + ((j + 1) >> 4)] : 1ull << 32;
+        bool e = j < n && (ka >> 32) == (kb >> 32);
+        if (e && by_rows) {
+            const long long pa = key_pos(ka), pb = key_pos(kb);
+            const float* ra = rows->lg + (size_t)(pa < rows->m ? rows->mem[pa] : rows->lo + (pa - rows->m)) * rows->R;
+            const float* rb = rows->lg + (size_t)(pb < rows->m ? rows->mem[pb] : rows->lo + (pb - rows->m)) * rows->R;
+            for (int r = 0; r < rows->R; ++r) e = e && as_u32(ra[r]) == as_u32(rb[r]);
+        }
         any = any || (__ballot(e) != 0ull);
     }
     return any;
@@ -1500,16 +1516,27 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
             rank_runs4(keyA, keyB, reinterpret_cast<uint64_t*>(en), Lr);
         }
         lds_barrier();
-        // exact ties among the first M + 1 ranked scores?  One pair per thread, any hit raises the flag.
-        {
+        // exact ties among the first M + 1 ranked scores that call for torch.topk's order?  The loop's rule (oracle
+        // orc_topm_loop, round 5): two NEIGHBOURS of equal score whose logit rows are bit-identical (tie_order 2: any two of
+        // equal score).  One pair per thread, any hit raises the flag.
+        if (a.tie_order != 0) {
             const int npair = a.m < Lr - 1 ? a.m : Lr - 1;
             bool hit = false;
-            for (int j = tid; j < npair; j += SCAN_NT) hit = hit || (sorted[j] >> 32) == (sorted[j + 1] >> 32);
+            for (int j = tid; j < npair; j += SCAN_NT) {
+                if ((sorted[j] >> 32) != (sorted[j + 1] >> 32)) continue;
+                bool same = true;
+                if (a.tie_order == 1) {
+                    const float* ra = xc + key_pos(sorted[j]) * ld;
+                    const float* rb = xc + key_pos(sorted[j + 1]) * ld;
+                    for (int rr = 0; rr < R; ++rr) same = same && as_u32(ra[rr]) == as_u32(rb[rr]);
+                }
+                hit = hit || same;
+            }
             if (__ballot(hit) != 0ull && lane == 0) ccount[2 + par] = 1;
         }
         lds_barrier();
         bool boundary_tie = Lr > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);   // bit-equal score keys (the oracle's rule: two NaNs tie)
-        if (a.tie_order == 1 && ccount[2 + par] != 0) {
+        if (a.tie_order != 0 && ccount[2 + par] != 0) {
             // torch.topk's order under ties depends on the WHOLE candidate array, so every chunk key goes back to its
             // place, all L candidates are ranked and the replay runs on them (rare)
             const unsigned long long ts0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
@@ -1989,11 +2016,24 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
             lds_barrier();
             rank_runs(keyA, sorted, reinterpret_cast<uint64_t*>(smem + OFF_RUNS), Lc);
             lds_barrier();
-            if (a.tie_order == 1) {
-                // (ties among the first M + 1 ranks only: without one torch.topk's result is the canonical order)
+            if (a.tie_order != 0) {
+                // (ties among the first M + 1 ranks only: without one torch.topk's result is the canonical order - and, the
+                //  loop's rule, oracle orc_topm_loop: only between NEIGHBOURS whose logit rows are bit-identical; two
+                //  different rows whose scores collide in the last bit keep the canonical order.  tie_order 2: any tie)
                 const int npair = M < Lc - 1 ? M : Lc - 1;
                 bool hit = false;
-                for (int j = tid; j < npair; j += NT) hit = hit || (sorted[j] >> 32) == (sorted[j + 1] >> 32);
+                for (int j = tid; j < npair; j += NT) {
+                    if ((sorted[j] >> 32) != (sorted[j + 1] >> 32)) continue;
+                    bool same = true;
+                    if (a.tie_order == 1) {
+                        const uint4* ra = reinterpret_cast<const uint4*>(xc + key_pos(sorted[j]) * LD);
+                        const uint4* rb = reinterpret_cast<const uint4*>(xc + key_pos(sorted[j + 1]) * LD);
+                        const uint4 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+                        same = a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w &&
+                               a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+                    }
+                    hit = hit || same;
+                }
                 if (__ballot(hit) != 0ull && lane == 0) ccount[7] = 1;
                 lds_barrier();
             }
@@ -2002,7 +2042,7 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
             const int Lk = tied ? Lc : Lr;                       // candidates in `sorted`
             if (Lk > M && (sorted[M - 1] >> 32) == (sorted[M] >> 32)) tie = 1;      // (before the replay reorders the first M)
         }
-        if (tied && a.tie_order == 1 && ccount[7] != 0)
+        if (tied && a.tie_order != 0 && ccount[7] != 0)
             tie_order_slow(sorted, keyA, Lc, M, reinterpret_cast<int*>(smem + OFF_STK));
         FAST_STAMP(5);
         {
@@ -2128,7 +2168,7 @@ __global__ __launch_bounds__(256) void topm_kernel(TopmArgs a) {
     uint64_t* sorted = sort_desc(keyA, keyB, a.L, a.n2);
     if (a.tie && tid == 0)
         a.tie[b] = (a.L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32)) ? 1 : 0;
-    if (a.tie_order == 1 && ranked_ties(sorted, a.L, a.m, tid & 63))
+    if (a.tie_order != 0 && ranked_ties(sorted, a.L, a.m, tid & 63))
         torch_tie_order<256>(sorted, sorted == keyA ? keyB : keyA, a.L, a.m, reinterpret_cast<int*>(smem + a.stk_off), tid);
     for (int j = tid; j < a.m; j += 256) a.top[(size_t)b * a.m + j] = key_pos(sorted[j]);
 }
@@ -2368,14 +2408,14 @@ __device__ __attribute__((noinline)) bool select_top_large(int n2, int L, int ne
 // is then the answer.  Returns whether that happened (workgroup-uniform).  All threads; contains barriers.
 // (Not inlined, like the sort; `tail` = LDS offset of the stack / leaf bitmap / range lists behind the keys.)
 __device__ __attribute__((noinline)) bool large_tie_replay(int L, int m, int n2, int tie_order, int* lists, int tail,
-                                                           uint64_t* canon, bool rst) {
+                                                           uint64_t* canon, bool rst, const TieRows* rows = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     int* stk = reinterpret_cast<int*>(smem + tail);
     unsigned long long* leaf = reinterpret_cast<unsigned long long*>(stk + 3 * stdorder::STACK_RANGES);
     int* queue = reinterpret_cast<int*>(leaf + LARGE_LEAF_WORDS);
     const int tid = threadIdx.x;
-    if (tie_order != 1 || !ranked_ties_padded(keys, L, m, tid & 63)) return false;
+    if (tie_order == 0 || !ranked_ties_padded(keys, L, m, tid & 63, tie_order, rows)) return false;
     unsigned long long* tiebits = reinterpret_cast<unsigned long long*>(queue + 2 + 2 * BLOCK_QCAP);
     uint64_t hold[LARGE_KPT];
 #pragma unroll
@@ -2757,8 +2797,9 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
         LARGE_STAMP(5);
         if (tid == 0 && L > m && (keys[large_slot(m - 1)] >> 32) == (keys[large_slot(m)] >> 32)) tie = 1;
         // (the exponentials' workspace is free by now: the canonical ranking goes there when it fits - 8 B per candidate)
+        const TieRows rows = {lg, mem, lo, m, R};
         const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail,
-                                               R >= 2 ? reinterpret_cast<uint64_t*>(xT) : nullptr, a.rstamp != 0);
+                                               R >= 2 ? reinterpret_cast<uint64_t*>(xT) : nullptr, a.rstamp != 0, &rows);
         LARGE_STAMP(6);
         const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
         const bool want_score = a.mem_score != nullptr && it + 1 == a.it1;
@@ -3285,7 +3326,7 @@ IPSX_API int ipsx_set_persistent_wait_ms(int ms) {
 
 IPSX_API int ipsx_set_tie_order(int mode) {
     const int prev = ipsx::g_tie_order;
-    if (mode == 0 || mode == 1) ipsx::g_tie_order = mode;
+    if (mode >= 0 && mode <= 2) ipsx::g_tie_order = mode;
     return prev;
 }
 

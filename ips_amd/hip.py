@@ -43,19 +43,27 @@ def precision():
     return p
 
 
+_TIE_MODES = {"canonical": 0, "torch": 1, "torch_all": 2}
+
+
 def tie_order():
-    """'torch' (default): equal scores come out in the order torch.topk returns on CPU (the reference's), replayed on
-    the device only when ties occur; 'canonical' (IPSX_TIE_ORDER=canonical): earlier candidate position first."""
+    """How equal scores are ordered (``IPSX_TIE_ORDER``).
+    'torch' (default): the order torch.topk returns on CPU (the reference's), replayed on the device - in the selection
+    loops only where the tie is between bit-IDENTICAL candidates (duplicated patches: they tie in the reference's own
+    arithmetic too); two different candidates whose scores collide in the last bit of this arithmetic keep the canonical
+    order (in the reference's arithmetic they are an ulp apart: a replay reproduces nothing of it, and costs 100+ us per
+    iteration at 10,000 candidates).  ``ipsx_topm`` - scores only - replays on every tie.
+    'torch_all': replay wherever scores tie (rounds 1-4).  'canonical': earlier candidate position first, never a replay."""
     t = os.environ.get("IPSX_TIE_ORDER", "torch").lower()
-    if t not in ("torch", "canonical"):
-        raise ValueError("IPSX_TIE_ORDER must be 'torch' or 'canonical', got {!r}".format(t))
+    if t not in _TIE_MODES:
+        raise ValueError("IPSX_TIE_ORDER must be 'torch', 'torch_all' or 'canonical', got {!r}".format(t))
     return t
 
 
 def set_tie_order(mode):
-    """Switch the tie order at run time ('torch' | 'canonical'); returns the previous one."""
-    prev = lib().ipsx_set_tie_order({"torch": 1, "canonical": 0}[mode])
-    return "torch" if prev == 1 else "canonical"
+    """Switch the tie order at run time ('torch' | 'torch_all' | 'canonical'); returns the previous one."""
+    prev = lib().ipsx_set_tie_order(_TIE_MODES[mode])
+    return {v: k for k, v in _TIE_MODES.items()}[prev]
 
 
 def dedup_blank():
@@ -310,7 +318,7 @@ def lib():
         if L.ipsx_version() // 100 != ABI_MAJOR:
             raise RuntimeError("libipsx.so ABI version {} != {}.x (include/ipsx.h: the major number changes with every "
                                "incompatible change of an exported signature)".format(L.ipsx_version(), ABI_MAJOR))
-        L.ipsx_set_tie_order({"torch": 1, "canonical": 0}[tie_order()])
+        L.ipsx_set_tie_order(_TIE_MODES[tie_order()])
         if os.environ.get("IPSX_SCAN_R8", "1") == "0":      # diagnostic: the 8-row loop shapes through scan_fast_kernel
             L.ipsx_dbg_scan_r8.argtypes = [C.c_int]
             L.ipsx_dbg_scan_r8(0)

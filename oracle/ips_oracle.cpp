@@ -99,7 +99,7 @@ static std::vector<int> mfma_order(int K) {
 
 ORC_API float orc_expf(float x) { return det_expf(x); }
 ORC_API float orc_wave_sum64(const float* x, int64_t n) { return wave_sum64(x, n); }
-ORC_API int orc_version(void) { return 101; }
+ORC_API int orc_version(void) { return 102; }
 
 // ------------------------------------------------------------------ encoder ops
 // nn.BatchNorm2d / BatchNorm1d in eval mode (architecture/ips_net.py:37,58 via
@@ -499,6 +499,31 @@ ORC_API void orc_topm_aten(const float* scores, int L, int M, int64_t* top) {
     for (int j = 0; j < M; ++j) top[j] = q[j].second;
 }
 
+// The tie rule of the selection LOOP (round 5).  torch.topk's order differs from the canonical one only where scores are
+// bit-equal, and the device replays libstdc++'s routines to follow it - 100+ us per iteration at 10,000 candidates.  Two
+// kinds of equal scores exist: candidates whose attention logits are bit-IDENTICAL rows (duplicated patches - blank
+// Megapixel-MNIST patches without positional encoding: they tie in the reference's own arithmetic too, and its order is
+// torch's), and DIFFERENT rows whose scores happen to collide in the last bit of THIS arithmetic (in the reference's
+// oneDNN / Sleef arithmetic those two are an ulp apart and other pairs collide: on the CAMELYON bench slide 18 of 255
+// iterations here, none there - replaying torch on them reproduces nothing of the reference).  So: the canonical order,
+// unless two NEIGHBOURS among the first M + 1 canonical ranks have equal scores AND bit-identical logit rows - then
+// torch.topk's order on the whole array, as before.  lg: (L, R) logits of the candidates, row-major.
+ORC_API void orc_topm_loop(const float* scores, const float* lg, int L, int R, int M, int64_t* top, int32_t* tie) {
+    std::vector<uint64_t> key(L);
+    for (int l = 0; l < L; ++l) key[l] = rank_key(scores[l], (uint32_t)l);
+    std::sort(key.begin(), key.end(), std::greater<uint64_t>());
+    if (tie) *tie = (M < L && (key[M - 1] >> 32) == (key[M] >> 32)) ? 1 : 0;
+    bool structural = false;
+    const int n = M < L - 1 ? M : L - 1;
+    for (int j = 0; j < n && !structural; ++j)
+        if ((key[j] >> 32) == (key[j + 1] >> 32)) {
+            const uint32_t a = 0xFFFFFFFFu - (uint32_t)(key[j] & 0xFFFFFFFFu), b = 0xFFFFFFFFu - (uint32_t)(key[j + 1] & 0xFFFFFFFFu);
+            structural = std::memcmp(lg + (size_t)a * R, lg + (size_t)b * R, (size_t)R * sizeof(float)) == 0;
+        }
+    if (structural) orc_topm_aten(scores, L, M, top);
+    else for (int j = 0; j < M; ++j) top[j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(key[j] & 0xFFFFFFFFu));
+}
+
 // The loop of IPSNet.ips (ips_net.py:206-241) for ONE image, on embeddings:
 //   memory = first M patches; for each chunk of I: candidates = memory ++ chunk
 //   (:231-232), emb_pos = emb + gather(pos, idx) (:235-236), scores (:145), top-M
@@ -506,14 +531,15 @@ ORC_API void orc_topm_aten(const float* scores, int L, int M, int64_t* top) {
 // The K projection is recomputed for every candidate in every iteration exactly
 // as the reference does.  emb (N,d); pos (N,d) or NULL; out: mem_idx (M) final,
 // trace_idx (n_iter,M) per-iteration memory or NULL, trace_score (n_iter,M) or
-// NULL, tie (n_iter) or NULL.  aten_ties != 0 selects orc_topm_aten.
+// NULL, tie (n_iter) or NULL.  aten_ties: 0 the canonical order, 1 the loop's rule (orc_topm_loop: torch.topk's order
+// where bit-identical candidates tie), 2 torch.topk's order wherever scores tie (orc_topm_aten).
 ORC_API void orc_ips_scan(const float* emb, const float* pos, const float* wk, const float* qs,
                           int64_t N, int d, int h, int dk, int T, int M, int I, int aten_ties,
                           int64_t* mem_idx, int64_t* trace_idx, float* trace_score, int32_t* tie) {
     std::vector<int64_t> mem(M), cand, top(M);
     for (int j = 0; j < M; ++j) mem[j] = j;
     const int n_iter = (int)((N - M + I - 1) / I);
-    std::vector<float> x, sc;
+    std::vector<float> x, sc, lgv;
     for (int it = 0; it < n_iter; ++it) {
         const int64_t lo = (int64_t)it * I + M, hi = std::min<int64_t>(lo + I, N);
         cand.assign(mem.begin(), mem.end());
@@ -526,9 +552,12 @@ ORC_API void orc_ips_scan(const float* emb, const float* pos, const float* wk, c
                 x[(size_t)l * d + c] = pos ? e + pos[cand[l] * d + c] : e;
             }
         sc.resize(L);
-        orc_scores(x.data(), wk, qs, L, d, h, dk, T, sc.data(), nullptr);
+        lgv.resize((size_t)L * h * T);
+        orc_logits(x.data(), nullptr, wk, qs, L, d, h, dk, T, lgv.data());          // (= orc_scores, with the logits kept)
+        orc_scores_from_logits(lgv.data(), L, h, T, sc.data(), nullptr);
         int32_t tf = 0;
-        if (aten_ties) orc_topm_aten(sc.data(), L, M, top.data());
+        if (aten_ties == 1) orc_topm_loop(sc.data(), lgv.data(), L, h * T, M, top.data(), nullptr);
+        else if (aten_ties) orc_topm_aten(sc.data(), L, M, top.data());
         else orc_topm(sc.data(), L, M, top.data(), &tf);
         if (tie) tie[it] = tf;
         for (int j = 0; j < M; ++j) {

@@ -93,11 +93,19 @@ def bn_affine(bn):
     return alpha, shift
 
 
-def topm(scores, M, aten_ties=False):
+def topm(scores, M, aten_ties=False, rows=None):
+    """``torch.topk(scores, M)[1]`` of one row: the canonical tie rule (earlier position first), ``aten_ties``: torch's
+    CPU order wherever scores tie (orc_topm_aten) - or, with ``rows`` = the candidates' (L, R) attention logits, the
+    selection LOOP's rule (orc_topm_loop): torch's order when two tied neighbours among the first M + 1 ranks are
+    bit-identical rows, the canonical order otherwise."""
     s, sp = _f(scores)
     top = np.empty(M, dtype=np.int64)
     tie = C.c_int32(0)
-    if aten_ties:
+    if aten_ties and rows is not None:
+        r, rp = _f(rows)
+        assert r.ndim == 2 and r.shape[0] == s.size
+        lib().orc_topm_loop(sp, rp, s.size, r.shape[1], M, top.ctypes.data_as(i64p), C.byref(tie))
+    elif aten_ties:
         lib().orc_topm_aten(sp, s.size, M, top.ctypes.data_as(i64p))
     else:
         lib().orc_topm(sp, s.size, M, top.ctypes.data_as(i64p), C.byref(tie))

@@ -844,7 +844,7 @@ def _oracle_scan_from_logits(lg, M, I, H, T, aten_ties):
         cand = np.concatenate([cur, np.arange(lo, min(lo + I, N), dtype=np.int64)])
         s = np.empty(len(cand), dtype=np.float32)
         L.orc_scores_from_logits(orc._f(lg[cand])[1], len(cand), H, T, s.ctypes.data_as(orc.f32p), None)
-        cur = cand[orc.topm(s, M, aten_ties=aten_ties)[0]]
+        cur = cand[orc.topm(s, M, aten_ties=aten_ties, rows=lg[cand])[0]]     # (the LOOP's tie rule: orc_topm_loop)
     return cur
 
 
@@ -961,7 +961,7 @@ def test_scan_beyond_the_lds_matches_oracle(N, M, I, H, T, levels):
             cand = np.concatenate([cur, np.arange(lo, min(lo + I, N), dtype=np.int64)])
             s = np.empty(len(cand), dtype=np.float32)
             L.orc_scores_from_logits(orc._f(lg[b][cand])[1], len(cand), H, T, s.ctypes.data_as(orc.f32p), None)
-            top = orc.topm(s, M, aten_ties=True)[0]
+            top = orc.topm(s, M, aten_ties=True, rows=lg[b][cand])[0]          # (the LOOP's tie rule: orc_topm_loop)
             cur, last = cand[top], s[top]
         assert np.array_equal(mem[b], cur), (b, int((mem[b] != cur).sum()), np.nonzero(mem[b] != cur)[0][:8])
         assert ulp_diff(sc[b], last) == 0

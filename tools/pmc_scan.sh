@@ -1,6 +1,7 @@
 # rocprofv3 counters of the selection loop alone (tools/scan_stamps.py cam): dynamic instruction counts and busy cycles per launch
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$ROOT"
 out=${1:-gpurun_out/pmc_scan}
 mkdir -p $out
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES -d $out/pmc1 -o pmc1 --output-format csv -- python3 tools/scan_stamps.py cam > $out/pmc1.log 2>&1

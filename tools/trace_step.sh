@@ -1,6 +1,7 @@
 # kernel timeline of the last calls of a bench.py run:  bash tools/trace_step.sh <config> [rows of timeline] [extra bench args]
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$ROOT"
 cfg=${1:-cam}; n=${2:-40}; shift; shift
 out=gpurun_out/trace_$cfg
 mkdir -p $out
