@@ -52,12 +52,24 @@ __device__ __forceinline__ void rm_zero(RowMoments& m) {
 
 // one k-group's four values of this lane: two packed adds, two packed fmas (v_pk_add_f32 / v_pk_fma_f32 - the roundings
 // of the scalar operations, half the instructions)
+// (spelled out: the compiler splits the vector forms into four v_add_f32 + four v_fma_f32 - eight VALU instructions per
+//  stage of the projector's GEMM instead of four, each of them matrix-pipe time)
+__device__ __forceinline__ rm_f32x2 rm_pk_add(rm_f32x2 a, rm_f32x2 b) {
+    rm_f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ rm_f32x2 rm_pk_fma(rm_f32x2 a, rm_f32x2 b, rm_f32x2 c) {
+    rm_f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ void rm_add(RowMoments& m, rm_f32x4 v) {
     const rm_f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-    m.s01 = m.s01 + lo;
-    m.s23 = m.s23 + hi;
-    m.q01 = __builtin_elementwise_fma(lo, lo, m.q01);
-    m.q23 = __builtin_elementwise_fma(hi, hi, m.q23);
+    m.s01 = rm_pk_add(m.s01, lo);
+    m.s23 = rm_pk_add(m.s23, hi);
+    m.q01 = rm_pk_fma(lo, lo, m.q01);
+    m.q23 = rm_pk_fma(hi, hi, m.q23);
 }
 
 // (mean, rstd) of the row whose halves lanes i and i + 32 hold - the same bits in both (a + b == b + a)
