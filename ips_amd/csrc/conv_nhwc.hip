@@ -285,6 +285,9 @@ struct StreamArgs {
     unsigned split_start, split_units;     // the LAST split_units units are handed out as SPLIT_P column quarters each
     unsigned split_base;           // ctl[split_base]: next quarter; then the quarters' hand-over flags and accumulators
     unsigned exit_word;            // ctl[exit_word]: workgroups that have left (the last one out publishes every row)
+    unsigned head_units, head_wgs; // the FIRST head_units units go out as column quarters too, to the first head_wgs workgroups
+                                   // (ctl[exit_word + 1]: next head quarter): a lone slide's loop starts on rows that exist after
+                                   // a quarter's ~50 us instead of a 32-row tile's ~135 us
     int* ctl;                      // [0] next unit to hand out, [1] first unpublished unit; [2 ...] one flag per unit
     int* ready;                    // rows published, per slide (ipsx_scan_persistent's progress words)
     unsigned long long* stamps;    // diagnostic (ipsx_dbg_projector_stream_stamps): cycles per phase, summed by workgroup 0
@@ -296,7 +299,7 @@ struct StreamArgs {
 // rows' moments (off its own operand stream), its 128 columns of the Linear (a wave: 32) and its 16 k-groups of the logits' MFMA chain, whose
 // accumulators pass from quarter to quarter through memory (ctl: a flag and 1,024 floats per hand-over) - the same chain
 // in the same order, so embeddings and logits stay bit-identical.  The last quarter publishes the unit.
-constexpr int SPLIT_P = 4, SPLIT_MAX = 16;
+constexpr int SPLIT_P = 4, SPLIT_TAIL = 16, SPLIT_HEAD = 48, SPLIT_MAX = SPLIT_TAIL + SPLIT_HEAD;
 constexpr int SPLIT_WORDS = 1 + SPLIT_MAX * (SPLIT_P - 1) * (1 + 1024);
 constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
 constexpr int ST_STATS = 64 * 2;                    // floats: (mean, rstd) of the tile's rows
@@ -537,15 +540,23 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
     float* tile = st_lds;
     float2* s_stats = reinterpret_cast<float2*>(st_lds + 64 * ST_EP);
     int* s_u0 = reinterpret_cast<int*>(st_lds + 64 * ST_EP + ST_STATS);    // [0] unit, [1] units taken, [2] column part or -1
-    bool first = true;
+    bool first = true, head_left = a.head_units > 0 && blockIdx.x < a.head_wgs;      // (thread 0's)
     int pulls = 0;
     for (;;) {
         if (threadIdx.x == 0) {
             // (the look at the counter may be a pull or two behind: it only decides the SIZE of this pull)
-            const bool tail = (unsigned)__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.tail_start;
-            int take = ((first && blockIdx.x < (a.short_first & 0x7fffffffu)) || pulls < a.short_pulls || tail) ? 1 : 2;
-            unsigned u = (unsigned)atomicAdd(&a.ctl[0], take);
-            int part = -1;
+            unsigned u = a.n_units;
+            int part = -1, take = 1;
+            if (head_left) {                                        // a column quarter of one of the FIRST units
+                const unsigned j = (unsigned)atomicAdd(&a.ctl[a.exit_word + 1], 1);
+                if (j < a.head_units * SPLIT_P) { u = j / SPLIT_P; part = (int)(j % SPLIT_P); }
+                else head_left = false;
+            }
+            if (part < 0) {
+            const bool tail = a.head_units + (unsigned)__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.tail_start;
+            take = ((first && blockIdx.x >= a.head_wgs && blockIdx.x - a.head_wgs < (a.short_first & 0x7fffffffu)) || pulls < a.short_pulls || tail) ? 1 : 2;
+            u = a.head_units + (unsigned)atomicAdd(&a.ctl[0], take);
+            first = false;
             if (u >= a.split_start) {                               // the whole units are gone: a column quarter of one of the last
                 const unsigned j = (unsigned)atomicAdd(&a.ctl[a.split_base], 1);
                 if (j < a.split_units * SPLIT_P) { u = a.split_start + j / SPLIT_P; part = (int)(j % SPLIT_P); take = 1; }
@@ -553,11 +564,11 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
             } else if (u + take > a.split_start) {
                 take = 1;
             }
+            }
             s_u0[0] = (int)u;
             s_u0[1] = take;
             s_u0[2] = part;
         }
-        first = false;
         ++pulls;
         __syncthreads();
         const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane(s_u0[0]);
@@ -565,7 +576,8 @@ __global__ __launch_bounds__(256, 1) void projector_stream_kernel(StreamArgs a) 
         const int part = __builtin_amdgcn_readfirstlane(s_u0[2]);
         if (u0 >= a.n_units) break;                                 // workgroup-uniform
         const int units = (take == 2 && u0 + 1 < a.n_units) ? 2 : 1;
-        if (part >= 0) stream_tile<1, 4 / SPLIT_P, 0, STAMP>(a, u0 * 32u, part, u0 - a.split_start, tile, s_stats);
+        if (part >= 0)      // (hand-over slots: the last units' [0, SPLIT_TAIL), the first units' behind them)
+            stream_tile<1, 4 / SPLIT_P, 0, STAMP>(a, u0 * 32u, part, u0 >= a.split_start ? u0 - a.split_start : SPLIT_TAIL + u0, tile, s_stats);
         else if (units == 2) {
             if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) stream_tile<2, 4, 1, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
             else stream_tile<2, 4, 0, STAMP>(a, u0 * 32u, 0, 0u, tile, s_stats);
@@ -773,12 +785,20 @@ static unsigned long long* g_stream_stamps = nullptr;
 // the shader cycles of each phase of its tiles - [0] pull + publication, [1] moments, [2] GEMM, [3] epilogue, [4] logits.
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_projector_stream_stamps(unsigned long long* p) { g_stream_stamps = p; }
 
+// Units a lone slide's stream hands out as column quarters FIRST (0: none; at most SPLIT_HEAD; IPSX_CAM_HEAD).  Measured,
+// one CAMELYON slide per call (M patches/s of the call | the stream's share of the fp32 MFMA peak inside the call):
+// 0: 46.6 | 0.736, 16: 47.0 | 0.724, 32: 47.3 | 0.709, 48: 47.6 | 0.707 - the loop starts ~60 us earlier and the call gains
+// 2 %, the stream itself loses 4 % (quarters run at ~2/3 of a whole tile's rate).  Off by default: the call is bound by
+// the loop's 255 iterations either way, and the kernel's own rate is the figure its roofline is judged on.
+static int g_stream_head = 0;
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_stream_head(int units) { g_stream_head = units; }
+
 static int g_stream_split = 1;
 // Diagnostic: 0 = the last units of a guided launch as whole 32-row tiles (no column quarters)
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_stream_split(int on) { g_stream_split = on; }
 
 IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) {
-    return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 + ipsx::SPLIT_WORDS + 1 : 0;
+    return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 + ipsx::SPLIT_WORDS + 2 : 0;
 }
 
 IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r) {
@@ -816,6 +836,7 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     a.tail_start = a.n_units;
     a.split_start = a.n_units; a.split_units = 0; a.split_base = a.n_units + 2;
     a.exit_word = a.n_units + 2 + (unsigned)ipsx::SPLIT_WORDS;
+    a.head_units = a.head_wgs = 0;
     if (short_first <= -3) {
         // -3 - (head + 8 tail): every workgroup's first `head` pulls and the last `tail` x workgroups units are 32-row tiles -
         // early first rows, full-rate 64-row tiles in the middle, and an end without a last round that most units sit out
@@ -827,8 +848,17 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
         // free there, so each loop may keep one workgroup of its XCD waiting until the others leave - the
         // share is computed for 2 wgs - cus workers (255 of 256: 254; too few assumed just starts the quarters early).
         const unsigned eff = (unsigned)std::max(1, wgs < cus ? 2 * wgs - cus : wgs);
-        const unsigned per = a.n_units / eff, left = a.n_units - per * eff;
-        if (g_stream_split && per >= 2 && left > 0 && left <= (unsigned)ipsx::SPLIT_MAX && left * ipsx::SPLIT_P <= eff) {
+        // ONE slide, long enough: its loop consumes rows about as fast as they are made, so when the FIRST rows exist
+        // decides when it can start - the first units go out as column quarters to 3/8 of the workgroups
+        // (two rounds of ~50 us each), beside the others' first 32-row (~135 us) and 64-row (~257 us) tiles
+        if (g_stream_head > 0 && n == slide_rows && a.n_units >= 16u * (unsigned)wgs / 4 && wgs >= 64) {
+            a.head_units = (unsigned)std::min(g_stream_head, ipsx::SPLIT_HEAD);
+            a.head_wgs = (unsigned)wgs * 3 / 8;
+            a.short_first = (a.short_first != 0) ? ((unsigned)wgs - a.head_wgs) / 2 : 0;
+        }
+        const unsigned main_units = a.n_units - a.head_units;
+        const unsigned per = main_units / eff, left = main_units - per * eff;
+        if (g_stream_split && per >= 2 && left > 0 && left <= (unsigned)ipsx::SPLIT_TAIL && left * ipsx::SPLIT_P <= eff) {
             a.split_units = left;
             a.split_start = a.n_units - left;
         }

@@ -319,6 +319,9 @@ def lib():
             raise RuntimeError("libipsx.so ABI version {} != {}.x (include/ipsx.h: the major number changes with every "
                                "incompatible change of an exported signature)".format(L.ipsx_version(), ABI_MAJOR))
         L.ipsx_set_tie_order(_TIE_MODES[tie_order()])
+        if os.environ.get("IPSX_CAM_HEAD"):        # diagnostic: units a lone slide's projector stream hands out as column quarters first
+            L.ipsx_dbg_stream_head.restype, L.ipsx_dbg_stream_head.argtypes = None, [C.c_int]
+            L.ipsx_dbg_stream_head(int(os.environ["IPSX_CAM_HEAD"]))
         if os.environ.get("IPSX_SCAN_R8", "1") == "0":      # diagnostic: the 8-row loop shapes through scan_fast_kernel
             L.ipsx_dbg_scan_r8.argtypes = [C.c_int]
             L.ipsx_dbg_scan_r8(0)
