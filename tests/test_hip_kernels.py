@@ -335,6 +335,39 @@ def test_ips_finish_is_the_two_gathers_the_index_copy_and_the_status_mirror():
     assert not hip.ips_finish_supported(torch.zeros((1, 4, 3), device=DEV), None)          # rows of 12 bytes: the gathers take over
 
 
+@pytest.mark.parametrize("head", [16, 48])
+def test_projector_stream_with_the_first_units_in_column_quarters(head):
+    """The optional head of a lone slide's stream (IPSX_CAM_HEAD / ipsx_dbg_stream_head): the FIRST units go out as column
+    quarters to 3/8 of the workgroups, beside the others' whole tiles - embeddings and logits stay those of the launch by
+    launch projector, every unit is published, the progress word ends on the row count."""
+    conf, _ = synth.bench_workload("cam")
+    from ips_amd.architecture.ips_net import IPSNet
+    net = synth.fill_weights(IPSNet(torch.device(DEV), conf), 7).to(DEV).eval()
+    plan = hip.EncoderPlan(net.encoder, False)
+    ca = net.transf.crs_attn
+    vq, R = ca.folded_query(), ca.H * ca.n_token
+    n = 65536 - 19
+    x = torch.from_numpy(rnd((n, conf.n_chan_in), 77, 2.0) + 0.25).to(DEV)
+    want_emb = plan.encode(x)
+    want_lg = hip.logits(want_emb.view(1, n, -1), None, vq, R)[0]
+    fn = hip.lib().ipsx_dbg_stream_head
+    fn.restype, fn.argtypes = None, [C.c_int]
+    fn(head)
+    try:
+        for rep in range(2):
+            emb = torch.full_like(want_emb, float("nan"))
+            lg = torch.full_like(want_lg, float("nan"))
+            ctl = torch.zeros((plan.stream_ctl_words(n),), dtype=torch.int32, device=DEV)
+            ready = torch.zeros((1,), dtype=torch.int32, device=DEV)
+            plan.stream(x, vq, R, emb, lg, ctl, ready, workgroups=255, short_first=-11)
+            torch.cuda.synchronize()
+            units = -(-n // 32)
+            assert bool((ctl[2:2 + units] == 1).all()) and int(ready.item()) == n and int(ctl[1].item()) == units
+            assert torch.equal(emb, want_emb) and torch.equal(lg, want_lg)
+    finally:
+        fn(0)
+
+
 @pytest.mark.parametrize("n,f", [(1, 2048), (31, 2048), (33, 64), (130, 1024), (4097, 2048), (257, 8), (64, 2056)])
 def test_projector_moments_and_column_sums_are_the_oracles(n, f):
     """ipsx_projector_stats (row_moments_kernel: the moments in the order the GEMM's operand stream gives them, round 5)
