@@ -50,4 +50,19 @@ python tools/trunk_stream_bench.py > "$OUT/trunk_stream_bench.txt" 2>&1
 python tools/loop_beside.py > "$OUT/loop_beside.txt" 2>&1
 python tools/scan_beside.py > "$OUT/scan_beside.txt" 2>&1
 python -m pytest tests/test_bench_parity.py tests/test_seed_sweep.py -q -m gpu -s 2>&1 | grep -v "amdgpu.ids" > "$OUT/parity_rates.txt"
+# round 5: the default bench line as the driver runs it, kernel timelines of one-image / one-slide calls, the tie orders on the
+# shipped CAMELYON sizes, per-layer rates of the 50-px trunk, the compiler's resource table, the stream's launch-time spread, soak
+python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+for c in b1 cam cam_native; do bash tools/trace_step.sh $c 12 2>&1 | grep -v "amdgpu.ids" > "$OUT/${c}_timeline.txt"; done
+{ for m in torch torch_all canonical; do
+    echo "IPSX_TIE_ORDER=$m python bench.py --config cam_native:"
+    IPSX_TIE_ORDER=$m python bench.py --config cam_native --cpu-seconds 0 2>/dev/null | python -c "
+import json, sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); p = d['parity']
+print('   %.2f M patches/s, %.3f ms per call; same SET as the reference every image: %s, slots_equal %.4f, selected_in_common %.4f' % (d['value'] / 1e6, d['ms_per_step'], p['selected_in_common'] == 1.0, p['slots_equal'], p['selected_in_common']))"
+  done; } > "$OUT/cam_native_tie_orders.txt" 2>&1
+python tools/conv_layers.py 14400 2>&1 | grep -v "amdgpu.ids" > "$OUT/conv_layers_native50.txt"
+python tools/kernel_resources.py > "$OUT/kernel_resources.txt" 2>/dev/null
+python tools/stream_outliers.py 40 2>&1 | grep -v "amdgpu.ids" > "$OUT/stream_outliers.txt"
+python tools/soak.py 150 20 2>&1 | grep -v "amdgpu.ids" > "$OUT/soak.txt"
 echo done
