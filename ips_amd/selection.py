@@ -274,6 +274,7 @@ class Selection:
         """(B, N, ...) patches (device, or host for lazy loading) -> mem_idx (B, M) int64 on the device."""
         net = self.net
         net._device_patches = None
+        self._done = self._unfinished = None       # (whatever a call that raised half-way left behind)
         if patches.is_cuda and self.can_stream_image(patches):
             return self.image_stream(patches, pos_enc)
         if patches.is_cuda and self.can_overlap(patches):

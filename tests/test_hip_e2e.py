@@ -504,7 +504,7 @@ def test_one_image_every_schedule_selects_the_same_patches(N, monkeypatch):
         x = synth.make_patches(conf, 1, seed=5).to(DEV)
         assert net.selection.can_stream_image(x)
         res = []
-        for env in ({}, {"IPSX_IMAGE_STREAM": "0"}, {"IPSX_OVERLAP_SCAN": "0"}):
+        for env in ({}, {"IPSX_NATIVE_CALL": "0"}, {"IPSX_IMAGE_STREAM": "0"}, {"IPSX_OVERLAP_SCAN": "0"}):      # (default: one library call)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             torch.manual_seed(3)                           # (shuffle draws from torch's generator)
@@ -808,7 +808,8 @@ def test_every_variant_of_the_feature_pipeline_selects_the_same_patches(B, N, mo
     net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
     x = synth.make_patches(conf, B, seed=3).to(dev)
     res = {}
-    for name, env in (("default", {}), ("per-part launches", {"IPSX_SCAN_PERSIST": "0"}), ("after", {"IPSX_OVERLAP_SCAN": "0"}),
+    for name, env in (("default", {}), ("the entry points one by one instead of ONE library call", {"IPSX_NATIVE_CALL": "0"}),
+                      ("per-part launches", {"IPSX_SCAN_PERSIST": "0"}), ("after", {"IPSX_OVERLAP_SCAN": "0"}),
                       ("launch by launch beside the persistent loop", {"IPSX_CAM_STREAM": "0"}),
                       ("latency-shaped parts", {"IPSX_CAM_PARTS": "latency", "IPSX_CAM_STREAM": "0"})):
         for k, v in env.items():
