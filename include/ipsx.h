@@ -23,7 +23,8 @@
  *     fetches 4 consecutive k with one 16-byte load); all others ascend;
  *   - eval BatchNorm is the affine y = fma(acc, alpha, shift) with
  *     alpha = gamma * (1/sqrt(var+eps)), shift = beta - mean*alpha;
- *   - exp() is ipsx's own fma polynomial (identical bits on host and device);
+ *   - exp() is ipsx's own fma polynomial (identical bits on host and device); softmax weights are
+ *     e * (1 / den): ONE IEEE division per (head, token) row, a multiplication per candidate (round 5);
  *   - row sums (softmax denominators, the transformer's LayerNorm moments) are 64 strided
  *     partial sums combined by an xor butterfly (the wavefront reduction order);
  *   - the projector (ipsx_projector*) evaluates Linear(LayerNorm(x)) with the LayerNorm FOLDED

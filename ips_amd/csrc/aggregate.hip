@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_ctx_kernel(CtxArgs a) {
         float s = 0.0f;
         for (int i = lane; i < a.m; i += 64) s = s + det_expf(lg[(size_t)i * R + r] - mx);
         s = wave_butterfly_sum(s);
-        if (lane == 0) { rmax[r] = mx; rden[r] = s; }
+        if (lane == 0) { rmax[r] = mx; rden[r] = 1.0f / s; }         // (the reciprocal: oracle orc_scores_from_logits)
     }
     __syncthreads();
     const float* v = a.v + (size_t)b * a.m * hdv;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_ctx_kernel(CtxArgs a) {
         const float mx = rmax[r], den = rden[r];
         float acc = 0.0f;
         for (int l = 0; l < a.m; ++l) {
-            const float w = det_expf(lg[(size_t)l * R + r] - mx) / den;
+            const float w = det_expf(lg[(size_t)l * R + r] - mx) * den;
             acc = __builtin_fmaf(w, v[(size_t)l * hdv + col], acc);
         }
         a.ctx[((size_t)b * a.T + t) * hdv + col] = acc;

@@ -307,7 +307,7 @@ __device__ __forceinline__ void row_stats(const CandView& v, int L, float* rmax,
         float s = 0.0f;
         for (int i = lane; i < L; i += 64) s = s + det_expf(v.get(i, r) - m);
         s = wave_butterfly_sum(s);
-        if (lane == 0) { rmax[r] = m; rden[r] = s; }
+        if (lane == 0) { rmax[r] = m; rden[r] = 1.0f / s; }        // (the RECIPROCAL: weights are e * (1 / den), oracle orc_scores_from_logits)
     }
 }
 
@@ -319,7 +319,7 @@ __device__ __forceinline__ float cand_score(const CandView& v, int l, int h, int
         float sh = 0.0f;
         for (int hh = 0; hh < h; ++hh) {
             const int r = hh * T + t;
-            const float a = det_expf(v.get(l, r) - rmax[r]) / rden[r];
+            const float a = det_expf(v.get(l, r) - rmax[r]) * rden[r];
             if (attn) attn[((size_t)hh * T + t) * L + l] = a;
             sh = sh + a;
         }
@@ -1400,24 +1400,24 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
 #pragma unroll
             for (int u = 0; u < LCH; ++u) { s0 = s0 + v0[u]; s1 = s1 + v1[u]; }
             wave_sum2(s0, s1, lane);
-            if (lane == 0) { rden[r0] = s0; if (has1) rden[r1] = s1; }
+            if (lane == 0) { rden[r0] = 1.0f / s0; if (has1) rden[r1] = 1.0f / s1; }      // (reciprocals: one division per row)
         }
         lds_barrier();
         FAST_STAMP(3);
-        // P4: attention weights e / den by every thread, transposed through the spare buffer; then one lane per
+        // P4: attention weights e * (1 / den) by every thread, transposed through the spare buffer; then one lane per
         // (candidate, token) adds its H weights in ascending head order and the T lanes of a candidate their tokens
         {
             const float den = rden[r];
             float ev[EPT];
 #pragma unroll
-            for (int k = 0; k < EPT; ++k) {                      // (all reads in flight before the first division)
+            for (int k = 0; k < EPT; ++k) {                      // (all reads in flight before the first product)
                 const int l = lrow0 + k * lstep;
                 ev[k] = l < L ? ec[l * ld + r] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
                 const int l = lrow0 + k * lstep;
-                if (l < L) en[l * ld + r] = ev[k] / den;
+                if (l < L) en[l * ld + r] = ev[k] * den;
             }
         }
         lds_barrier();
@@ -1881,7 +1881,7 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
 #pragma unroll
             for (int u = 0; u < 8; ++u) s0 = s0 + ((lane + 64 * u < Lc) ? v0[u] : 0.0f);
             s0 = wave_butterfly_sum(s0);
-            if (lane == 0) rden[wave] = s0;
+            if (lane == 0) rden[wave] = 1.0f / s0;              // (the reciprocal: one division per row, eight products per candidate)
         } else {
             CAM_PREP(0);
             CAM_PREP(1);
@@ -1892,11 +1892,11 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
         FAST_STAMP(3);
         uint64_t key = 0ull;
         if (wave < 8) {
-            // weights e / den, heads added in ascending order, mean over the 8 heads (one token: the mean over tokens is the
+            // weights e * (1 / den), heads added in ascending order, mean over the 8 heads (one token: the mean over tokens is the
             // identity) - the operations of scan_fast_kernel's weight and score phases on this candidate
             const float4 d0 = *reinterpret_cast<const float4*>(rden), d1 = *reinterpret_cast<const float4*>(rden + 4);
-            const float w0 = ev0.x / d0.x, w1 = ev0.y / d0.y, w2 = ev0.z / d0.z, w3 = ev0.w / d0.w;
-            const float w4 = ev1.x / d1.x, w5 = ev1.y / d1.y, w6 = ev1.z / d1.z, w7 = ev1.w / d1.w;
+            const float w0 = ev0.x * d0.x, w1 = ev0.y * d0.y, w2 = ev0.z * d0.z, w3 = ev0.w * d0.w;
+            const float w4 = ev1.x * d1.x, w5 = ev1.y * d1.y, w6 = ev1.z * d1.z, w7 = ev1.w * d1.w;
             float sh = 0.0f;
             sh = sh + w0; sh = sh + w1; sh = sh + w2; sh = sh + w3; sh = sh + w4; sh = sh + w5; sh = sh + w6; sh = sh + w7;
             const float q = sh / (float)H;
@@ -2647,7 +2647,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
                         if (l0 + 64 * u < L) sum = sum + v[u];
                 }
                 sum = wave_butterfly_sum(sum);
-                if (lane == 0) rden[r] = sum;
+                if (lane == 0) rden[r] = 1.0f / sum;                // (the reciprocal: weights are e * (1 / den))
             }
             __syncthreads();
             LARGE_STAMP(3);
@@ -2767,7 +2767,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
                         if (l0 + 64 * u < L) sum = sum + v[u];
                 }
                 sum = wave_butterfly_sum(sum);
-                if (lane == 0) rden[r] = sum;
+                if (lane == 0) rden[r] = 1.0f / sum;                // (the reciprocal: weights are e * (1 / den))
             }
             __syncthreads();
             LARGE_STAMP(3);
@@ -2781,7 +2781,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
                     float sh = 0.0f;
                     for (int hh = 0; hh < a.h; ++hh) {
                         const int r = hh * a.T + t;
-                        sh = sh + xT[(size_t)r * Lp + l] / rden[r];
+                        sh = sh + xT[(size_t)r * Lp + l] * rden[r];
                     }
                     st = st + sh / (float)a.h;
                 }

@@ -99,7 +99,7 @@ static std::vector<int> mfma_order(int K) {
 
 ORC_API float orc_expf(float x) { return det_expf(x); }
 ORC_API float orc_wave_sum64(const float* x, int64_t n) { return wave_sum64(x, n); }
-ORC_API int orc_version(void) { return 102; }
+ORC_API int orc_version(void) { return 103; }
 
 // ------------------------------------------------------------------ encoder ops
 // nn.BatchNorm2d / BatchNorm1d in eval mode (architecture/ips_net.py:37,58 via
@@ -430,7 +430,11 @@ ORC_API void orc_scores_from_logits(const float* lg, int L, int h, int T, float*
         for (int l = 0; l < L; ++l) { float v = lg[(size_t)l * R + r]; m = (v > m || v != v) ? v : m; }
         for (int l = 0; l < L; ++l) e[l] = det_expf(lg[(size_t)l * R + r] - m);
         mx[r] = m;
-        den[r] = wave_sum64(e.data(), L);
+        // the weights are e * (1 / den): ONE IEEE division per (head, token) row and a multiplication per candidate
+        // (round 5; it was a division per candidate - eight per candidate and iteration at CAMELYON, a tenth of the
+        // device loop's instructions).  Against a true quotient the product is off by at most an ulp: a rounding-level
+        // decision like the summation orders, pinned by the fixtures.
+        den[r] = 1.0f / wave_sum64(e.data(), L);
     }
     for (int l = 0; l < L; ++l) {
         float st = 0.0f;
@@ -438,7 +442,7 @@ ORC_API void orc_scores_from_logits(const float* lg, int L, int h, int T, float*
             float sh = 0.0f;
             for (int hh = 0; hh < h; ++hh) {
                 const int r = hh * T + t;
-                const float a = det_expf(lg[(size_t)l * R + r] - mx[r]) / den[r];
+                const float a = det_expf(lg[(size_t)l * R + r] - mx[r]) * den[r];
                 if (attn) attn[((size_t)hh * T + t) * L + l] = a;
                 sh = sh + a;
             }
