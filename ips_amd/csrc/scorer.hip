@@ -1722,6 +1722,27 @@ __device__ __forceinline__ int search_run_u32(const uint32_t* run, uint32_t m, u
     return (int)(lo + key_gt(last, m));
 }
 
+// two searches at once, their dependent reads interleaved: (run A, key mA, own-run mask) and (run B, key mB) - what the first
+// 128 threads do in the ranking (a memory key's pair AND a survivor's pair: done one after the other the second search's 11
+// dependent LDS round trips kept waves 0 and 1 at the barrier 1,000-1,500 cycles after everybody else, round 5)
+__device__ __forceinline__ void search_run_u32_x2(const uint32_t* runA, uint32_t mA, uint32_t ownA, const uint32_t* runB, uint32_t mB,
+                                                  uint32_t& eqA, uint32_t& eqB, int& cA, int& cB) {
+    uint32_t loA = 0, loB = 0;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 2) {
+        const uint32_t a1 = runA[loA + step - 1], a2 = runA[loA + 2 * step - 1], a3 = runA[loA + 3 * step - 1];
+        const uint32_t b1 = runB[loB + step - 1], b2 = runB[loB + 2 * step - 1], b3 = runB[loB + 3 * step - 1];
+        loA += (key_gt(a1, mA) + key_gt(a2, mA) + key_gt(a3, mA)) * step;
+        loB += (key_gt(b1, mB) + key_gt(b2, mB) + key_gt(b3, mB)) * step;
+    }
+    const uint32_t lastA = runA[loA], nxtA = runA[loA < 63 ? loA + 1 : 63];
+    const uint32_t lastB = runB[loB], nxtB = runB[loB < 63 ? loB + 1 : 63];
+    eqA = min(eqA, min((lastA ^ mA) | ownA, (nxtA ^ mA) | ownA));
+    eqB = min(eqB, min(lastB ^ mB, nxtB ^ mB));
+    cA = (int)(loA + key_gt(lastA, mA));
+    cB = (int)(loB + key_gt(lastB, mB));
+}
+
 template <bool STAMP, bool PERSIST>
 __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned long long* stamps) {
     using namespace cam;
@@ -1950,10 +1971,22 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
         if (ks <= SMAX) {
             const uint32_t* const skeys = reinterpret_cast<const uint32_t*>(keyA + M);       // survivor i: words 2 i (position), 2 i + 1 (score)
             uint32_t eq = 0xFFFFFFFFu;                           // becomes 0 when this thread sees two equal scores
-            {   // pass A: memory key kk against run rb (wave-uniform: is it the key's own run?)
+            {   // pass A: memory key kk against run rb (wave-uniform: is it the key's own run?); pass B, on the first 4 SMAX
+                // threads (waves 0 and 1, wave-uniform): survivor i against run rb2 - the same threads' two searches run
+                // interleaved (search_run_u32_x2)
                 const int kk = tid & (M - 1), rb = tid >> 8;
                 const uint32_t m = sc32[kk];
-                int c = search_run_u32(runs32 + 64 * rb, m, (wave & 3) == rb ? 0xFFFFFFFFu : 0u, eq);
+                const uint32_t own = (wave & 3) == rb ? 0xFFFFFFFFu : 0u;
+                int c, c2 = 0;
+                const int rb2 = tid >> 5, i2 = tid & (SMAX - 1);
+                const bool passb = ks > 0 && wave < 2;               // (tid < 4 SMAX = 128)
+                uint32_t m2 = 0u, eq2 = 0xFFFFFFFFu;
+                if (passb) {
+                    m2 = skeys[2 * (i2 < ks ? i2 : 0) + 1];
+                    search_run_u32_x2(runs32 + 64 * rb, m, own, runs32 + 64 * rb2, m2, eq, eq2, c, c2);
+                } else {
+                    c = search_run_u32(runs32 + 64 * rb, m, own, eq);
+                }
                 if (rb == 0) {
                     for (int i = 0; i < ks; ++i) {               // (workgroup-uniform trip count; broadcast reads)
                         const uint32_t sv = skeys[2 * i + 1];
@@ -1962,20 +1995,16 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
                     }
                 }
                 pr[rb * PRW + kk] = c;
-            }
-            if (ks > 0 && tid < 4 * SMAX) {                      // pass B: (survivor, run) pairs on the first waves
-                const int rb = tid >> 5, i = tid & (SMAX - 1);
-                if (i < ks) {
-                    const uint32_t m = skeys[2 * i + 1];
-                    int c = search_run_u32(runs32 + 64 * rb, m, 0u, eq);
-                    if (rb == 0) {
+                if (passb && i2 < ks) {
+                    if (rb2 == 0) {
                         for (int j = 0; j < ks; ++j) {
                             const uint32_t sv = skeys[2 * j + 1];
-                            c += (int)key_gt(sv, m);
-                            eq = min(eq, (sv ^ m) | (j == i ? 0xFFFFFFFFu : 0u));
+                            c2 += (int)key_gt(sv, m2);
+                            eq2 = min(eq2, (sv ^ m2) | (j == i2 ? 0xFFFFFFFFu : 0u));
                         }
                     }
-                    pr[rb * PRW + M + i] = c;
+                    pr[rb2 * PRW + M + i2] = c2;
+                    eq = min(eq, eq2);
                 }
             }
             if (__ballot(eq == 0u) != 0ull && lane == 0) ccount[2 + par] = 1;
