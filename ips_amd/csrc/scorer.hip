@@ -1987,21 +1987,19 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
                 } else {
                     c = search_run_u32(runs32 + 64 * rb, m, own, eq);
                 }
-                if (rb == 0) {
-                    for (int i = 0; i < ks; ++i) {               // (workgroup-uniform trip count; broadcast reads)
-                        const uint32_t sv = skeys[2 * i + 1];
-                        c += (int)key_gt(sv, m);
-                        eq = min(eq, sv ^ m);
-                    }
+                // the counts against the (unsorted) survivors are dealt out over the four partial counts of a key - survivors
+                // rb, rb + 4, ... ride on the threads of run rb (it was all of them on run 0's: waves 0-3 late at the barrier)
+                for (int i = rb; i < ks; i += 4) {               // (wave-uniform trip count; broadcast reads)
+                    const uint32_t sv = skeys[2 * i + 1];
+                    c += (int)key_gt(sv, m);
+                    eq = min(eq, sv ^ m);
                 }
                 pr[rb * PRW + kk] = c;
                 if (passb && i2 < ks) {
-                    if (rb2 == 0) {
-                        for (int j = 0; j < ks; ++j) {
-                            const uint32_t sv = skeys[2 * j + 1];
-                            c2 += (int)key_gt(sv, m2);
-                            eq2 = min(eq2, (sv ^ m2) | (j == i2 ? 0xFFFFFFFFu : 0u));
-                        }
+                    for (int j = rb2; j < ks; j += 4) {
+                        const uint32_t sv = skeys[2 * j + 1];
+                        c2 += (int)key_gt(sv, m2);
+                        eq2 = min(eq2, (sv ^ m2) | (j == i2 ? 0xFFFFFFFFu : 0u));
                     }
                     pr[rb2 * PRW + M + i2] = c2;
                     eq = min(eq, eq2);
