@@ -88,8 +88,9 @@ if args.profile:
         for _ in range(10):
             do_step()
         torch.cuda.synchronize()
-    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+    rows = sorted((e for e in prof.key_averages() if e.device_time_total > 0), key=lambda e: -e.device_time_total)
     tot = sum(e.device_time_total for e in rows)
+    # (rows WITH device time only: rounds 2-4 also counted the profiler's runtime-side records - "679 kernels" were 274)
     print("device time per step %.3f ms over %d kernels" % (tot / 1e4, sum(e.count for e in rows) // 10))
     for e in rows[:30]:
         print("  %-90s %4d x %8.1f us  %5.1f%%" % (e.key[:90], e.count // 10, e.device_time_total / e.count, 100 * e.device_time_total / tot))
