@@ -15,7 +15,22 @@
 
 #include "ipsx_common.h"
 
+#include <atomic>
+#include <time.h>
+
 namespace {
+
+// Diagnostic (ipsx_dbg_call_host_gap; tools/soak.py): host time between the moment the loop's launch was handed to the
+// runtime and the moment its producer's launch returned - the window in which a descheduled host thread (a container's
+// CPU quota, a collector in another thread's interpreter) leaves a resident loop waiting for rows.  [0] longest (ns),
+// [1] calls whose window was longer than 10 ms, [2] calls
+std::atomic<unsigned long long> g_gap_max{0}, g_gap_long{0}, g_gap_calls{0};
+
+inline unsigned long long host_ns() {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (unsigned long long)t.tv_sec * 1000000000ull + (unsigned long long)t.tv_nsec;
+}
 
 constexpr int kSlots = 64, kDevices = 16;
 
@@ -63,6 +78,7 @@ IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
     IPSX_TRY(hip_ok(hipMemsetAsync(c->words, 0, (size_t)c->words_total * sizeof(int32_t), main), "fill"));
     IPSX_TRY(hip_ok(hipEventRecord(ev->fork, main), "event"));
     IPSX_TRY(hip_ok(hipStreamWaitEvent(side, ev->fork, 0), "wait"));
+    const unsigned long long h0 = host_ns();
     IPSX_TRY(ipsx_scan_persistent_ws(c->logits, c->b, c->n, c->m, c->i, c->h, c->n_token, c->mem_idx, nullptr, tie, ready,
                                      c->b > 1 ? 1 : 0, status, c->loops, c->scan_workspace, c->scan_workspace_bytes, side));
     // producers must not take the compute units before a loop has its own (see ipsx_scan_gate)
@@ -81,6 +97,13 @@ IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
     else
         IPSX_TRY(ipsx_projector_stream(c->lin, static_cast<const float*>(c->x), (int64_t)c->b * c->n, c->n, c->ln_eps, c->emb, c->v_packed,
                                        c->r, c->logits, ctl, ready, c->workgroups, c->short_first, main));
+    {
+        const unsigned long long gap = host_ns() - h0;
+        unsigned long long seen = g_gap_max.load(std::memory_order_relaxed);
+        while (gap > seen && !g_gap_max.compare_exchange_weak(seen, gap, std::memory_order_relaxed)) {}
+        if (gap > 10000000ull) g_gap_long.fetch_add(1, std::memory_order_relaxed);
+        g_gap_calls.fetch_add(1, std::memory_order_relaxed);
+    }
     if (slot >= 0 && slot < kSlots) IPSX_TRY(hip_ok(hipEventRecord(ev->t1[slot], main), "timing event"));
     IPSX_TRY(hip_ok(hipEventRecord(ev->join, side), "event"));
     IPSX_TRY(hip_ok(hipStreamWaitEvent(main, ev->join, 0), "wait"));
@@ -97,4 +120,12 @@ IPSX_API int ipsx_ips_call_elapsed(int slot, float* ms) {
     if (!ev || !ev->t0[slot]) return fail(IPSX_EINVAL, "ips_call_elapsed: slot %d was never recorded on this device", slot);
     const hipError_t e = hipEventElapsedTime(ms, ev->t0[slot], ev->t1[slot]);
     return e == hipSuccess ? IPSX_OK : fail(IPSX_EHIP, "ips_call_elapsed: %s", hipGetErrorString(e));
+}
+
+// Diagnostic (not part of include/ipsx.h): out3 = {longest host window loop launch -> producer launched (ns), windows > 10 ms,
+// calls} since the last look; clears them
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_call_host_gap(unsigned long long* out3) {
+    out3[0] = g_gap_max.exchange(0);
+    out3[1] = g_gap_long.exchange(0);
+    out3[2] = g_gap_calls.exchange(0);
 }

@@ -61,10 +61,53 @@ def main():
         print("   %s: %d gate launches, longest gate wait %.3f ms (its loop became resident %.3f ms after the gate started), gates "
               "that gave up %d, loops that gave up %d" % (tag, v[0], v[1] / 1e5, late, v[2], v[5]), flush=True)
 
+    hgap = hip.lib().ipsx_dbg_call_host_gap
+    hgap.restype, hgap.argtypes = None, [C.c_void_p]
+    host = {"max_ms": 0.0, "long": 0, "calls": 0}
+
+    def host_gap(tag=None):
+        """the library call's own clock: host time from the loop's launch to its producer's launch having returned"""
+        buf = (C.c_ulonglong * 3)()
+        hgap(buf)
+        host["max_ms"] = max(host["max_ms"], buf[0] / 1e6)
+        host["long"] += int(buf[1])
+        host["calls"] += int(buf[2])
+        if tag:
+            print("   %s: host window loop launch -> producer launched, longest %.3f ms over %d library calls (%d longer than 10 ms)" % (
+                tag, buf[0] / 1e6, buf[2], buf[1]), flush=True)
+
+    def throttled():
+        """the container's CPU quota: (periods throttled, ms throttled) of /sys/fs/cgroup/cpu.stat, None if not readable"""
+        for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+            try:
+                kv = dict(l.split() for l in open(path).read().splitlines())
+            except OSError:
+                continue
+            t = kv.get("throttled_usec")
+            return int(kv.get("nr_throttled", 0)), (int(t) / 1e3 if t is not None else int(kv.get("throttled_time", 0)) / 1e6)
+        return None
+    thr0 = throttled()
+
+    # torch sizes its CPU pools by the machine (256 hardware threads on the GPU box), the container may run 16 of them at a
+    # time (cpu.max): building a net on 128 threads then stalls the whole process for the rest of a 100 ms quota period -
+    # anywhere, also between two launches of one ips() call.  IPSX_SOAK_THREADS=0 leaves torch's default (the stalls on record
+    # in profiles/r05_soak_long.txt)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else max(1, int(q) // int(per))
+    except (OSError, ValueError):
+        pass
+    want_threads = int(os.environ.get("IPSX_SOAK_THREADS", str(min(quota or 8, os.cpu_count() or 8) // 2 or 1)))
+    if want_threads > 0:
+        torch.set_num_threads(want_threads)
+    print("host: %s CPUs visible, container quota %s, torch intra-op threads %d" % (os.cpu_count(), quota, torch.get_num_threads()), flush=True)
+
     def note(rounds, leg, call, before):
         if hip._PERSIST_STRIKES != before:
             events.append((rounds, leg, call))
             print("   loop timeout seen by the host: round %d, leg %s, %s" % (rounds, leg, call), flush=True)
+            host_gap("at that moment")
         return hip._PERSIST_STRIKES
     inputs, want, stats = {}, {}, {}
     t_start = time.perf_counter()
@@ -120,6 +163,7 @@ def main():
         gc.collect()                                # (net <-> selection <-> plan reference one another: the collector frees them)
         if rounds % 10 == 0:
             gate_log("rounds %d-%d" % (rounds - 9, rounds))
+            host_gap("rounds %d-%d" % (rounds - 9, rounds))
         torch.cuda.synchronize()
         print("round %d: %.0f s, allocated %.1f MB, reserved %.1f MB, persistent timeouts so far %d%s" % (
             rounds, time.perf_counter() - t_start, torch.cuda.memory_allocated() / 2**20, torch.cuda.memory_reserved() / 2**20,
@@ -132,6 +176,11 @@ def main():
                                                        st["mismatch"], st["fixture_equal"]))
         ok = ok and st["mismatch"] == 0
     total = sum(st["calls"] for st in stats.values())
+    host_gap()
+    thr1 = throttled()
+    print("host: longest window loop launch -> producer launched %.3f ms over %d library calls, %d longer than 10 ms; the container's "
+          "CPU quota throttled it %s" % (host["max_ms"], host["calls"], host["long"],
+                                         "in %d periods, %.0f ms in all" % (thr1[0] - thr0[0], thr1[1] - thr0[1]) if thr0 and thr1 else "(cpu.stat not readable)"))
     print("%d ips() calls in %.0f s over %d rounds; persistent timeouts %d %s; pipelines switched off: %s; %s" % (
         total, time.perf_counter() - t_start, rounds, hip._PERSIST_STRIKES, events, bool(hip._PERSIST_OFF), "OK" if ok else "MISMATCH"))
     sys.exit(0 if ok else 1)
