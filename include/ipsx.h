@@ -465,8 +465,8 @@ int ipsx_ips_finish(const void* patches, int64_t patch_row_bytes, int64_t patch_
  *          (ipsx_trunk_stream_ctl_words / ipsx_projector_stream_ctl_words); zeroed by the call.
  *   timing_slot in [0, 64): the producer's launch is bracketed by a library-owned HIP event pair; ipsx_ips_call_elapsed
  *          (slot, &ms) reads it once the stream has been synchronised.  -1: no events.
- * The two hand-over events are the library's, one pair per device: calls for ONE device come from one thread at a time
- * (like every handle-free entry point here: no internal locking).                                                      */
+ * The two hand-over events are the library's, one pair per device; the call enqueues under a per-device lock, so calls
+ * from several threads (on streams of their own) do not mix their hand-overs.                                          */
 typedef struct ipsx_ips_call {
     int b; int64_t n; int m, i, h, n_token;
     float* logits; int64_t* mem_idx; int32_t* words; int64_t words_total;

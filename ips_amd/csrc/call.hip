@@ -16,6 +16,7 @@
 #include "ipsx_common.h"
 
 #include <atomic>
+#include <mutex>
 #include <time.h>
 
 namespace {
@@ -38,6 +39,7 @@ struct DeviceEvents {
     hipEvent_t fork = nullptr, join = nullptr;          // main -> side (the loop follows the fill), side -> main (the end follows the loop)
     hipEvent_t t0[kSlots] = {}, t1[kSlots] = {};
     bool ok = false;
+    std::mutex enqueue;          // one call's launches and hand-overs go out as a block: the events are shared by the device's calls
 };
 
 DeviceEvents* device_events() {
@@ -45,6 +47,7 @@ DeviceEvents* device_events() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevices) return nullptr;
     DeviceEvents& e = ev[dev];
+    std::lock_guard<std::mutex> lock(e.enqueue);
     if (!e.ok) {
         if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -67,6 +70,7 @@ IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
     IPSX_REQUIRE(c->words_total >= 2 * (int64_t)c->b + 1, "ips_call: control words");
     DeviceEvents* ev = device_events();
     if (!ev) return fail(IPSX_EHIP, "ips_call: no events on this device");
+    std::lock_guard<std::mutex> lock(ev->enqueue);
     hipStream_t main = as_stream(c->stream), side = as_stream(c->side_stream);
     int32_t* const tie = c->words;
     int32_t* const ready = c->words + c->b;
@@ -117,7 +121,10 @@ IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
 IPSX_API int ipsx_ips_call_elapsed(int slot, float* ms) {
     IPSX_REQUIRE(ms && slot >= 0 && slot < kSlots, "ips_call_elapsed: bad arguments");
     DeviceEvents* ev = device_events();
-    if (!ev || !ev->t0[slot]) return fail(IPSX_EINVAL, "ips_call_elapsed: slot %d was never recorded on this device", slot);
+    if (ev) ev->enqueue.lock();
+    const bool recorded = ev && ev->t0[slot];
+    if (ev) ev->enqueue.unlock();
+    if (!recorded) return fail(IPSX_EINVAL, "ips_call_elapsed: slot %d was never recorded on this device", slot);
     const hipError_t e = hipEventElapsedTime(ms, ev->t0[slot], ev->t1[slot]);
     return e == hipSuccess ? IPSX_OK : fail(IPSX_EHIP, "ips_call_elapsed: %s", hipGetErrorString(e));
 }

@@ -720,6 +720,43 @@ def test_stream_hand_over_stress(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_library_calls_from_two_threads_keep_their_hand_overs_apart():
+    """ipsx_ips_call_run shares one pair of hand-over events per device and enqueues under a per-device lock: two host
+    threads, each with a net and a stream of its own (one image on the fused trunk, one slide through the projector), 40
+    calls each at the same time - every call selects what the same net selects alone."""
+    import threading
+    dev = torch.device(DEV)
+    confs = [synth.mnist_conf(N=2500, M=64, I=64), synth.camelyon_conf(N=8192, M=256, I=256)]
+    nets = [synth.fill_weights(IPSNet(dev, c), 3 + k).to(DEV).eval() for k, c in enumerate(confs)]
+    xs = [synth.make_patches(c, 1, seed=4 + k).to(DEV) for k, c in enumerate(confs)]
+    want = []
+    for net, x in zip(nets, xs):
+        net.ips(x)
+        assert net.selection.scan_status is not None          # the resident-loop pipeline, through the library call
+        want.append(net.last_mem_idx.clone())
+    torch.cuda.synchronize()
+    wrong, errors = [0, 0], []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(40):
+                    nets[k].ips(xs[k])
+                    wrong[k] += 0 if torch.equal(nets[k].last_mem_idx, want[k]) else 1
+                st.synchronize()
+        except Exception as e:                                 # noqa: BLE001 - reported by the assert below
+            errors.append(repr(e))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads) and not errors, errors
+    assert wrong == [0, 0]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groups", [1, 2, 3, 5])
 def test_persistent_loops_of_several_slides_on_fewer_workgroups(groups):
     """ipsx_scan_persistent_on: the loops of 5 slides (the CAMELYON shape, M = I = 256) on 1 / 2 / 3 / 5 resident
