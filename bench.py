@@ -129,7 +129,15 @@ def host_description():
     except OSError:
         pass
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return {"cpu_model": model, "nproc": os.cpu_count(), "cpus_available": avail}
+    # the container's CPU quota (cgroup v2 cpu.max, "quota period" in us): threads beyond it are throttled, not run - on
+    # the GPU boxes 256 logical CPUs are visible and 16 may run at a time, which is why 16 threads win the table below
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cpus_available": avail, "cpu_quota": quota}
 
 
 def cpu_baseline(conf, x, budget_s):
@@ -192,8 +200,8 @@ def cpu_baseline(conf, x, budget_s):
             break
     whole = b_s == B and n_s == N
     return {"value": b_s * n_s * reps / dt, "unit": "patches/s", "cores": torch.get_num_threads(),
-            "threads": torch.get_num_threads(), "nproc": host["nproc"], "cpus_available": avail, "cpu_model": host["cpu_model"],
-            "kind": "port",
+            "threads": torch.get_num_threads(), "nproc": host["nproc"], "cpus_available": avail, "cpu_quota": host["cpu_quota"],
+            "cpu_model": host["cpu_model"], "kind": "port",
             "thread_table": table,
             "thread_table_on": "%d image(s) x %d patches (the whole batch, patch axis cut at a chunk boundary: the sample's own "
                                "per-iteration shape), faster of two ips() calls per count" % (B, n_tab),
