@@ -679,6 +679,11 @@ def main():
     from ips_amd import hip
 
     hip.lib()                                                   # fail loudly if the extension is missing
+    # torch sizes its CPU pools by the machine; a container that may run fewer CPUs than it shows freezes the whole process
+    # for the rest of a quota period when the pools burn it (building a net, drawing the inputs) - also in the middle of a
+    # timed call (DESIGN 6 "Soak").  The GPU legs need no CPU pool; the CPU baseline sets its own counts
+    host = host_description()
+    torch.set_num_threads(max(1, min(8, int(host["cpu_quota"] or host["cpus_available"]) // max(world, 1) or 1)))
     if args.dedup_blank:
         os.environ["IPSX_DEDUP_BLANK"] = "1"
     os.environ["IPSX_PRECISION"] = args.precision
