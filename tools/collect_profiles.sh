@@ -65,4 +65,10 @@ python tools/conv_layers.py 14400 2>&1 | grep -v "amdgpu.ids" > "$OUT/conv_layer
 python tools/kernel_resources.py > "$OUT/kernel_resources.txt" 2>/dev/null
 python tools/stream_outliers.py 40 2>&1 | grep -v "amdgpu.ids" > "$OUT/stream_outliers.txt"
 python tools/soak.py 150 20 2>&1 | grep -v "amdgpu.ids" > "$OUT/soak.txt"
+# the soak with torch's default CPU pools (the container's CPU quota then freezes the process: DESIGN 6 "Soak"), and fuzzing
+# against the oracle / of the schedules against each other
+IPSX_SOAK_THREADS=0 python tools/soak.py 240 20 2>&1 | grep -v "amdgpu.ids" > "$OUT/soak_default_threads.txt"
+python tools/fuzz_scan.py 1000 30000 4000 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_scan.txt"
+python tools/fuzz_e2e.py 100 400 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_e2e.txt"
+python tools/fuzz_pipelines.py 0 750 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_pipelines.txt"
 echo done
