@@ -459,8 +459,9 @@ int ipsx_ips_finish(const void* patches, int64_t patch_row_bytes, int64_t patch_
  * `side_stream` (ipsx_scan_persistent_ws), the gate, the producer on `stream` (ipsx_trunk_stream when `trunk` is set -
  * b == 1 -, ipsx_projector_stream when `lin` is set), the conditional recovery launch (ipsx_scan_range_if_ws) and the end
  * of the call (ipsx_ips_finish), with the two cross-stream hand-overs between them.  Same kernels, same results as the
- * entry points called one by one; the host's share of a call drops from ~12 calls to one, and nothing can stall the host
- * between the launch of the loop and the launch of the producer it waits for.
+ * entry points called one by one; the host's share of a call drops from ~12 calls to one, and nothing of the caller's
+ * runtime (an interpreter's collector or allocator) sits between the launch of the loop and the launch of the producer it
+ * waits for - a host thread the OS deschedules there still can: the loop's wait is bounded and the call then redoes it.
  *   words: words_total int32 = tie flags [b] | progress words [b] | status | the producer's control words
  *          (ipsx_trunk_stream_ctl_words / ipsx_projector_stream_ctl_words); zeroed by the call.
  *   timing_slot in [0, 64): the producer's launch is bracketed by a library-owned HIP event pair; ipsx_ips_call_elapsed

@@ -8,7 +8,8 @@
 // time per call, of which ~100 us sit IN FRONT of the producer's launch: a synchronised call of one image was 0.92 ms
 // around a 0.77 ms kernel.  Enqueued here the host's share is one call; and nothing of the interpreter - the
 // garbage collector, the allocator, another thread holding the GIL - can stall the host between the launch of the loop
-// and the launch of the producer it waits for (tools/soak.py: what a loop's rare timeouts were made of).
+// and the launch of the producer it waits for (tools/soak.py: what a loop's rare timeouts were made of; what still can is
+// the OS descheduling the thread, e.g. a container's CPU quota - see ipsx_dbg_call_host_gap below).
 //
 // Timing: slots of HIP event pairs owned by the library bracket the PRODUCER's launch on request (bench.py's roofline
 // figure: torch's own event objects cannot be recorded from here).
