@@ -60,8 +60,10 @@ extern "C" {
  *         contract changed (LayerNorm folded into the epilogue: ipsx_projector* need lin->colsum, ipsx_projector_stats
  *         returns the moments in the operand-stream order); ipsx_weight_colsum added; the two stream kernels publish their
  *         last rows themselves (one more control word each: ipsx_*_stream_ctl_words), ipsx_ips_finish, ipsx_ips_call_run /
- *         ipsx_ips_call_elapsed added */
-#define IPSX_VERSION 300
+ *         ipsx_ips_call_elapsed added
+ *   3.01  round 5 (additions only): ipsx_pack_conv_weights_batch, ipsx_conv2d_lds_nhwc_stats (+ _slabs),
+ *         ipsx_bn_train_forward_partials */
+#define IPSX_VERSION 301
 
 #define IPSX_OK            0
 #define IPSX_EINVAL       -1      /* bad argument / unsupported shape */
@@ -91,6 +93,12 @@ int ipsx_pack_conv_weight(const float* w_oihw, int c_out, int c_in, int kh, int 
  * on dy the data gradient of the convolution. */
 int ipsx_pack_conv_weight_strided(const float* w, int64_t base, int c_out, int c_in, int kh, int kw, int64_t s_out,
                                   int64_t s_in, int64_t s_ky, int64_t s_kx, float* packed, void* stream);
+/* Up to 32 of those as ONE launch (the training step re-packs every convolution's weights, in forward and in data-gradient
+ * form, after each optimizer step: training/iterative.py:155-163).  Same bits as the single calls. */
+typedef struct ipsx_pack_job {
+    const float* w; int64_t base; int c_out, c_in, kh, kw; int64_t s_out, s_in, s_ky, s_kx; float* packed;
+} ipsx_pack_job;
+int ipsx_pack_conv_weights_batch(const ipsx_pack_job* jobs, int n_jobs, void* stream);
 
 /* bf16 variant for the reduced-precision trunk: [C_out/32][K/16][64 lanes][8 bf16], round to nearest even */
 size_t ipsx_packed_conv_weight_bf16_bytes(int c_out, int c_in, int kh, int kw);
@@ -169,6 +177,14 @@ int ipsx_conv2d_affine_nhwc(const ipsx_conv* cv, const float* x, const float* re
  * w_packed (ipsx_pack_conv_weight[_strided]); alpha / shift are ignored. */
 int ipsx_conv2d_lds_nhwc_supported(int c_in, int c_out, int k, int stride, int pad, int h, int w);
 int ipsx_conv2d_lds_nhwc(const ipsx_conv* cv, const float* x, float* y, int64_t n, int h, int w, void* stream);
+/* The same with the BatchNorm BATCH STATISTICS of the output taken off the accumulators (training step: conv -> bn of a
+ * torchvision BasicBlock, architecture/ips_net.py:273 under net.train()): partial[slab][0 | 1][C_out] = sum (y - shift[c]),
+ * sum (y - shift[c])^2 over the slab's output rows, slab = 4 patches, ipsx_conv2d_lds_nhwc_stats_slabs(n) of them; shift: a
+ * per-channel constant near the mean (the BatchNorm's running mean; NULL = 0).  ipsx_bn_train_forward_partials combines them
+ * (fp64, slab order: deterministic) and applies the BatchNorm - the reduction pass over y is gone.  partial NULL: plain. */
+int64_t ipsx_conv2d_lds_nhwc_stats_slabs(int64_t n);
+int ipsx_conv2d_lds_nhwc_stats(const ipsx_conv* conv, const float* x, float* y, int64_t n, int h, int w, const float* shift,
+                               float* partial, void* stream);
 /* Weight gradient of that convolution for the training step (reference: loss.backward() of training/iterative.py:157-163
  * through the BasicBlocks of architecture/ips_net.py:264-283):
  *   dw[co][ky][kx][ci] = sum over (img, oy, ox) of dy[img,oy,ox,co] * x[img, stride*oy + ky - pad, stride*ox + kx - pad, ci]
@@ -525,6 +541,12 @@ size_t ipsx_bn_train_workspace_floats(int64_t rows, int c);
 int ipsx_bn_train_forward(const float* x, const float* residual, int64_t rows, int c, const float* gamma,
                           const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                           int relu, float* y, float* save_mean, float* save_invstd, float* workspace, void* stream);
+/* ipsx_bn_train_forward without its reduction pass: the per-slab partial sums come from the convolution that produced x
+ * (ipsx_conv2d_lds_nhwc_stats), taken around `shift` (may alias running_mean: it is read before the update). */
+int ipsx_bn_train_forward_partials(const float* x, const float* residual, int64_t rows, int c, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                   int relu, float* y, float* save_mean, float* save_invstd, const float* partial,
+                                   int64_t slabs, const float* shift, void* stream);
 int ipsx_bn_train_backward(const float* dy, const float* y, const float* x, int64_t rows, int c, const float* gamma,
                            const float* save_mean, const float* save_invstd, int relu, float* dx, float* dresidual,
                            float* dgamma, float* dbeta, float* workspace, void* stream);

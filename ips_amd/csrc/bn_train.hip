@@ -98,10 +98,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float4* __restrict
 // per 4 channels.
 //   BWD = false: mean, invstd (+ running statistics, momentum update with the unbiased variance as torch does)
 //   BWD = true : d_beta = sum g, d_gamma = sum g * xhat
+// (x: the shift the partial sums were taken around, per channel - row 0 of the activation, or, for partial sums that come
+//  from a convolution's epilogue, the running mean itself: no __restrict__ on the two, the read precedes the update)
 template <bool BWD>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, const float* x,
                                                           BnShape s, float eps, float momentum,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* running_mean, float* __restrict__ running_var,
                                                           float* __restrict__ out0, float* __restrict__ out1) {
     __shared__ double red[2][64][4];
     const int cl = threadIdx.x & 3, gl = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         out1[c] = (float)a;          // d_beta
     } else {
         const double n = (double)s.rows, m1 = a / n;
-        const double mean = (double)x[c] + m1;
+        const double mean = (x ? (double)x[c] : 0.0) + m1;
         double var = b / n - m1 * m1;
         var = var > 0.0 ? var : 0.0;
         out0[c] = (float)mean;
@@ -231,6 +233,28 @@ IPSX_API int ipsx_bn_train_forward(const float* x, const float* residual, int64_
         reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(beta), total4, s.cg, relu,
         reinterpret_cast<float4*>(y));
     return launched("bn_train_forward");
+}
+
+IPSX_API int ipsx_bn_train_forward_partials(const float* x, const float* residual, int64_t rows, int c, const float* gamma,
+                                            const float* beta, float eps, float momentum, float* running_mean,
+                                            float* running_var, int relu, float* y, float* save_mean, float* save_invstd,
+                                            const float* partial, int64_t slabs, const float* shift, void* stream) {
+    BnShape s;
+    IPSX_REQUIRE(bn_shape(rows, c, &s), "bn_train_forward_partials: rows = %lld, C = %d (C / 4 must be a power of two <= 256)",
+                 (long long)rows, c);
+    IPSX_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && partial && slabs > 0 && slabs < (1 << 30),
+                 "bn_train_forward_partials: bad arguments");
+    hipStream_t st = as_stream(stream);
+    s.slabs = (int)slabs;                                   // the producer's slabs (bn_finalize_kernel only counts them)
+    bn_finalize_kernel<false><<<dim3((unsigned)cdiv(c, 4)), dim3(256), 0, st>>>(partial, shift, s, eps, momentum, running_mean,
+                                                                                  running_var, save_mean, save_invstd);
+    const long long total4 = (long long)rows * s.cg;
+    bn_apply_kernel<<<dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st>>>(
+        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(residual),
+        reinterpret_cast<const float4*>(save_mean), reinterpret_cast<const float4*>(save_invstd),
+        reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(beta), total4, s.cg, relu,
+        reinterpret_cast<float4*>(y));
+    return launched("bn_train_forward_partials");
 }
 
 IPSX_API int ipsx_bn_train_backward(const float* dy, const float* y, const float* x, int64_t rows, int c,

@@ -660,34 +660,81 @@ struct LdsConvArgs {
     float* y;              // (n, WOUT, WOUT, COUT) channels-last
     const float* wp;       // ipsx_pack_conv_weight layout
     long long n;
+    // BatchNorm batch statistics off the accumulators (training step; ipsx_conv2d_lds_nhwc_stats): per workgroup - a slab of
+    // 4 patches' output rows - and output channel  sum (y - shift), sum (y - shift)^2  -> stats[blockIdx][0 | 1][COUT], what
+    // bn_reduce_kernel<false> would compute in a pass of its own over y (csrc/bn_train.hip; the combination over the slabs
+    // stays bn_finalize_kernel's, fp64 in slab order).  shift: a per-channel constant near the mean (the BatchNorm's running
+    // mean), NULL = 0.  stats NULL: a plain convolution.
+    float* stats;
+    const float* shift;
 };
+
+// sum and sum of squares of (v - k) over this lane's 16 registers of one accumulator tile
+__device__ __forceinline__ void tile_moments(const f32x16& v, float k, float& s1, float& s2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float d = v[r] - k;
+        s1 = s1 + d;
+        s2 = __builtin_fmaf(d, d, s2);
+    }
+}
 
 // 64 -> 64, 3x3, stride 1, 8x8 maps: wave = patch (conv_l1)
 __global__ __launch_bounds__(256, 2) void conv_lds_l1_kernel(LdsConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 slabs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p = (long long)blockIdx.x * 4 + wave;
-    if (p >= a.n) return;                                                 // (no workgroup barriers in this kernel)
+    const bool live = p < a.n;
+    if (!live && !a.stats) return;                                        // (no workgroup barrier without statistics)
     float* S = lds + wave * SLAB;
-    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)p * 4096);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int e = (k * 64 + lane) * 4;                               // pixel e / 64, channel e % 64
-        *reinterpret_cast<float4*>(S + (e >> 6) * PS1 + (e & 63)) = src[k * 64 + lane];
-    }
-    for (int z = lane; z < PS1; z += 64) S[ZP1 * PS1 + z] = 0.0f;
-    wave_fence();
-    f32x16 acc[2][2];
-    conv_l1(a.wp, S, acc, lane);
     const int i = lane & 31, half = lane >> 5;
-    float* dst = a.y + (size_t)p * 4096;
+    float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+    if (live) {
+        const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)p * 4096);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int k = 0; k < 16; ++k) {
+            const int e = (k * 64 + lane) * 4;                           // pixel e / 64, channel e % 64
+            *reinterpret_cast<float4*>(S + (e >> 6) * PS1 + (e & 63)) = src[k * 64 + lane];
+        }
+        for (int z = lane; z < PS1; z += 64) S[ZP1 * PS1 + z] = 0.0f;
+        wave_fence();
+        f32x16 acc[2][2];
+        conv_l1(a.wp, S, acc, lane);
+        float* dst = a.y + (size_t)p * 4096;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dst[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + nt * 32 + i] = acc[mt][nt][r];
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + nt * 32 + i] = acc[mt][nt][r];
+        if (a.stats) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float k = a.shift ? a.shift[nt * 32 + i] : 0.0f;
+                tile_moments(acc[0][nt], k, s1[nt], s2[nt]);             // rows in a fixed order: deterministic
+                tile_moments(acc[1][nt], k, s1[nt], s2[nt]);
+            }
+        }
+    }
+    if (a.stats) {
+        // the lane halves hold different pixels of the same channel; then the four patches of the slab, in patch order
+        wave_fence();                                                     // (this wave's reads of its slab are over)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            s1[nt] = s1[nt] + __shfl_xor(s1[nt], 32, 64);
+            s2[nt] = s2[nt] + __shfl_xor(s2[nt], 32, 64);
+            if (half == 0) { S[nt * 32 + i] = s1[nt]; S[64 + nt * 32 + i] = s2[nt]; }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float t1 = lds[lane], t2 = lds[64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { t1 = t1 + lds[w * SLAB + lane]; t2 = t2 + lds[w * SLAB + 64 + lane]; }
+            a.stats[(size_t)blockIdx.x * 128 + lane] = t1;
+            a.stats[(size_t)blockIdx.x * 128 + 64 + lane] = t2;
+        }
+    }
 }
 
 // CIN -> 128 onto 4x4 maps (conv_l2): 4 patches per workgroup, wave w owns output channels 32 w .. 32 w + 31
@@ -715,6 +762,25 @@ __global__ __launch_bounds__(256, 2) void conv_lds_l2_kernel(LdsConvArgs a) {
             const int pl = 2 * mt + (r >> 3), pix = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
             if (p_first + pl < a.n) a.y[((size_t)(p_first + pl) * 16 + pix) * 128 + n] = acc[mt][r];
         }
+    if (a.stats) {
+        // this wave owns channel n for all 64 rows of the slab (4 patches x 16 pixels): half of them on each lane half
+        const float k = a.shift ? a.shift[n] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = (p_first + 2 * mt + (r >> 3) < a.n) ? acc[mt][r] - k : 0.0f;
+                s1 = s1 + d;
+                s2 = __builtin_fmaf(d, d, s2);
+            }
+        s1 = s1 + __shfl_xor(s1, 32, 64);
+        s2 = s2 + __shfl_xor(s2, 32, 64);
+        if (half == 0) {
+            a.stats[(size_t)blockIdx.x * 256 + n] = s1;
+            a.stats[(size_t)blockIdx.x * 256 + 128 + n] = s2;
+        }
+    }
 }
 
 static bool is_conv(const ipsx_conv& c, int ci, int co, int k, int s, int p) {
@@ -902,6 +968,13 @@ IPSX_API int ipsx_conv2d_lds_nhwc_supported(int c_in, int c_out, int k, int stri
 }
 
 IPSX_API int ipsx_conv2d_lds_nhwc(const ipsx_conv* cv, const float* x, float* y, int64_t n, int h, int w, void* stream) {
+    return ipsx_conv2d_lds_nhwc_stats(cv, x, y, n, h, w, nullptr, nullptr, stream);
+}
+
+IPSX_API int64_t ipsx_conv2d_lds_nhwc_stats_slabs(int64_t n) { return n > 0 ? ipsx::cdiv(n, 4) : 0; }
+
+IPSX_API int ipsx_conv2d_lds_nhwc_stats(const ipsx_conv* cv, const float* x, float* y, int64_t n, int h, int w, const float* shift,
+                                        float* partial, void* stream) {
     IPSX_REQUIRE(cv && cv->w_packed && x && y && n >= 0, "conv2d_lds_nhwc: bad arguments");
     const int kind = cv->kh == cv->kw ? lds_conv_kind(cv->c_in, cv->c_out, cv->kh, cv->stride, cv->pad, h, w) : 0;
     IPSX_REQUIRE(kind != 0, "conv2d_lds_nhwc: %d -> %d, %dx%d / %d on %dx%d maps is not one of the fused trunk's stages", cv->c_in,
@@ -909,6 +982,7 @@ IPSX_API int ipsx_conv2d_lds_nhwc(const ipsx_conv* cv, const float* x, float* y,
     if (n == 0) return IPSX_OK;
     ipsx::LdsConvArgs a;
     a.x = x; a.y = y; a.wp = cv->w_packed; a.n = n;
+    a.stats = partial; a.shift = partial ? shift : nullptr;
     const size_t lds = (size_t)4 * ipsx::SLAB * sizeof(float);
     const dim3 grid((unsigned)ipsx::cdiv(n, 4)), block(256);
     hipStream_t s = ipsx::as_stream(stream);

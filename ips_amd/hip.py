@@ -172,6 +172,7 @@ _EXPORTS = {
     "ipsx_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_pack_conv_weight_strided": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                                 C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ipsx_pack_conv_weights_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ipsx_packed_conv_weight_bf16_bytes": (C.c_size_t, [C.c_int] * 4),
     "ipsx_pack_conv_weight_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ipsx_packed_conv_weight_x3_bytes": (C.c_size_t, [C.c_int] * 4),
@@ -187,6 +188,12 @@ _EXPORTS = {
                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_conv2d_lds_nhwc_supported": (C.c_int, [C.c_int] * 7),
     "ipsx_conv2d_lds_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_conv2d_lds_nhwc_stats_slabs": (C.c_int64, [C.c_int64]),
+    "ipsx_conv2d_lds_nhwc_stats": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "ipsx_bn_train_forward_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_wgrad_nhwc_supported": (C.c_int, [C.c_int] * 6),
     "ipsx_conv2d_wgrad_nhwc_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int] * 4),
     "ipsx_conv2d_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -1266,17 +1273,79 @@ def _pack_conv_view(weight, dgrad=False):
     return packed, n_out, n_in
 
 
-def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False):
+class PackJob(C.Structure):
+    """``ipsx_pack_job`` of include/ipsx.h"""
+    _fields_ = [("w", C.c_void_p), ("base", C.c_int64), ("c_out", C.c_int), ("c_in", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("s_out", C.c_int64), ("s_in", C.c_int64), ("s_ky", C.c_int64), ("s_kx", C.c_int64), ("packed", C.c_void_p)]
+
+
+_PACK_BATCH_MAX = 32
+
+
+def pack_conv_views(views):
+    """``_pack_conv_view`` of several (weight, dgrad) pairs as ONE launch per 32 (ipsx_pack_conv_weights_batch): the packed
+    tensors are slices of one buffer.  -> list of packed tensors, in the order of ``views``."""
+    if not views:
+        return []
+    dev = views[0][0].device
+    sizes = []
+    for weight, dgrad in views:
+        co, ci, kh, kw = weight.shape
+        n_out, n_in = (ci, co) if dgrad else (co, ci)
+        sizes.append(lib().ipsx_packed_conv_weight_elems(n_out, n_in, kh, kw))
+    arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    out, off = [], 0
+    for sz in sizes:
+        out.append(arena[off:off + sz])
+        off += sz
+    for k0 in range(0, len(views), _PACK_BATCH_MAX):
+        chunk = views[k0:k0 + _PACK_BATCH_MAX]
+        jobs = (PackJob * len(chunk))()
+        for j, (weight, dgrad) in enumerate(chunk):
+            co, ci, kh, kw = weight.shape
+            s_co, s_ci, s_kh, s_kw = weight.stride()
+            if dgrad:
+                jobs[j].c_out, jobs[j].c_in = ci, co
+                jobs[j].base, jobs[j].s_out, jobs[j].s_in, jobs[j].s_ky, jobs[j].s_kx = (kh - 1) * s_kh + (kw - 1) * s_kw, s_ci, s_co, -s_kh, -s_kw
+            else:
+                jobs[j].c_out, jobs[j].c_in = co, ci
+                jobs[j].base, jobs[j].s_out, jobs[j].s_in, jobs[j].s_ky, jobs[j].s_kx = 0, s_co, s_ci, s_kh, s_kw
+            jobs[j].kh, jobs[j].kw = kh, kw
+            jobs[j].w, jobs[j].packed = weight.data_ptr(), out[k0 + j].data_ptr()
+        _ck(lib().ipsx_pack_conv_weights_batch(C.byref(jobs), len(chunk), _stream()), "ipsx_pack_conv_weights_batch")
+    return out
+
+
+def conv_lds_supported(conv, h, w):
+    """True when ``conv2d_nhwc`` would run this ``nn.Conv2d`` on the LDS-resident stage kernels (maps of 32-px patches) -
+    the ones that can hand the BatchNorm behind them its batch statistics (``conv2d_nhwc(..., stats_shift=...)``)."""
+    kh, kw = conv.kernel_size
+    return bool(kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0" and os.environ.get("IPSX_TRAIN_CONV_STATS", "1") != "0"
+                and lib().ipsx_conv2d_lds_nhwc_supported(conv.in_channels, conv.out_channels, kh, conv.stride[0], conv.padding[0], h, w))
+
+
+def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False, packed=None, stats_shift=None):
     """Plain convolution of a channels-last (P, C_in, h, w) tensor with an OIHW ``weight`` on the fp32 matrix cores
-    (conv_nhwc_kernel): -> channels-last (P, C_out, ho, wo)."""
+    (conv_nhwc_kernel): -> channels-last (P, C_out, ho, wo).  ``packed``: the weight already packed for this direction
+    (``pack_conv_views``).  ``stats_shift`` (a (C_out,) tensor; only where ``conv_lds_supported``): -> (y, partial, slabs),
+    the output's per-slab sums around that shift for ``bn_train_forward_partials``."""
     if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous(memory_format=_CL):
         raise ValueError("expected a float32 channels-last (P, C, H, W) tensor")
     kh, kw = weight.shape[2:]
     n, _, h, w = x.shape
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    packed, co, ci = _pack_conv_view(weight.detach(), dgrad_weights)
+    if packed is None:
+        packed, co, ci = _pack_conv_view(weight.detach(), dgrad_weights)
+    else:
+        co, ci = (weight.shape[1], weight.shape[0]) if dgrad_weights else (weight.shape[0], weight.shape[1])
     cv = Conv(ci, co, kh, kw, stride, pad, _p(packed), None, None, None)
     y = torch.empty((n, co, ho, wo), dtype=torch.float32, device=x.device, memory_format=_CL)
+    if stats_shift is not None:
+        slabs = int(lib().ipsx_conv2d_lds_nhwc_stats_slabs(n))
+        partial = torch.empty((max(slabs, 1), 2, co), dtype=torch.float32, device=x.device)
+        _ck(lib().ipsx_conv2d_lds_nhwc_stats(C.byref(cv), _p(x), _p(y), n, h, w, _p(stats_shift), _p(partial), _stream()),
+            "ipsx_conv2d_lds_nhwc_stats")
+        return y, partial, slabs
     if kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0" and lib().ipsx_conv2d_lds_nhwc_supported(ci, co, kh, stride, pad, h, w):
         # the maps of 32-px patches: the fused trunk's stage kernels, map LDS-resident for all taps
         _ck(lib().ipsx_conv2d_lds_nhwc(C.byref(cv), _p(x), _p(y), n, h, w, _stream()), "ipsx_conv2d_lds_nhwc")
@@ -1287,7 +1356,7 @@ def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False):
     return y
 
 
-def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw):
+def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw, packed=None):
     """Data gradient of ``conv2d_nhwc``: the same kernel on dy with the weights rotated by 180 degrees and transposed; a
     strided layer first spreads dy over a zero map of the input's size (needs kernel - 1 = 2 pad)."""
     co, ci, kh, kw = weight.shape
@@ -1296,7 +1365,7 @@ def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw):
         spread = torch.empty((n, co, in_hw[0], in_hw[1]), dtype=torch.float32, device=dy.device, memory_format=_CL).zero_()
         spread[:, :, ::stride, ::stride] = dy
         dy = spread
-    return conv2d_nhwc(dy, weight, 1, kh - 1 - pad, dgrad_weights=True)
+    return conv2d_nhwc(dy, weight, 1, kh - 1 - pad, dgrad_weights=True, packed=packed)
 
 
 # ipsx_conv2d_wgrad_nhwc addresses x and dy through 32-bit buffer offsets: either activation of ONE call stays below this
@@ -1355,6 +1424,21 @@ def bn_train_forward(x, residual, gamma, beta, eps, momentum, running_mean, runn
     _ck(lib().ipsx_bn_train_forward(_p(x), _p(residual), rows, c, _p(_f32(gamma)), _p(_f32(beta)), eps, momentum,
                                     _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
                                     _p(ws), _stream()), "ipsx_bn_train_forward")
+    return y, mean, invstd
+
+
+def bn_train_forward_partials(x, residual, gamma, beta, eps, momentum, running_mean, running_var, relu, partial, slabs, shift):
+    """``bn_train_forward`` without its reduction pass: ``partial`` (slabs, 2, C) are the sums ``conv2d_nhwc(..., stats_shift=
+    shift)`` took off its accumulators (``shift`` may be ``running_mean`` itself)."""
+    rows, c = _rows_cl(x)
+    if residual is not None and _rows_cl(residual) != (rows, c):
+        raise ValueError("residual shape")
+    y = torch.empty_like(x)
+    stat = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    mean, invstd = stat[:c], stat[c:]
+    _ck(lib().ipsx_bn_train_forward_partials(_p(x), _p(residual), rows, c, _p(_f32(gamma)), _p(_f32(beta)), eps, momentum,
+                                             _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
+                                             _p(partial), slabs, _p(shift), _stream()), "ipsx_bn_train_forward_partials")
     return y, mean, invstd
 
 

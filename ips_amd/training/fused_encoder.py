@@ -98,26 +98,100 @@ class _Conv(torch.autograd.Function):
     by 180 degrees and transposed), weight gradient ``conv_wgrad_kernel`` (csrc/conv_wgrad.hip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad):
+    def forward(ctx, x, weight, stride, pad, packs=None):
         x = x.contiguous(memory_format=_CL)
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, pad)
-        return hip.conv2d_nhwc(x, weight.detach(), stride, pad)
+        ctx.packed_dgrad = packs[1] if packs is not None else None
+        return hip.conv2d_nhwc(x, weight.detach(), stride, pad, packed=packs[0] if packs is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         stride, pad = ctx.geom
         dy = dy.contiguous(memory_format=_CL)
-        dx = hip.conv2d_nhwc_dgrad(dy, weight, stride, pad, x.shape[2:]) if ctx.needs_input_grad[0] else None
+        dx = hip.conv2d_nhwc_dgrad(dy, weight, stride, pad, x.shape[2:], packed=ctx.packed_dgrad) if ctx.needs_input_grad[0] else None
         dw = hip.conv2d_nhwc_wgrad(x, dy, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def _conv(conv, x):
-    if conv_enabled() and x.is_cuda and x.dtype == torch.float32 and hip.conv_train_supported(conv):
-        return _Conv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+class _ConvBnAct(torch.autograd.Function):
+    """conv -> batch-norm (batch statistics) [-> + residual] [-> relu] as ONE node, for the convolutions that run on the
+    LDS-resident stage kernels: the convolution's epilogue hands the BatchNorm its per-slab sums (around the running mean),
+    so the statistics cost no pass over the convolution's output (``ipsx_conv2d_lds_nhwc_stats`` +
+    ``ipsx_bn_train_forward_partials``; VERDICT r04: "BatchNorm statistics fused into the convolutions' epilogues").
+    Backward = ``_BnAct.backward`` followed by ``_Conv.backward``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, bn, relu, stride, pad, packs):
+        x = x.contiguous(memory_format=_CL)
+        if residual is not None:
+            residual = residual.contiguous(memory_format=_CL)
+        shift = bn.running_mean
+        c, partial, slabs = hip.conv2d_nhwc(x, weight.detach(), stride, pad, packed=packs[0] if packs is not None else None,
+                                            stats_shift=shift)
+        y, mean, invstd = hip.bn_train_forward_partials(c, residual, gamma, beta, bn.eps, bn.momentum, bn.running_mean,
+                                                        bn.running_var, relu, partial, slabs, shift)
+        ctx.relu, ctx.has_res, ctx.geom = relu, residual is not None, (stride, pad)
+        ctx.packed_dgrad = packs[1] if packs is not None else None
+        ctx.save_for_backward(x, weight, c, y if relu else None, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, c, y, gamma, mean, invstd = ctx.saved_tensors
+        stride, pad = ctx.geom
+        dy = dy.contiguous(memory_format=_CL)
+        dc, dres, dgamma, dbeta = hip.bn_train_backward(dy, y, c, gamma, mean, invstd, ctx.relu, ctx.has_res)
+        dx = hip.conv2d_nhwc_dgrad(dc, weight, stride, pad, x.shape[2:], packed=ctx.packed_dgrad) if ctx.needs_input_grad[0] else None
+        dw = hip.conv2d_nhwc_wgrad(x, dc, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None
+
+
+def conv_bn_act(conv, bn, x, packs=None, residual=None, relu=True):
+    """``bn_act(_conv(conv, x), bn, residual, relu)`` - as one node with the statistics off the convolution's epilogue where
+    the convolution runs on the LDS-resident kernels."""
+    if _conv_ok(conv, x) and hip.conv_lds_supported(conv, x.shape[2], x.shape[3]) and bn.momentum is not None:
+        return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, relu, conv.stride[0], conv.padding[0],
+                                packs.get(conv) if packs else None)
+    return bn_act(_conv(conv, x, packs), bn, residual, relu)
+
+
+def _conv_ok(conv, x):
+    return conv_enabled() and x.is_cuda and x.dtype == torch.float32 and hip.conv_train_supported(conv)
+
+
+def _conv(conv, x, packs=None):
+    if _conv_ok(conv, x):
+        return _Conv.apply(x, conv.weight, conv.stride[0], conv.padding[0], packs.get(conv) if packs else None)
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def pack_all(encoder, x):
+    """The packed weights of every convolution of the trunk that runs on libipsx's kernels - forward form, and the
+    data-gradient form (rotated by 180 degrees, transposed) where a gradient flows back through the layer's input - in ONE
+    launch (they were one launch each per call and direction: 19 of the step's kernels).  -> {conv: (forward, dgrad | None)}"""
+    if not (conv_enabled() and x.is_cuda and x.dtype == torch.float32):
+        return {}
+    mods = list(encoder.children())
+    convs = [(mods[0], False)]                           # (module, a gradient w.r.t. its input is needed)
+    for stage in mods[4:-1]:
+        for blk in stage:
+            convs += [(blk.conv1, True), (blk.conv2, True)]
+            if blk.downsample is not None:
+                convs.append((blk.downsample[0], True))
+    grad = torch.is_grad_enabled()
+    views, slots = [], []
+    for conv, back in convs:
+        if not hip.conv_train_supported(conv):
+            continue
+        w = conv.weight.detach()
+        slots.append((conv, len(views), back and grad))
+        views.append((w, False))
+        if back and grad:
+            views.append((w, True))
+    packed = hip.pack_conv_views(views)
+    return {conv: (packed[k], packed[k + 1] if both else None) for conv, k, both in slots}
 
 
 def encode(encoder, x, taps=None):
@@ -132,7 +206,8 @@ def encode(encoder, x, taps=None):
         x = x.as_strided(x.shape, (x.shape[2] * x.shape[3], 1, x.shape[3], 1))
     else:
         x = x.contiguous(memory_format=_CL)
-    h = _conv(conv1, x)
+    packs = pack_all(encoder, x)
+    h = _conv(conv1, x, packs)
     h = bn_act(h, bn1, None, True)
     h = pool(h)
     if taps is not None:
@@ -140,13 +215,12 @@ def encode(encoder, x, taps=None):
     for stage in mods[4:-1]:
         for blk in stage:
             idt = h
-            o = bn_act(_conv(blk.conv1, h), blk.bn1, None, True)
+            o = conv_bn_act(blk.conv1, blk.bn1, h, packs, None, True)
             if taps is not None:
                 taps.append(o)
-            o = _conv(blk.conv2, o)
             if blk.downsample is not None:
-                idt = bn_act(_conv(blk.downsample[0], h), blk.downsample[1], None, False)
-            h = bn_act(o, blk.bn2, idt, True)
+                idt = conv_bn_act(blk.downsample[0], blk.downsample[1], h, packs, None, False)
+            h = conv_bn_act(blk.conv2, blk.bn2, o, packs, idt, True)
             if taps is not None:
                 taps.append(h)
     # num_batches_tracked of every BatchNorm that ran, in one launch (nn.BatchNorm2d adds 1 per forward in train mode)

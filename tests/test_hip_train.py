@@ -55,6 +55,28 @@ def test_conv_train_kernels_match_torch(P, ci, co, k, s, H):
     assert torch.equal(again.contiguous(), wh.grad.contiguous())
 
 
+def test_batched_weight_packing_equals_the_single_launches():
+    """``hip.pack_conv_views`` (ONE launch per 32 weights: what ``fused_encoder.pack_all`` hands the step's convolutions)
+    against ``_pack_conv_view`` per weight and direction - the same bits, for contiguous and channels-last weights, the
+    1-channel stem, 1x1 layers, and more than 32 jobs."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = [(64, 1, 7, 7), (64, 64, 3, 3), (128, 64, 3, 3), (128, 64, 1, 1), (128, 128, 3, 3), (256, 128, 3, 3), (64, 3, 7, 7)]
+    views = []
+    for rep in range(3):
+        for k, sh in enumerate(shapes):
+            w = torch.randn(sh, generator=g).cuda()
+            if (k + rep) % 2:
+                w = w.contiguous(memory_format=torch.channels_last)
+            views.append((w, False))
+            if sh[1] >= 64:
+                views.append((w, True))
+    assert len(views) > 32
+    got = hip.pack_conv_views(views)
+    for (w, dgrad), p in zip(views, got):
+        want = hip._pack_conv_view(w, dgrad)[0]
+        assert p.shape == want.shape and torch.equal(p, want), (tuple(w.shape), dgrad)
+
+
 def test_weight_gradient_of_activations_beyond_one_buffer_is_sliced(monkeypatch):
     """conv2d_nhwc_wgrad on activations of 2 GiB and more (ipsx_conv2d_wgrad_nhwc addresses one 2 GiB buffer per call):
     whole-image slices, added in slice order.  First with the limit lowered so that a small case is cut into four slices
@@ -142,6 +164,44 @@ def test_bn_train_kernels_match_torch(P, C, H, relu, res):
     assert torch.equal(y, y2) and torch.equal(mean, mean2)
 
 
+@pytest.mark.parametrize("P,ci,co,k,s,H", [(16, 64, 64, 3, 1, 8), (1023, 64, 64, 3, 1, 8), (5, 64, 128, 3, 2, 8), (34, 64, 128, 1, 2, 8),
+                                             (7, 128, 128, 3, 1, 4), (1024, 128, 128, 3, 1, 4), (1, 64, 64, 3, 1, 8)])
+def test_conv_epilogue_statistics_feed_the_batch_norm(P, ci, co, k, s, H):
+    """``conv2d_nhwc(..., stats_shift=)``: the LDS-resident convolutions take the BatchNorm's batch statistics off their
+    accumulators - per slab of 4 patches, around a shift near the mean - and ``bn_train_forward_partials`` combines them:
+    the same convolution output bit for bit, sums that match float64 sums of it, and a BatchNorm (+ residual + ReLU) that
+    agrees with the one that makes a reduction pass of its own (ragged patch counts: the last slab is partly empty)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(P + ci + 7 * k)
+    x = (torch.randn((P, ci, H, H), generator=g) + 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((co, ci, k, k), generator=g) * (2.0 / (ci * k * k)) ** 0.5).to(dev)
+    pad = k // 2
+    shift = (torch.randn(co, generator=g) * 0.3).to(dev)
+    plain = hip.conv2d_nhwc(x, w, s, pad)
+    y, partial, slabs = hip.conv2d_nhwc(x, w, s, pad, stats_shift=shift)
+    assert torch.equal(y, plain) and slabs == (P + 3) // 4 and partial.shape == (slabs, 2, co)
+    d = y.double() - shift.double().view(1, -1, 1, 1)
+    assert _rel(partial[:, 0].double().sum(0), d.sum((0, 2, 3))) < 1e-5
+    assert _rel(partial[:, 1].double().sum(0), (d * d).sum((0, 2, 3))) < 1e-6
+    gamma, beta = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
+    res = torch.randn(y.shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    rm0, rv0 = shift.clone(), (torch.rand(co, generator=g) + 0.5).to(dev)
+    rm1, rv1, rm2, rv2 = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    want, mean_w, inv_w = hip.bn_train_forward(y, res, gamma, beta, 1e-5, 0.1, rm1, rv1, True)
+    # (the shift IS the running mean buffer, as the training path passes it: read before it is updated)
+    y2, partial2, _ = hip.conv2d_nhwc(x, w, s, pad, stats_shift=rm2)
+    got, mean_g, inv_g = hip.bn_train_forward_partials(y2, res, gamma, beta, 1e-5, 0.1, rm2, rv2, True, partial2, slabs, rm2)
+    assert _rel(mean_g, mean_w) < 1e-6 and _rel(inv_g, inv_w) < 2e-6
+    assert _rel(got, want) < 5e-6
+    assert _rel(rm2, rm1) < 1e-6 and _rel(rv2, rv1) < 2e-6
+    ref_mean = y.double().mean((0, 2, 3))
+    ref_var = y.double().var((0, 2, 3), unbiased=False)
+    assert _rel(mean_g.double(), ref_mean) < 1e-6 and _rel(inv_g.double(), 1 / torch.sqrt(ref_var + 1e-5)) < 2e-6
+    # deterministic
+    y3, partial3, _ = hip.conv2d_nhwc(x, w, s, pad, stats_shift=shift)
+    assert torch.equal(partial3, partial)
+
+
 def test_bn_train_rejects_unsupported_channel_counts():
     assert not hip.bn_train_supported(16, 48)
     assert not hip.bn_train_supported(16, 6)
@@ -220,6 +280,30 @@ def test_fused_encoder_matches_float64_autograd(conf_fn, patch):
             else:
                 assert _rel(ba.double(), bb) < 1e-5, na
     assert clean >= 1
+
+
+def test_conv_bn_node_equals_the_two_nodes(monkeypatch):
+    """``fused_encoder.encode`` with the statistics off the convolutions' epilogues (one conv+bn node per BasicBlock half)
+    against the same encoder with ``IPSX_TRAIN_CONV_STATS=0`` (convolution and BatchNorm as two nodes, the BatchNorm making
+    its own reduction pass): embeddings, every gradient and the running statistics agree to fp32 rounding."""
+    dev = torch.device("cuda:0")
+    conf = synth.mnist_conf(N=64, M=8, I=8)
+    base = synth.fill_weights(IPSNet(dev, conf), 3).to(dev).train()
+    x = synth.make_patches(conf, 2, seed=5).to(dev)[:, :40].reshape(80, 1, 32, 32)
+    outs = []
+    for stats in ("1", "0"):
+        monkeypatch.setenv("IPSX_TRAIN_CONV_STATS", stats)
+        enc = copy.deepcopy(base.encoder)
+        y = fused_encoder.encode(enc, x)
+        (y * torch.linspace(-1, 1, y.shape[1], device=dev)).sum().backward()
+        outs.append((y.detach(), [p.grad.clone() for p in enc.parameters()],
+                     [b.clone() for n, b in enc.named_buffers() if "running" in n]))
+    (y1, g1, b1), (y0, g0, b0) = outs
+    assert _rel(y1, y0) < 2e-5
+    for a, b in zip(g1, g0):
+        assert _rel(a, b) < 2e-4
+    for a, b in zip(b1, b0):
+        assert _rel(a, b) < 1e-5
 
 
 def test_training_forward_uses_the_fused_path_and_env_switches_it_off(monkeypatch):
