@@ -62,7 +62,7 @@ extern "C" {
  *         last rows themselves (one more control word each: ipsx_*_stream_ctl_words), ipsx_ips_finish, ipsx_ips_call_run /
  *         ipsx_ips_call_elapsed added
  *   3.01  round 5 (additions only): ipsx_pack_conv_weights_batch, ipsx_conv2d_lds_nhwc_stats (+ _slabs),
- *         ipsx_bn_train_forward_partials */
+ *         ipsx_bn_train_forward_partials, ipsx_stem7x7s2_nhwc (+ _supported) */
 #define IPSX_VERSION 301
 
 #define IPSX_OK            0
@@ -182,6 +182,12 @@ int ipsx_conv2d_lds_nhwc(const ipsx_conv* cv, const float* x, float* y, int64_t 
  * sum (y - shift[c])^2 over the slab's output rows, slab = 4 patches, ipsx_conv2d_lds_nhwc_stats_slabs(n) of them; shift: a
  * per-channel constant near the mean (the BatchNorm's running mean; NULL = 0).  ipsx_bn_train_forward_partials combines them
  * (fp64, slab order: deterministic) and applies the BatchNorm - the reduction pass over y is gone.  partial NULL: plain. */
+/* The 1 -> 64 channel 7x7 / 2 stem on 32 x 32 patches as a stand-alone layer, channels-last output (n, 16, 16, 64): the
+ * training step's first convolution (ips_net.py:29-31 under net.train()) on the matrix cores - the fused trunk's stem
+ * without its BatchNorm / ReLU / max-pool epilogue; same bits as ipsx_conv2d_affine_to_nhwc without affine. */
+int ipsx_stem7x7s2_nhwc_supported(int c_in, int c_out, int kh, int kw, int stride, int pad, int h, int w);
+int ipsx_stem7x7s2_nhwc(const ipsx_conv* conv, const float* x, float* y, int64_t n, const float* shift, float* partial,
+                        void* stream);          /* shift / partial: as ipsx_conv2d_lds_nhwc_stats (slabs of 4 patches); NULL: none */
 int64_t ipsx_conv2d_lds_nhwc_stats_slabs(int64_t n);
 int ipsx_conv2d_lds_nhwc_stats(const ipsx_conv* conv, const float* x, float* y, int64_t n, int h, int w, const float* shift,
                                float* partial, void* stream);

@@ -194,6 +194,8 @@ _EXPORTS = {
     "ipsx_bn_train_forward_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ipsx_stem7x7s2_nhwc_supported": (C.c_int, [C.c_int] * 8),
+    "ipsx_stem7x7s2_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_wgrad_nhwc_supported": (C.c_int, [C.c_int] * 6),
     "ipsx_conv2d_wgrad_nhwc_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int] * 4),
     "ipsx_conv2d_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -1320,7 +1322,12 @@ def conv_lds_supported(conv, h, w):
     """True when ``conv2d_nhwc`` would run this ``nn.Conv2d`` on the LDS-resident stage kernels (maps of 32-px patches) -
     the ones that can hand the BatchNorm behind them its batch statistics (``conv2d_nhwc(..., stats_shift=...)``)."""
     kh, kw = conv.kernel_size
-    return bool(kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0" and os.environ.get("IPSX_TRAIN_CONV_STATS", "1") != "0"
+    if os.environ.get("IPSX_TRAIN_CONV_STATS", "1") == "0":
+        return False
+    if conv.in_channels == 1:                    # the 32-px trunk's stem on the matrix cores (csrc/stem_train.hip)
+        return bool(os.environ.get("IPSX_TRAIN_STEM_MFMA", "1") != "0" and lib().ipsx_stem7x7s2_nhwc_supported(
+            1, conv.out_channels, kh, kw, conv.stride[0], conv.padding[0], h, w))
+    return bool(kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0"
                 and lib().ipsx_conv2d_lds_nhwc_supported(conv.in_channels, conv.out_channels, kh, conv.stride[0], conv.padding[0], h, w))
 
 
@@ -1343,12 +1350,18 @@ def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False, packed=None, stats_
     if stats_shift is not None:
         slabs = int(lib().ipsx_conv2d_lds_nhwc_stats_slabs(n))
         partial = torch.empty((max(slabs, 1), 2, co), dtype=torch.float32, device=x.device)
-        _ck(lib().ipsx_conv2d_lds_nhwc_stats(C.byref(cv), _p(x), _p(y), n, h, w, _p(stats_shift), _p(partial), _stream()),
-            "ipsx_conv2d_lds_nhwc_stats")
+        if ci == 1:
+            _ck(lib().ipsx_stem7x7s2_nhwc(C.byref(cv), _p(x), _p(y), n, _p(stats_shift), _p(partial), _stream()), "ipsx_stem7x7s2_nhwc")
+        else:
+            _ck(lib().ipsx_conv2d_lds_nhwc_stats(C.byref(cv), _p(x), _p(y), n, h, w, _p(stats_shift), _p(partial), _stream()),
+                "ipsx_conv2d_lds_nhwc_stats")
         return y, partial, slabs
     if kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0" and lib().ipsx_conv2d_lds_nhwc_supported(ci, co, kh, stride, pad, h, w):
         # the maps of 32-px patches: the fused trunk's stage kernels, map LDS-resident for all taps
         _ck(lib().ipsx_conv2d_lds_nhwc(C.byref(cv), _p(x), _p(y), n, h, w, _stream()), "ipsx_conv2d_lds_nhwc")
+    elif ci == 1 and os.environ.get("IPSX_TRAIN_STEM_MFMA", "1") != "0" and lib().ipsx_stem7x7s2_nhwc_supported(ci, co, kh, kw, stride, pad, h, w):
+        # the 32-px trunk's stem on the matrix cores (csrc/stem_train.hip)
+        _ck(lib().ipsx_stem7x7s2_nhwc(C.byref(cv), _p(x), _p(y), n, None, None, _stream()), "ipsx_stem7x7s2_nhwc")
     elif ci == 1:       # one input channel (NCHW = channels-last memory): the stem kernel, channels-last output
         _ck(lib().ipsx_conv2d_affine_to_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_to_nhwc")
     else:

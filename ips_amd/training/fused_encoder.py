@@ -207,8 +207,7 @@ def encode(encoder, x, taps=None):
     else:
         x = x.contiguous(memory_format=_CL)
     packs = pack_all(encoder, x)
-    h = _conv(conv1, x, packs)
-    h = bn_act(h, bn1, None, True)
+    h = conv_bn_act(conv1, bn1, x, packs, None, True)
     h = pool(h)
     if taps is not None:
         taps.append(h)

@@ -55,6 +55,33 @@ def test_conv_train_kernels_match_torch(P, ci, co, k, s, H):
     assert torch.equal(again.contiguous(), wh.grad.contiguous())
 
 
+@pytest.mark.parametrize("P", [1, 5, 1024, 1027])
+def test_training_stem_on_the_matrix_cores_equals_the_direct_convolution(P, monkeypatch):
+    """The 1-channel 7x7 / 2 stem of the 32-px trunk (csrc/stem_train.hip: the fused trunk's stem without its epilogue)
+    against the generic direct convolution it replaces in the training step (``IPSX_TRAIN_STEM_MFMA=0``): the same fma chains in
+    the same order - bit for bit - and float64 torch to rounding."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(P)
+    x = torch.randn((P, 1, 32, 32), generator=g).to(dev)
+    x = x.as_strided(x.shape, (1024, 1, 32, 1))                      # (channels-last strides of a 1-channel tensor)
+    w = (torch.randn((64, 1, 7, 7), generator=g) * 0.2).to(dev)
+    got = hip.conv2d_nhwc(x, w, 2, 3)
+    monkeypatch.setenv("IPSX_TRAIN_STEM_MFMA", "0")
+    want = hip.conv2d_nhwc(x, w, 2, 3)
+    assert got.shape == (P, 64, 16, 16) and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+    ref = F.conv2d(x.double().contiguous(), w.double(), None, 2, 3)
+    assert _rel(got.double(), ref) < 1e-6
+    monkeypatch.delenv("IPSX_TRAIN_STEM_MFMA")
+    # ... and with the BatchNorm statistics off its accumulators (slabs of 4 patches, around a shift)
+    shift = (torch.randn(64, generator=g) * 0.3).to(dev)
+    y, partial, slabs = hip.conv2d_nhwc(x, w, 2, 3, stats_shift=shift)
+    assert torch.equal(y, got) and slabs == (P + 3) // 4 and partial.shape == (slabs, 2, 64)
+    d = y.double() - shift.double().view(1, -1, 1, 1)
+    assert _rel(partial[:, 0].double().sum(0), d.sum((0, 2, 3))) < 1e-5
+    assert _rel(partial[:, 1].double().sum(0), (d * d).sum((0, 2, 3))) < 1e-6
+
+
 def test_batched_weight_packing_equals_the_single_launches():
     """``hip.pack_conv_views`` (ONE launch per 32 weights: what ``fused_encoder.pack_all`` hands the step's convolutions)
     against ``_pack_conv_view`` per weight and direction - the same bits, for contiguous and channels-last weights, the
