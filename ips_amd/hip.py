@@ -1319,8 +1319,9 @@ def pack_conv_views(views):
 
 
 def conv_lds_supported(conv, h, w):
-    """True when ``conv2d_nhwc`` would run this ``nn.Conv2d`` on the LDS-resident stage kernels (maps of 32-px patches) -
-    the ones that can hand the BatchNorm behind them its batch statistics (``conv2d_nhwc(..., stats_shift=...)``)."""
+    """True when ``conv2d_nhwc`` would run this ``nn.Conv2d`` on a kernel that can hand the BatchNorm behind it its batch
+    statistics (``conv2d_nhwc(..., stats_shift=...)``): the LDS-resident stage kernels (maps of 32-px patches) and the
+    1-channel stem on the matrix cores."""
     kh, kw = conv.kernel_size
     if os.environ.get("IPSX_TRAIN_CONV_STATS", "1") == "0":
         return False
