@@ -62,7 +62,7 @@ extern "C" {
  *         last rows themselves (one more control word each: ipsx_*_stream_ctl_words), ipsx_ips_finish, ipsx_ips_call_run /
  *         ipsx_ips_call_elapsed added
  *   3.01  round 5 (additions only): ipsx_pack_conv_weights_batch, ipsx_conv2d_lds_nhwc_stats (+ _slabs),
- *         ipsx_bn_train_forward_partials, ipsx_stem7x7s2_nhwc (+ _supported) */
+ *         ipsx_bn_train_forward_partials, ipsx_stem7x7s2_nhwc (+ _supported), ipsx_conv2d_dgrad_s2_lds_nhwc (+ _supported) */
 #define IPSX_VERSION 301
 
 #define IPSX_OK            0
@@ -188,6 +188,14 @@ int ipsx_conv2d_lds_nhwc(const ipsx_conv* cv, const float* x, float* y, int64_t 
 int ipsx_stem7x7s2_nhwc_supported(int c_in, int c_out, int kh, int kw, int stride, int pad, int h, int w);
 int ipsx_stem7x7s2_nhwc(const ipsx_conv* conv, const float* x, float* y, int64_t n, const float* shift, float* partial,
                         void* stream);          /* shift / partial: as ipsx_conv2d_lds_nhwc_stats (slabs of 4 patches); NULL: none */
+/* The data gradient of the 32-px trunk's strided convolution (64 -> 128 channels, 3x3 / 2, 8x8 -> 4x4 maps; the arguments of
+ * _supported describe that FORWARD convolution): dy (n, 4, 4, 128) -> dx (n, 8, 8, 64), channels-last, taken by parity class
+ * of the input pixel - nine taps instead of the thirty-six of a stride-1 convolution over dy spread on a zero map.
+ * w_packed_dgrad: ipsx_pack_conv_weight_strided of the weights rotated by 180 degrees and transposed (128 -> 64, 3x3). */
+int ipsx_conv2d_dgrad_s2_lds_nhwc_supported(int c_in, int c_out, int k, int stride, int pad, int h, int w);
+int ipsx_conv2d_dgrad_s2_lds_nhwc(const float* w_packed_dgrad, int k, const float* dy, float* dx, int64_t n, void* stream);
+                                  /* k = 3 (pad 1), or k = 1: the 1x1 / 2 projection beside it (pad 0; three of four input pixels
+                                   * receive zeros) */
 int64_t ipsx_conv2d_lds_nhwc_stats_slabs(int64_t n);
 int ipsx_conv2d_lds_nhwc_stats(const ipsx_conv* conv, const float* x, float* y, int64_t n, int h, int w, const float* shift,
                                float* partial, void* stream);

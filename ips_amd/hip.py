@@ -194,6 +194,8 @@ _EXPORTS = {
     "ipsx_bn_train_forward_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ipsx_conv2d_dgrad_s2_lds_nhwc_supported": (C.c_int, [C.c_int] * 7),
+    "ipsx_conv2d_dgrad_s2_lds_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ipsx_stem7x7s2_nhwc_supported": (C.c_int, [C.c_int] * 8),
     "ipsx_stem7x7s2_nhwc": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ipsx_conv2d_wgrad_nhwc_supported": (C.c_int, [C.c_int] * 6),
@@ -1374,6 +1376,15 @@ def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw, packed=None):
     """Data gradient of ``conv2d_nhwc``: the same kernel on dy with the weights rotated by 180 degrees and transposed; a
     strided layer first spreads dy over a zero map of the input's size (needs kernel - 1 = 2 pad)."""
     co, ci, kh, kw = weight.shape
+    if (stride > 1 and kh == kw and os.environ.get("IPSX_TRAIN_DGRAD_S2", "1") != "0"
+            and lib().ipsx_conv2d_dgrad_s2_lds_nhwc_supported(ci, co, kh, stride, pad, in_hw[0], in_hw[1])):
+        # the 32-px trunk's strided layer by parity class of the input pixel: no spread map (csrc/dgrad_s2.hip)
+        if packed is None:
+            packed = _pack_conv_view(weight.detach(), True)[0]
+        n = dy.shape[0]
+        dx = torch.empty((n, ci, in_hw[0], in_hw[1]), dtype=torch.float32, device=dy.device, memory_format=_CL)
+        _ck(lib().ipsx_conv2d_dgrad_s2_lds_nhwc(_p(packed), kh, _p(dy), _p(dx), n, _stream()), "ipsx_conv2d_dgrad_s2_lds_nhwc")
+        return dx
     if stride > 1:
         n = dy.shape[0]
         spread = torch.empty((n, co, in_hw[0], in_hw[1]), dtype=torch.float32, device=dy.device, memory_format=_CL).zero_()

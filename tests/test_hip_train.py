@@ -82,6 +82,46 @@ def test_training_stem_on_the_matrix_cores_equals_the_direct_convolution(P, monk
     assert _rel(partial[:, 1].double().sum(0), (d * d).sum((0, 2, 3))) < 1e-6
 
 
+@pytest.mark.parametrize("P", [1, 7, 1026])
+def test_strided_projection_data_gradient(P, monkeypatch):
+    """The 1x1 / 2 projection's data gradient on the same kernel (one tap; three of four input pixels get zeros)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(P)
+    w = (torch.randn((128, 64, 1, 1), generator=g) * 0.1).to(dev)
+    dy = torch.randn((P, 128, 4, 4), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    got = hip.conv2d_nhwc_dgrad(dy, w, 2, 0, (8, 8))
+    x = torch.zeros((P, 64, 8, 8), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(x, w.double(), None, 2, 0).backward(dy.double())
+    assert _rel(got.double(), x.grad) < 2e-6
+    assert float(got[:, :, 1::2].abs().max()) == 0.0 and float(got[:, :, :, 1::2].abs().max()) == 0.0
+    monkeypatch.setenv("IPSX_TRAIN_DGRAD_S2", "0")
+    assert _rel(got, hip.conv2d_nhwc_dgrad(dy, w, 2, 0, (8, 8))) < 5e-6
+
+
+@pytest.mark.parametrize("P", [1, 6, 1024, 1027])
+def test_strided_data_gradient_by_parity_class(P, monkeypatch):
+    """The data gradient of the 32-px trunk's 64 -> 128 channel 3x3 / 2 layer (csrc/dgrad_s2.hip: input pixels by parity
+    class, nine taps instead of thirty-six) against float64 autograd, and against the stride-1 convolution over dy spread on a
+    zero map that it replaces (``IPSX_TRAIN_DGRAD_S2=0``) to fp32 rounding (another summation order)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(P)
+    w = (torch.randn((128, 64, 3, 3), generator=g) * 0.05).to(dev)
+    dy = torch.randn((P, 128, 4, 4), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    got = hip.conv2d_nhwc_dgrad(dy, w, 2, 1, (8, 8))
+    assert got.shape == (P, 64, 8, 8) and got.is_contiguous(memory_format=torch.channels_last)
+    x = torch.zeros((P, 64, 8, 8), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(x, w.double(), None, 2, 1).backward(dy.double())
+    assert _rel(got.double(), x.grad) < 2e-6
+    monkeypatch.setenv("IPSX_TRAIN_DGRAD_S2", "0")
+    spread = hip.conv2d_nhwc_dgrad(dy, w, 2, 1, (8, 8))
+    assert _rel(got, spread) < 5e-6
+    # with the weights packed ahead (what the training step hands over), and a channels-last weight tensor
+    monkeypatch.delenv("IPSX_TRAIN_DGRAD_S2")
+    wcl = w.contiguous(memory_format=torch.channels_last)
+    packed = hip.pack_conv_views([(wcl, True)])[0]
+    assert torch.equal(hip.conv2d_nhwc_dgrad(dy, wcl, 2, 1, (8, 8), packed=packed), got)
+
+
 def test_batched_weight_packing_equals_the_single_launches():
     """``hip.pack_conv_views`` (ONE launch per 32 weights: what ``fused_encoder.pack_all`` hands the step's convolutions)
     against ``_pack_conv_view`` per weight and direction - the same bits, for contiguous and channels-last weights, the
