@@ -1382,6 +1382,9 @@ def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw, packed=None):
         if packed is None:
             packed = _pack_conv_view(weight.detach(), True)[0]
         n = dy.shape[0]
+        if dy.dtype != torch.float32 or tuple(dy.shape[1:]) != (co, in_hw[0] // 2, in_hw[1] // 2):
+            raise ValueError("dy: expected float32 (P, %d, %d, %d)" % (co, in_hw[0] // 2, in_hw[1] // 2))
+        dy = dy.contiguous(memory_format=_CL)
         dx = torch.empty((n, ci, in_hw[0], in_hw[1]), dtype=torch.float32, device=dy.device, memory_format=_CL)
         _ck(lib().ipsx_conv2d_dgrad_s2_lds_nhwc(_p(packed), kh, _p(dy), _p(dx), n, _stream()), "ipsx_conv2d_dgrad_s2_lds_nhwc")
         return dx
