@@ -62,7 +62,8 @@ extern "C" {
  *         last rows themselves (one more control word each: ipsx_*_stream_ctl_words), ipsx_ips_finish, ipsx_ips_call_run /
  *         ipsx_ips_call_elapsed added
  *   3.01  round 5 (additions only): ipsx_pack_conv_weights_batch, ipsx_conv2d_lds_nhwc_stats (+ _slabs),
- *         ipsx_bn_train_forward_partials, ipsx_stem7x7s2_nhwc (+ _supported), ipsx_conv2d_dgrad_s2_lds_nhwc (+ _supported) */
+ *         ipsx_bn_train_forward_partials, ipsx_stem7x7s2_nhwc (+ _supported), ipsx_conv2d_dgrad_s2_lds_nhwc (+ _supported),
+ *         ipsx_maxpool_3x3s2_bwd_nhwc (+ _supported) */
 #define IPSX_VERSION 301
 
 #define IPSX_OK            0
@@ -212,6 +213,11 @@ size_t ipsx_conv2d_wgrad_nhwc_workspace_bytes(int64_t n, int c_in, int c_out, in
 int ipsx_conv2d_wgrad_nhwc(const float* x, const float* dy, int64_t n, int h, int w, int c_in, int c_out, int kh, int kw,
                            int stride, int pad, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 int ipsx_maxpool_3x3s2_nhwc(const float* x, float* y, int64_t n, int c, int h, int w, void* stream);
+/* Its backward pass for the training step (16 x 16 maps, C % 32 == 0): dx (n, 16, 16, C) from x and dy (n, 8, 8, C), the
+ * gradient of a window to its first maximum in row-major order - ATen's max_pool2d_with_indices_backward bit for bit, without
+ * an index tensor. */
+int ipsx_maxpool_3x3s2_bwd_nhwc_supported(int c, int h, int w);
+int ipsx_maxpool_3x3s2_bwd_nhwc(const float* x, const float* dy, float* dx, int64_t n, int c, int h, int w, void* stream);
 /* (n,hw,c) -> (n,c) */
 int ipsx_avgpool_nhwc(const float* x, float* y, int64_t n, int c, int hw, void* stream);
 /* nn.MaxPool2d(3, 2, 1) */

@@ -202,6 +202,8 @@ _EXPORTS = {
     "ipsx_conv2d_wgrad_nhwc_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int] * 4),
     "ipsx_conv2d_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_maxpool_3x3s2_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ipsx_maxpool_3x3s2_bwd_nhwc_supported": (C.c_int, [C.c_int] * 3),
+    "ipsx_maxpool_3x3s2_bwd_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_avgpool_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_maxpool_3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_avgpool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
@@ -1453,6 +1455,32 @@ def bn_train_forward(x, residual, gamma, beta, eps, momentum, running_mean, runn
                                     _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
                                     _p(ws), _stream()), "ipsx_bn_train_forward")
     return y, mean, invstd
+
+
+def maxpool_train_supported(x):
+    """Can ``maxpool_3x3s2_nhwc`` / ``maxpool_3x3s2_bwd_nhwc`` take this activation (the training step's pooling behind the
+    stem: float32 on the GPU, 16 x 16 maps, a multiple of 32 channels)?"""
+    return bool(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and os.environ.get("IPSX_TRAIN_POOL", "1") != "0"
+                and lib().ipsx_maxpool_3x3s2_bwd_nhwc_supported(x.shape[1], x.shape[2], x.shape[3]))
+
+
+def maxpool_3x3s2_nhwc(x):
+    """nn.MaxPool2d(3, 2, 1) of a channels-last (P, C, h, w) activation -> channels-last (P, C, ho, wo)."""
+    x = x.contiguous(memory_format=_CL)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device, memory_format=_CL)
+    _ck(lib().ipsx_maxpool_3x3s2_nhwc(_p(x), _p(y), n, c, h, w, _stream()), "ipsx_maxpool_3x3s2_nhwc")
+    return y
+
+
+def maxpool_3x3s2_bwd_nhwc(x, dy):
+    """The gradient of ``maxpool_3x3s2_nhwc`` w.r.t. x (ATen's rule: a window's gradient goes to its first maximum)."""
+    x = x.contiguous(memory_format=_CL)
+    dy = dy.contiguous(memory_format=_CL)
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    _ck(lib().ipsx_maxpool_3x3s2_bwd_nhwc(_p(x), _p(dy), _p(dx), n, c, h, w, _stream()), "ipsx_maxpool_3x3s2_bwd_nhwc")
+    return dx
 
 
 def bn_train_forward_partials(x, residual, gamma, beta, eps, momentum, running_mean, running_var, relu, partial, slabs, shift):

@@ -88,6 +88,29 @@ def bn_act(x, bn, residual=None, relu=True):
     return _BnAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
 
 
+class _MaxPool(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) behind the stem on libipsx's kernels: forward without an index tensor, backward by finding every
+    window's first maximum again (ATen's rule, bit for bit; csrc/pool_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous(memory_format=_CL)
+        ctx.save_for_backward(x)
+        return hip.maxpool_3x3s2_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return hip.maxpool_3x3s2_bwd_nhwc(x, dy)
+
+
+def _pool(pool, x):
+    if (isinstance(pool, nn.MaxPool2d) and pool.kernel_size in (3, (3, 3)) and pool.stride in (2, (2, 2)) and pool.padding in (1, (1, 1))
+            and pool.dilation in (1, (1, 1)) and not pool.ceil_mode and hip.maxpool_train_supported(x)):
+        return _MaxPool.apply(x)
+    return pool(x)
+
+
 def conv_enabled():
     return os.environ.get("IPSX_TRAIN_CONV", "1") != "0"
 
@@ -208,7 +231,7 @@ def encode(encoder, x, taps=None):
         x = x.contiguous(memory_format=_CL)
     packs = pack_all(encoder, x)
     h = conv_bn_act(conv1, bn1, x, packs, None, True)
-    h = pool(h)
+    h = _pool(pool, h)
     if taps is not None:
         taps.append(h)
     for stage in mods[4:-1]:

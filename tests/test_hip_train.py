@@ -122,6 +122,25 @@ def test_strided_data_gradient_by_parity_class(P, monkeypatch):
     assert torch.equal(hip.conv2d_nhwc_dgrad(dy, wcl, 2, 1, (8, 8), packed=packed), got)
 
 
+@pytest.mark.parametrize("P,C", [(1, 64), (5, 32), (1024, 64), (3, 128)])
+def test_maxpool_backward_is_atens_bit_for_bit(P, C):
+    """``maxpool_3x3s2_nhwc`` / ``maxpool_3x3s2_bwd_nhwc`` (the training step's pooling behind the stem) against ATen on
+    post-ReLU-like inputs - most windows hold several equal zeros, so WHICH maximum receives the gradient matters: ATen gives
+    it to the first one in row-major order, and so must this - values and gradients bit for bit."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(P + C)
+    x = torch.relu(torch.randn((P, C, 16, 16), generator=g) - 0.4).to(dev).contiguous(memory_format=torch.channels_last)
+    x[0, :, :3, :3] = 0.0                                            # (an all-equal window at the padded corner)
+    dy = torch.randn((P, C, 8, 8), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    xs = x.clone().requires_grad_()
+    want = F.max_pool2d(xs, 3, 2, 1)
+    want.backward(dy)
+    got = hip.maxpool_3x3s2_nhwc(x)
+    assert torch.equal(got, want.detach())
+    dx = hip.maxpool_3x3s2_bwd_nhwc(x, dy)
+    assert dx.is_contiguous(memory_format=torch.channels_last) and torch.equal(dx, xs.grad)
+
+
 def test_batched_weight_packing_equals_the_single_launches():
     """``hip.pack_conv_views`` (ONE launch per 32 weights: what ``fused_encoder.pack_all`` hands the step's convolutions)
     against ``_pack_conv_view`` per weight and direction - the same bits, for contiguous and channels-last weights, the
