@@ -104,7 +104,7 @@ def parse():
                          "(headline image 0 alone), native50, traffic, cam, cam_native (the reference's shipped M = I = 5000)")
     ap.add_argument("--also", default="all",
                     help="default run only: which other BASELINE configurations are timed into `also_measured` ('all', 'none', "
-                         "or a comma list of b1,mnist3000,cam,cam_x16,cam_native,traffic,native50; at N > 1 only mnist3000 - "
+                         "or a comma list of b1,mnist3000,cam,cam_x16,cam_native,traffic,native50,rank_shard_model; at N > 1 only mnist3000 - "
                          "configs[2], sharded - and the single-rank time of the headline, `n1_value_same_workload`)")
     ap.add_argument("--also-steps", type=int, default=0,
                     help="timed calls per `also_measured` leg, each way (0 = sized per leg: ~0.3 s of calls, 10 to 40)")
@@ -244,29 +244,109 @@ _ALSO = {
 }
 
 
-def measure_precision(net, x, steps, precision, fixture):
+def measure_precision(net, x, steps, precision, fixture, storage="f32"):
     """The same workload with another trunk arithmetic (opt-in; never the headline `value`), reported next to the
-    exact-fp32 headline together with its own parity object."""
+    exact-fp32 headline together with its own parity object.  ``storage``: the patch tensor's storage type - BASELINE
+    configs[4] names fp16 storage (``bf16_f16``: the tensor is converted BEFORE the timed region, as a loader that stores
+    halves would hand it over; a third of the bytes the trunk reads)."""
     for name in ("encode", "encode_indexed", "stream", "image_stream"):   # drop the event-recording wrappers of the headline run
         net._plan.__dict__.pop(name, None)
     net.ips(x)
     ref_idx = net.last_mem_idx.clone()
+    xs = x if storage == "f32" else x.to({"f16": torch.float16, "bf16": torch.bfloat16}[storage])
     os.environ["IPSX_PRECISION"] = precision
     try:
         for _ in range(3):
-            net.ips(x)
+            net.ips(xs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            net.ips(x)
+            net.ips(xs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        same = bool(torch.equal(net.last_mem_idx, ref_idx))
-        par = parity(fixture, net.last_mem_idx)
+        got = net.last_mem_idx
+        same = bool(torch.equal(got, ref_idx))
+        a, b = got.cpu().numpy(), ref_idx.cpu().numpy()
+        common = float(np.mean([len(set(u) & set(v)) / len(u) for u, v in zip(a.tolist(), b.tolist())]))
+        par = parity(fixture, got)
     finally:
         os.environ["IPSX_PRECISION"] = "fp32"
-    return {"value": x.shape[0] * x.shape[1] * steps / dt, "unit": "patches/s", "ms_per_step": 1e3 * dt / steps,
-            "same_indices_as_f32": same, "parity": par, "what": _ALSO[precision]}
+    rate = x.shape[0] * x.shape[1] * steps / dt
+    peak = {"fp32x3": BF16_MFMA_PEAK_TFLOPS / 6, "bf16": BF16_MFMA_PEAK_TFLOPS}[precision]
+    return {"value": rate, "unit": "patches/s", "ms_per_step": 1e3 * dt / steps, "patch_storage": storage,
+            "same_indices_as_f32": same, "selected_in_common_with_f32": common, "slots_equal_to_f32": float((a == b).mean()),
+            "parity": par,
+            "roofline_call": {"bound": "mfma", "achieved": rate * FLOP_PER_PATCH["mnist"] / 1e12, "peak": peak, "unit": "TFLOP/s",
+                              "frac": rate * FLOP_PER_PATCH["mnist"] / 1e12 / peak,
+                              "what": "whole ips() calls back to back x algorithmic encoder FLOP per patch"},
+            "what": _ALSO[precision] + ("" if storage == "f32" else "; patches stored as %s (BASELINE configs[4])" % storage)}
+
+
+def rank_shard_model(args, ctx, name="mnist", worlds=(2, 4, 8), steps=10):
+    """ONE rank's share of the sharded headline on the ONE GPU of this box - a MODEL of a rank,
+    not a scaling measurement.  For G in ``worlds``: rank 0's pieces of ``ips_amd.dist.shard_plan`` (its encoder launches,
+    its logits, every part's loop iterations on the side stream, the winners' gather), with the two collectives replaced by
+    device copies of the same sizes (``dist.LoopbackGroup``: the other ranks' logits are computed beforehand, outside the
+    timed region).  What it cannot see: link latency, waiting for the slowest rank.  Next to each G the same rows cut by
+    the fixed 50 / 30 / 15 / 5 % shares of rounds 1-5."""
+    from ips_amd import hip, synth
+    from ips_amd import dist as ipsd
+    from ips_amd.architecture import IPSNet
+    dev = ctx.dev
+    conf, B = synth.bench_workload(name)
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    x = synth.make_patches(conf, B, seed=21).to(dev)
+    N = conf.N
+    ca = net.transf.crs_attn
+    R = ca.H * ca.n_token
+
+    def timed_calls(fn):
+        for _ in range(3):
+            fn()
+        lat = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            lat.append(1e3 * (time.perf_counter() - c0))
+        return statistics.median(lat)
+
+    n1_ms = timed_calls(lambda: net.ips(x))
+    want = net.last_mem_idx.clone()
+    emb = net._plan.encode(x.reshape(B * N, *x.shape[2:])).view(B, N, -1)
+    full_logits = torch.empty((B, N, R), dtype=torch.float32, device=dev)
+    hip.logits(emb, net.pos_enc if net.use_pos else None, ca.folded_query(), R, out=full_logits)
+    del emb
+    out = {"what": "MODEL, not a scaling measurement: rank 0's own launches of the sharded %s on ONE GPU (encoder pieces, logits, "
+                   "loop ranges on the side stream, winners' gather), the all-gather / all-reduce replaced by device copies "
+                   "of the same sizes; no link latency, no waiting for the slowest rank" % name,
+           "workload": LABEL[name] + ", B=%d" % B, "n1_ms_same_process": n1_ms, "units": hip.device_geometry(dev).cus, "per_world": {}}
+    for G in worlds:
+        rec = {}
+        for label in ("launch_aware", "fixed_shares"):
+            plan = ipsd.shard_plan(net, B, N, G, tuple(x.shape[2:]))
+            if label == "fixed_shares":
+                fixed = ipsd.ShardPlan(N, conf.M, conf.I, G, B)
+                fixed.model = plan.model
+                plan = fixed
+            local = x[:, plan.indices(0).to(dev)].contiguous()
+            grp = ipsd.LoopbackGroup(G, 0, full_logits, x)
+            timings = []
+            ms = timed_calls(lambda: ipsd.ips_sharded(net, local, N, group=grp, plan=plan, timings=timings))
+            torch.cuda.synchronize()
+            paid, ideal = plan.rounds(0)
+            rec[label] = {"ms_per_call": ms, "its": plan.its, "launch_patches": plan.launches(0),
+                          "rounds_paid": paid, "rounds_ideal_one_launch": ideal, "modelled_plan_ms": plan.cost_us() / 1e3,
+                          "phases": ipsd.phase_ms(timings[-steps:]),
+                          "indices_equal_to_single_gpu": bool(torch.equal(net.last_mem_idx, want))}
+            del local
+        rec["modelled_patches_per_s_if_every_rank_took_this_long"] = B * N / (rec["launch_aware"]["ms_per_call"] * 1e-3)
+        rec["modelled_speedup_over_n1"] = n1_ms / rec["launch_aware"]["ms_per_call"]
+        out["per_world"][str(G)] = rec
+    del net, x, full_logits
+    torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic(workload, kernel_name, enc_patches, n_launch):
@@ -358,7 +438,8 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
         fixture = None
     x_host = x
     if world > 1:
-        mine = ipsd.local_indices(n_total, conf.M, conf.I, rank, world)
+        shard = ipsd.shard_plan(net, x.shape[0], n_total, world, tuple(x.shape[2:]))     # launch-aware cuts (dist.py)
+        mine = shard.indices(rank)
         x = x[:, mine].contiguous()                             # this rank's shard of every image
     n_mine = x.shape[1]
     if args.storage != "f32":
@@ -543,7 +624,7 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
                                       batch, conf.M, conf.I, conf.n_token,
                                       "use_pos" if conf.use_pos else "no pos-enc",
                                       "" if world == 1 else ", %d of the %d patches of every image per GPU" % (n_mine, n_total)),
-                       "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, ipsd.PARTS) if world > 1 else "single GPU",
+                       "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, len(shard.its) - 1) if world > 1 else "single GPU",
                        "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy),
                        "patch_storage": args.storage},
             "timing": "value = patches per call / median over the %d timed calls, each bracketed by barrier + device sync "
@@ -567,6 +648,9 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
             out["config"]["workload"] += " (slide 0 = the fixture's, the other %d drawn on the device: relu(N(0,1)))" % n_extra
         if world > 1:
             out["parity_all_ranks"] = all(r["indices_equal"] for r in recs) if par else None
+            paid, ideal = shard.rounds(0)
+            out["shard_plan"] = {"first_iteration_of_every_part": shard.its, "rank0_launch_patches": shard.launches(0),
+                                 "rounds_paid": paid, "rounds_ideal_one_launch": ideal, "model": shard.model.kind}
             out["per_rank"] = recs
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                   "devices": [r["device"] for r in recs], "one_gpu_per_rank": not share}
@@ -598,6 +682,8 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
                                             % (int(net._plan.n_encoded.item()), enc_patches // n_launch)})
         if headline and world == 1 and name == "mnist" and args.precision == "fp32" and not (args.dedup_blank or args.lazy) and batch == B:
             out["also_measured"] = {p: measure_precision(net, x, steps, p, fixture) for p in ("fp32x3", "bf16")}
+            # BASELINE configs[4] as written: half-precision STORAGE of the patches + the bf16 matrix pipe
+            out["also_measured"]["bf16_f16"] = measure_precision(net, x, steps, "bf16", fixture, storage="f16")
         if world == 1 and cpu_seconds > 0:
             ctx.cpu_job = (conf, x_host, cpu_seconds)           # timed by main(), last and under a guard (see there)
         out["host"] = host_description()
@@ -725,21 +811,28 @@ def main():
     if default_run and args.also != "none":
         import threading
         legs = [l for l in ALSO_LEGS if args.also == "all" or l[0] in args.also.split(",")]
+
+        # the headline is measured: a leg that does not come back must not cost it - the line goes out without the rest,
+        # and the exit code (EXIT_WATCHDOG) tells the caller that a GPU leg hung
+        def bail(leg):
+            out["also_measured_incomplete"] = "leg %r did not finish within %d s; the line was printed without it and the legs behind it" % (leg, args.leg_timeout)
+            print(json.dumps(out), flush=True)
+            faulthandler.dump_traceback(file=sys.stderr)
+            os._exit(EXIT_WATCHDOG)
         for leg, cfg, b in legs:
-            # the headline is measured: a leg that does not come back must not cost it - the line goes out without the rest,
-            # and the exit code (EXIT_WATCHDOG) tells the caller that a GPU leg hung
-            def bail(leg=leg):
-                out["also_measured_incomplete"] = "leg %r did not finish within %d s; the line was printed without it and the legs behind it" % (leg, args.leg_timeout)
-                print(json.dumps(out), flush=True)
-                faulthandler.dump_traceback(file=sys.stderr)
-                os._exit(EXIT_WATCHDOG)
-            guard = threading.Timer(args.leg_timeout, bail)
+            guard = threading.Timer(args.leg_timeout, bail, kwargs={"leg": leg})
             guard.daemon = True
             guard.start()
             rec = measure(args, ctx, cfg, batch=b, steps=None if args.also_steps <= 0 else min(args.steps, args.also_steps),
                           warmup=min(args.warmup, 3), cpu_seconds=0.0, headline=False)
             guard.cancel()
             out.setdefault("also_measured", {})[leg] = slim(rec)
+        if args.also == "all" or "rank_shard_model" in args.also.split(","):
+            guard = threading.Timer(args.leg_timeout, bail, kwargs={"leg": "rank_shard_model"})
+            guard.daemon = True
+            guard.start()
+            out["rank_shard_model"] = rank_shard_model(args, ctx)
+            guard.cancel()
     if rank == 0 and getattr(ctx, "cpu_job", None) is not None:
         # the CPU baseline comes last and under a guard: it is the one leg whose duration this script does not control (a
         # host that throttles 64 threads down to a few cores can turn its thread table into minutes) - the measured GPU

@@ -31,11 +31,13 @@ import torch.distributed as dist
 from . import hip
 
 PARTS = 4
-# Cumulative share of the loop iterations per part.  The encoder works through the parts in order while the scan of
-# the previous part runs beside it; what stays exposed is the scan of the LAST part, so the parts shrink towards the
-# end (the encoder's workgroup rounds add up the same way whatever the cut).
-PART_SHARES = (0.5, 0.8, 0.95, 1.0)
+DEFAULT_UNITS = 256            # compute units of an MI355X in SPX mode: what a plan assumes where no GPU is visible (CPU tests)
 
+# Cumulative share of the loop iterations per part - the cut used where the launch model has nothing to say (encoders whose
+# cost is linear in the rows) and one of the candidates everywhere else.  The encoder works through the parts in order while
+# the scan of the previous part runs beside it; what stays exposed is the scan of the LAST part, so the parts shrink towards
+# the end.
+PART_SHARES = (0.5, 0.8, 0.95, 1.0)
 
 # When the loop, not the encoder, is the long pole (feature inputs: a projector row costs less than its share of a
 # loop iteration) the order flips: a small first part lets the loop start early, and every later part is ready
@@ -58,15 +60,205 @@ def part_iterations(n_iter, parts=PARTS, shares=None):
     return its
 
 
-def partition(N, M, I, world, parts=PARTS):
+class LaunchModel:
+    """What one rank's launches cost, in microseconds: just enough of a model to place the cuts of the patch axis.
+
+    The fused trunk works in ROUNDS of 8 patches per compute unit (two workgroups of four wavefronts = patches per unit,
+    csrc/fused_trunk.hip::fused_launch): a launch of n patches costs ``n // round`` whole rounds plus what its remainder
+    costs - up to a quarter round through the two-wavefronts-per-patch kernel (0.28 of a round), up to a half round at one
+    wavefront per SIMD (0.54), up to three quarters through the pair kernel at three per SIMD (0.80), a whole round beyond
+    (measured, patches -> ms on 256 units: 512 0.15, 1024 0.29, 1536 0.43, 2048 0.54).  A cut of the patch axis that leaves
+    a rank 2,688 patches pays two rounds for 1.3 rounds of work; the same rows cut at 2,048 + ... pay for what they are.
+    ``round == 0``: an encoder whose cost is linear in its rows (layer-by-layer trunks, the projector).
+
+    Side stream, per part: ``t_xchg`` (logits kernel, all-gather, the copy into the call's logits, the loop's launch) and
+    ``t_iter`` per loop iteration - times ``BESIDE`` while the encoder still has launches in flight: a loop workgroup that
+    shares its compute unit with fp32 MFMA wavefronts takes 24 us per iteration instead of 6.7 (tools/scan_beside.py).
+    The numbers are rough on purpose; the plan they lead to is priced on the GPU by
+    ``bench.py``'s ``rank_shard_model`` leg."""
+
+    REST_STEPS = ((0.25, 0.28), (0.5, 0.54), (0.75, 0.80), (1.0, 1.0))
+    BESIDE = 3.5
+
+    def __init__(self, round=0, t_round=0.0, t_row=0.0, t_launch=10.0, t_iter=7.0, t_xchg=60.0, kind="rows"):
+        self.round, self.t_round, self.t_row = int(round), float(t_round), float(t_row)
+        self.t_launch, self.t_iter, self.t_xchg, self.kind = float(t_launch), float(t_iter), float(t_xchg), kind
+
+    def rounds(self, n):
+        """Rounds a launch of n rows costs (fractional: the remainder's kernels); 0 for a linear encoder."""
+        if n <= 0 or not self.round:
+            return 0.0
+        full, rest = divmod(int(n), self.round)
+        if rest:
+            f = rest / self.round
+            full += next(c for lim, c in self.REST_STEPS if f <= lim)
+        return float(full)
+
+    def encode_us(self, n):
+        if n <= 0:
+            return 0.0
+        return self.t_launch + (self.rounds(n) * self.t_round if self.round else n * self.t_row)
+
+    def key(self):
+        return (self.kind, self.round, round(self.t_round, 3), round(self.t_row, 6), self.t_launch, round(self.t_iter, 3), self.t_xchg)
+
+
+def default_units():
+    """Compute units of the GPU this process drives (every rank of a node sees the same kind), DEFAULT_UNITS without one."""
+    if torch.cuda.is_available():
+        return hip.device_geometry(torch.device("cuda", torch.cuda.current_device())).cus
+    return DEFAULT_UNITS
+
+
+def loop_iteration_us(M, I, H, T):
+    """Rough duration of one iteration of the selection loop kernels: ~4 us at the CAMELYON shape and
+    6.7 us at the MNIST shape (both 4,096 logits per iteration), 92 us at 10,000 candidates of 8 logits."""
+    L, R = M + I, H * T
+    if L > 1024:
+        return 92.0 * L * R / 80000.0
+    if (M, I, H, T) == (256, 256, 8, 1):                  # scan_cam_kernel's shape
+        return 4.2
+    return 2.5 + L * R / 1000.0
+
+
+# seconds of fp32 matrix-pipe time per FLOP and compute unit at the rates the kernels reach (157.3 TFLOP/s over 256 units)
+_UNIT_FLOPS = 157.3e12 / 256
+
+
+def _conv_macs(encoder, patch_shape):
+    """Multiply-adds of one patch through an image trunk (a meta-device pass over a copy of the modules)."""
+    import copy
+    macs = [0]
+
+    def hook(m, inp, out):
+        macs[0] += out[0].numel() * m.in_channels // m.groups * m.kernel_size[0] * m.kernel_size[1]
+    try:
+        enc = copy.deepcopy(encoder).to("meta").eval()
+        hs = [m.register_forward_hook(hook) for m in enc.modules() if isinstance(m, torch.nn.Conv2d)]
+        with torch.no_grad():
+            enc(torch.empty((1,) + tuple(patch_shape[-3:]), device="meta"))
+        for h in hs:
+            h.remove()
+    except Exception:                                     # a trunk the meta device cannot run: a mid-sized guess
+        return 100e6
+    return float(macs[0])
+
+
+def launch_model(net, patch_shape, units=None, precision=None):
+    """The ``LaunchModel`` of ``net``'s encoder on patches of ``patch_shape`` (..., C, h, w) or (..., F)."""
+    units = int(units or default_units())
+    ca = net.transf.crs_attn
+    t_iter = loop_iteration_us(net.M, net.I, ca.H, ca.n_token)
+    precision = precision or hip.precision()
+    if net.is_image and tuple(patch_shape[-3:]) == (1, 32, 32) and len(net.encoder) == 7:
+        # the fused trunk: 8 patches per unit and round.  fp32: 37.26 MFLOP per patch at 0.88 of the unit's pipe; the split
+        # trunks on the bf16 pipe: 26 M / 6.8 M patches/s per 256 units (DESIGN.md 6)
+        t_round = {"bf16": 8 * 256 / 26.0, "fp32x3": 8 * 256 / 6.8}.get(precision, 8 * 37257216 / (_UNIT_FLOPS * 0.88) * 1e6)
+        return LaunchModel(round=8 * units, t_round=t_round, t_iter=t_iter, kind="fused32:" + precision)
+    if net.is_image:
+        key = ("macs", tuple(patch_shape[-3:]))
+        cache = net.__dict__.setdefault("_launch_model_cache", {})
+        if key not in cache:
+            cache[key] = _conv_macs(net.encoder, patch_shape)
+        t_row = 2 * cache[key] / (_UNIT_FLOPS * units * 0.8) * 1e6
+        n_conv = sum(1 for m in net.encoder.modules() if isinstance(m, torch.nn.Conv2d))
+        return LaunchModel(t_row=t_row, t_launch=8.0 * n_conv, t_iter=t_iter, kind="layers")
+    F = int(patch_shape[-1])
+    return LaunchModel(t_row=2.0 * F * net.D / (_UNIT_FLOPS * units * 0.75) * 1e6, t_launch=15.0, t_iter=t_iter, kind="rows")
+
+
+def _plan_cost(its, N, M, I, world, B, model):
+    """Microseconds from the first launch to the end of the last loop iteration on one rank: the encoder works through the
+    parts on the main stream, a part's exchange and loop iterations follow it on the side stream."""
+    P = len(its) - 1
+    done, main = [], 0.0
+    for k in range(P):
+        e0 = 0 if k == 0 else min(N, M + its[k] * I)
+        e1 = N if k == P - 1 else min(N, M + its[k + 1] * I)
+        main += model.encode_us(B * -(-(e1 - e0) // world))
+        done.append(main)
+    side = 0.0
+    for k in range(P):
+        side = max(side, done[k]) + model.t_xchg
+        n = its[k + 1] - its[k]
+        slow = model.t_iter * model.BESIDE
+        beside = min(n, int(max(0.0, main - side) // slow))         # iterations that run while the encoder is still busy
+        side += beside * slow + (n - beside) * model.t_iter
+    return side
+
+
+_PLAN_CACHE = {}
+
+
+def plan_iterations(N, M, I, world, B=1, model=None, parts=PARTS):
+    """First loop iteration of every part (``its[0] = 0``, ``its[-1] = n_iter``), chosen for the LAUNCHES it gives a rank.
+
+    Without a model (or with a linear one and nothing to gain): the fixed shares.  With the fused trunk's model the cuts are
+    searched: from the previous cut, the next one is the last chunk boundary up to which the rank's piece of the part -
+    ``B * ceil(rows / world)`` patches - still fits r whole rounds (or r rounds and one of the remainder's steps), for every
+    r; the plan whose simulated time (``_plan_cost``) is smallest wins, fewer parts on a tie.  So a part is a whole number
+    of rounds on every rank wherever the sizes allow it, the last part takes what is left, and a rank with less than a
+    handful of rounds gets two parts or one.  Chunk boundaries are the only cuts: the result does not depend on them."""
+    n_iter = math.ceil((N - M) / I)
+    if model is None:
+        return part_iterations(n_iter, parts)
+    key = (N, M, I, world, B, parts, model.key())
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        return list(hit)
+    cands = {tuple(part_iterations(n_iter, p, sh)) for p in range(1, parts + 1)
+             for sh in (PART_SHARES, PART_SHARES_LOOP_BOUND, None)}
+    if model.round:
+        def piece(it0, it1):
+            e0 = 0 if it0 == 0 else M + it0 * I
+            return B * -(-(min(N, M + it1 * I) - e0) // world)
+
+        def last_fitting(it0, limit):
+            """Largest it1 in (it0, n_iter) whose piece stays within ``limit`` patches, or None."""
+            e0 = 0 if it0 == 0 else M + it0 * I
+            rows = (limit // B) * world                    # B * ceil(rows / world) <= limit  <=>  rows <= (limit // B) * world
+            it1 = min((e0 + rows - M) // I, n_iter - 1)
+            return it1 if it1 > it0 else None
+
+        total_rounds = max(1.0, piece(0, n_iter) / model.round)
+
+        def grow(prefix, left):
+            cands.add(tuple(prefix + [n_iter]))
+            if left <= 1:
+                return
+            it0 = prefix[-1]
+            rest_rounds = piece(it0, n_iter) / model.round
+            if rest_rounds <= 0.25:
+                return
+            limits = set()
+            rs = range(0, int(rest_rounds) + 1)
+            if len(rs) > 10:                               # long axes: a spread of round counts, not every one
+                rs = sorted({int(round(rest_rounds * f)) for f in (0.08, 0.15, 0.25, 0.35, 0.5, 0.65, 0.8, 0.9, 0.95)} |
+                            {1, 2, int(rest_rounds) - 1, int(rest_rounds)})
+            for r in rs:
+                for frac, _ in ((0.0, 0.0),) + (LaunchModel.REST_STEPS[:3] if total_rounds < 6 else ()):
+                    lim = int((r + frac) * model.round)
+                    if lim > 0:
+                        limits.add(lim)
+            nxt = {last_fitting(it0, lim) for lim in limits}
+            for it1 in sorted(x for x in nxt if x is not None):
+                grow(prefix + [it1], left - 1)
+
+        grow([0], parts)
+    best = min(cands, key=lambda c: (round(_plan_cost(c, N, M, I, world, B, model), 3), len(c), c))
+    _PLAN_CACHE[key] = best
+    return list(best)
+
+
+def partition(N, M, I, world, parts=PARTS, B=1, model=None):
     """Cut [0, N) into parts at chunk boundaries and every part into `world` pieces.
 
     Returns ``(its, edges, piece)``: ``its[k]`` = first loop iteration of part k (``its[-1]`` = n_iter),
     ``edges[k]`` = first patch of part k, ``piece[k]`` = padded piece length of part k; rank r owns
     patches ``[edges[k] + r*piece[k], min(edges[k] + (r+1)*piece[k], edges[k+1]))`` of every part k.
+    ``model`` (a ``LaunchModel``) and ``B`` (images per call) make the cuts launch-aware: ``plan_iterations``.
     """
-    n_iter = math.ceil((N - M) / I)
-    its = part_iterations(n_iter, parts)
+    its = plan_iterations(N, M, I, world, B, model, parts)
     P = len(its) - 1
     edges = [0] + [min(N, M + it * I) for it in its[1:]]
     edges[-1] = N
@@ -74,56 +266,139 @@ def partition(N, M, I, world, parts=PARTS):
     return its, edges, piece
 
 
+class ShardPlan:
+    """The partition of one call shape: which patches every rank holds and in which order, which loop iterations follow
+    which part.  Every rank builds the same plan from (net, B, N, world, units); ``ips_sharded`` cross-checks that once per
+    shape.  ``indices(rank)`` is what the caller shards the patch axis with."""
+
+    def __init__(self, N, M, I, world, B=1, model=None, parts=PARTS):
+        self.N, self.M, self.I, self.world, self.B, self.model = N, M, I, world, B, model
+        self.its, self.edges, self.piece = partition(N, M, I, world, parts, B, model)
+
+    def spans(self, rank):
+        """Global [lo, hi) ranges a rank owns, in local order (one per part, possibly empty)."""
+        out = []
+        for k, q in enumerate(self.piece):
+            lo = min(self.edges[k] + rank * q, self.edges[k + 1])
+            out.append((lo, min(lo + q, self.edges[k + 1])))
+        return out
+
+    def indices(self, rank):
+        """1-D int64 tensor of the global patch indices a rank holds, in local order."""
+        spans = self.spans(rank)
+        return torch.cat([torch.arange(lo, hi, dtype=torch.int64) for lo, hi in spans]) if spans else torch.empty(0, dtype=torch.int64)
+
+    def launches(self, rank):
+        """Patches of every encoder launch of a rank (B images' pieces of every part)."""
+        return [self.B * (hi - lo) for lo, hi in self.spans(rank)]
+
+    def rounds(self, rank=0):
+        """(rounds the rank's launches cost under the model, the same rows as ONE ideal launch) - fractional rounds."""
+        n = self.launches(rank)
+        if self.model is None or not self.model.round:
+            return 0.0, 0.0
+        return sum(self.model.rounds(v) for v in n), sum(n) / self.model.round
+
+    def cost_us(self):
+        return _plan_cost(self.its, self.N, self.M, self.I, self.world, self.B, self.model) if self.model is not None else None
+
+    def signature(self):
+        """A number every rank must agree on (cross-checked by ``ips_sharded``)."""
+        import zlib
+        return zlib.crc32(repr((self.N, self.M, self.I, self.world, self.B, self.its, self.edges, self.piece)).encode())
+
+    def owner_maps(self, device):
+        """owner[j] = rank holding global patch j, lpos[j] = its position in that rank's local tensor."""
+        owner = torch.empty(self.N, dtype=torch.int64)
+        lpos = torch.empty(self.N, dtype=torch.int64)
+        for r in range(self.world):
+            base = 0
+            for lo, hi in self.spans(r):
+                owner[lo:hi] = r
+                lpos[lo:hi] = torch.arange(base, base + hi - lo)
+                base += hi - lo
+        return owner.to(device), lpos.to(device)
+
+
+def shard_plan(net, B, N, world, patch_shape=None, units=None, parts=PARTS, precision=None):
+    """The ``ShardPlan`` of a call of ``B`` images of ``N`` patches over ``world`` ranks with ``net``'s encoder.
+    ``patch_shape``: (C, h, w) of a patch / (F,) of a feature row - needed for image encoders (the fused trunk takes
+    1 x 32 x 32 patches only)."""
+    if patch_shape is None:
+        if net.is_image:
+            raise ValueError("shard_plan: patch_shape=(C, h, w) is needed for an image encoder")
+        patch_shape = (net.encoder[1].in_features,)
+    model = launch_model(net, tuple(patch_shape), units, precision)
+    return ShardPlan(N, net.M, net.I, world, B, model, parts)
+
+
 def local_spans(N, M, I, rank, world, parts=PARTS):
-    """Global [lo, hi) ranges this rank owns, in local order (one per part, possibly empty)."""
-    _, edges, piece = partition(N, M, I, world, parts)
-    out = []
-    for k, q in enumerate(piece):
-        lo = min(edges[k] + rank * q, edges[k + 1])
-        out.append((lo, min(lo + q, edges[k + 1])))
-    return out
+    """Fixed-share partition (no launch model): global [lo, hi) ranges a rank owns."""
+    return ShardPlan(N, M, I, world, parts=parts).spans(rank)
 
 
 def local_indices(N, M, I, rank, world, parts=PARTS):
-    """1-D int64 tensor of the global patch indices a rank holds, in local order."""
-    spans = local_spans(N, M, I, rank, world, parts)
-    return torch.cat([torch.arange(lo, hi, dtype=torch.int64) for lo, hi in spans]) if spans else torch.empty(0, dtype=torch.int64)
+    """Fixed-share partition (no launch model): the global patch indices a rank holds, in local order.  Callers of
+    ``ips_sharded`` use ``shard_plan(net, B, N, world, patch_shape).indices(rank)`` - or pass ``plan=`` explicitly."""
+    return ShardPlan(N, M, I, world, parts=parts).indices(rank)
 
 
-def _owner_maps(N, M, I, world, device, parts=PARTS):
-    """owner[j] = rank holding global patch j, lpos[j] = its position in that rank's local tensor."""
-    owner = torch.empty(N, dtype=torch.int64)
-    lpos = torch.empty(N, dtype=torch.int64)
-    for r in range(world):
-        base = 0
-        for lo, hi in local_spans(N, M, I, r, world, parts):
-            owner[lo:hi] = r
-            lpos[lo:hi] = torch.arange(base, base + hi - lo)
-            base += hi - lo
-    return owner.to(device), lpos.to(device)
+class LoopbackGroup:
+    """A stand-in for a process group on ONE GPU (``bench.py``'s ``rank_shard_model`` leg): this process is rank ``rank`` of
+    ``world``; the all-gather of a part's logits is a device copy of the same bytes out of ``full_logits`` (B, N, R) - the
+    other ranks' pieces, computed beforehand - and the winners' all-reduce a device copy out of ``full_patches``.  It prices
+    a rank's OWN launches (encoder pieces, logits, loop ranges, copies of the collectives' sizes); it is a model of a rank,
+    not a measurement of a node: no link latency, no waiting for the slowest rank."""
+
+    def __init__(self, world, rank, full_logits, full_patches):
+        self.world, self.rank, self.full_logits, self.full_patches = world, rank, full_logits, full_patches
+
+
+def _world_rank(group):
+    if isinstance(group, LoopbackGroup):
+        return group.world, group.rank
+    return dist.get_world_size(group), dist.get_rank(group)
 
 
 @torch.no_grad()
-def ips_sharded(net, local_patches, N, group=None, timings=None):
-    """IPS over ``N`` patches of which this rank holds ``local_patches`` = patches[:, local_indices(...)].
+def ips_sharded(net, local_patches, N, group=None, timings=None, plan=None):
+    """IPS over ``N`` patches of which this rank holds ``local_patches`` = patches[:, plan.indices(rank)].
 
-    ``net`` is an ``IPSNet`` whose ``conf.N`` (positional table) is the GLOBAL ``N``.
+    ``net`` is an ``IPSNet`` whose ``conf.N`` (positional table) is the GLOBAL ``N``.  ``plan``: the ``ShardPlan`` the
+    caller sharded with; by default ``shard_plan(net, B, N, world, patch shape)`` - the launch-aware partition, the same
+    on every rank (cross-checked once per shape).
     Shuffling is the caller's business here (shard after shuffling).  Returns
     ``(mem_patch, mem_pos, mem_idx)`` identical on every rank.
 
     ``timings`` (GPU path only): a list that receives one dict of HIP events per call - see ``phase_ms`` - so that a
     run can say where a rank's time went (encoder, exchange, loop, what of the loop stayed exposed).
     """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank = _world_rank(group)
     M, I, D = net.M, net.I, net.D
     if M >= N:
         raise ValueError("sharded IPS needs N > M")
-    its, edges, piece = partition(N, M, I, world)
-    spans = local_spans(N, M, I, rank, world)
-    n_local = sum(hi - lo for lo, hi in spans)
     B = local_patches.shape[0]
+    if plan is None:
+        pkey = (B, N, world, tuple(local_patches.shape[2:]), hip.precision(), default_units())
+        cached = net.__dict__.get("_shard_plan")
+        if cached is None or cached[0] != pkey:
+            cached = net.__dict__["_shard_plan"] = (pkey, shard_plan(net, B, N, world, tuple(local_patches.shape[2:])))
+        plan = cached[1]
+    if (plan.N, plan.M, plan.I, plan.world) != (N, M, I, world):
+        raise ValueError("ips_sharded: the plan is for (N, M, I, world) = %r, the call for %r"
+                         % ((plan.N, plan.M, plan.I, plan.world), (N, M, I, world)))
+    its, edges, piece = plan.its, plan.edges, plan.piece
+    spans = plan.spans(rank)
+    n_local = sum(hi - lo for lo, hi in spans)
     assert local_patches.shape[1] == n_local, "rank %d expects %d patches, got %d" % (rank, n_local, local_patches.shape[1])
+    if not isinstance(group, LoopbackGroup) and world > 1 and net.__dict__.get("_shard_plan_checked") != (plan.signature(), world):
+        # every rank must have cut the axis the same way (the plan depends on the device's unit count): once per shape
+        sig = torch.tensor([plan.signature(), -plan.signature()], dtype=torch.int64,
+                           device=local_patches.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(sig, op=dist.ReduceOp.MAX, group=group)
+        if int(sig[0]) != plan.signature() or int(sig[1]) != -plan.signature():
+            raise RuntimeError("ips_sharded: the ranks disagree on the partition (different GPUs per rank?) - pass the same plan= everywhere")
+        net.__dict__["_shard_plan_checked"] = (plan.signature(), world)
     dev = local_patches.device
     was_training = net.training
     if was_training:
@@ -204,7 +479,7 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
                         ev["enc"].append(done)
                         x0, x1, s1 = mk(), mk(), mk()
                         x0.record(side)
-                    gathered = _all_gather(mine, world, group, out=bufs["gathered"][k])
+                    gathered = _all_gather(mine, world, group, out=bufs["gathered"][k], part=(edges[k], edges[k + 1]))
                     logits[:, edges[k]:edges[k + 1]] = gathered.permute(1, 0, 2, 3).reshape(B, world * q, width)[:, :part_len]
                     if ev is not None:
                         x1.record(side)
@@ -226,9 +501,9 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
             mem_idx = _scan_aten(net, all_emb)
 
         # assemble the winners: every rank contributes the rows it owns, zeros elsewhere
-        key = (N, M, I, world, str(dev))
+        key = (plan.signature(), str(dev))
         if getattr(net, "_owner_key", None) != key:
-            net._owner_maps, net._owner_key = _owner_maps(N, M, I, world, dev), key
+            net._owner_maps, net._owner_key = plan.owner_maps(dev), key
         owner, lpos = net._owner_maps
         owned = owner[mem_idx] == rank
         local_idx = torch.where(owned, lpos[mem_idx], torch.zeros_like(mem_idx)).clamp_(0, max(n_local - 1, 0))
@@ -237,7 +512,12 @@ def ips_sharded(net, local_patches, N, group=None, timings=None):
             mem_patch = mem_patch * owned.view(B, M, *(1,) * (mem_patch.dim() - 2)).to(mem_patch.dtype)
         else:
             mem_patch = torch.zeros((B, M) + tuple(local_patches.shape[2:]), dtype=local_patches.dtype, device=dev)
-        mem_patch = _all_reduce(mem_patch, group)
+        if isinstance(group, LoopbackGroup):
+            # the all-reduce's stand-in: the rows other ranks own arrive by a device copy of the same size
+            others = _take(group.full_patches, mem_idx)
+            mem_patch = torch.where(owned.view(B, M, *(1,) * (mem_patch.dim() - 2)), mem_patch, others)
+        else:
+            mem_patch = _all_reduce(mem_patch, group)
         mem_pos = _take(net.pos_enc, mem_idx) if net.use_pos else None
         if on_gpu and ev is not None:
             ev["end"].record(main)
@@ -268,9 +548,30 @@ def phase_ms(timings):
     return {k: v / len(timings) for k, v in acc.items()}
 
 
-def _all_gather(mine, world, group, out=None):
+def _all_gather(mine, world, group, out=None, part=None):
     """(world, *mine.shape) from every rank's `mine` (into ``out`` when given).  RCCL moves device buffers directly; any
-    other backend (gloo: the CPU tests, and GPU ranks without RCCL between them) goes through host memory."""
+    other backend (gloo: the CPU tests, and GPU ranks without RCCL between them) goes through host memory.  A
+    ``LoopbackGroup`` copies the other ranks' pieces of ``part`` = (first row, end row) out of its precomputed logits."""
+    if isinstance(group, LoopbackGroup):
+        # what the collective delivers - every rank's piece, (world, B, q, R) - arrives by ONE device copy of that size
+        # out of a staging tensor made once per part (the other ranks' logits, computed beforehand); this rank's own
+        # piece goes on top
+        lo, hi = part
+        q = mine.shape[1]
+        key = (lo, hi, q, world)
+        staged = group.__dict__.setdefault("_staged", {}).get(key)
+        if staged is None:
+            staged = torch.zeros((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            for r in range(world):
+                a = min(lo + r * q, hi)
+                b = min(a + q, hi)
+                if b > a:
+                    staged[r, :, :b - a].copy_(group.full_logits[:, a:b])
+            group._staged[key] = staged
+        gathered = out if out is not None else torch.empty_like(staged)
+        gathered.copy_(staged)
+        gathered[group.rank].copy_(mine)
+        return gathered
     if dist.get_backend(group) == "nccl":
         gathered = out if out is not None else torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(gathered, mine, group=group)

@@ -32,7 +32,7 @@ def _worker(rank, world, port, case, out):
         net = g.net("cpu")
         x = g.patches()
         N = x.shape[1]
-        mine = ipsd.local_indices(N, net.M, net.I, rank, world)
+        mine = ipsd.shard_plan(net, x.shape[0], N, world, tuple(x.shape[2:])).indices(rank)
         mem_patch, mem_pos, mem_idx = ipsd.ips_sharded(net, x[:, mine].contiguous(), N)
         ok = np.array_equal(mem_idx.numpy(), g.mem_idx)
         full_patch, full_pos = net.ips(x)
@@ -84,16 +84,76 @@ def test_sharded_ips_equals_single_process(case):
         assert dict(out) == {0: True, 1: True}
 
 
+def _models():
+    fused = ipsd.LaunchModel(round=2048, t_round=551.0, t_iter=6.6, kind="fused32:fp32")
+    fast = ipsd.LaunchModel(round=2048, t_round=79.0, t_iter=6.6, kind="fused32:bf16")
+    rows = ipsd.LaunchModel(t_row=0.018, t_launch=15.0, t_iter=4.2, kind="rows")
+    return (None, fused, fast, rows)
+
+
 def test_partition_covers_every_patch_once_and_respects_chunk_boundaries():
-    for N, M, I in ((301, 16, 24), (2500, 64, 64), (20000, 64, 64), (40, 16, 64), (1000, 32, 48), (65536, 256, 256)):
+    for N, M, I in ((301, 16, 24), (2500, 64, 64), (20000, 64, 64), (40, 16, 64), (1000, 32, 48), (65536, 256, 256), (65, 64, 64)):
         for world in (1, 2, 3, 4, 8):
-            its, edges, piece = ipsd.partition(N, M, I, world)
-            assert its[0] == 0 and edges[0] == 0 and edges[-1] == N
-            for k in range(1, len(edges) - 1):
-                assert (edges[k] - M) % I == 0 and edges[k] == M + its[k] * I      # parts end where a chunk ends
-            got = torch.cat([ipsd.local_indices(N, M, I, r, world) for r in range(world)])
-            assert sorted(got.tolist()) == list(range(N))
-            # every part's pieces are in rank order: the gathered (rank, piece) layout IS the patch order
-            for k in range(len(piece)):
-                los = [ipsd.local_spans(N, M, I, r, world)[k] for r in range(world)]
-                assert los[0][0] == edges[k] and all(a[1] == b[0] or b[0] == b[1] for a, b in zip(los, los[1:]))
+            for B in (1, 3, 16):
+                for model in _models():
+                    plan = ipsd.ShardPlan(N, M, I, world, B, model)
+                    its, edges, piece = plan.its, plan.edges, plan.piece
+                    n_iter = -(-(N - M) // I)
+                    assert its[0] == 0 and its[-1] == n_iter and edges[0] == 0 and edges[-1] == N
+                    assert all(a < b for a, b in zip(its, its[1:])) and len(its) - 1 <= ipsd.PARTS
+                    for k in range(1, len(edges) - 1):
+                        assert (edges[k] - M) % I == 0 and edges[k] == M + its[k] * I      # parts end where a chunk ends
+                    got = torch.cat([plan.indices(r) for r in range(world)])
+                    assert sorted(got.tolist()) == list(range(N))
+                    # every part's pieces are in rank order: the gathered (rank, piece) layout IS the patch order
+                    for k in range(len(piece)):
+                        los = [plan.spans(r)[k] for r in range(world)]
+                        assert los[0][0] == edges[k] and all(a[1] == b[0] or b[0] == b[1] for a, b in zip(los, los[1:]))
+                    owner, lpos = plan.owner_maps("cpu")
+                    for r in range(world):
+                        mine = plan.indices(r)
+                        assert torch.equal(owner[mine], torch.full_like(mine, r)) and torch.equal(lpos[mine], torch.arange(mine.numel()))
+    # the plain functions are the fixed-share partition
+    assert ipsd.local_indices(301, 16, 24, 1, 2).tolist() == ipsd.ShardPlan(301, 16, 24, 2).indices(1).tolist()
+
+
+def test_partition_gives_every_rank_whole_rounds_of_the_fused_trunk():
+    """BASELINE configs[1] at the reference's batch (16 x 2,500 patches of 32 px) on 2 / 4 / 8 ranks of
+    256 units.  The fixed 50 / 30 / 15 / 5 % cut gave rank 0 launches of 2,688 / 1,408 / 768 / 144 patches at 8 ranks: 5
+    rounds of the fused trunk (8 patches per unit) for 2.45 rounds of work.  The launch-aware plan: every launch but the last
+    is a whole number of rounds, the last one's remainder is what the pair kernel / a half round takes, and the rounds paid
+    stay within 1.15 of one ideal launch - also by the coarse count (whole rounds, a remainder up to a quarter / half / three
+    quarters of a round as 0.25 / 0.5 / 0.75)."""
+    import math
+    from ips_amd import synth
+    from ips_amd.architecture import IPSNet
+    for name in ("mnist", "mnist3000"):
+        conf, B = synth.bench_workload(name)
+        net = IPSNet(torch.device("cpu"), conf)
+        for world in (1, 2, 4, 8):
+            plan = ipsd.shard_plan(net, B, conf.N, world, (1, 32, 32), units=256, precision="fp32")
+            assert plan.model.round == 2048
+            n = plan.launches(0)
+            paid, ideal = plan.rounds(0)
+            coarse = sum(v // 2048 + math.ceil((v % 2048) / 512) / 4 for v in n)
+            assert all(v % 2048 == 0 for v in n[:-1]), (name, world, n)
+            assert paid <= 1.15 * ideal and coarse <= 1.15 * ideal, (name, world, n, paid, coarse, ideal)
+            # the fixed shares on the same model, for the record (and so that the plan is never worse than them)
+            old = ipsd.ShardPlan(conf.N, conf.M, conf.I, world, B)
+            old.model = plan.model
+            assert plan.cost_us() <= old.cost_us() + 1e-6
+            if name == "mnist" and world == 8:
+                assert sum(math.ceil(v / 2048) for v in old.launches(0)) == 5 and old.rounds(0)[0] > 1.25 * ideal
+            # every rank's launches, not only rank 0's
+            for r in range(1, world):
+                pr, ir = plan.rounds(r)
+                assert pr <= 1.15 * max(ir, ideal)
+    # a rank with less than a round of work is not cut into four
+    conf, _ = synth.bench_workload("mnist")
+    net = IPSNet(torch.device("cpu"), conf)
+    assert len(ipsd.shard_plan(net, 1, conf.N, 8, (1, 32, 32), units=256, precision="fp32").its) <= 3
+    # the plan is a pure function of its arguments (every rank builds the same one)
+    a = ipsd.shard_plan(net, 16, conf.N, 4, (1, 32, 32), units=256, precision="fp32")
+    b = ipsd.shard_plan(IPSNet(torch.device("cpu"), conf), 16, conf.N, 4, (1, 32, 32), units=256, precision="fp32")
+    assert a.signature() == b.signature()
+    assert a.signature() != ipsd.shard_plan(net, 16, conf.N, 4, (1, 32, 32), units=304, precision="fp32").signature()
