@@ -443,7 +443,14 @@ def ips_sharded(net, local_patches, N, group=None, timings=None, plan=None):
             indexed = net._plan.fused(local_patches.shape)                 # encode a column range without copying it
         if indexed:
             flat = local_patches.reshape(B * n_local, *local_patches.shape[2:])
-            rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1) * n_local
+            ikey = (plan.signature(), rank, str(dev))
+            if getattr(net, "_shard_index_key", None) != ikey:         # int32 patch indices of every part, cached per plan
+                rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1) * n_local
+                net._shard_index, b0 = [], 0
+                for lo_, hi_ in spans:
+                    net._shard_index.append((rows + torch.arange(b0, b0 + hi_ - lo_, device=dev, dtype=torch.int32)).reshape(-1))
+                    b0 += hi_ - lo_
+                net._shard_index_key = ikey
         ev = None
         if timings is not None and on_gpu:
             mk = lambda: torch.cuda.Event(enable_timing=True)
@@ -457,8 +464,7 @@ def ips_sharded(net, local_patches, N, group=None, timings=None, plan=None):
             mine = bufs["mine"][k] if on_gpu else torch.zeros((B, q, width), dtype=torch.float32, device=dev)
             if n_k > 0:
                 if indexed:
-                    cols = torch.arange(base, base + n_k, device=dev, dtype=torch.int32)
-                    emb = net._plan.encode_indexed(flat, (rows + cols).reshape(-1)).view(B, n_k, D)
+                    emb = net._plan.encode_indexed(flat, net._shard_index[k]).view(B, n_k, D)
                 else:
                     part = local_patches[:, base:base + n_k]
                     emb = net._embed(part.reshape(-1, *local_patches.shape[2:])).view(B, n_k, D)

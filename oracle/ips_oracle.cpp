@@ -310,6 +310,11 @@ ORC_API void orc_linear(const float* x, const float* w, const float* bias, int64
 // x[8g + 4h + j] for g ascending (sum: fp32 add from +0; sum of squares: one fma per element) - folded as
 // ((c0 + c1) + (c2 + c3)) per half and half 0 + half 1.  mean = sum / F, var = E[x^2] - mean^2 (one fma, clamped at 0),
 // rstd = 1 / sqrt(var + eps).  F is a multiple of 8.
+// Round 6 (advisor, round 5): E[x^2] - mean^2 loses (mean / std)^2 * 2^-24 of the variance.  A row whose one-pass variance
+// is below 1/65 of its E[x^2] (mean^2 / var > 64: |mean| > 8 std) gets its second moment AGAIN, centred: the same eight
+// chains over d = x - mean, q = fma(d, d, q), the same fold, var = sum / F - nn.LayerNorm's own two-pass form
+// (ips_net.py:56).  Rows of well-conditioned features (every fixture) never take that path: their bits are unchanged.
+#define ORC_RM_RECENTRE 65.0f
 static void projector_moments(const float* x, int f, float eps, float* mean_out, float* rstd_out) {
     float t[2], u[2];
     for (int h = 0; h < 2; ++h) {
@@ -327,6 +332,18 @@ static void projector_moments(const float* x, int f, float eps, float* mean_out,
     const float mean = sum / (float)f, ex2 = sumsq / (float)f;
     float var = __builtin_fmaf(-mean, mean, ex2);
     var = var > 0.0f ? var : 0.0f;
+    if (var * ORC_RM_RECENTRE < ex2) {
+        for (int h = 0; h < 2; ++h) {
+            float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int g = 0; g * 8 < f; ++g)
+                for (int j = 0; j < 4; ++j) {
+                    const float d = x[g * 8 + 4 * h + j] - mean;
+                    q[j] = __builtin_fmaf(d, d, q[j]);
+                }
+            u[h] = (q[0] + q[1]) + (q[2] + q[3]);
+        }
+        var = (u[0] + u[1]) / (float)f;
+    }
     *mean_out = mean;
     *rstd_out = 1.0f / sqrtf(var + eps);
 }

@@ -1,0 +1,172 @@
+"""How much MARGIN is left between this arithmetic and a flipped selection.
+
+Every arithmetic decision of the hot path (summation orders, the folded query, ``e * (1 / den)``, the folded LayerNorm)
+moves scores by rounding-level amounts against the reference's oneDNN / Sleef values; the selection stays the reference's
+as long as those amounts are small against the gap at the top-M boundary.  ``tests/golden/margin.npz``
+(tools/gen_golden_margin.py: the imported reference run once more on every fixture's inputs) holds, per iteration, the
+reference's M-th and (M+1)-th score and the two patches that own them.  Here the same two candidates are scored in the
+same candidate set (the reference's memory of the iteration before + the chunk) by the oracle (CPU) and by the kernels
+(GPU), and
+
+    margin = (s_M - s_{M+1})_reference / max(|s_M - s_M_reference|, |s_{M+1} - s_{M+1}_reference|)
+
+is taken over every iteration whose relative gap is above the fixtures' noise floor (1e-5: below it the reference itself
+is not reproducible - its oneDNN convolutions move by ~1e-6 with the batch size).  The test prints the table
+and asserts margin >= 10 per fixture family: a contract change that spends margin shows up here as a smaller number
+before it shows up as a wrong index.
+"""
+
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ips_amd import synth
+from tests.util import GOLDEN_DIR, ORACLE_FAST_CASES
+
+GAP_FLOOR = 1e-5
+MIN_MARGIN = 10.0
+SMALL = ["mnist_mini", "mnist_ragged", "mnist_onechunk", "mnist_tok1", "mnist_full", "mnist_native50", "traffic_tiny",
+         "traffic_full", "cam_small", "cam_b2"]
+# the scalar CPU oracle replays these in seconds (the image trunks of the bench workloads run on the GPU only)
+CPU_SEEDS = {"mnist32": range(0, 24, 2), "mnist50": range(0, 20, 4), "traffic": range(0, 20, 5), "cam": range(0, 20)}
+CPU_BENCH = ["cam", "cam_native"]
+GPU_BENCH = ["mnist", "mnist3000", "native50", "traffic", "cam", "cam_native"]
+
+
+def record(name):
+    z = np.load(os.path.join(GOLDEN_DIR, "margin.npz"))
+    return z[name + ":edge_score"], z[name + ":edge_idx"].astype(np.int64)
+
+
+def margins(emb, pos, scores_fn, trace_idx, edge_score, edge_idx, M, I):
+    """-> (smallest margin over the judged iterations, largest relative score difference, iterations judged, iterations
+    at or below the floor).  ``emb`` (B, N, D), ``pos`` (1 | B, N, D) or None, ``scores_fn``: (L, D) rows -> (L,) scores."""
+    B, N, _ = emb.shape
+    worst, pert_max, judged, below = math.inf, 0.0, 0, 0
+    for b in range(B):
+        for it in range(trace_idx.shape[1]):
+            es = edge_score[b, it].astype(np.float64)
+            if not np.isfinite(es).all():
+                continue
+            lo = M + it * I
+            mem = np.arange(M) if it == 0 else trace_idx[b, it - 1].astype(np.int64)
+            cand = np.concatenate((mem, np.arange(lo, min(lo + I, N))))
+            x = emb[b][cand]
+            if pos is not None:
+                x = x + pos[min(b, pos.shape[0] - 1)][cand]
+            sc = np.asarray(scores_fn(x), dtype=np.float64)
+            at = [int(np.nonzero(cand == j)[0][0]) for j in edge_idx[b, it]]
+            pert = max(abs(sc[at[0]] - es[0]), abs(sc[at[1]] - es[1]))
+            pert_max = max(pert_max, pert / es[0])
+            gap = es[0] - es[1]
+            if gap / es[0] <= GAP_FLOOR:
+                below += 1
+                continue
+            judged += 1
+            worst = min(worst, gap / pert if pert > 0 else math.inf)
+    return worst, pert_max, judged, below
+
+
+def cases_cpu():
+    out = [("small", c) for c in SMALL if c in ORACLE_FAST_CASES]
+    out += [("seeds_" + f, k) for f in sorted(CPU_SEEDS) for k in CPU_SEEDS[f]]
+    out += [("bench", n) for n in CPU_BENCH]
+    return out
+
+
+def load_case(kind, key):
+    """-> (record name, conf, weight seed, q_gain, patches, trace_idx)"""
+    if kind == "small":
+        z = np.load(os.path.join(GOLDEN_DIR, key + ".npz"))
+        conf = synth.Conf(**json.loads(str(z["conf"])))
+        return key, conf, int(z["weight_seed"]), 8.0, synth.make_patches(conf, int(z["B"]), seed=int(z["patch_seed"])), z["trace_idx"]
+    if kind == "bench":
+        z = np.load(os.path.join(GOLDEN_DIR, "bench_%s.npz" % key))
+        conf, B = synth.bench_workload(key)
+        return "bench_" + key, conf, 7, 8.0, synth.make_patches(conf, B, seed=21), z["trace_idx"]
+    family = kind[len("seeds_"):]
+    z = np.load(os.path.join(GOLDEN_DIR, "seeds_%s.npz" % family))
+    conf, B, wseed, q_gain, x = synth.seed_case(family, key)
+    return "seeds_%s:c%d" % (family, key), conf, wseed, q_gain, x, z["c%d_trace_idx" % key]
+
+
+def summarise(rows, who):
+    fam = {}
+    for name, (worst, pert, judged, below) in rows:
+        f = name.split(":")[0] if name.startswith("seeds_") else name
+        w, p, j, bl = fam.get(f, (math.inf, 0.0, 0, 0))
+        fam[f] = (min(w, worst), max(p, pert), j + judged, bl + below)
+    print("\n%-22s %10s %14s %8s %8s   (%s)" % ("fixture", "margin", "max rel diff", "judged", "<=floor", who))
+    for f, (w, p, j, bl) in sorted(fam.items()):
+        print("%-22s %10.1f %14.2e %8d %8d" % (f, w, p, j, bl))
+    return fam
+
+
+def test_margin_record_covers_the_fixtures():
+    z = np.load(os.path.join(GOLDEN_DIR, "margin.npz"))
+    names = {k.rsplit(":", 1)[0] for k in z.files}
+    assert set(SMALL) <= names and {"bench_" + n for n in synth.BENCH_WORKLOADS} <= names
+    for family, (_, _, n) in ((f, synth.SEED_FAMILIES[f]()) for f in synth.SEED_FAMILIES):
+        assert {"seeds_%s:c%d" % (family, k) for k in range(n)} <= names
+    for name in names:                                    # the record and the fixtures describe the same runs
+        es, ei = z[name + ":edge_score"], z[name + ":edge_idx"]
+        ok = np.isfinite(es).all(-1)
+        assert (es[ok][:, 0] >= es[ok][:, 1]).all() and (ei[ok] >= 0).all()
+    for n in synth.BENCH_WORKLOADS:                       # its gaps are the bench fixtures' gaps
+        es = z["bench_%s:edge_score" % n].astype(np.float32)
+        gap = np.load(os.path.join(GOLDEN_DIR, "bench_%s.npz" % n))["rel_gap"]
+        assert np.allclose((es[..., 0] - es[..., 1]) / es[..., 0], gap, rtol=0, atol=1e-6)
+
+
+def test_oracle_margin_against_the_reference_scores():
+    from ips_amd.architecture import IPSNet
+    from oracle.oracle import Oracle
+    rows = []
+    for kind, key in cases_cpu():
+        name, conf, wseed, q_gain, x, trace = load_case(kind, key)
+        net = synth.fill_weights(IPSNet(torch.device("cpu"), conf), wseed, q_gain=q_gain).eval()
+        orc = Oracle(net)
+        B, N = x.shape[:2]
+        emb = orc.encode(x.numpy().reshape(B * N, *x.shape[2:])).reshape(B, N, -1)
+        pos = net.pos_enc.numpy() if conf.use_pos else None
+        es, ei = record(name)
+        rows.append((name, margins(emb, pos, orc.scores, trace, es, ei, conf.M, conf.I)))
+    fam = summarise(rows, "oracle vs the reference's recorded scores")
+    for f, (w, p, j, bl) in fam.items():
+        assert j == 0 or w >= MIN_MARGIN, "%s: the oracle's scores are within 1/%.1f of the boundary gap of the reference's" % (f, w)
+        assert p <= 1e-4
+
+
+@pytest.mark.gpu
+def test_kernel_margin_against_the_reference_scores():
+    from ips_amd.architecture import IPSNet
+    dev = torch.device("cuda:0")
+    rows = []
+    todo = [("small", c) for c in SMALL] + [("seeds_" + f, k) for f in sorted(synth.SEED_FAMILIES)
+                                            for k in range(synth.SEED_FAMILIES[f]()[2])] + [("bench", n) for n in GPU_BENCH]
+    for kind, key in todo:
+        name, conf, wseed, q_gain, x, trace = load_case(kind, key)
+        net = synth.fill_weights(IPSNet(dev, conf), wseed, q_gain=q_gain).to(dev).eval()
+        if kind == "bench":
+            synth.use_fixture_pos_table(net, np.load(os.path.join(GOLDEN_DIR, "bench_%s.npz" % key)))
+        elif kind.startswith("seeds_"):
+            synth.use_fixture_pos_table(net, np.load(os.path.join(GOLDEN_DIR, "%s.npz" % kind)))
+        B, N = x.shape[:2]
+        with torch.no_grad():
+            emb = net._embed(x.to(dev).reshape(B * N, *x.shape[2:])).view(B, N, -1).cpu().numpy()
+        pos = net.pos_enc.cpu().numpy() if conf.use_pos else None
+
+        def scores(rows_, net=net):
+            with torch.no_grad():
+                return net.transf.get_scores(torch.from_numpy(rows_).to(dev).unsqueeze(0))[0].cpu().numpy()
+        es, ei = record(name)
+        rows.append((name, margins(emb, pos, scores, trace, es, ei, conf.M, conf.I)))
+        del net
+    fam = summarise(rows, "HIP kernels vs the reference's recorded scores")
+    for f, (w, p, j, bl) in fam.items():
+        assert j == 0 or w >= MIN_MARGIN, "%s: the kernels' scores are within 1/%.1f of the boundary gap of the reference's" % (f, w)
+        assert p <= 1e-4

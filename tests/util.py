@@ -12,7 +12,7 @@ from ips_amd.architecture import IPSNet
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
-                      if f.endswith(".npz") and not f.startswith(("loop_", "bench_", "seeds_")))
+                      if f.endswith(".npz") and not f.startswith(("loop_", "bench_", "seeds_", "margin")))
 # what the CPU oracle replays in seconds (the rest is checked on the GPU only)
 ORACLE_FAST_CASES = [c for c in GOLDEN_CASES if c not in ("traffic_full", "mnist_native50")]
 
