@@ -33,6 +33,10 @@
  *     (h, j) over x[8g + 4h + j], g ascending: exactly what lane (row, half h) of the GEMM's
  *     operand stream holds - folded ((c0+c1)+(c2+c3)) per half, half 0 + half 1;
  *     mean = sum / F, var = fma(-mean, mean, sumsq / F) clamped at 0, rstd = 1 / sqrt(var + eps).
+ *     Round 6: a row with var * 17 < sumsq / F (mean^2 / var > 16 - both forms above cancel there) is CENTRED, as
+ *     nn.LayerNorm itself does: over d = x - mean the same eight chains sum d and d * d, mean' = mean + E[d],
+ *     var = fma(-E[d], E[d], E[d^2]) clamped at 0; acc = the chain over (x - mean') * w, t = acc.  Its statistics read
+ *     (mean', -rstd): the SIGN of rstd marks the row.  Well-conditioned rows never take this path (bits unchanged).
  */
 #ifndef IPSX_H
 #define IPSX_H
@@ -281,7 +285,7 @@ int ipsx_patchify_sparse(const int64_t* index, const float* value, const int64_t
 int ipsx_weight_colsum(const float* w, int c_out, int c_in, float* colsum, void* stream);
 int ipsx_projector(const ipsx_conv* lin, const float* x, int64_t n, float ln_eps,
                    float* out, void* workspace, size_t workspace_bytes, void* stream);
-size_t ipsx_projector_workspace_bytes(int64_t n);      /* 8 bytes per row: (mean, rstd) */
+size_t ipsx_projector_workspace_bytes(int64_t n);      /* 8 bytes per row: (mean, rstd); rstd < 0: a centred row (above) */
 /* the two halves of ipsx_projector, for callers that compute the row statistics (n x 2 floats: mean, rstd) ahead of
  * the GEMM - e.g. on another stream, beside the GEMM of an earlier slab (the pass is HBM-bound, the GEMM MFMA-bound) */
 int ipsx_projector_stats(const float* x, int64_t n, int f, float ln_eps, float* stats, void* stream);

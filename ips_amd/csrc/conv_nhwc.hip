@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const unsigned m = min(m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.m_total - 1);
                 const float2 st = reinterpret_cast<const float2*>(a.stats)[m];
-                nmean[NORM ? mt : 0][NORM ? r : 0] = -st.x;
-                rstd[NORM ? mt : 0][NORM ? r : 0] = st.y;
+                nmean[NORM ? mt : 0][NORM ? r : 0] = st.y < 0.0f ? 0.0f : -st.x;      // (mean, -rstd): a centred row, below
+                rstd[NORM ? mt : 0][NORM ? r : 0] = __builtin_fabsf(st.y);
             }
     }
 #pragma unroll
@@ -244,6 +244,28 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(NhwcArgs a) {
                 if (a.relu) v = v > 0.0f ? v : 0.0f;
                 a.y[idx] = v;
             }
+    }
+    if (NORM) {
+        // rows the statistics mark as centred (ipsx_rowstats.h: mean^2 / var > 64 - never on well-conditioned features): this
+        // wave's columns of them again, as the chain over (x - mean) * w
+        const unsigned mrow = m_base + lane;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(mrow < a.m_total && reinterpret_cast<const float2*>(a.stats)[min(mrow, a.m_total - 1)].y < 0.0f);
+        while (todo) {
+            const unsigned m = m_base + (unsigned)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float2 st = reinterpret_cast<const float2*>(a.stats)[m];
+            for (int c = lane; c < NTW * 32; c += 64) {
+                const int n = nt0 * 32 + c;
+                if (n >= a.c_out) continue;
+                const size_t idx = (size_t)m * a.c_out + n;
+                float v = centred_row_dot(a.x + (size_t)m * a.c_in, st.x, a.wp, a.kgs, n) * -st.y;
+                if (a.alpha) v = __builtin_fmaf(v, a.alpha[n], a.shift ? a.shift[n] : 0.0f);
+                else if (a.shift) v = v + a.shift[n];
+                if (a.res) v = v + a.res[idx];
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                a.y[idx] = v;
+            }
+        }
     }
 }
 
@@ -317,6 +339,29 @@ constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + ST_STATS * 4 + 16;
 __device__ __forceinline__ void bufstore(__amdgpu_buffer_rsrc_t r, f32x4 v, unsigned voff) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, 0, 0);
+}
+
+// The rows of a tile that the statistics mark as centred (ipsx_rowstats.h), again, on the centred row: columns [c0, c0 +
+// ncol) into the LDS copy of the tile.  Not inlined: a rare path that must not cost the tile's GEMM registers.
+__device__ __attribute__((noinline)) void stream_centred_rows(const float* __restrict__ x, const float* __restrict__ wp,
+                                                              const float* __restrict__ alpha, const float* __restrict__ shift,
+                                                              int relu, int c_in, int kgs, unsigned n, unsigned row0, int c0,
+                                                              int ncol, float* tile, const float2* s_stats,
+                                                              unsigned long long todo) {
+    while (todo) {
+        const int lr = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float2 st = s_stats[lr];
+        const float* xrow = x + (size_t)min(row0 + (unsigned)lr, n - 1) * c_in;
+        for (int c = threadIdx.x; c < ncol; c += 256) {
+            const int nn = c0 + c;
+            float v = centred_row_dot(xrow, st.x, wp, kgs, nn) * -st.y;
+            if (alpha) v = __builtin_fmaf(v, alpha[nn], shift ? shift[nn] : 0.0f);
+            else if (shift) v = v + shift[nn];
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            tile[lr * ST_EP + nn] = v;
+        }
+    }
 }
 
 // MB: the row block (32 rows) whose moments THIS wavefront sums - every wavefront of a workgroup streams the same rows
@@ -412,8 +457,11 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
     ST_STAMP(2);
 
     // ---- the rows' moments meet in the LDS (two wavefronts hold each block's: the same bits)
+    // (a row whose mean dwarfs its spread comes back as (mean, -rstd): its moments were recentred, its Linear is redone
+    //  on the centred row below - ipsx_rowstats.h; never on well-conditioned features)
     {
-        const float2 st = rm_finish(mom, a.c_in, a.eps, lane);
+        const unsigned mrow = min(row0 + MB * 32u + (unsigned)i, a.n - 1);
+        const float2 st = rm_finish(mom, a.c_in, a.eps, lane, a.x + (size_t)mrow * a.c_in + 4 * half);
         if (lane < 32) s_stats[MB * 32 + i] = st;
     }
     __syncthreads();
@@ -423,9 +471,10 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const float4 st = *reinterpret_cast<const float4*>(s_stats + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-            nmean[mt][r >> 1] = f32x2{-st.x, -st.z};
-            rstd[mt][r >> 1] = f32x2{st.y, st.w};
+            nmean[mt][r >> 1] = f32x2{st.y < 0.0f ? 0.0f : -st.x, st.w < 0.0f ? 0.0f : -st.z};
+            rstd[mt][r >> 1] = f32x2{__builtin_fabsf(st.y), __builtin_fabsf(st.w)};
         }
+    const unsigned long long centred_rows = __builtin_amdgcn_ballot_w64(lane < 32 * MT && s_stats[lane < 32 * MT ? lane : 0].y < 0.0f);
 
     // ---- folded LayerNorm, BatchNorm affine, ReLU: into the LDS copy of the tile (the logits read it; the wavefronts
     // that have no logits to do carry it to HBM meanwhile, 16 bytes per lane - rounds 3-4 stored 4 bytes per lane from here)
@@ -452,6 +501,11 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
             }
     }
     __syncthreads();
+    if (centred_rows != 0ull) {                                    // workgroup-uniform (every wave read the same statistics); rare
+        stream_centred_rows(a.x, a.wp, a.alpha, a.shift, a.relu, a.c_in, a.kgs, a.n, row0, part * (16 / P) * 32, 4 * NTW * 32,
+                            tile, s_stats, centred_rows);
+        __syncthreads();
+    }
     ST_STAMP(3);
 
     // ---- the tile's embeddings to HBM, by the wavefronts the logits leave idle (rows beyond the end: the buffer's bounds

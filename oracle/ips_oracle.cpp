@@ -310,11 +310,14 @@ ORC_API void orc_linear(const float* x, const float* w, const float* bias, int64
 // x[8g + 4h + j] for g ascending (sum: fp32 add from +0; sum of squares: one fma per element) - folded as
 // ((c0 + c1) + (c2 + c3)) per half and half 0 + half 1.  mean = sum / F, var = E[x^2] - mean^2 (one fma, clamped at 0),
 // rstd = 1 / sqrt(var + eps).  F is a multiple of 8.
-// Round 6 (advisor, round 5): E[x^2] - mean^2 loses (mean / std)^2 * 2^-24 of the variance.  A row whose one-pass variance
-// is below 1/65 of its E[x^2] (mean^2 / var > 64: |mean| > 8 std) gets its second moment AGAIN, centred: the same eight
-// chains over d = x - mean, q = fma(d, d, q), the same fold, var = sum / F - nn.LayerNorm's own two-pass form
-// (ips_net.py:56).  Rows of well-conditioned features (every fixture) never take that path: their bits are unchanged.
-#define ORC_RM_RECENTRE 65.0f
+// Round 6 (advisor, round 5): E[x^2] - mean^2 loses (mean / std)^2 * 2^-24 of the variance, and the folded form
+// acc - mean * colsum cancels the same way.  A row whose one-pass variance is below 1/17 of its E[x^2] (mean^2 / var > 16:
+// |mean| > 4 std) is CENTRED, as nn.LayerNorm itself does (ips_net.py:56): over d = x - mean the same eight chains sum d
+// and d * d (sd = sd + d; q = fma(d, d, q)), folded the same way; mean' = mean + E[d] (a constant row's residual is exact:
+// mean' is the constant), var = fma(-E[d], E[d], E[d^2]) clamped at 0; the Linear then runs on x - mean' (orc_projector).
+// The statistics say so in the sign: (mean', -rstd).  Rows of well-conditioned features (every fixture) never take that
+// path: their bits are unchanged.  Device: ipsx_rowstats.h rm_finish / rm_recentred.
+#define ORC_RM_RECENTRE 17.0f
 static void projector_moments(const float* x, int f, float eps, float* mean_out, float* rstd_out) {
     float t[2], u[2];
     for (int h = 0; h < 2; ++h) {
@@ -329,23 +332,31 @@ static void projector_moments(const float* x, int f, float eps, float* mean_out,
         u[h] = (q[0] + q[1]) + (q[2] + q[3]);
     }
     const float sum = t[0] + t[1], sumsq = u[0] + u[1];
-    const float mean = sum / (float)f, ex2 = sumsq / (float)f;
+    float mean = sum / (float)f;
+    const float ex2 = sumsq / (float)f;
     float var = __builtin_fmaf(-mean, mean, ex2);
     var = var > 0.0f ? var : 0.0f;
-    if (var * ORC_RM_RECENTRE < ex2) {
+    const bool centred = var * ORC_RM_RECENTRE < ex2;
+    if (centred) {
         for (int h = 0; h < 2; ++h) {
-            float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float sd[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int g = 0; g * 8 < f; ++g)
                 for (int j = 0; j < 4; ++j) {
                     const float d = x[g * 8 + 4 * h + j] - mean;
+                    sd[j] = sd[j] + d;
                     q[j] = __builtin_fmaf(d, d, q[j]);
                 }
+            t[h] = (sd[0] + sd[1]) + (sd[2] + sd[3]);
             u[h] = (q[0] + q[1]) + (q[2] + q[3]);
         }
-        var = (u[0] + u[1]) / (float)f;
+        const float dm = (t[0] + t[1]) / (float)f;
+        var = __builtin_fmaf(-dm, dm, (u[0] + u[1]) / (float)f);
+        var = var > 0.0f ? var : 0.0f;
+        mean = mean + dm;
     }
     *mean_out = mean;
     *rstd_out = 1.0f / sqrtf(var + eps);
+    if (centred) *rstd_out = -*rstd_out;             // (mean', -rstd): a CENTRED row - its Linear runs on x - mean' (orc_projector)
 }
 
 ORC_API void orc_projector_moments(const float* x, int64_t n, int f, float eps, float* stats /* (n, 2): mean, rstd */) {
@@ -378,13 +389,22 @@ ORC_API void orc_projector(const float* x, int64_t n, int f, int d, float ln_eps
     std::vector<float> cs(d), st((size_t)n * 2);
     orc_weight_colsum(w, d, f, cs.data());
     orc_projector_moments(x, n, f, ln_eps, st.data());
-    linear_impl(x, w, nullptr, n, f, d, out, 1);                  // on the matrix cores
+    // rows marked centred (mean^2 / var > 16) go through the matrix cores' chain as x - mean, t = acc; all others raw
+    std::vector<float> xc;
+    const float* xin = x;
+    for (int64_t r = 0; r < n; ++r)
+        if (st[2 * r + 1] < 0.0f) {
+            if (xc.empty()) { xc.assign(x, x + (size_t)n * f); xin = xc.data(); }
+            for (int c = 0; c < f; ++c) xc[(size_t)r * f + c] = x[(size_t)r * f + c] - st[2 * r];
+        }
+    linear_impl(xin, w, nullptr, n, f, d, out, 1);                // on the matrix cores
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < n; ++r) {
-        const float nm = -st[2 * r], rstd = st[2 * r + 1];
+        const bool centred = st[2 * r + 1] < 0.0f;
+        const float nm = -st[2 * r], rstd = fabsf(st[2 * r + 1]);
         for (int o = 0; o < d; ++o) {
             const float sh = __builtin_fmaf(bias[o], alpha[o], shift[o]);
-            const float t = __builtin_fmaf(nm, cs[o], out[r * d + o]);
+            const float t = centred ? out[r * d + o] : __builtin_fmaf(nm, cs[o], out[r * d + o]);
             const float u = t * rstd;
             const float v = __builtin_fmaf(u, alpha[o], sh);
             out[r * d + o] = v > 0.0f ? v : 0.0f;

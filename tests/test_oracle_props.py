@@ -95,3 +95,44 @@ def test_device_tie_order_restatement_is_clean_under_sanitizers():
     out = subprocess.run([os.path.join(root, "oracle", "check_stdorder_asan"), "6000"], capture_output=True, text=True,
                          timeout=600, env=env)
     assert out.returncode == 0 and "mismatching cases 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_projector_stays_accurate_where_the_mean_dwarfs_the_spread():
+    """Advisor r05 (medium).  The projector folds its LayerNorm into the Linear's epilogue (one pass over every feature row);
+    E[x^2] - mean^2 and acc - mean * colsum both cancel when a row's mean is large against its spread.  Rows with
+    mean^2 / var > 16 are therefore centred like nn.LayerNorm (reference architecture/ips_net.py:56) does it: moments
+    around the mean, mean refined by E[x - mean], Linear on x - mean.  Against float64 LayerNorm -> Linear -> BatchNorm1d ->
+    ReLU at mean / std from 0 to 1000 and on constant rows, through the WHOLE projector (not only the moments)."""
+    import ctypes as C
+    import torch
+    from ips_amd import synth
+    from ips_amd.architecture import IPSNet
+    from oracle.oracle import Oracle
+    conf = synth.camelyon_conf(N=64, M=8, I=8)
+    net = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 3).eval()
+    oracle = Oracle(net)
+    enc64 = synth.fill_weights(IPSNet(torch.device("cpu"), conf), 3).eval().encoder.double()
+    rng = np.random.default_rng(5)
+    worst = {}
+    for ratio in (0.0, 1.0, 3.5, 4.0, 4.5, 8.0, 30.0, 100.0, 1000.0):
+        x = (rng.standard_normal((48, conf.n_chan_in)) + ratio).astype(np.float32)
+        got = oracle.encode(x)
+        with torch.no_grad():
+            want = enc64(torch.from_numpy(x).double()).numpy()
+            ref32 = net.encoder(torch.from_numpy(x)).numpy()              # the reference's own fp32 arithmetic
+        worst[ratio] = (float(np.abs(got - want).max()), float(np.abs(ref32 - want).max()))
+        st = np.empty((48, 2), dtype=np.float32)
+        orc.lib().orc_projector_moments(orc._f(x)[1], C.c_int64(48), conf.n_chan_in, C.c_float(1e-5), st.ctypes.data_as(orc.f32p))
+        assert (st[:, 1] < 0).all() if ratio >= 4.5 else (st[:, 1] > 0).all() if ratio <= 3.5 else True
+        rstd64 = 1.0 / np.sqrt(x.astype(np.float64).var(1) + 1e-5)
+        assert (np.abs(np.abs(st[:, 1]) - rstd64) / rstd64).max() <= 2e-5
+    print({k: "%.1e (torch fp32: %.1e)" % v for k, v in worst.items()})
+    # (at mean / std = 1000 the row itself carries 1e-4 std of rounding per element: the reference's own fp32 path is no better)
+    assert all(v[0] <= 6e-5 for k, v in worst.items() if k <= 100.0) and worst[1000.0][0] <= max(5e-4, worst[1000.0][1])
+    # constant rows: LayerNorm gives exact zeros, so every such row is relu(BatchNorm(bias)) - whatever the constant
+    x = np.empty((4, conf.n_chan_in), dtype=np.float32)
+    x[0], x[1], x[2], x[3] = 3.7, -1e-3, 65504.0, 0.0
+    got = oracle.encode(x)
+    with torch.no_grad():
+        want = enc64(torch.from_numpy(x).double()).numpy()
+    assert np.abs(got - want).max() <= 1e-6 and np.array_equal(got[0], got[3]) and np.array_equal(got[0], got[2])
