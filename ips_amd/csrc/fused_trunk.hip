@@ -148,7 +148,11 @@ __device__ __forceinline__ void stem_pool(const FusedArgs& a, const void* Sv, f3
 #pragma unroll
         for (int x = 0; x < 8; ++x) prev[nt][x] = -__builtin_huge_valf();
 
-#pragma unroll 1
+    // (the split trunks unroll the eight row pairs: with t a constant the pooled row lands in its registers directly - as a
+    //  loop the placement below is a chain of uniform branches whose joins cost ~260 register moves per row pair, 8 k
+    //  cycles per patch: nothing against the fp32 trunk's 600 k, a third of the bf16 trunk's stem)
+    constexpr int UNROLL_T = PL == 0 ? 1 : 8;
+#pragma unroll UNROLL_T
     for (int t = 0; t < 8; ++t) {
         // lane's output pixel: row 2t + (i>>4), col ox.  Step (kg, j) of the contract feeds
         // k = 8kg + 4*half + j -> tap (k/7, k%7): the upper half's tap is 4 columns right of the
@@ -646,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
 }
 
 #include "fused_trunk_split.h"
+#include "fused_trunk_bf16v2.h"
 #include "fused_trunk_pair.h"
 
 // ------------------------------------------------------------------ the stages as stand-alone convolutions (training step)
@@ -804,6 +809,7 @@ bool fused_trunk_supported(const ipsx_trunk* t) {
     return !(off && off[0] == '1');
 }
 
+static int g_bf16_build = 0;      // diagnostic (ipsx_dbg_bf16_build): 0 the second build of the bf16 trunk, 1 the first
 static int g_pair_mode = 0;       // diagnostic (ipsx_dbg_fused_trunk_pair): 0 the rule below, 1 never, 2 every patch through the pair kernel
 
 static int device_cus() {
@@ -856,6 +862,27 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
             attr_split = true;
         }
         const dim3 grid((unsigned)cdiv(n, 4)), block(256);
+        // the bf16 trunk's second build (fused_trunk_bf16v2.h; round 6) unless IPSX_BF16_BUILD=1 asks for the first
+        static const bool bf16_v1 = [] { const char* e = getenv("IPSX_BF16_BUILD"); return e && e[0] == '1'; }();
+        if (!x3 && !(bf16_v1 || g_bf16_build == 1) ) {
+            static bool attr_v2 = false;
+            if (!attr_v2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v2_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v2_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+                attr_v2 = true;
+            }
+            // One workgroup per quad by default.  IPSX_BF16_PERSIST=1: two workgroups per unit take the launch's quads in
+            // turn (no dispatch gap between quads, the next quad's pixels prefetched) - faster alone (+5 %), but a selection
+            // loop that is to run BESIDE the launch needs a whole unit's registers (16 waves of 128) and finds none until the
+            // launch is over: measured inside ips() 26.5 -> 22.2 M patches/s, so it is not the default
+            static const bool persist = [] { const char* e = getenv("IPSX_BF16_PERSIST"); return e && e[0] == '1'; }();
+            const dim3 pgrid((unsigned)(persist ? std::min<int64_t>(cdiv(n, 4), 2 * (int64_t)device_cus()) : cdiv(n, 4)));
+            if (stamps) fused_trunk_bf16v2_kernel<true><<<pgrid, block, V2_LDS, s>>>(a, stamps);
+            else fused_trunk_bf16v2_kernel<false><<<pgrid, block, V2_LDS, s>>>(a, nullptr);
+            return launched("fused_trunk_bf16v2");
+        }
         if (x3 && stamps) fused_trunk_x3_kernel<true><<<grid, block, ldsx, s>>>(a, stamps);
         else if (x3) fused_trunk_x3_kernel<false><<<grid, block, ldsx, s>>>(a, nullptr);
         else if (stamps) fused_trunk_bf16_kernel<true><<<grid, block, ldsx, s>>>(a, stamps);
@@ -1048,6 +1075,8 @@ IPSX_API int ipsx_pack_stem_weight_split(const float* w, int c_out, int planes, 
 // Diagnostic switch (not part of include/ipsx.h; tests/test_hip_kernels.py, tools): which of the two exact fp32 kernels
 // encodes - 0 the product's rule, 1 fused_trunk_kernel only, 2 fused_trunk_pair_kernel only.
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_fused_trunk_pair(int mode) { ipsx::g_pair_mode = mode; }
+// which build of the bf16 trunk IPSX_PRECISION=bf16 launches: 0 the second (fused_trunk_bf16v2.h), 1 the first (fused_trunk_split.h)
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_bf16_build(int build) { ipsx::g_bf16_build = build; }
 
 // Diagnostic entry point (not part of include/ipsx.h): the fused trunk with s_memtime stamps,
 // 16 x uint64 per wavefront = per patch, in launch order.  Used by tools/fused_stamps.py only.

@@ -569,6 +569,37 @@ def test_bf16_trunk_tracks_fp32_within_tolerance(monkeypatch):
     assert float(err) < 3e-3, float(err)      # a bf16 rounding flip of one activation is 4e-3 of that activation
 
 
+@pytest.mark.parametrize("storage", [torch.float32, torch.float16])
+def test_bf16_trunk_builds_agree(monkeypatch, storage):
+    """Round 6: the bf16 trunk's second build (csrc/fused_trunk_bf16v2.h: 8x8 stage by channel tile x patch pair, deep
+    operand rings, ping-pong LDS images) does the FIRST build's arithmetic - same operand rounding, same products in the
+    same order, fp32 identity: the embeddings are bit-identical, whole workgroups and ragged ends, an index list, half-stored
+    patches."""
+    g = Golden("mnist_full")
+    net = g.net(DEV)
+    plan = hip.EncoderPlan(net.encoder, True)
+    fn = hip.lib().ipsx_dbg_bf16_build
+    fn.restype, fn.argtypes = None, [C.c_int]
+    x_all = g.patches()[0, :1203].to(DEV).to(storage)
+    monkeypatch.setenv("IPSX_PRECISION", "bf16")
+    try:
+        for n in (1, 2, 3, 4, 5, 7, 8, 203, 1203):
+            x = x_all[:n].contiguous()
+            fn(1)
+            first = plan.encode(x)
+            fn(0)
+            second = plan.encode(x)
+            assert torch.isfinite(second).all() and torch.equal(first, second), n
+        idx = torch.randperm(1203, generator=torch.Generator().manual_seed(5))[:333].to(torch.int32).to(DEV)
+        fn(1)
+        first = plan.encode_indexed(x_all, idx)
+        fn(0)
+        second = plan.encode_indexed(x_all, idx)
+        assert torch.equal(first, second) and torch.equal(second, plan.encode(x_all[idx.long()].contiguous()))
+    finally:
+        fn(0)
+
+
 def test_fp32x3_trunk_has_fp32_accuracy(monkeypatch):
     """IPSX_PRECISION=fp32x3: every fp32 operand of the residual stages as three bf16 terms, six products on the
     bf16 matrix pipe, fp32 accumulation.  Not bit-identical to the fma chains of the fp32 kernel, but as close to
