@@ -1,0 +1,481 @@
+// scan_fast.hip - scan_fast_kernel: the LDS-resident selection loop for every shape the reference ships up to 1,024
+// candidates per iteration (one workgroup per image replays IPSNet.ips's chunk loop, architecture/ips_net.py:213-241, on the
+// cached logits; see scan_common.h for the organisation of the loop).
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "scan_common.h"
+
+namespace ipsx {
+
+template <int R, int T, int EPT, int LCH, bool STAMP, bool PERSIST>
+__global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // prefetch registers per (prefetching) thread: 4, 5 for 32 rows x up to 512 candidates - the reference's shipped
+    // Megapixel-MNIST sizes (M = I = 100, 4 tokens: a chunk is 3,200 logits for 704 prefetching threads)
+    constexpr int PF = scan_pf(R, LCH);
+    if (!PERSIST && scan_skipped(a.cond, a.cond_mask)) return;
+    // encoder workgroups share this compute unit (their matrix-pipe work coexists with this VALU-bound loop); where the
+    // two compete for issue slots the loop - the serial part of the job - goes first
+    __builtin_amdgcn_s_setprio(3);
+    if (PERSIST) {
+        // 128 registers per lane x 16 waves = the whole register file of the compute unit: it is ours alone (callers
+        // size the producers' launches for the remaining compute units)
+        asm volatile("v_mov_b32 v127, 0" ::: "v127");
+        // resident: tell the gate on the producing stream (ipsx_scan_gate) that the encoder may start
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_or(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.plog[4], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    constexpr int H = R / T, ld = R + 1;
+    constexpr int log2R = R == 8 ? 3 : (R == 16 ? 4 : (R == 32 ? 5 : 6));
+    constexpr int log2T = T == 1 ? 0 : (T == 2 ? 1 : (T == 4 ? 2 : 3));
+    static_assert((1 << log2R) == R && (1 << log2T) == T && H * T == R, "scan_fast_kernel: R, T powers of two");
+    const int Lmax = a.m + a.i;
+    uint64_t* keyA = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* keyB = keyA + a.n2;
+    int* candA = reinterpret_cast<int*>(keyB + a.n2);
+    int* candB = candA + Lmax;
+    uint32_t* pmax = reinterpret_cast<uint32_t*>(candB + Lmax + ((4 - ((2 * Lmax) & 3)) & 3));   // [R][16], 16-byte aligned
+    uint32_t* wmin = pmax + 16 * R;               // [16] (16-byte aligned): per wave, the lowest score key of its memory rows
+    int* ccount = reinterpret_cast<int*>(wmin + 16);          // [0]: chunk candidates that can still reach the top M;
+                                                              // [1]: lowest memory score key; [2], [3]: tie flag (by parity)
+    int* nanflag = ccount + 4;                    // [2]: a NaN among this iteration's logits (by parity)
+    uint32_t* prevk = reinterpret_cast<uint32_t*>(ccount + 8);     // [2][R]: bits of the row maxima of the previous iteration
+    float* rden = reinterpret_cast<float*>(prevk + 2 * R);
+    float* xA = rden + R;
+    float* xB = xA + (size_t)Lmax * ld;
+    float* eA = xB + (size_t)Lmax * ld;
+    float* eB = eA + (size_t)Lmax * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float* lg = a.lg + (size_t)b * a.n * R;
+    const int r = tid & (R - 1), lrow0 = tid >> log2R;
+    constexpr int lstep = SCAN_NT >> log2R;
+
+    int* cand = candA;
+    int* cnew = candB;
+    float* xc = xA;
+    float* xn = xB;
+    float* ec = eA;
+    float* en = eB;
+    // persistent launch: rows below ready_known exist.  Wave 0 polls, everybody learns the result through LDS; a negative
+    // value (cancelled / timed out) ends the kernel.  The wait is bounded by a.wait_ticks of the 100 MHz clock WITHOUT
+    // PROGRESS: the clock restarts whenever any progress word of the call has moved (lane k watches word k), so a slide
+    // whose turn at the projector comes late waits as long as the slides in front of it are being worked on - and a call
+    // whose producers cannot run at all (serialised kernels) gives up after wait_ticks (default 50 ms) and is redone by
+    // the conditional launch behind it.
+    long long ready_known = 0;
+    uint32_t* const mkey = pmax;                   // [R] max key of the memory rows, [R] of the chunk rows (see fold_row_max)
+    uint32_t* const ckey = pmax + R;
+    if (tid < 2 * R) pmax[tid] = 0u;
+    lds_barrier();
+    SCAN_WAIT_ROWS(std::min<long long>(a.n, a.it0 * a.i + a.m + a.i));
+    {
+        uint32_t km = 0u;
+        for (int k = 0; k < EPT; ++k) {
+            const int l = lrow0 + k * lstep;
+            if (l < a.m) {
+                const size_t row = a.it0 == 0 ? (size_t)l : (size_t)a.mem_idx[(size_t)b * a.m + l];
+                const float v = scan_load<PERSIST>(lg + row * R + r);
+                xc[l * ld + r] = v;
+                km = max(km, max_key(v));
+            }
+        }
+        fold_row_max<R>(km, mkey, lane);
+    }
+    for (int j = tid; j < a.m; j += SCAN_NT) cand[j] = a.it0 == 0 ? j : (int)a.mem_idx[(size_t)b * a.m + j];
+    if (tid < 2) { nanflag[tid] = 0; ccount[2 + tid] = 0; }
+    const long long n_iter = a.it1 - a.it0;
+    // The chunk of iteration it + 1 is fetched into registers during iteration it - 1 .. it and moved into the spare
+    // buffers, together with its exponentials under the CURRENT row maxima, while the ranking of iteration it runs
+    // (below: "prep").  With more than 128 candidates the ranking occupies waves 0-4 only, so the prefetch registers live
+    // in the threads of waves 5-15 (PF0 = 320 and the number of prefetching threads are multiples of R: a prefetching
+    // thread's elements belong to its own row r).
+    constexpr int PF0 = LCH > 2 ? 320 : 0, PFT = SCAN_NT - PF0;
+    const int pt = tid - PF0;                                  // < 0: this thread prefetches nothing
+    float pf[PF];
+    {
+        const long long lo = a.it0 * a.i + a.m;
+        const int cnt = n_iter > 0 ? (int)std::min<long long>(a.i, a.n - lo) : 0;
+        uint32_t kc = 0u;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {                    // first chunk: straight into its rows
+            const int e = tid + SCAN_NT * k;
+            if (e < cnt * R) {
+                const float v = scan_load<PERSIST>(lg + (size_t)lo * R + e);
+                xc[(a.m + (e >> log2R)) * ld + r] = v;
+                kc = max(kc, max_key(v));
+            }
+        }
+        fold_row_max<R>(kc, ckey, lane);
+        for (int j = tid; j < cnt; j += SCAN_NT) cand[a.m + j] = (int)(lo + j);
+        const long long lo1 = lo + a.i;
+        const int cnt1 = n_iter > 1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+        if (cnt1 > 0) SCAN_WAIT_ROWS(lo1 + cnt1);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int e = pt + PFT * k;
+            pf[k] = (pt >= 0 && e < cnt1 * R) ? scan_load<PERSIST>(lg + (size_t)lo1 * R + e) : 0.0f;
+        }
+    }
+    int tie = 0;
+    uint64_t* const sorted = keyB;
+    for (long long it = a.it0; it < a.it1; ++it) {
+        const long long lo = it * a.i + a.m;
+        const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+        const int L = a.m + cnt;
+        const int par = (int)((it - a.it0) & 1);
+        // P0: nothing to stage - this iteration's chunk rows (and, speculatively, their exponentials) were written by the
+        // previous iteration's prep (or by the prologue)
+        lds_barrier();
+        FAST_STAMP(0);
+        // P1: row maxima = the larger of the two key words of the row (memory rows: folded in by the previous iteration's
+        // gather; chunk rows: by its prep) - two LDS reads instead of a pass over the rows, a cross-lane and a cross-wave
+        // reduction and a barrier.  The words are cleared after the next barrier, when everybody has read them.
+        if (tid == 0) {                                        // (all last read several barriers ago)
+            ccount[0] = 0; ccount[1] = -1; ccount[2 + (par ^ 1)] = 0;
+        }
+        const uint32_t mk = max(mkey[r], ckey[r]);
+        const uint32_t mbits = as_u32(max_key_value(mk));
+        const float rowmax = as_float(mbits);
+        // the exponentials of the memory rows are those of the previous iteration while the row's maximum is the same
+        const bool changed = it == a.it0 || prevk[par * R + r] != mbits;
+        if (tid < R) prevk[(par ^ 1) * R + r] = mbits;
+        FAST_STAMP(1);
+        // P2: exp(x - max) where it is new: the whole column of every row r whose maximum moved (that includes the chunk
+        // rows, whose speculative exponentials were taken under the old maximum; at the first iteration of a launch every
+        // column).  A column is L elements: one per thread of the first L threads, all lanes busy - done by the thread
+        // that owns the element instead, the lanes of the unchanged rows idle through every exp (7 of 8, on all 16 waves).
+        {
+            unsigned long long moved = __ballot(changed) & (R == 64 ? ~0ull : ((1ull << R) - 1ull));   // lane r < R holds row r
+            while (moved) {
+                const int rr = __ffsll((long long)moved) - 1;
+                moved &= moved - 1ull;
+                exp_column(xc + rr, ec + rr, L, ld, __shfl(rowmax, rr, 64));
+            }
+        }
+        lds_barrier();
+        if (tid < 2 * R) pmax[tid] = 0u;                       // the maxima have been read by everybody: clear for the next folds
+        FAST_STAMP(2);
+        // P3: softmax denominators in the contract's order: lane j adds rows j, j + 64, ... ascending, xor butterfly
+        for (int r0 = wave; r0 < R; r0 += 32) {
+            const int r1 = r0 + 16;
+            const bool has1 = r1 < R;
+            float v0[LCH], v1[LCH];
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) {                    // every read in flight before the first add; slots beyond L
+                const int i = lane + 64 * u;                   // add an exact + 0.0
+                v0[u] = i < L ? ec[i * ld + r0] : 0.0f;
+                v1[u] = (i < L && has1) ? ec[i * ld + r1] : 0.0f;
+            }
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) { s0 = s0 + v0[u]; s1 = s1 + v1[u]; }
+            wave_sum2(s0, s1, lane);
+            if (lane == 0) { rden[r0] = 1.0f / s0; if (has1) rden[r1] = 1.0f / s1; }      // (reciprocals: one division per row)
+        }
+        lds_barrier();
+        FAST_STAMP(3);
+        // P4: attention weights e * (1 / den) by every thread, transposed through the spare buffer; then one lane per
+        // (candidate, token) adds its H weights in ascending head order and the T lanes of a candidate their tokens
+        {
+            const float den = rden[r];
+            float ev[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {                      // (all reads in flight before the first product)
+                const int l = lrow0 + k * lstep;
+                ev[k] = l < L ? ec[l * ld + r] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int l = lrow0 + k * lstep;
+                if (l < L) en[l * ld + r] = ev[k] * den;
+            }
+        }
+        lds_barrier();
+        // Keys: the M memory keys go to keyA[0, M); a chunk candidate keeps its key in a register until it is known
+        // whether it can still reach the top M (below)
+        constexpr int KT = (LCH * 64 * T + SCAN_NT - 1) / SCAN_NT;
+        uint64_t mykey[KT];
+        uint32_t lowest = 0xFFFFFFFFu;                           // lowest score key among this lane's memory candidates
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int e = kt * SCAN_NT + tid, l = e >> log2T, t = e & (T - 1);
+            mykey[kt] = 0ull;
+            if (e < a.n2 * T) {                                  // (workgroup-uniform up to the last trip)
+                float q = 0.0f;
+                if (l < L) {
+                    const float* wrow = en + l * ld + t;
+                    float wh[H];                                 // all reads in flight together
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh) wh[hh] = wrow[hh * T];
+                    float sh = 0.0f;
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh) sh = sh + wh[hh];
+                    q = sh / (float)H;
+                }
+                float st = q;
+                if (T > 1) {
+                    st = 0.0f;
+#pragma unroll
+                    for (int tt = 0; tt < T; ++tt) st = st + __shfl(q, (lane & ~(T - 1)) + tt, 64);
+                }
+                if (t == 0 && l < L) {
+                    mykey[kt] = rank_key(st / (float)T, (uint32_t)l);
+                    if (l < a.m) {
+                        keyA[l] = mykey[kt];
+                        lowest = min(lowest, (uint32_t)(mykey[kt] >> 32));
+                    }
+                }
+            }
+        }
+        // (64 lanes on one LDS address serialise: the wave reduces first - DPP inside a row of 16, two cross-row steps)
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x124, 0xF, 0xF, false));    // row_ror:4
+        lowest = min(lowest, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)lowest, 0x128, 0xF, 0xF, false));    // row_ror:8
+        lowest = min(lowest, lane_xor_u32<16>(lowest, lane));
+        lowest = min(lowest, lane_xor_u32<32>(lowest, lane));
+        if (lane == 0 && lowest != 0xFFFFFFFFu) atomicMin(reinterpret_cast<unsigned int*>(ccount + 1), lowest);
+        lds_barrier();
+        // A chunk candidate whose score is below the lowest memory score cannot be among the M best of memory + chunk
+        // (the M memory candidates alone beat it), and in a long scan that is almost every one of them: only the others
+        // - equal scores included, so exact ties are all still there - are appended behind the memory keys and ranked.
+        {
+            const uint32_t tau = (uint32_t)ccount[1];             // lowest memory score key (ds_min_u32 above)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int e = kt * SCAN_NT + tid, l = e >> log2T;
+                const bool in = mykey[kt] != 0ull && l >= a.m && (uint32_t)(mykey[kt] >> 32) >= tau;
+                const unsigned long long mask = __ballot(in);
+                if (mask != 0ull) {                              // wave-uniform
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(ccount, __popcll(mask));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (in) keyA[a.m + base + __popcll(mask & ((1ull << lane) - 1ull))] = mykey[kt];
+                }
+            }
+        }
+        lds_barrier();
+        const int Lr = a.m + ccount[0];                          // candidates that take part in the ranking
+        // prep of iteration it + 1 (fills the issue slots the ranking leaves idle): its chunk into rows m.. of the SPARE
+        // buffers (they become the current ones at the end of this iteration; the weights that lived in `en` are dead, the
+        // ranking's scratch sits in its first rows only), with exponentials under this iteration's maxima - right when
+        // the maxima do not move, which the next iteration checks bitwise; then the loads of the chunk after that
+        {
+            const long long lo1 = lo + a.i;
+            const int cnt1 = it + 1 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo1)) : 0;
+            uint32_t kc = 0u;
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int e = pt + PFT * k;
+                if (pt >= 0 && e < cnt1 * R) {
+                    const int row = a.m + (e >> log2R);
+                    xn[row * ld + r] = pf[k];
+                    en[row * ld + r] = det_expf_np(pf[k] - rowmax);
+                    kc = max(kc, max_key(pf[k]));
+                }
+            }
+            if (pt >= 0) fold_row_max<R>(kc, ckey, lane);          // (whole waves: PF0 is a multiple of 64)
+            for (int j = tid; j < cnt1; j += SCAN_NT) cnew[a.m + j] = (int)(lo1 + j);
+        }
+        if (STAMP && tid == 0) tacc[7] += (unsigned long long)(Lr - a.m);
+        if (STAMP && PERSIST && tid == 0 && b == 0 && it < 512) stamps[8 * gridDim.x + 4 * it] = __builtin_amdgcn_s_memtime() - tlast;
+        FAST_STAMP(4);
+        if (Lr <= 192) {                     // counting rank below the crossover of the two rankings (~200 keys)
+            int P = 1;
+            while (P < 64 && 2 * P * Lr <= SCAN_NT) P <<= 1;
+            rank_scatter(keyA, keyB, Lr, P);
+        } else {
+            rank_runs4(keyA, keyB, reinterpret_cast<uint64_t*>(en), Lr);
+        }
+        lds_barrier();
+        // exact ties among the first M + 1 ranked scores that call for torch.topk's order?  The loop's rule (oracle
+        // orc_topm_loop, round 5): two NEIGHBOURS of equal score whose logit rows are bit-identical (tie_order 2: any two of
+        // equal score).  One pair per thread, any hit raises the flag.
+        if (a.tie_order != 0) {
+            const int npair = a.m < Lr - 1 ? a.m : Lr - 1;
+            bool hit = false;
+            for (int j = tid; j < npair; j += SCAN_NT) {
+                if ((sorted[j] >> 32) != (sorted[j + 1] >> 32)) continue;
+                bool same = true;
+                if (a.tie_order == 1) {
+                    const float* ra = xc + key_pos(sorted[j]) * ld;
+                    const float* rb = xc + key_pos(sorted[j + 1]) * ld;
+                    for (int rr = 0; rr < R; ++rr) same = same && as_u32(ra[rr]) == as_u32(rb[rr]);
+                }
+                hit = hit || same;
+            }
+            if (__ballot(hit) != 0ull && lane == 0) ccount[2 + par] = 1;
+        }
+        lds_barrier();
+        bool boundary_tie = Lr > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);   // bit-equal score keys (the oracle's rule: two NaNs tie)
+        if (a.tie_order != 0 && ccount[2 + par] != 0) {
+            // torch.topk's order under ties depends on the WHOLE candidate array, so every chunk key goes back to its
+            // place, all L candidates are ranked and the replay runs on them (rare)
+            const unsigned long long ts0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int l = (kt * SCAN_NT + tid) >> log2T;
+                if (mykey[kt] != 0ull && l >= a.m) keyA[l] = mykey[kt];
+            }
+            lds_barrier();
+            if (L <= 192) {
+                int P = 1;
+                while (P < 64 && 2 * P * L <= SCAN_NT) P <<= 1;
+                rank_scatter(keyA, keyB, L, P);
+            } else {
+                rank_runs(keyA, keyB, reinterpret_cast<uint64_t*>(en), L);
+            }
+            lds_barrier();
+            boundary_tie = L > a.m && (sorted[a.m - 1] >> 32) == (sorted[a.m] >> 32);
+            const unsigned long long ts1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+            tie_order_slow(keyB, keyA, L, a.m, reinterpret_cast<int*>(smem + a.stk_off));
+            if (STAMP && PERSIST && tid == 0 && b == 0) {
+                stamps[8 * gridDim.x + 2044] = ts1 - ts0;
+                stamps[8 * gridDim.x + 2045] = __builtin_amdgcn_s_memtime() - ts1;
+            }
+        }
+        if (STAMP && PERSIST && tid == 0 && b == 0 && it < 512) { stamps[8 * gridDim.x + 4 * it + 1] = __builtin_amdgcn_s_memtime() - tlast; stamps[8 * gridDim.x + 4 * it + 2] = __builtin_amdgcn_s_memrealtime(); }
+        FAST_STAMP(5);
+        // the loads of the chunk after the next one, issued HERE - behind the ranking, not in the prep in front of it: the
+        // ranking's searches reload a spilled register pair, the compiler therefore drains the vector-memory counter in
+        // front of them, and loads issued before that point were waited for on the spot (1.2 k cycles per iteration by
+        // every wave, in-kernel stamps); from here they fly through the gather and the first phases of the next
+        // iteration, which touch the LDS only
+        {
+            const long long lo2 = lo + 2 * a.i;
+            const int cnt2 = it + 2 < a.it1 ? (int)std::max<long long>(0, std::min<long long>(a.i, a.n - lo2)) : 0;
+            if (cnt2 > 0) SCAN_WAIT_ROWS(lo2 + cnt2);
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int e = pt + PFT * k;
+                pf[k] = (pt >= 0 && e < cnt2 * R) ? scan_load<PERSIST>(lg + (size_t)lo2 * R + e) : 0.0f;
+            }
+        }
+        // P6: new memory: indices, logit rows and exponentials of the winners, into the other buffers
+        for (int j = tid; j < a.m; j += SCAN_NT) cnew[j] = cand[key_pos(sorted[j])];
+        {
+            int src[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int j = lrow0 + k * lstep;
+                src[k] = j < a.m ? (int)key_pos(sorted[j]) * ld + r : 0;
+            }
+            float gx[EPT], ge[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) { gx[k] = xc[src[k]]; ge[k] = ec[src[k]]; }
+            uint32_t km = 0u;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int j = lrow0 + k * lstep;
+                if (j < a.m) { xn[j * ld + r] = gx[k]; en[j * ld + r] = ge[k]; km = max(km, max_key(gx[k])); }
+            }
+            fold_row_max<R>(km, mkey, lane);                       // maxima of the NEW memory rows, for the next iteration
+        }
+        if (tid == 0 && boundary_tie) tie = 1;
+        { int* t = cand; cand = cnew; cnew = t; }
+        { float* t = xc; xc = xn; xn = t; }
+        { float* t = ec; ec = en; en = t; }
+        FAST_STAMP(6);
+        // no barrier here: the next iteration's first phase writes rows m.. of the new buffers only, and its barrier
+        // orders everything before the maxima are read
+    }
+    lds_barrier();
+    for (int j = tid; j < a.m; j += SCAN_NT) {
+        a.mem_idx[(size_t)b * a.m + j] = cand[j];
+        if (a.mem_score) a.mem_score[(size_t)b * a.m + j] = n_iter > 0 ? key_score(sorted[j]) : 0.0f;
+    }
+    if (a.tie && tid == 0 && tie) a.tie[b] = 1;
+    if (STAMP && tid == 0)
+        for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] = tacc[k];
+}
+
+FastPlan scan_fast_plan(int m, int i, int h, int n_token) {
+    FastPlan p = {false, 1, 2, 0};
+    const int R = h * n_token, Lmax = m + i, n2 = next_pow2(Lmax);
+    if (!((R == 8 && n_token == 1) || (R == 32 && n_token == 4))) return p;      // the instantiated (R, T) pairs
+    while ((size_t)p.ept * SCAN_NT < (size_t)Lmax * R) p.ept <<= 1;
+    p.lch = Lmax <= 128 ? 2 : (Lmax <= 512 ? 8 : 16);
+    const size_t stage = (size_t)Lmax * (R + 1) * 4;
+    const int pad = (4 - ((2 * Lmax) & 3)) & 3;
+    const size_t fixed = (size_t)n2 * 16 + (size_t)(2 * Lmax + pad) * 4 + (size_t)R * 19 * 4 + 96;
+    p.lds = ((fixed + 4 * stage + 15) & ~(size_t)15) + STK_BYTES;
+    const bool scratch_fits = (size_t)((Lmax + 63) / 64) * 64 * 8 <= (size_t)m * (R + 1) * 4;     // inside the memory rows
+    const bool pf_fits = (size_t)i * R <= (size_t)(Lmax > 128 ? SCAN_NT - 320 : SCAN_NT) * scan_pf(R, p.lch);
+    p.ok = p.ept <= 8 && Lmax <= SCAN_NT && pf_fits && scratch_fits && p.lds <= kLdsLimit;
+    return p;
+}
+
+static void fill_scan_args(ScanArgs& a, const ScanCall& c) {
+    a.plog = persist_log();
+    a.lg = c.logits; a.n = c.n; a.m = c.m; a.i = c.i; a.h = c.h; a.T = c.n_token; a.n2 = next_pow2(c.m + c.i);
+    a.it0 = c.it_begin; a.it1 = c.it_end;
+    a.mem_idx = reinterpret_cast<long long*>(c.mem_idx); a.mem_score = c.mem_score; a.tie = c.tie_flag;
+    a.ready = c.ready; a.status = c.status; a.ready_stride = c.ready_stride;
+    a.ready_words = c.ready ? (c.ready_stride ? std::min(c.b, 64) : 1) : 0;
+    a.wait_ticks = (unsigned long long)g_persist_wait_ms * 100000ull;
+    a.cond = c.cond; a.cond_mask = c.cond_mask;
+    a.slides = c.b;
+    a.tie_order = g_tie_order;
+    a.use_lds = 1;
+}
+
+int launch_scan_fast(const ScanCall& c, const FastPlan& fp) {
+    const int b = c.b, R = c.h * c.n_token, n_token = c.n_token;
+    void* const stream = c.stream;
+    ScanArgs a;
+    fill_scan_args(a, c);
+    a.stk_off = (int)(fp.lds - STK_BYTES);
+    const size_t fast = fp.lds;
+    const int ept = fp.ept, lch = fp.lch;
+    unsigned long long* st = g_scan_stamps;
+#define IPSX_LAUNCH_FAST(RR, TT, E, C, S)                                                                           \
+    do {                                                                                                            \
+        if (a.ready) {                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, false, true>),   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                       \
+            scan_fast_kernel<RR, TT, E, C, false, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, nullptr); \
+        } else {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<RR, TT, E, C, S, false>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);                       \
+            scan_fast_kernel<RR, TT, E, C, S, false><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st); \
+        }                                                                                                           \
+        return launched("scan");                                                                                    \
+    } while (0)
+#define IPSX_LAUNCH_FAST_C(RR, TT, E)                                                                               \
+    do {                                                                                                            \
+        if (lch == 2) IPSX_LAUNCH_FAST(RR, TT, E, 2, false);                                                        \
+        else if (lch == 8) IPSX_LAUNCH_FAST(RR, TT, E, 8, false);                                                   \
+        else IPSX_LAUNCH_FAST(RR, TT, E, 16, false);                                                                \
+    } while (0)
+#define IPSX_LAUNCH_FAST_E(RR, TT)                                                                                  \
+    do {                                                                                                            \
+        if (ept == 1) IPSX_LAUNCH_FAST_C(RR, TT, 1);                                                                \
+        else if (ept == 2) IPSX_LAUNCH_FAST_C(RR, TT, 2);                                                           \
+        else if (ept == 4) IPSX_LAUNCH_FAST_C(RR, TT, 4);                                                           \
+        else IPSX_LAUNCH_FAST_C(RR, TT, 8);                                                                         \
+    } while (0)
+    IPSX_REQUIRE(c.workgroups <= 0 || c.workgroups >= b, "scan_persistent_on: fewer workgroups than images only for the shapes of "
+                 "ipsx_scan_persistent_groupable");
+    // the diagnostic (stamped) build exists for the two benchmark shapes
+    if (st && a.ready && R == 8 && n_token == 1 && ept == 4 && lch == 8) {      // stamped persistent loop (diagnostic)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_fast_kernel<8, 1, 4, 8, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);
+        scan_fast_kernel<8, 1, 4, 8, true, true><<<dim3((unsigned)b), dim3(SCAN_NT), fast, as_stream(stream)>>>(a, st);
+        return launched("scan");
+    }
+    if (st && R == 8 && n_token == 1 && ept == 4 && lch == 8) IPSX_LAUNCH_FAST(8, 1, 4, 8, true);
+    if (st && R == 32 && n_token == 4 && ept == 4 && lch == 2) IPSX_LAUNCH_FAST(32, 4, 4, 2, true);
+    if (R == 8 && n_token == 1) IPSX_LAUNCH_FAST_E(8, 1);
+    IPSX_LAUNCH_FAST_E(32, 4);
+#undef IPSX_LAUNCH_FAST_C
+#undef IPSX_LAUNCH_FAST_E
+#undef IPSX_LAUNCH_FAST
+}
+
+}  // namespace ipsx
