@@ -86,22 +86,43 @@ IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
     const unsigned long long h0 = host_ns();
     IPSX_TRY(ipsx_scan_persistent_ws(c->logits, c->b, c->n, c->m, c->i, c->h, c->n_token, c->mem_idx, nullptr, tie, ready,
                                      c->b > 1 ? 1 : 0, status, c->loops, c->scan_workspace, c->scan_workspace_bytes, side));
+    // From here on the resident loop is in flight on the side stream.  A step that fails must not leave it behind
+    // un-joined (advisor, round 5): the loop would spin to its bound, the caller's next call would zero `words` on the
+    // main stream while that old loop still reads them, and nothing would order the two.  Every failure below therefore
+    // goes through `bail`: the loop is told to give up (ready < 0: it leaves at once and sets bit 0 of the status word),
+    // `join` is still recorded on the side stream and waited for on the main stream, and the error is returned.
+    auto bail = [&](int rc) {
+        (void)hipMemsetAsync(ready, 0xFF, (size_t)c->b * sizeof(int32_t), main);     // every progress word negative: give up
+        (void)hipEventRecord(ev->join, side);
+        (void)hipStreamWaitEvent(main, ev->join, 0);
+        return rc;
+    };
+#define IPSX_TRY_JOINED(expr)                 \
+    do {                                      \
+        const int rc_ = (expr);               \
+        if (rc_ != IPSX_OK) return bail(rc_); \
+    } while (0)
     // producers must not take the compute units before a loop has its own (see ipsx_scan_gate)
-    IPSX_TRY(ipsx_scan_gate(status, main));
+    IPSX_TRY_JOINED(ipsx_scan_gate(status, main));
     const int slot = c->timing_slot;
     if (slot >= 0 && slot < kSlots) {
-        if (!ev->t0[slot]) {
-            IPSX_TRY(hip_ok(hipEventCreate(&ev->t0[slot]), "timing event"));
-            IPSX_TRY(hip_ok(hipEventCreate(&ev->t1[slot]), "timing event"));
+        if (!ev->t0[slot]) {                      // both events, or neither: a half-made pair would record a null event later
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                return bail(fail(IPSX_EHIP, "ips_call: timing event"));
+            }
+            ev->t0[slot] = e0;
+            ev->t1[slot] = e1;
         }
-        IPSX_TRY(hip_ok(hipEventRecord(ev->t0[slot], main), "timing event"));
+        IPSX_TRY_JOINED(hip_ok(hipEventRecord(ev->t0[slot], main), "timing event"));
     }
     if (c->trunk)
-        IPSX_TRY(ipsx_trunk_stream(c->trunk, static_cast<const float*>(c->x), c->n, c->emb, c->pos, c->v_packed, c->r, c->logits, ctl,
-                                   ready, c->workgroups, c->quad_pulls, main));
+        IPSX_TRY_JOINED(ipsx_trunk_stream(c->trunk, static_cast<const float*>(c->x), c->n, c->emb, c->pos, c->v_packed, c->r, c->logits, ctl,
+                                          ready, c->workgroups, c->quad_pulls, main));
     else
-        IPSX_TRY(ipsx_projector_stream(c->lin, static_cast<const float*>(c->x), (int64_t)c->b * c->n, c->n, c->ln_eps, c->emb, c->v_packed,
-                                       c->r, c->logits, ctl, ready, c->workgroups, c->short_first, main));
+        IPSX_TRY_JOINED(ipsx_projector_stream(c->lin, static_cast<const float*>(c->x), (int64_t)c->b * c->n, c->n, c->ln_eps, c->emb, c->v_packed,
+                                              c->r, c->logits, ctl, ready, c->workgroups, c->short_first, main));
     {
         const unsigned long long gap = host_ns() - h0;
         unsigned long long seen = g_gap_max.load(std::memory_order_relaxed);
@@ -109,9 +130,10 @@ IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
         if (gap > 10000000ull) g_gap_long.fetch_add(1, std::memory_order_relaxed);
         g_gap_calls.fetch_add(1, std::memory_order_relaxed);
     }
-    if (slot >= 0 && slot < kSlots) IPSX_TRY(hip_ok(hipEventRecord(ev->t1[slot], main), "timing event"));
-    IPSX_TRY(hip_ok(hipEventRecord(ev->join, side), "event"));
+    if (slot >= 0 && slot < kSlots) IPSX_TRY_JOINED(hip_ok(hipEventRecord(ev->t1[slot], main), "timing event"));
+    IPSX_TRY_JOINED(hip_ok(hipEventRecord(ev->join, side), "event"));
     IPSX_TRY(hip_ok(hipStreamWaitEvent(main, ev->join, 0), "wait"));
+#undef IPSX_TRY_JOINED
     // a loop that gave up waiting is redone here, in the same call (a no-op otherwise)
     IPSX_TRY(ipsx_scan_range_if_ws(c->logits, c->b, c->n, c->m, c->i, c->h, c->n_token, 0, n_iter, c->mem_idx, nullptr, tie, status, 1,
                                    c->scan_workspace, c->scan_workspace_bytes, main));

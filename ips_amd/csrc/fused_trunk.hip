@@ -868,9 +868,9 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
             static bool attr_v2 = false;
             if (!attr_v2) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v2_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v2_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
                 attr_v2 = true;
             }
             // One workgroup per quad by default.  IPSX_BF16_PERSIST=1: two workgroups per unit take the launch's quads in
@@ -879,8 +879,10 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
             // launch is over: measured inside ips() 26.5 -> 22.2 M patches/s, so it is not the default
             static const bool persist = [] { const char* e = getenv("IPSX_BF16_PERSIST"); return e && e[0] == '1'; }();
             const dim3 pgrid((unsigned)(persist ? std::min<int64_t>(cdiv(n, 4), 2 * (int64_t)device_cus()) : cdiv(n, 4)));
-            if (stamps) fused_trunk_bf16v2_kernel<true><<<pgrid, block, V2_LDS, s>>>(a, stamps);
-            else fused_trunk_bf16v2_kernel<false><<<pgrid, block, V2_LDS, s>>>(a, nullptr);
+            // (diagnostic: IPSX_BF16_ONE_WG=1 asks for more LDS than two workgroups get - ONE workgroup, one wave per SIMD)
+            static const size_t lds_v2 = [] { const char* e = getenv("IPSX_BF16_ONE_WG"); return (size_t)(e && e[0] == '1' ? 100 * 1024 : V2_LDS); }();
+            if (stamps) fused_trunk_bf16v2_kernel<true><<<pgrid, block, lds_v2, s>>>(a, stamps);
+            else fused_trunk_bf16v2_kernel<false><<<pgrid, block, lds_v2, s>>>(a, nullptr);
             return launched("fused_trunk_bf16v2");
         }
         if (x3 && stamps) fused_trunk_x3_kernel<true><<<grid, block, ldsx, s>>>(a, stamps);

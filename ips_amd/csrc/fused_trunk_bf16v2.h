@@ -20,9 +20,17 @@
 // Arithmetic: exactly the first build's (same operand rounding, same products; fp32 identity) - the embeddings of the two
 // builds are bit-identical (tests/test_hip_kernels.py::test_bf16_trunk_builds_agree).
 
-constexpr int V2_SLAB = XL<1>::SLAB;          // 9,360 B: a patch's 8x8 image (65 pixel rows of 144 B)
+// A patch's slab: its 8x8 image (65 pixel rows of 144 B = 9,360 B) rounded up to a multiple of 256 B.  The 4x4 stage reads
+// TWO patches per ds_read_b128 (lanes 0-15 | 16-31); the LDS serves such a read in groups of 16 lanes that mix the two
+// patches, conflict-free only when the second patch's rows fall on the bank slots the first one leaves free - which they do
+// when the patches lie a multiple of 256 B apart.  (The first build's 9,360 B put 7 of 16 lanes of every group on a taken
+// slot: the 4x4 stage ran at 1.8-2.1 x its matrix-pipe time even with the unit to itself, 2.8 beside a second wave -
+// it was LDS-bound.)  The 4x4 images (17 rows of 272 B) get a stride of their own, V2_S2, for the same reason.
+constexpr int V2_SLAB = (XL<1>::SLAB + 255) & ~255;      // 9,472 B
+constexpr int V2_S2 = ((XZ2 + 1) * XP2 + 255) & ~255;   // 4,864 B: a patch's 4x4 image (16 pixel rows + the zero row)
 constexpr int V2_BUF = 4 * V2_SLAB;           // one set of images: the four patches' slabs, one after the other
-constexpr int V2_LDS = 2 * V2_BUF;            // 74,880 B per workgroup
+constexpr int V2_LDS = 2 * V2_BUF;            // 75,776 B per workgroup
+static_assert(V2_LDS <= 80 * 1024 && 4 * V2_S2 <= V2_BUF && V2_SLAB >= 16 * PS2 * 4, "two workgroups per unit");
 
 #define V2_SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define V2_SG_LDS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
@@ -43,11 +51,12 @@ __device__ __forceinline__ unsigned v2_tap_off(int tap, int h, int i, int half) 
 __device__ __forceinline__ void conv_l1v2(const void* __restrict__ wp, const char* P0, int rt, f32x16 (&acc)[4], int lane) {
     constexpr int WR = 8, XR = 3, G = 36;          // weight ring (7 K-steps ahead), activation ring (2 ahead), K-steps
     const int i = lane & 31, half = lane >> 5;
-    const char* wb = reinterpret_cast<const char*>(wp) + (size_t)rt * G * 1024 + lane * 16;
+    const char* wb = reinterpret_cast<const char*>(wp) + (size_t)rt * G * 1024;      // wave-uniform: scalar base ...
+    const unsigned lo = lane * 16;                                                  // ... + the only vector part
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) zero(acc[ct]);
     uint4 wr[WR], xr[XR][4];
-#define V2_LOADW(g) wr[(g) % WR] = *reinterpret_cast<const uint4*>(wb + (size_t)((g) < G ? (g) : G - 1) * 1024)
+#define V2_LOADW(g) wr[(g) % WR] = *reinterpret_cast<const uint4*>(wb + (size_t)((g) < G ? (g) : G - 1) * 1024 + lo)
 #define V2_LOADX(g)                                                                                              \
     do {                                                                                                         \
         const int g_ = (g) < G ? (g) : G - 1;                                                                    \
@@ -106,7 +115,7 @@ __device__ __forceinline__ void epilogue_l1v2(char* Q0, const float* __restrict_
 // (same tiles, same products as fused_trunk_split.h conv_l2s<1, ...>: wave = 32 output channels x the four patches' 64
 //  pixels; a K-step = 2 MFMAs - 64 pipe cycles - on 1 KB of weights, so the weight ring holds TWELVE K-steps, requested
 //  eleven ahead; activations three ahead.  Passes of 12 K-steps: both rings close.)
-template <int CIN, int WIN, int RB, int ZR, int STRIDE, int KS>
+template <int CIN, int WIN, int RB, int ZR, int STRIDE, int KS, int PSTR>
 __device__ __forceinline__ void conv_l2v2(const void* __restrict__ wp, const char* lds, f32x16 (&acc)[2], int lane, int wave) {
     constexpr int TAPS = KS * KS, SPT = CIN / 16, G = TAPS * SPT;          // K-steps per tap, K-steps
     constexpr int TPP = TAPS < 3 ? TAPS : 3, PASS = TPP * SPT;             // a pass = 3 taps (12 or 24 K-steps; 1x1: all 4)
@@ -115,7 +124,8 @@ __device__ __forceinline__ void conv_l2v2(const void* __restrict__ wp, const cha
     static_assert(G % PASS == 0 && (G == PASS || (PASS % XR == 0 && PASS % WR == 0)) && XA < SPT, "passes close the rings");
     const int i = lane & 31, half = lane >> 5;
     const int pix = i & 15, oy = pix >> 2, ox = pix & 3;
-    const char* wb = reinterpret_cast<const char*>(wp) + (size_t)wave * G * 1024 + lane * 16;
+    const char* wb = reinterpret_cast<const char*>(wp) + (size_t)wave * G * 1024;    // wave-uniform
+    const unsigned lo = lane * 16;
     zero(acc[0]); zero(acc[1]);
     uint4 wr[WR], xr[XR][2];
     // this lane's source pixel row for a tap (the zero row for a halo tap): computed once per tap, the K-steps of a tap are
@@ -126,17 +136,17 @@ __device__ __forceinline__ void conv_l2v2(const void* __restrict__ wp, const cha
         const int ky = tap / KS, kx = tap - ky * KS;
         const int iy = oy * STRIDE + ky - PAD, ix = ox * STRIDE + kx - PAD;
         const bool ok = (unsigned)iy < (unsigned)WIN && (unsigned)ix < (unsigned)WIN;
-        return (unsigned)((i >> 4) * V2_SLAB + 16 * half + (ok ? iy * WIN + ix : ZR) * RB);
+        return (unsigned)((i >> 4) * PSTR + 16 * half + (ok ? iy * WIN + ix : ZR) * RB);
     };
 #pragma unroll
-    for (int g = 0; g < WR - 1; ++g) wr[g] = *reinterpret_cast<const uint4*>(wb + (size_t)(g < G ? g : G - 1) * 1024);
+    for (int g = 0; g < WR - 1; ++g) wr[g] = *reinterpret_cast<const uint4*>(wb + (size_t)(g < G ? g : G - 1) * 1024 + lo);
     unsigned rows[TPP + 1];
 #pragma unroll
     for (int t = 0; t <= TPP; ++t) rows[t] = tap_row(t);
 #pragma unroll
     for (int g = 0; g < XA; ++g) {
         xr[g][0] = *reinterpret_cast<const uint4*>(lds + rows[0] + g * 32);
-        xr[g][1] = *reinterpret_cast<const uint4*>(lds + rows[0] + g * 32 + 2 * V2_SLAB);
+        xr[g][1] = *reinterpret_cast<const uint4*>(lds + rows[0] + g * 32 + 2 * PSTR);
     }
 #pragma unroll 1
     for (int g0 = 0; g0 < G; g0 += PASS) {
@@ -146,9 +156,9 @@ __device__ __forceinline__ void conv_l2v2(const void* __restrict__ wp, const cha
             {   // activations of K-step g + XA: tap (u + XA) / SPT of this pass (the last: the first tap of the next pass)
                 const unsigned p = rows[(u + XA) / SPT] + ((u + XA) % SPT) * 32;
                 xr[(u + XA) % XR][0] = *reinterpret_cast<const uint4*>(lds + p);
-                xr[(u + XA) % XR][1] = *reinterpret_cast<const uint4*>(lds + p + 2 * V2_SLAB);
+                xr[(u + XA) % XR][1] = *reinterpret_cast<const uint4*>(lds + p + 2 * PSTR);
             }
-            wr[(u + WR - 1) % WR] = *reinterpret_cast<const uint4*>(wb + (size_t)(g + WR - 1 < G ? g + WR - 1 : G - 1) * 1024);
+            wr[(u + WR - 1) % WR] = *reinterpret_cast<const uint4*>(wb + (size_t)(g + WR - 1 < G ? g + WR - 1 : G - 1) * 1024 + lo);
             acc[0] = MFMA16(wr[u % WR], xr[u % XR][0], acc[0]);
             acc[1] = MFMA16(wr[u % WR], xr[u % XR][1], acc[1]);
             V2_SG_MFMA(1); V2_SG_LDS(2); V2_SG_VMEM(1); V2_SG_MFMA(1);
@@ -188,6 +198,39 @@ __device__ __forceinline__ void v2_fetch(const FusedArgs& a, long long pi, int l
 // PERSISTENT: the workgroup takes quads blockIdx.x, blockIdx.x + gridDim.x, ... of the launch (the grid is two workgroups
 // per unit): no dispatch gap between one quad and the next, and the next quad's pixels are requested while the 4x4 stage
 // of the current one runs.
+// epilogue of the 4x4 stage (fused_trunk_split.h epilogue_l2s<1, MODE>'s arithmetic) with this build's patch strides:
+// v[ct][r] = channel 32 wave + (r&3) + 8(r>>2) + 4 half of patch 2 ct + (i>>4), pixel i & 15.  MODE 0: BN + ReLU -> bf16 image
+// (patches V2_S2 apart);  1: BN + identity + ReLU -> image, identity updated;  2: like 1, stored as fp32 [pix][PS2] (patches
+// V2_SLAB apart) for the average pool
+template <int MODE>
+__device__ __forceinline__ void epilogue_l2v2(char* lds, const float* __restrict__ al, const float* __restrict__ sh,
+                                              const f32x16 (&acc)[2], f32x16 (&id2)[2], int lane, int wave) {
+    const int i = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch = 32 * wave + 8 * g + 4 * half;
+        const float4 A = *reinterpret_cast<const float4*>(al + ch), B = *reinterpret_cast<const float4*>(sh + ch);
+        const float Aa[4] = {A.x, A.y, A.z, A.w}, Bb[4] = {B.x, B.y, B.z, B.w};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = __builtin_fmaf(acc[ct][4 * g + j], Aa[j], Bb[j]);
+                if (MODE != 0) x = x + id2[ct][4 * g + j];
+                x = x > 0.0f ? x : 0.0f;
+                if (MODE != 0) id2[ct][4 * g + j] = x;
+                v[j] = x;
+            }
+            if (MODE == 2)
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(lds + (2 * ct + (i >> 4)) * V2_SLAB) + (i & 15) * PS2 + ch) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            else
+                store_planes4<1>(lds + (2 * ct + (i >> 4)) * V2_S2 + (i & 15) * XP2 + 2 * ch, XP2, v);
+        }
+    }
+}
+
 template <bool STAMP>
 __device__ __forceinline__ void fused_trunk_bf16v2_body(const FusedArgs& a, unsigned long long* stamps, char* ldsx) {
     constexpr int R1 = XL<1>::R1, R2 = XL<1>::R2;
@@ -305,8 +348,8 @@ __device__ __forceinline__ void fused_trunk_bf16v2_body(const FusedArgs& a, unsi
 
     // ---- layer2 (the first build's tiles: wave = 32 output channels x the four patches): 8x8 images in set 1
     f32x16 t2[2], id2[2];
-    conv_l2v2<64, 8, R1, XZ1, 2, 3>(a.wh[4], buf1, t2, lane, wave);
-    conv_l2v2<64, 8, R1, XZ1, 2, 1>(a.wh_down, buf1, id2, lane, wave);
+    conv_l2v2<64, 8, R1, XZ1, 2, 3, V2_SLAB>(a.wh[4], buf1, t2, lane, wave);
+    conv_l2v2<64, 8, R1, XZ1, 2, 1, V2_SLAB>(a.wh_down, buf1, id2, lane, wave);
     {   // projection shortcut: BatchNorm only, kept in fp32 registers
         const int half = lane >> 5;
 #pragma unroll
@@ -321,21 +364,21 @@ __device__ __forceinline__ void fused_trunk_bf16v2_body(const FusedArgs& a, unsi
         }
     }
     IPSX_STAMP(11);
-    epilogue_l2s<1, 0>(buf0, a.al[4], a.sh[4], t2, id2, lane, wave);          // 4x4 images into set 0 (set 1 is still read)
-    for (int z = lane; z < R2 / 4; z += 64) reinterpret_cast<unsigned*>(Sb + XZ2 * R2)[z] = 0u;
+    epilogue_l2v2<0>(buf0, a.al[4], a.sh[4], t2, id2, lane, wave);          // 4x4 images into set 0 (set 1 is still read)
+    for (int z = lane; z < R2 / 4; z += 64) reinterpret_cast<unsigned*>(buf0 + wave * V2_S2 + XZ2 * R2)[z] = 0u;
     __syncthreads();                                  // every wave is done with the 8x8 images
-    for (int z = lane; z < R2 / 4; z += 64) reinterpret_cast<unsigned*>(Sb + V2_BUF + XZ2 * R2)[z] = 0u;
+    for (int z = lane; z < R2 / 4; z += 64) reinterpret_cast<unsigned*>(buf1 + wave * V2_S2 + XZ2 * R2)[z] = 0u;
     // l2.0.c2: set 0 -> 1;  l2.1.c1: 1 -> 0;  l2.1.c2: 0 -> fp32 [pix][PS2] in set 1 (the average pool reads it)
-    conv_l2v2<128, 4, R2, XZ2, 1, 3>(a.wh[5], buf0, t2, lane, wave);
-    epilogue_l2s<1, 1>(buf1, a.al[5], a.sh[5], t2, id2, lane, wave);
+    conv_l2v2<128, 4, R2, XZ2, 1, 3, V2_S2>(a.wh[5], buf0, t2, lane, wave);
+    epilogue_l2v2<1>(buf1, a.al[5], a.sh[5], t2, id2, lane, wave);
     __syncthreads();
     IPSX_STAMP(12);
-    conv_l2v2<128, 4, R2, XZ2, 1, 3>(a.wh[6], buf1, t2, lane, wave);
-    epilogue_l2s<1, 0>(buf0, a.al[6], a.sh[6], t2, id2, lane, wave);
+    conv_l2v2<128, 4, R2, XZ2, 1, 3, V2_S2>(a.wh[6], buf1, t2, lane, wave);
+    epilogue_l2v2<0>(buf0, a.al[6], a.sh[6], t2, id2, lane, wave);
     __syncthreads();
     IPSX_STAMP(13);
-    conv_l2v2<128, 4, R2, XZ2, 1, 3>(a.wh[7], buf0, t2, lane, wave);
-    epilogue_l2s<1, 2>(buf1, a.al[7], a.sh[7], t2, id2, lane, wave);
+    conv_l2v2<128, 4, R2, XZ2, 1, 3, V2_S2>(a.wh[7], buf0, t2, lane, wave);
+    epilogue_l2v2<2>(buf1, a.al[7], a.sh[7], t2, id2, lane, wave);
     __syncthreads();
     IPSX_STAMP(14);
     for (int o = threadIdx.x; o < 4 * 128; o += 256) {

@@ -38,7 +38,14 @@ template <int PL> struct XL {
 
 __device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) { return (unsigned)bf16_bits(a) | ((unsigned)bf16_bits(b) << 16); }
+// (a, b) -> two bfloat16 in one register, a in the low half: ONE v_cvt_pk_bf16_f32 (written as two scalar conversions and an
+// or, the compiler paired the wrong elements and repaired the order with four more instructions per pair)
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    const pk_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_bf16x2));
+}
 
 // 4 consecutive channels of one pixel -> PL planes, 4 bf16 (8 bytes) per plane; PL = 3: hi + mid + lo == x exactly
 template <int PL>
