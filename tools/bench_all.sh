@@ -13,5 +13,6 @@ IPSX_IMAGE_STREAM=0 python bench.py --config b1 --cpu-seconds 0 2>/dev/null     
 IPSX_IMAGE_STREAM=0 python bench.py --config b1 --cpu-seconds 0 --no-kernel-events 2>/dev/null  # ... and without the bench's own event records
 python bench.py --precision fp32x3 --cpu-seconds 0 2>/dev/null
 python bench.py --precision bf16 --cpu-seconds 0 2>/dev/null
+python bench.py --precision bf16 --storage f16 --cpu-seconds 0 2>/dev/null      # BASELINE configs[4] as written: fp16-stored patches
 python bench.py --lazy --cpu-seconds 0 2>/dev/null
 python bench.py --dedup-blank --cpu-seconds 0 2>/dev/null

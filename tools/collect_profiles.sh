@@ -26,10 +26,10 @@ for c in mnist cam native50 traffic; do
 done
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic_before.json"
 python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip,fused_trunk_pair.h "fused_trunk_kernel|fused_trunk_pair_kernel" 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err"
-python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam_parts 8 conv_nhwc.hip,aggregate.hip,scorer.hip > "$OUT/pmc_cam_parts.json" 2> "$OUT/pmc_cam_parts.err"
+python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam_parts 8 conv_nhwc.hip,aggregate.hip,scorer.hip,scan_cam.hip,scan_common.h,logits.hip > "$OUT/pmc_cam_parts.json" 2> "$OUT/pmc_cam_parts.err"
 python tools/pmc_traffic.py /tmp/pmc_stream_FETCH_SIZE /tmp/pmc_stream_WRITE_SIZE cam 5 conv_nhwc.hip,ipsx_rowstats.h "projector_stream_kernel" 65536 > "$OUT/pmc_cam.json" 2> "$OUT/pmc_cam.err"
-python tools/pmc_traffic.py /tmp/pmc_traffic_FETCH_SIZE /tmp/pmc_traffic_WRITE_SIZE traffic 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_traffic_signs.json" 2> "$OUT/pmc_traffic_signs.err"
-python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err"
+python tools/pmc_traffic.py /tmp/pmc_traffic_FETCH_SIZE /tmp/pmc_traffic_WRITE_SIZE traffic 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip,scan_fast.hip,scan_common.h,logits.hip > "$OUT/pmc_traffic_signs.json" 2> "$OUT/pmc_traffic_signs.err"
+python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip,scan_fast.hip,scan_common.h,logits.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err"
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
 python tools/scan_compare.py > "$OUT/scan_compare.txt" 2>&1
 python tools/scan_stamps.py camwaves > "$OUT/scan_camwaves.txt" 2>&1
@@ -71,4 +71,14 @@ IPSX_SOAK_THREADS=0 python tools/soak.py 240 20 2>&1 | grep -v "amdgpu.ids" > "$
 python tools/fuzz_scan.py 1000 30000 4000 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_scan.txt"
 python tools/fuzz_e2e.py 100 400 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_e2e.txt"
 python tools/fuzz_pipelines.py 0 750 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_pipelines.txt"
+# round 6: the bf16 trunk's phases (second build; alone on its unit; the first build), the parity margins, the sharded path
+# with more than one rank on this GPU (fp32 and configs[4]: bf16 pipe + fp16-stored patches)
+python tools/fused_stamps.py 40000 bf16 2>&1 | grep -v "amdgpu.ids" > "$OUT/fused_stamps_bf16v2.txt"
+{ echo "# IPSX_BF16_ONE_WG=1: one workgroup per unit (one wave per SIMD)"; IPSX_BF16_ONE_WG=1 python tools/fused_stamps.py 40000 bf16; } 2>&1 | grep -v "amdgpu.ids" >> "$OUT/fused_stamps_bf16v2.txt"
+{ echo "# IPSX_BF16_BUILD=1: the first build (fused_trunk_split.h)"; IPSX_BF16_BUILD=1 python tools/fused_stamps.py 40000 bf16; } 2>&1 | grep -v "amdgpu.ids" >> "$OUT/fused_stamps_bf16v2.txt"
+python tools/fused_stamps.py 40000 fp32x3 2>&1 | grep -v "amdgpu.ids" > "$OUT/fused_stamps_x3.txt"
+python -m pytest tests/test_parity_margin.py -q -m gpu -s 2>&1 | grep -v "amdgpu.ids" > "$OUT/parity_margin.txt"
+for w in 2 4; do for ps in "fp32 f32" "bf16 f16"; do set -- $ps
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $w --master-addr 127.0.0.1 --master-port 2957$w tools/dist_check.py --backend gloo --share-gpu --bench-shape --precision $1 --storage $2 --cases mnist_ragged,mnist_full 2>&1 | grep "rank "
+done; done > "$OUT/dist_check.txt"
 echo done

@@ -14,9 +14,9 @@ for c in "$@"; do
   done
   case $c in
     mnist) python tools/pmc_traffic.py /tmp/pmc_mnist_FETCH_SIZE /tmp/pmc_mnist_WRITE_SIZE mnist 8 fused_trunk.hip,fused_trunk_pair.h "fused_trunk_kernel|fused_trunk_pair_kernel" 10000 > "$OUT/pmc_mnist.json" 2> "$OUT/pmc_mnist.err";;
-    traffic) python tools/pmc_traffic.py /tmp/pmc_traffic_FETCH_SIZE /tmp/pmc_traffic_WRITE_SIZE traffic 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_traffic_signs.json" 2> "$OUT/pmc_traffic_signs.err";;
-    native50) python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err";;
-    cam) python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam_parts 8 conv_nhwc.hip,aggregate.hip,scorer.hip > "$OUT/pmc_cam_parts.json" 2> "$OUT/pmc_cam_parts.err";;
+    traffic) python tools/pmc_traffic.py /tmp/pmc_traffic_FETCH_SIZE /tmp/pmc_traffic_WRITE_SIZE traffic 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip,scan_fast.hip,scan_common.h,logits.hip > "$OUT/pmc_traffic_signs.json" 2> "$OUT/pmc_traffic_signs.err";;
+    native50) python tools/pmc_traffic.py /tmp/pmc_native50_FETCH_SIZE /tmp/pmc_native50_WRITE_SIZE native50 8 fused_stage.hip,conv_nhwc.hip,conv.hip,trunk.hip,scorer.hip,scan_fast.hip,scan_common.h,logits.hip > "$OUT/pmc_native50.json" 2> "$OUT/pmc_native50.err";;
+    cam) python tools/pmc_traffic.py /tmp/pmc_cam_FETCH_SIZE /tmp/pmc_cam_WRITE_SIZE cam_parts 8 conv_nhwc.hip,aggregate.hip,scorer.hip,scan_cam.hip,scan_common.h,logits.hip > "$OUT/pmc_cam_parts.json" 2> "$OUT/pmc_cam_parts.err";;
   esac
 done
 cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
