@@ -383,391 +383,6 @@ def _patches(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# ------------------------------------------------------------------ encoder plan
-def _bn_affine(bn, bias=None):
-    """Per-channel (alpha, shift) of an eval-mode BatchNorm, on the device."""
-    c = bn.num_features
-    out = torch.empty((2, c), dtype=torch.float32, device=bn.weight.device)
-    lin_bias = _f32(bias.detach()) if bias is not None else None
-    _ck(lib().ipsx_bn_affine(_p(_f32(bn.weight.detach())), _p(_f32(bn.bias.detach())),
-                             _p(_f32(bn.running_mean)), _p(_f32(bn.running_var)), _p(lin_bias),
-                             C.c_float(bn.eps), c, _p(out[0]), _p(out[1]), _stream()), "ipsx_bn_affine")
-    return out
-
-
-def _pack_conv(weight):
-    co, ci, kh, kw = weight.shape
-    n = lib().ipsx_packed_conv_weight_elems(co, ci, kh, kw)
-    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
-    _ck(lib().ipsx_pack_conv_weight(_p(_f32(weight.detach())), co, ci, kh, kw, _p(packed), _stream()),
-        "ipsx_pack_conv_weight")
-    return packed
-
-
-class _PlanHold:
-    """``EncoderPlan.hold()``: the plan's weight check runs on entry and is skipped until exit."""
-    __slots__ = ("plan",)
-
-    def __init__(self, plan):
-        self.plan = plan
-
-    def __enter__(self):
-        self.plan._refresh()
-        self.plan._held += 1
-
-    def __exit__(self, *exc):
-        self.plan._held -= 1
-
-
-class EncoderPlan:
-    """Device-side description of ``IPSNet.encoder``: packed weights + BN affines.
-
-    Parameters change every optimiser step and BatchNorm running statistics move
-    in every training-mode forward, so the plan is keyed on the tensors'
-    ``_version`` counters / storage pointers and re-packed when any moved.
-    """
-
-    def __init__(self, encoder, is_image):
-        self.encoder, self.is_image = encoder, is_image
-        self._sig = None
-        self._holders = None
-        self._keep = []
-        self._ws = None
-        self._ws_small = 0
-        self._held = 0
-
-    def _walk(self):
-        """The module tree, flattened ONCE: every module's child dictionary (the structural fingerprint is the ids of their
-        values, re-read in every call - plain dictionary reads, ~5 us for a ResNet trunk, where ``encoder.modules()`` costs
-        ~100 us in front of the first launch of EVERY ips() call), the (dictionary, key) slot of every parameter / buffer
-        that exists, and the slots that are None today (a bias or a running statistic that appears later is seen)."""
-        kids, slots, empty = [], [], []
-        for mod in self.encoder.modules():
-            kids.append(mod._modules)
-            for d in (mod._parameters, mod._buffers):
-                for k, t in d.items():
-                    (slots if t is not None else empty).append((d, k))
-        return kids, slots, empty
-
-    @staticmethod
-    def _structure(kids):
-        return tuple(id(c) for d in kids for c in d.values())
-
-    def _signature(self):
-        """(storage pointer, version counter) of every parameter and buffer + the ids of every child module: a tensor that
-        is replaced, moved or written in place, a child module exchanged at ANY depth (``layer2[0].bn1 = ...``,
-        ``convert_sync_batchnorm``), an entry that appears, disappears or stops being None - each re-packs the plan."""
-        h = self._holders
-        if h is not None:
-            try:
-                if self._structure(h[1]) != h[0] or any(d[k] is not None for d, k in h[3]):
-                    h = None
-            except KeyError:
-                h = None
-        for _ in range(2):
-            if h is None:
-                kids, slots, empty = self._walk()
-                h = self._holders = (self._structure(kids), kids, slots, empty)
-            sig = [precision(), weights_generation(), h[0]]
-            try:
-                for d, k in h[2]:
-                    t = d[k]
-                    sig.append((t.data_ptr(), t._version))
-                return tuple(sig)
-            except (KeyError, AttributeError):         # an entry was removed / set to None since the walk: walk again
-                h = None
-        raise RuntimeError("EncoderPlan: the encoder's parameters changed while they were being read")
-
-    def _conv(self, conv, bn, prec=0, stem=False):
-        packed = _pack_conv(conv.weight)
-        aff = _bn_affine(bn)
-        self._keep += [packed, aff]
-        half = None
-        if prec and stem:
-            if tuple(conv.weight.shape[1:]) == (1, 7, 7):     # the split trunks exist for the 1x32x32 stem only
-                w = _f32(conv.weight.detach())
-                planes = 1 if prec == 1 else 3
-                half = torch.empty(lib().ipsx_packed_stem_weight_split_bytes(w.shape[0], planes), dtype=torch.uint8, device=w.device)
-                _ck(lib().ipsx_pack_stem_weight_split(_p(w), w.shape[0], planes, _p(half), _stream()), "ipsx_pack_stem_weight_split")
-                self._keep.append(half)
-        elif prec:
-            w = _f32(conv.weight.detach())
-            co, ci, kh, kw = w.shape
-            size, pack = ((lib().ipsx_packed_conv_weight_bf16_bytes, lib().ipsx_pack_conv_weight_bf16) if prec == 1 else
-                          (lib().ipsx_packed_conv_weight_x3_bytes, lib().ipsx_pack_conv_weight_x3))
-            half = torch.empty(size(co, ci, kh, kw), dtype=torch.uint8, device=w.device)
-            _ck(pack(_p(w), co, ci, kh, kw, _p(half), _stream()), "ipsx_pack_conv_weight_bf16/x3")
-            self._keep.append(half)
-        return Conv(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
-                    conv.stride[0], conv.padding[0], _p(packed), _p(aff[0]), _p(aff[1]), _p(half))
-
-    def _rebuild(self):
-        self._keep = []
-        enc = self.encoder
-        if self.is_image:
-            mods = list(enc.children())
-            bf16 = {"fp32": 0, "bf16": 1, "fp32x3": 2}[precision()]
-            blocks = []
-            for stage in mods[4:-1]:
-                for blk in stage.children():
-                    b = Block()
-                    pairs = [(getattr(blk, "conv%d" % i), getattr(blk, "bn%d" % i))
-                             for i in (1, 2, 3) if hasattr(blk, "conv%d" % i)]
-                    b.n_conv = len(pairs)
-                    for j, (cv, bn) in enumerate(pairs):
-                        b.conv[j] = self._conv(cv, bn, bf16)
-                    b.has_down = int(blk.downsample is not None)
-                    if b.has_down:
-                        b.down = self._conv(blk.downsample[0], blk.downsample[1], bf16)
-                    blocks.append(b)
-            self._blocks = (Block * len(blocks))(*blocks)
-            t = Trunk()
-            t.stem = self._conv(mods[0], mods[1], bf16, stem=True)
-            t.c_in = mods[0].in_channels
-            t.n_block = len(blocks)
-            t.blocks = C.cast(self._blocks, C.POINTER(Block))
-            t.precision = bf16
-            t.patch_dtype = 0
-            self.trunk = t
-            self.d_out = blocks[-1].conv[blocks[-1].n_conv - 1].c_out
-        else:
-            ln, lin, bn = enc[0], enc[1], enc[2]
-            w = lin.weight.detach()
-            packed = _pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1))
-            aff = _bn_affine(bn, bias=lin.bias)
-            # the LayerNorm in front of the Linear is folded into the GEMM's epilogue: rstd * (x W^T - mean * colsum(W))
-            colsum = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
-            wf = _f32(w)
-            _ck(lib().ipsx_weight_colsum(_p(wf), w.shape[0], w.shape[1], _p(colsum), _stream()), "ipsx_weight_colsum")
-            self._keep += [packed, aff, colsum, wf]
-            self.lin = Conv(w.shape[1], w.shape[0], 1, 1, 1, 0, _p(packed), _p(aff[0]), _p(aff[1]), None, _p(colsum))
-            self.ln_eps = float(ln.eps)
-            self.d_out = w.shape[0]
-
-    def _workspace(self, nbytes, device):
-        # grown on demand; given back when much smaller requests keep coming (one large evaluation call must not pin
-        # tens of GiB for the rest of a training run) - after several in a row, not after one: lazy slabs of 1/6, 1/2 and
-        # full size, or an eval call between training steps, would otherwise free and re-allocate gigabytes per call
-        small = self._ws is not None and self._ws.numel() > (256 << 20) and nbytes < self._ws.numel() // 4
-        self._ws_small = self._ws_small + 1 if small else 0
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device or self._ws_small >= 8:
-            self._ws = None
-            self._ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-            self._ws_small = 0
-        return self._ws
-
-    def _refresh(self):
-        if self._held:
-            return
-        sig = self._signature()
-        if sig != self._sig:
-            self._rebuild()
-            self._sig = sig
-
-    def hold(self):
-        """Context manager: check the weights once, then skip the check until the block ends - for a caller that makes
-        several encode calls while the weights cannot change (one no-grad ``ips()`` call; the check walks ~80 tensors)."""
-        return _PlanHold(self)
-
-    def fused(self, x_shape):
-        """True when encode_indexed is available for patches of this (C, h, w)."""
-        if not self.is_image:
-            return False
-        self._refresh()
-        self.trunk.h, self.trunk.w = x_shape[-2], x_shape[-1]
-        return x_shape[-3] == self.trunk.c_in and lib().ipsx_trunk_kernel(C.byref(self.trunk)).startswith(b"fused")
-
-    def encode_indexed(self, flat, index):
-        """flat (P, C, h, w) contiguous on the GPU, index (n,) int32 -> (n, D) embeddings of flat[index]."""
-        self._refresh()
-        flat = _patches(flat)
-        self.trunk.patch_dtype = _PATCH_DTYPES[flat.dtype]
-        out = torch.empty((index.numel(), self.d_out), dtype=torch.float32, device=flat.device)
-        try:
-            _ck(lib().ipsx_trunk_encode_indexed(C.byref(self.trunk), _p(flat), _p(index), index.numel(), _p(out),
-                                                _stream()), "ipsx_trunk_encode_indexed")
-        finally:
-            self.trunk.patch_dtype = 0
-        return out
-
-    def encode_plain(self, x, out=None):
-        """The image trunk on every patch of ``x`` (no dedup)."""
-        x = _patches(x)
-        n = x.shape[0]
-        if out is None:
-            out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
-        self.trunk.patch_dtype = _PATCH_DTYPES[x.dtype]
-        try:
-            # Layer-by-layer trunks: the batch goes through in two halves on two streams.  The stem and the max-pool are
-            # HBM-bound (together 11-13 % of the trunk's time for 1 % of its arithmetic), the residual stages MFMA-bound:
-            # side by side, one half's stem / pool / epilogues fill what the other half's convolutions leave idle
-            # (50-px MNIST 14.25 -> 13.89 ms, traffic signs 22.75 -> 22.11 ms; three streams gain less).  Same kernels on
-            # the same patches: results are unchanged.  IPSX_LAYERED_STREAMS=1 switches it off.
-            ns = int(os.environ.get("IPSX_LAYERED_STREAMS", "2"))
-            if ns > 1 and n >= 1024 and not lib().ipsx_trunk_kernel(C.byref(self.trunk)).startswith(b"fused"):
-                cuts = [n * k // ns for k in range(ns + 1)]
-                nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), max(cuts[k + 1] - cuts[k] for k in range(ns)))
-                # the library's budget (a share of the free memory) is per CALL: the ns concurrent calls split it - each
-                # chunks its part of the batch to the workspace it is given
-                budget = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), 1 << 40)
-                nb = min(nb, max(budget // ns, lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), 1)))
-                nb -= nb % 256
-                ws = self._workspace(ns * nb, x.device)
-                if len(getattr(self, "_sides", [])) < ns - 1:
-                    self._sides = [torch.cuda.Stream(device=x.device) for _ in range(ns - 1)]
-                main = torch.cuda.current_stream(x.device)
-                for k in range(1, ns):
-                    st = self._sides[k - 1]
-                    st.wait_stream(main)
-                    with torch.cuda.stream(st):
-                        _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x[cuts[k]:cuts[k + 1]]), cuts[k + 1] - cuts[k],
-                                                    _p(out[cuts[k]:cuts[k + 1]]), _p(ws[k * nb:]), nb, _stream()), "ipsx_trunk_encode")
-                _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x[:cuts[1]]), cuts[1], _p(out[:cuts[1]]), _p(ws[:nb]), nb, _stream()),
-                    "ipsx_trunk_encode")
-                for st in self._sides[:ns - 1]:
-                    main.wait_stream(st)
-                return out
-            nb = lib().ipsx_trunk_workspace_bytes(C.byref(self.trunk), n)
-            ws = self._workspace(nb, x.device)
-            _ck(lib().ipsx_trunk_encode(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb, _stream()), "ipsx_trunk_encode")
-        finally:
-            self.trunk.patch_dtype = 0
-        return out
-
-    def row_stats(self, x, out=None):
-        """(mean, rstd) of every feature row of ``x`` (P, F) -> (P, 2): the LayerNorm moments the projector's GEMM applies
-        to its operand; for callers that run this HBM-bound pass ahead of / beside the GEMM (``encode(x, stats=...)``)."""
-        self._refresh()
-        x = _f32(x)
-        if out is None:
-            out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
-        _ck(lib().ipsx_projector_stats(_p(x), x.shape[0], x.shape[1], C.c_float(self.ln_eps), _p(out), _stream()),
-            "ipsx_projector_stats")
-        return out
-
-    def image_stream_supported(self, x_shape, D, R):
-        """Can ``image_stream`` encode patches of this shape (the fused fp32 1x32x32 trunk, 128 features, R <= 32)?"""
-        if not self.is_image or not self.fused(x_shape) or precision() != "fp32":
-            return False
-        return bool(lib().ipsx_trunk_stream_supported(C.byref(self.trunk), int(D), int(R)))
-
-    def image_stream(self, x, pos, vq, R, emb, logits, ctl, ready, workgroups=0, quad_pulls=-1):
-        """Trunk + logits of ONE image's patches ``x`` (P, 1, 32, 32) as one persistent launch that advances ``ready`` (the
-        progress word of ``scan_persistent``) as patches complete: ``emb`` (P, 128) and ``logits`` (P, R) are the outputs,
-        ``pos`` (P, 128) or None is added to the embeddings for the logits, ``ctl`` =
-        ``torch.zeros(image_stream_ctl_words(P), int32)`` zeroed before every call, ``vq`` the folded query."""
-        self._refresh()
-        x = _patches(x)
-        if pos is not None and (pos.stride(-1) != 1 or pos.stride(-2) != pos.shape[-1]):
-            pos = pos.contiguous()
-        _ck(lib().ipsx_trunk_stream(C.byref(self.trunk), _p(x), x.shape[0], _p(emb), _p(pos), _p(vq), int(R), _p(logits),
-                                    _p(ctl), _p(ready), int(workgroups), int(quad_pulls), _stream()), "ipsx_trunk_stream")
-        return emb
-
-    @staticmethod
-    def image_stream_ctl_words(n):
-        return int(lib().ipsx_trunk_stream_ctl_words(int(n)))
-
-    def stream_supported(self, n, R):
-        """Can ``stream`` run this projector on ``n`` rows with ``R`` logits per row?"""
-        if self.is_image:
-            return False
-        self._refresh()
-        return bool(lib().ipsx_projector_stream_supported(C.byref(self.lin), int(n), int(R)))
-
-    def stream(self, x, vq, R, emb, logits, ctl, ready, workgroups=0, short_first=-1, slide_rows=None):
-        """Projector + logits of the feature rows ``x`` (P, F) - one slide, or several one after the other, ``slide_rows``
-        each - as one persistent launch that advances ``ready`` (the progress word(s) of ``scan_persistent``, one per
-        slide) as rows complete: ``emb`` (P, 512) and ``logits`` (P, R) are the outputs, ``ctl`` =
-        ``torch.zeros(stream_ctl_words(P), int32)`` zeroed before every call, ``vq`` the folded query."""
-        self._refresh()
-        x = _f32(x)
-        _ck(lib().ipsx_projector_stream(C.byref(self.lin), _p(x), x.shape[0], int(slide_rows or x.shape[0]),
-                                        C.c_float(self.ln_eps), _p(emb), _p(vq), int(R),
-                                        _p(logits), _p(ctl), _p(ready), int(workgroups), int(short_first), _stream()),
-            "ipsx_projector_stream")
-        return emb
-
-    @staticmethod
-    def stream_ctl_words(n):
-        return int(lib().ipsx_projector_stream_ctl_words(int(n)))
-
-    def encode(self, x, nonblank=None, stats=None, out=None, publish=None):
-        """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D).
-
-        ``nonblank`` (P int32, 1 = the patch has a non-zero element; e.g. from ``patchify_sparse``) switches on
-        the exact blank-patch dedup without the pass that looks for blank patches.  ``publish`` = (ready, value), with
-        ``stats``: the GEMM launch also does ``publish_rows(ready, value)`` for what was enqueued before it."""
-        self._refresh()
-        x = _patches(x) if self.is_image else _f32(x)
-        n = x.shape[0]
-        if x.dtype != torch.float32 and (dedup_blank() or nonblank is not None):
-            raise TypeError("blank-patch dedup reads float32 patches")
-        if out is None:
-            out = torch.empty((n, self.d_out), dtype=torch.float32, device=x.device)
-        elif tuple(out.shape) != (n, self.d_out) or out.dtype != torch.float32 or not out.is_contiguous():
-            raise ValueError("out must be a contiguous (P, D) float32 tensor")
-        if n == 0:
-            return out
-        if self.is_image:
-            self.trunk.h, self.trunk.w = x.shape[2], x.shape[3]
-            if x.shape[1] != self.trunk.c_in:
-                raise ValueError("patches have {} channels, encoder expects {}".format(x.shape[1], self.trunk.c_in))
-            if (dedup_blank() or nonblank is not None) and \
-                    lib().ipsx_trunk_kernel(C.byref(self.trunk)).startswith(b"fused_trunk"):      # any precision
-                nb = lib().ipsx_trunk_dedup_workspace_bytes(C.byref(self.trunk), n)
-                ws = self._workspace(nb, x.device)
-                self.n_encoded = torch.zeros((), dtype=torch.int32, device=x.device)
-                if nonblank is not None:
-                    if nonblank.dtype != torch.int32 or nonblank.numel() != n or not nonblank.is_contiguous():
-                        raise ValueError("nonblank must be a contiguous int32 tensor with one flag per patch")
-                    _ck(lib().ipsx_trunk_encode_dedup_flagged(C.byref(self.trunk), _p(x), n, _p(nonblank), _p(out), _p(ws),
-                                                              nb, _p(self.n_encoded), _stream()),
-                        "ipsx_trunk_encode_dedup_flagged")
-                else:
-                    _ck(lib().ipsx_trunk_encode_dedup(C.byref(self.trunk), _p(x), n, _p(out), _p(ws), nb,
-                                                      _p(self.n_encoded), _stream()), "ipsx_trunk_encode_dedup")
-                return out
-            if (dedup_blank() or nonblank is not None) and n > 1:
-                # layer-by-layer trunks (other patch sizes / depths): the same exact dedup with the index handling in
-                # torch - the layered launches are sized on the host, so the number of distinct patches is read back
-                # (one synchronisation per call; the fused trunk above needs none)
-                flags = nonblank.bool() if nonblank is not None else (x.flatten(1) != 0).any(1)
-                keep = torch.nonzero(flags).flatten()
-                blank = torch.nonzero(~flags).flatten()
-                if blank.numel() > 1:
-                    sel = torch.cat((keep, blank[:1]))
-                    uniq = self.encode_plain(x[sel])
-                    out[keep] = uniq[:keep.numel()]
-                    out[blank] = uniq[keep.numel():keep.numel() + 1]
-                    self.n_encoded = torch.tensor(sel.numel(), dtype=torch.int32, device=x.device)
-                    return out
-            return self.encode_plain(x, out)
-        elif stats is not None:
-            if stats.shape != (n, 2) or stats.dtype != torch.float32 or not stats.is_contiguous():
-                raise ValueError("stats must be a contiguous (P, 2) float32 tensor")
-            if publish is not None:
-                _ck(lib().ipsx_projector_apply_publish(C.byref(self.lin), _p(x), n, _p(stats), _p(out), _p(publish[0]),
-                                                       int(publish[1]), _stream()), "ipsx_projector_apply_publish")
-            else:
-                _ck(lib().ipsx_projector_apply(C.byref(self.lin), _p(x), n, _p(stats), _p(out), _stream()), "ipsx_projector_apply")
-        else:
-            nb = lib().ipsx_projector_workspace_bytes(n)
-            ws = self._workspace(nb, x.device)
-            _ck(lib().ipsx_projector(C.byref(self.lin), _p(x), n, C.c_float(self.ln_eps), _p(out),
-                                     _p(ws), nb, _stream()), "ipsx_projector")
-        return out
-
-
-def encoder_kernel_name(plan):
-    """Which kernel family the plan's encode() launches (for bench.py's roofline record)."""
-    if plan is None or plan._sig is None:
-        return None
-    if not plan.is_image:
-        return "row_stats_kernel + conv_nhwc_kernel<NORM> (projector)"
-    return lib().ipsx_trunk_kernel(C.byref(plan.trunk)).decode()
-
-
 # ------------------------------------------------------------------ scorer
 def query_proj(q, wq, temperature):
     """(T, D) queries, (H*Dk, D) weight -> (T, H*Dk) = (q @ wq.T) / temperature."""
@@ -1242,286 +857,7 @@ def head(emb, token, linear, act):
     return out
 
 
-# ---------------------------------------------------------------- training step (with-grad forward of the trunk)
-_CL = torch.channels_last
-
-
-def conv_train_supported(conv):
-    """Can the training step's convolutions of ``conv`` (an nn.Conv2d) run on the kernels of libipsx?  Forward and data
-    gradient: ``ipsx_conv2d_affine_nhwc`` (C_in % 32 == 0); weight gradient: ``ipsx_conv2d_wgrad_nhwc`` (channels % 64 == 0);
-    strided layers need "same" padding for the data gradient's formulation (kernel - 1 = 2 pad)."""
-    kh, kw = conv.kernel_size
-    s, p = conv.stride[0], conv.padding[0]
-    if (conv.bias is not None or conv.groups != 1 or conv.dilation != (1, 1) or conv.stride[0] != conv.stride[1]
-            or conv.padding[0] != conv.padding[1] or kh != kw or conv.weight.dtype != torch.float32):
-        return False
-    if s > 1 and kh - 1 != 2 * p:
-        return False
-    if conv.in_channels % 32 != 0 and conv.in_channels != 1:    # forward kernels: channels-last (C_in % 32 == 0) or the 1-channel stem
-        return False
-    return bool(lib().ipsx_conv2d_wgrad_nhwc_supported(conv.in_channels, conv.out_channels, kh, kw, s, p))
-
-
-def _pack_conv_view(weight, dgrad=False):
-    """``_pack_conv`` of a weight tensor as it lies in memory (any strides: no contiguous copy) - or, ``dgrad``, of the
-    weights rotated by 180 degrees and transposed: -> (packed, C_out, C_in) of the convolution they describe."""
-    co, ci, kh, kw = weight.shape
-    s_co, s_ci, s_kh, s_kw = weight.stride()
-    if dgrad:
-        n_out, n_in = ci, co
-        base, sn, sc, sky, skx = (kh - 1) * s_kh + (kw - 1) * s_kw, s_ci, s_co, -s_kh, -s_kw
-    else:
-        n_out, n_in = co, ci
-        base, sn, sc, sky, skx = 0, s_co, s_ci, s_kh, s_kw
-    packed = torch.empty(lib().ipsx_packed_conv_weight_elems(n_out, n_in, kh, kw), dtype=torch.float32, device=weight.device)
-    _ck(lib().ipsx_pack_conv_weight_strided(_p(weight), base, n_out, n_in, kh, kw, sn, sc, sky, skx, _p(packed), _stream()),
-        "ipsx_pack_conv_weight_strided")
-    return packed, n_out, n_in
-
-
-class PackJob(C.Structure):
-    """``ipsx_pack_job`` of include/ipsx.h"""
-    _fields_ = [("w", C.c_void_p), ("base", C.c_int64), ("c_out", C.c_int), ("c_in", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
-                ("s_out", C.c_int64), ("s_in", C.c_int64), ("s_ky", C.c_int64), ("s_kx", C.c_int64), ("packed", C.c_void_p)]
-
-
-_PACK_BATCH_MAX = 32
-
-
-def pack_conv_views(views):
-    """``_pack_conv_view`` of several (weight, dgrad) pairs as ONE launch per 32 (ipsx_pack_conv_weights_batch): the packed
-    tensors are slices of one buffer.  -> list of packed tensors, in the order of ``views``."""
-    if not views:
-        return []
-    dev = views[0][0].device
-    sizes = []
-    for weight, dgrad in views:
-        co, ci, kh, kw = weight.shape
-        n_out, n_in = (ci, co) if dgrad else (co, ci)
-        sizes.append(lib().ipsx_packed_conv_weight_elems(n_out, n_in, kh, kw))
-    arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-    out, off = [], 0
-    for sz in sizes:
-        out.append(arena[off:off + sz])
-        off += sz
-    for k0 in range(0, len(views), _PACK_BATCH_MAX):
-        chunk = views[k0:k0 + _PACK_BATCH_MAX]
-        jobs = (PackJob * len(chunk))()
-        for j, (weight, dgrad) in enumerate(chunk):
-            co, ci, kh, kw = weight.shape
-            s_co, s_ci, s_kh, s_kw = weight.stride()
-            if dgrad:
-                jobs[j].c_out, jobs[j].c_in = ci, co
-                jobs[j].base, jobs[j].s_out, jobs[j].s_in, jobs[j].s_ky, jobs[j].s_kx = (kh - 1) * s_kh + (kw - 1) * s_kw, s_ci, s_co, -s_kh, -s_kw
-            else:
-                jobs[j].c_out, jobs[j].c_in = co, ci
-                jobs[j].base, jobs[j].s_out, jobs[j].s_in, jobs[j].s_ky, jobs[j].s_kx = 0, s_co, s_ci, s_kh, s_kw
-            jobs[j].kh, jobs[j].kw = kh, kw
-            jobs[j].w, jobs[j].packed = weight.data_ptr(), out[k0 + j].data_ptr()
-        _ck(lib().ipsx_pack_conv_weights_batch(C.byref(jobs), len(chunk), _stream()), "ipsx_pack_conv_weights_batch")
-    return out
-
-
-def conv_lds_supported(conv, h, w):
-    """True when ``conv2d_nhwc`` would run this ``nn.Conv2d`` on a kernel that can hand the BatchNorm behind it its batch
-    statistics (``conv2d_nhwc(..., stats_shift=...)``): the LDS-resident stage kernels (maps of 32-px patches) and the
-    1-channel stem on the matrix cores."""
-    kh, kw = conv.kernel_size
-    if os.environ.get("IPSX_TRAIN_CONV_STATS", "1") == "0":
-        return False
-    if conv.in_channels == 1:                    # the 32-px trunk's stem on the matrix cores (csrc/stem_train.hip)
-        return bool(os.environ.get("IPSX_TRAIN_STEM_MFMA", "1") != "0" and lib().ipsx_stem7x7s2_nhwc_supported(
-            1, conv.out_channels, kh, kw, conv.stride[0], conv.padding[0], h, w))
-    return bool(kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0"
-                and lib().ipsx_conv2d_lds_nhwc_supported(conv.in_channels, conv.out_channels, kh, conv.stride[0], conv.padding[0], h, w))
-
-
-def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False, packed=None, stats_shift=None):
-    """Plain convolution of a channels-last (P, C_in, h, w) tensor with an OIHW ``weight`` on the fp32 matrix cores
-    (conv_nhwc_kernel): -> channels-last (P, C_out, ho, wo).  ``packed``: the weight already packed for this direction
-    (``pack_conv_views``).  ``stats_shift`` (a (C_out,) tensor; only where ``conv_lds_supported``): -> (y, partial, slabs),
-    the output's per-slab sums around that shift for ``bn_train_forward_partials``."""
-    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous(memory_format=_CL):
-        raise ValueError("expected a float32 channels-last (P, C, H, W) tensor")
-    kh, kw = weight.shape[2:]
-    n, _, h, w = x.shape
-    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    if packed is None:
-        packed, co, ci = _pack_conv_view(weight.detach(), dgrad_weights)
-    else:
-        co, ci = (weight.shape[1], weight.shape[0]) if dgrad_weights else (weight.shape[0], weight.shape[1])
-    cv = Conv(ci, co, kh, kw, stride, pad, _p(packed), None, None, None)
-    y = torch.empty((n, co, ho, wo), dtype=torch.float32, device=x.device, memory_format=_CL)
-    if stats_shift is not None:
-        slabs = int(lib().ipsx_conv2d_lds_nhwc_stats_slabs(n))
-        partial = torch.empty((max(slabs, 1), 2, co), dtype=torch.float32, device=x.device)
-        if ci == 1:
-            _ck(lib().ipsx_stem7x7s2_nhwc(C.byref(cv), _p(x), _p(y), n, _p(stats_shift), _p(partial), _stream()), "ipsx_stem7x7s2_nhwc")
-        else:
-            _ck(lib().ipsx_conv2d_lds_nhwc_stats(C.byref(cv), _p(x), _p(y), n, h, w, _p(stats_shift), _p(partial), _stream()),
-                "ipsx_conv2d_lds_nhwc_stats")
-        return y, partial, slabs
-    if kh == kw and os.environ.get("IPSX_TRAIN_CONV_LDS", "1") != "0" and lib().ipsx_conv2d_lds_nhwc_supported(ci, co, kh, stride, pad, h, w):
-        # the maps of 32-px patches: the fused trunk's stage kernels, map LDS-resident for all taps
-        _ck(lib().ipsx_conv2d_lds_nhwc(C.byref(cv), _p(x), _p(y), n, h, w, _stream()), "ipsx_conv2d_lds_nhwc")
-    elif ci == 1 and os.environ.get("IPSX_TRAIN_STEM_MFMA", "1") != "0" and lib().ipsx_stem7x7s2_nhwc_supported(ci, co, kh, kw, stride, pad, h, w):
-        # the 32-px trunk's stem on the matrix cores (csrc/stem_train.hip)
-        _ck(lib().ipsx_stem7x7s2_nhwc(C.byref(cv), _p(x), _p(y), n, None, None, _stream()), "ipsx_stem7x7s2_nhwc")
-    elif ci == 1:       # one input channel (NCHW = channels-last memory): the stem kernel, channels-last output
-        _ck(lib().ipsx_conv2d_affine_to_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_to_nhwc")
-    else:
-        _ck(lib().ipsx_conv2d_affine_nhwc(C.byref(cv), _p(x), None, _p(y), n, h, w, 0, _stream()), "ipsx_conv2d_affine_nhwc")
-    return y
-
-
-def conv2d_nhwc_dgrad(dy, weight, stride, pad, in_hw, packed=None):
-    """Data gradient of ``conv2d_nhwc``: the same kernel on dy with the weights rotated by 180 degrees and transposed; a
-    strided layer first spreads dy over a zero map of the input's size (needs kernel - 1 = 2 pad)."""
-    co, ci, kh, kw = weight.shape
-    if (stride > 1 and kh == kw and os.environ.get("IPSX_TRAIN_DGRAD_S2", "1") != "0"
-            and lib().ipsx_conv2d_dgrad_s2_lds_nhwc_supported(ci, co, kh, stride, pad, in_hw[0], in_hw[1])):
-        # the 32-px trunk's strided layer by parity class of the input pixel: no spread map (csrc/dgrad_s2.hip)
-        if packed is None:
-            packed = _pack_conv_view(weight.detach(), True)[0]
-        n = dy.shape[0]
-        if dy.dtype != torch.float32 or tuple(dy.shape[1:]) != (co, in_hw[0] // 2, in_hw[1] // 2):
-            raise ValueError("dy: expected float32 (P, %d, %d, %d)" % (co, in_hw[0] // 2, in_hw[1] // 2))
-        dy = dy.contiguous(memory_format=_CL)
-        dx = torch.empty((n, ci, in_hw[0], in_hw[1]), dtype=torch.float32, device=dy.device, memory_format=_CL)
-        _ck(lib().ipsx_conv2d_dgrad_s2_lds_nhwc(_p(packed), kh, _p(dy), _p(dx), n, _stream()), "ipsx_conv2d_dgrad_s2_lds_nhwc")
-        return dx
-    if stride > 1:
-        n = dy.shape[0]
-        spread = torch.empty((n, co, in_hw[0], in_hw[1]), dtype=torch.float32, device=dy.device, memory_format=_CL).zero_()
-        spread[:, :, ::stride, ::stride] = dy
-        dy = spread
-    return conv2d_nhwc(dy, weight, 1, kh - 1 - pad, dgrad_weights=True, packed=packed)
-
-
-# ipsx_conv2d_wgrad_nhwc addresses x and dy through 32-bit buffer offsets: either activation of ONE call stays below this
-# many bytes (csrc/conv_wgrad.hip: "call per slice and add"); conv2d_nhwc_wgrad slices the image axis accordingly
-_WGRAD_MAX_BYTES = (1 << 31) - (1 << 20)
-
-
-def conv2d_nhwc_wgrad(x, dy, weight_shape, stride, pad):
-    """Weight gradient of ``conv2d_nhwc`` -> (C_out, C_in, kh, kw) in channels-last memory order (ipsx_conv2d_wgrad_nhwc).
-    Activations of 2 GiB and more (the kernel's buffer range) are taken in slices of whole images, the slices' gradients
-    added in slice order (deterministic; the forward kernel slices per launch in the same way)."""
-    co, ci, kh, kw = weight_shape
-    n, _, h, w = x.shape
-    dy = dy.contiguous(memory_format=_CL)
-    ho, wo = dy.shape[2:]
-    per_image = 4 * max(h * w * ci, ho * wo * co)
-    step = max(1, min(n, _WGRAD_MAX_BYTES // per_image))
-    dw = torch.empty((co, ci, kh, kw), dtype=torch.float32, device=x.device, memory_format=_CL)
-    nb = max(lib().ipsx_conv2d_wgrad_nhwc_workspace_bytes(c, ci, co, kh, kw) for c in {step, n - (n - 1) // step * step})
-    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=x.device)
-    part = dw
-    for i0 in range(0, max(n, 1), step):
-        cnt = min(step, n - i0)
-        if i0 > 0 and part is dw:
-            part = torch.empty_like(dw)
-        _ck(lib().ipsx_conv2d_wgrad_nhwc(_p(x[i0:i0 + cnt]), _p(dy[i0:i0 + cnt]), cnt, h, w, ci, co, kh, kw, stride, pad,
-                                         _p(part), _p(ws), nb, _stream()), "ipsx_conv2d_wgrad_nhwc")
-        if part is not dw:
-            dw += part
-    return dw
-
-
-def _rows_cl(t):
-    """(P, C, H, W) channels-last tensor -> (rows, C) of its memory."""
-    if t.dim() != 4 or t.dtype != torch.float32 or not t.is_contiguous(memory_format=torch.channels_last):
-        raise ValueError("expected a float32 channels-last (P, C, H, W) tensor")
-    return t.shape[0] * t.shape[2] * t.shape[3], t.shape[1]
-
-
-def bn_train_supported(rows, c):
-    return bool(lib().ipsx_bn_train_supported(rows, c))
-
-
-def bn_train_forward(x, residual, gamma, beta, eps, momentum, running_mean, running_var, relu):
-    """Batch-statistics BatchNorm2d (+ residual) (+ ReLU) of a channels-last activation; updates the running
-    statistics in place.  Returns y (channels-last), mean, invstd."""
-    rows, c = _rows_cl(x)
-    if residual is not None and _rows_cl(residual) != (rows, c):
-        raise ValueError("residual shape")
-    y = torch.empty_like(x)                        # (preserves channels-last)
-    # mean | invstd are saved for backward, so they are an allocation of their own (2 C floats): carved out of the
-    # workspace they would keep its ~4 KB x C alive until backward, per BatchNorm (~20 MB per ResNet-18 step)
-    stat = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-    mean, invstd = stat[:c], stat[c:]
-    ws = torch.empty(max(1, _bn_workspace_floats(rows, c)), dtype=torch.float32, device=x.device)
-    _ck(lib().ipsx_bn_train_forward(_p(x), _p(residual), rows, c, _p(_f32(gamma)), _p(_f32(beta)), eps, momentum,
-                                    _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
-                                    _p(ws), _stream()), "ipsx_bn_train_forward")
-    return y, mean, invstd
-
-
-def maxpool_train_supported(x):
-    """Can ``maxpool_3x3s2_nhwc`` / ``maxpool_3x3s2_bwd_nhwc`` take this activation (the training step's pooling behind the
-    stem: float32 on the GPU, 16 x 16 maps, a multiple of 32 channels)?"""
-    return bool(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and os.environ.get("IPSX_TRAIN_POOL", "1") != "0"
-                and lib().ipsx_maxpool_3x3s2_bwd_nhwc_supported(x.shape[1], x.shape[2], x.shape[3]))
-
-
-def maxpool_3x3s2_nhwc(x):
-    """nn.MaxPool2d(3, 2, 1) of a channels-last (P, C, h, w) activation -> channels-last (P, C, ho, wo)."""
-    x = x.contiguous(memory_format=_CL)
-    n, c, h, w = x.shape
-    y = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device, memory_format=_CL)
-    _ck(lib().ipsx_maxpool_3x3s2_nhwc(_p(x), _p(y), n, c, h, w, _stream()), "ipsx_maxpool_3x3s2_nhwc")
-    return y
-
-
-def maxpool_3x3s2_bwd_nhwc(x, dy):
-    """The gradient of ``maxpool_3x3s2_nhwc`` w.r.t. x (ATen's rule: a window's gradient goes to its first maximum)."""
-    x = x.contiguous(memory_format=_CL)
-    dy = dy.contiguous(memory_format=_CL)
-    n, c, h, w = x.shape
-    dx = torch.empty_like(x)
-    _ck(lib().ipsx_maxpool_3x3s2_bwd_nhwc(_p(x), _p(dy), _p(dx), n, c, h, w, _stream()), "ipsx_maxpool_3x3s2_bwd_nhwc")
-    return dx
-
-
-def bn_train_forward_partials(x, residual, gamma, beta, eps, momentum, running_mean, running_var, relu, partial, slabs, shift):
-    """``bn_train_forward`` without its reduction pass: ``partial`` (slabs, 2, C) are the sums ``conv2d_nhwc(..., stats_shift=
-    shift)`` took off its accumulators (``shift`` may be ``running_mean`` itself)."""
-    rows, c = _rows_cl(x)
-    if residual is not None and _rows_cl(residual) != (rows, c):
-        raise ValueError("residual shape")
-    y = torch.empty_like(x)
-    stat = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-    mean, invstd = stat[:c], stat[c:]
-    _ck(lib().ipsx_bn_train_forward_partials(_p(x), _p(residual), rows, c, _p(_f32(gamma)), _p(_f32(beta)), eps, momentum,
-                                             _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(invstd),
-                                             _p(partial), slabs, _p(shift), _stream()), "ipsx_bn_train_forward_partials")
-    return y, mean, invstd
-
-
-_BN_MAX_SLABS = 512      # csrc/bn_train.hip BN_MAX_SLABS (ipsx_bn_train_workspace_floats never exceeds 2 * 512 * C)
-_BN_WS_FLOATS = {}
-
-
-def _bn_workspace_floats(rows, c):
-    """ipsx_bn_train_workspace_floats(rows, c), remembered per shape (a training step asks for the same few shapes)."""
-    key = (rows, c)
-    n = _BN_WS_FLOATS.get(key)
-    if n is None:
-        n = _BN_WS_FLOATS[key] = int(lib().ipsx_bn_train_workspace_floats(rows, c))
-    return n
-
-
-def bn_train_backward(dy, y, x, gamma, mean, invstd, relu, want_residual):
-    """-> dx, dresidual | None, dgamma, dbeta."""
-    rows, c = _rows_cl(x)
-    if _rows_cl(dy) != (rows, c):
-        raise ValueError("dy shape")
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_residual else None
-    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty_like(dgamma)
-    ws = torch.empty(max(1, _bn_workspace_floats(rows, c)), dtype=torch.float32, device=x.device)
-    _ck(lib().ipsx_bn_train_backward(_p(dy), _p(y), _p(x), rows, c, _p(_f32(gamma)), _p(mean), _p(invstd), int(relu),
-                                     _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), _stream()),
-        "ipsx_bn_train_backward")
-    return dx, dres, dgamma, dbeta
+# ------------------------------------------------------------------ the encoder plan and the training step's kernels
+# (modules of their own since round 6; every name stays reachable as ``hip.<name>``)
+from .hip_encoder import (EncoderPlan, _PlanHold, _bn_affine, _pack_conv, encoder_kernel_name)          # noqa: E402,F401
+from .hip_train import (PackJob, _BN_MAX_SLABS, _BN_WS_FLOATS, _CL, _PACK_BATCH_MAX, _WGRAD_MAX_BYTES, _bn_workspace_floats, _pack_conv_view, _rows_cl, bn_train_backward, bn_train_forward, bn_train_forward_partials, bn_train_supported, conv2d_nhwc, conv2d_nhwc_dgrad, conv2d_nhwc_wgrad, conv_lds_supported, conv_train_supported, maxpool_3x3s2_bwd_nhwc, maxpool_3x3s2_nhwc, maxpool_train_supported, pack_conv_views)          # noqa: E402,F401

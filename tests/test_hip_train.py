@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from ips_amd import hip, synth
+from ips_amd import hip, hip_train, synth
 from ips_amd.architecture import IPSNet
 from ips_amd.training import fused_encoder
 
@@ -174,7 +174,7 @@ def test_weight_gradient_of_activations_beyond_one_buffer_is_sliced(monkeypatch)
     x = torch.randn((P, ci, H, H), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     dy = torch.randn((P, co, 4, 4), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     whole = hip.conv2d_nhwc_wgrad(x, dy, (co, ci, 3, 3), 2, 1)
-    monkeypatch.setattr(hip, "_WGRAD_MAX_BYTES", 9 * 4 * ci * H * H)          # nine images per call: 9 + 9 + 9 + 6
+    monkeypatch.setattr(hip_train, "_WGRAD_MAX_BYTES", 9 * 4 * ci * H * H)          # nine images per call: 9 + 9 + 9 + 6
     sliced = hip.conv2d_nhwc_wgrad(x, dy, (co, ci, 3, 3), 2, 1)
     monkeypatch.undo()
     by_hand = None
