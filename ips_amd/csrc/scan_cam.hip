@@ -405,20 +405,21 @@ __global__ __launch_bounds__(cam::NT) void scan_cam_kernel(ScanArgs a, unsigned 
                 // (ties among the first M + 1 ranks only: without one torch.topk's result is the canonical order - and, the
                 //  loop's rule, oracle orc_topm_loop: only between NEIGHBOURS whose logit rows are bit-identical; two
                 //  different rows whose scores collide in the last bit keep the canonical order.  tie_order 2: any tie)
+                // (round 6: every later member of the run, not only the neighbour - see scan_fast_kernel)
                 const int npair = M < Lc - 1 ? M : Lc - 1;
                 bool hit = false;
-                for (int j = tid; j < npair; j += NT) {
-                    if ((sorted[j] >> 32) != (sorted[j + 1] >> 32)) continue;
-                    bool same = true;
-                    if (a.tie_order == 1) {
-                        const uint4* ra = reinterpret_cast<const uint4*>(xc + key_pos(sorted[j]) * LD);
-                        const uint4* rb = reinterpret_cast<const uint4*>(xc + key_pos(sorted[j + 1]) * LD);
-                        const uint4 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
-                        same = a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w &&
-                               a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+                for (int j = tid; j < npair && !hit; j += NT)
+                    for (int k = j + 1; k < Lc && !hit && (sorted[k] >> 32) == (sorted[j] >> 32); ++k) {
+                        bool same = true;
+                        if (a.tie_order == 1) {
+                            const uint4* ra = reinterpret_cast<const uint4*>(xc + key_pos(sorted[j]) * LD);
+                            const uint4* rb = reinterpret_cast<const uint4*>(xc + key_pos(sorted[k]) * LD);
+                            const uint4 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+                            same = a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w &&
+                                   a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+                        }
+                        hit = hit || same;
                     }
-                    hit = hit || same;
-                }
                 if (__ballot(hit) != 0ull && lane == 0) ccount[7] = 1;
                 lds_barrier();
             }

@@ -123,8 +123,8 @@ __device__ __forceinline__ bool ranked_ties(const uint64_t* sorted, int L, int m
 struct TieRows { const float* lg; const long long* mem; long long lo; int m, R; };
 
 // ties among the first m + 1 canonical ranks that call for torch.topk's order: tie_order 2 (and callers without rows) any
-// two neighbours of equal score; tie_order 1, the loop's rule (oracle orc_topm_loop): neighbours of equal score whose logit
-// rows are bit-identical
+// two neighbours of equal score; tie_order 1, the loop's rule (oracle orc_topm_loop): two members of one run of equal
+// scores (reaching into the first m + 1 ranks) whose logit rows are bit-identical
 // (the whole workgroup calls this: the pairs are dealt out to the wavefronts, the verdict is a barrier's OR - every
 //  wavefront going through all 5,000 pairs of the shipped CAMELYON sizes on its own was 13 us of a 94 us iteration)
 __device__ __forceinline__ bool ranked_ties_padded(const uint64_t* sorted, int L, int m, int lane, int tie_order = 2,
@@ -132,16 +132,22 @@ __device__ __forceinline__ bool ranked_ties_padded(const uint64_t* sorted, int L
     const int n = m < L - 1 ? m : L - 1;
     const bool by_rows = tie_order == 1 && rows != nullptr && rows->lg != nullptr;
     bool any = false;
-    for (int j = (int)threadIdx.x; j < n; j += (int)blockDim.x) {
-        const uint64_t ka = sorted[j + (j >> 4)], kb = sorted[j + 1 + ((j + 1) >> 4)];
-        bool e = (ka >> 32) == (kb >> 32);
-        if (e && by_rows) {
-            const long long pa = key_pos(ka), pb = key_pos(kb);
-            const float* ra = rows->lg + (size_t)(pa < rows->m ? rows->mem[pa] : rows->lo + (pa - rows->m)) * rows->R;
-            const float* rb = rows->lg + (size_t)(pb < rows->m ? rows->mem[pb] : rows->lo + (pb - rows->m)) * rows->R;
-            for (int r = 0; r < rows->R; ++r) e = e && as_u32(ra[r]) == as_u32(rb[r]);
+    // (round 6: member j against EVERY later member of its run of equal scores, not only its neighbour - oracle orc_topm_loop)
+    for (int j = (int)threadIdx.x; j < n && !any; j += (int)blockDim.x) {
+        const uint64_t ka = sorted[j + (j >> 4)];
+        for (int k = j + 1; k < L && !any; ++k) {
+            const uint64_t kb = sorted[k + (k >> 4)];
+            if ((ka >> 32) != (kb >> 32)) break;
+            bool e = true;
+            if (by_rows) {
+                const long long pa = key_pos(ka), pb = key_pos(kb);
+                const float* ra = rows->lg + (size_t)(pa < rows->m ? rows->mem[pa] : rows->lo + (pa - rows->m)) * rows->R;
+                const float* rb = rows->lg + (size_t)(pb < rows->m ? rows->mem[pb] : rows->lo + (pb - rows->m)) * rows->R;
+                for (int r = 0; r < rows->R; ++r) e = e && as_u32(ra[r]) == as_u32(rb[r]);
+            }
+            any = any || e;
+            if (!by_rows) break;                       // (any tie counts: the neighbour settles it)
         }
-        any = any || e;
     }
     (void)lane;
     return __syncthreads_or(any ? 1 : 0) != 0;

@@ -295,21 +295,23 @@ __global__ __launch_bounds__(SCAN_NT) void scan_fast_kernel(ScanArgs a, unsigned
         }
         lds_barrier();
         // exact ties among the first M + 1 ranked scores that call for torch.topk's order?  The loop's rule (oracle
-        // orc_topm_loop, round 5): two NEIGHBOURS of equal score whose logit rows are bit-identical (tie_order 2: any two of
-        // equal score).  One pair per thread, any hit raises the flag.
+        // orc_topm_loop): two candidates of one run of equal scores whose logit rows are bit-identical (tie_order 2: any two of
+        // equal score).  One run member per thread, any hit raises the flag.
         if (a.tie_order != 0) {
+            // (round 6: member j of the first M + 1 ranks against EVERY later member of its run of equal scores - not only its
+            //  neighbour: a duplicate pair with a colliding different row between them, or a run across the boundary)
             const int npair = a.m < Lr - 1 ? a.m : Lr - 1;
             bool hit = false;
-            for (int j = tid; j < npair; j += SCAN_NT) {
-                if ((sorted[j] >> 32) != (sorted[j + 1] >> 32)) continue;
-                bool same = true;
-                if (a.tie_order == 1) {
-                    const float* ra = xc + key_pos(sorted[j]) * ld;
-                    const float* rb = xc + key_pos(sorted[j + 1]) * ld;
-                    for (int rr = 0; rr < R; ++rr) same = same && as_u32(ra[rr]) == as_u32(rb[rr]);
+            for (int j = tid; j < npair && !hit; j += SCAN_NT)
+                for (int k = j + 1; k < Lr && !hit && (sorted[k] >> 32) == (sorted[j] >> 32); ++k) {
+                    bool same = true;
+                    if (a.tie_order == 1) {
+                        const float* ra = xc + key_pos(sorted[j]) * ld;
+                        const float* rb = xc + key_pos(sorted[k]) * ld;
+                        for (int rr = 0; rr < R; ++rr) same = same && as_u32(ra[rr]) == as_u32(rb[rr]);
+                    }
+                    hit = hit || same;
                 }
-                hit = hit || same;
-            }
             if (__ballot(hit) != 0ull && lane == 0) ccount[2 + par] = 1;
         }
         lds_barrier();

@@ -547,18 +547,21 @@ ORC_API void orc_topm_aten(const float* scores, int L, int M, int64_t* top) {
 // torch's), and DIFFERENT rows whose scores happen to collide in the last bit of THIS arithmetic (in the reference's
 // oneDNN / Sleef arithmetic those two are an ulp apart and other pairs collide: on the CAMELYON bench slide 18 of 255
 // iterations here, none there - replaying torch on them reproduces nothing of the reference).  So: the canonical order,
-// unless two NEIGHBOURS among the first M + 1 canonical ranks have equal scores AND bit-identical logit rows - then
+// unless two candidates of ONE RUN of equal scores that reaches into the first M + 1 canonical ranks have bit-identical logit rows - then
 // torch.topk's order on the whole array, as before.  lg: (L, R) logits of the candidates, row-major.
 ORC_API void orc_topm_loop(const float* scores, const float* lg, int L, int R, int M, int64_t* top, int32_t* tie) {
     std::vector<uint64_t> key(L);
     for (int l = 0; l < L; ++l) key[l] = rank_key(scores[l], (uint32_t)l);
     std::sort(key.begin(), key.end(), std::greater<uint64_t>());
     if (tie) *tie = (M < L && (key[M - 1] >> 32) == (key[M] >> 32)) ? 1 : 0;
+    // (round 6, advisor: not only NEIGHBOURS - in a run A, B, C of equal scores with A and C duplicates and B a different row
+    //  that collides with them, no neighbouring pair is identical: every member j of the first M ranks (the selected ones) is held against
+    //  EVERY later member of its run of equal scores, also beyond rank M - a run across the boundary decides who stays)
     bool structural = false;
     const int n = M < L - 1 ? M : L - 1;
     for (int j = 0; j < n && !structural; ++j)
-        if ((key[j] >> 32) == (key[j + 1] >> 32)) {
-            const uint32_t a = 0xFFFFFFFFu - (uint32_t)(key[j] & 0xFFFFFFFFu), b = 0xFFFFFFFFu - (uint32_t)(key[j + 1] & 0xFFFFFFFFu);
+        for (int k = j + 1; k < L && !structural && (key[k] >> 32) == (key[j] >> 32); ++k) {
+            const uint32_t a = 0xFFFFFFFFu - (uint32_t)(key[j] & 0xFFFFFFFFu), b = 0xFFFFFFFFu - (uint32_t)(key[k] & 0xFFFFFFFFu);
             structural = std::memcmp(lg + (size_t)a * R, lg + (size_t)b * R, (size_t)R * sizeof(float)) == 0;
         }
     if (structural) orc_topm_aten(scores, L, M, top);

@@ -136,3 +136,46 @@ def test_projector_stays_accurate_where_the_mean_dwarfs_the_spread():
     with torch.no_grad():
         want = enc64(torch.from_numpy(x).double()).numpy()
     assert np.abs(got - want).max() <= 1e-6 and np.array_equal(got[0], got[3]) and np.array_equal(got[0], got[2])
+
+
+def test_loop_tie_rule_sees_duplicates_across_a_colliding_row():
+    """Advisor r05 (low), round 6: the loops replay torch.topk's order when two candidates of ONE RUN of equal scores have
+    bit-identical logit rows - not only when they are neighbours.  A, B, C with equal scores, A and C duplicates, B a
+    different row that collides with them: no neighbouring pair is identical, the run is still a structural tie.  Also a run
+    that starts inside the first M ranks and continues beyond the boundary; and a run of colliding DIFFERENT rows, which
+    keeps the canonical order."""
+    import ctypes as C
+    L, R, M = 12, 8, 5
+    rng = np.random.default_rng(3)
+    lg = rng.standard_normal((L, R)).astype(np.float32)
+    base = np.linspace(1.0, 0.1, L).astype(np.float32)
+
+    def run(scores, rows):
+        top = np.empty(M, dtype=np.int64)
+        orc.lib().orc_topm_loop(orc._f(scores)[1], orc._f(rows)[1], L, R, M, top.ctypes.data_as(orc.i64p), None)
+        return top
+
+    def canonical(scores):
+        return np.array(sorted(range(L), key=lambda i: (-scores[i], i))[:M])
+
+    def torch_order(scores):
+        return torch.topk(torch.from_numpy(scores), M)[1].numpy()
+
+    # (1) A, B, C at ranks 1, 2, 3: equal scores, rows A == C != B
+    s = base.copy(); s[[4, 6, 9]] = s[1]                  # candidates 1, 4, 6, 9 share a score; make 1 unique again
+    s[1] = 2.0
+    rows = lg.copy(); rows[9] = rows[4]                   # 4 and 9 duplicates, 6 differs
+    assert not np.array_equal(rows[4], rows[6])
+    got = run(s, rows)
+    assert np.array_equal(got, torch_order(s))
+    # without the duplicate: three different rows collide -> canonical order, whatever torch does
+    assert np.array_equal(run(s, lg), canonical(s))
+    # (2) a run that reaches across the boundary: ranks M-1, M, M+1 tie, the duplicate of rank M-1 sits at rank M+1
+    s = base.copy(); s[[7, 10]] = s[4]                    # canonical ranks: 0,1,2,3,4 | 7,10 tie with 4 -> ranks 4,5,6
+    rows = lg.copy(); rows[10] = rows[4]
+    assert np.array_equal(run(s, rows), torch_order(s))
+    assert np.array_equal(run(s, lg), canonical(s))
+    # (3) duplicates that both lie beyond the boundary change nothing
+    s = base.copy(); s[11] = s[9]
+    rows = lg.copy(); rows[11] = rows[9]
+    assert np.array_equal(run(s, rows), canonical(s))
