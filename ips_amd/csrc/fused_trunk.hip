@@ -651,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_kernel(FusedArgs a, unsign
 
 #include "fused_trunk_split.h"
 #include "fused_trunk_bf16v2.h"
+#include "fused_trunk_bf16v3.h"
 #include "fused_trunk_pair.h"
 
 // ------------------------------------------------------------------ the stages as stand-alone convolutions (training step)
@@ -809,7 +810,7 @@ bool fused_trunk_supported(const ipsx_trunk* t) {
     return !(off && off[0] == '1');
 }
 
-static int g_bf16_build = 0;      // diagnostic (ipsx_dbg_bf16_build): 0 the second build of the bf16 trunk, 1 the first
+static int g_bf16_build = 0;      // diagnostic (ipsx_dbg_bf16_build): 0 the default build of the bf16 trunk (the third), 1 / 2 / 3 that build
 static int g_pair_mode = 0;       // diagnostic (ipsx_dbg_fused_trunk_pair): 0 the rule below, 1 never, 2 every patch through the pair kernel
 
 static int device_cus() {
@@ -862,9 +863,21 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
             attr_split = true;
         }
         const dim3 grid((unsigned)cdiv(n, 4)), block(256);
-        // the bf16 trunk's second build (fused_trunk_bf16v2.h; round 6) unless IPSX_BF16_BUILD=1 asks for the first
-        static const bool bf16_v1 = [] { const char* e = getenv("IPSX_BF16_BUILD"); return e && e[0] == '1'; }();
-        if (!x3 && !(bf16_v1 || g_bf16_build == 1) ) {
+        // the bf16 trunk's builds (round 6): IPSX_BF16_BUILD = 1 first (fused_trunk_split.h), 2 second, 3 third (default)
+        static const int bf16_env = [] { const char* e = getenv("IPSX_BF16_BUILD"); return e && e[0] >= '1' && e[0] <= '3' ? e[0] - '0' : 0; }();
+        const int bf16_build = g_bf16_build ? g_bf16_build : (bf16_env ? bf16_env : 3);
+        if (!x3 && bf16_build == 3 && !stamps) {
+            // the third build (fused_trunk_bf16v3.h): eight patches per workgroup, the 4x4 stage once over all eight
+            static bool attr_v3 = false;
+            if (!attr_v3) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v3_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+                attr_v3 = true;
+            }
+            fused_trunk_bf16v3_kernel<<<dim3((unsigned)cdiv(n, 8)), block, V3_LDS, s>>>(a);
+            return launched("fused_trunk_bf16v3");
+        }
+        if (!x3 && bf16_build != 1) {
             static bool attr_v2 = false;
             if (!attr_v2) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v2_kernel<false>),
@@ -1077,7 +1090,8 @@ IPSX_API int ipsx_pack_stem_weight_split(const float* w, int c_out, int planes, 
 // Diagnostic switch (not part of include/ipsx.h; tests/test_hip_kernels.py, tools): which of the two exact fp32 kernels
 // encodes - 0 the product's rule, 1 fused_trunk_kernel only, 2 fused_trunk_pair_kernel only.
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_fused_trunk_pair(int mode) { ipsx::g_pair_mode = mode; }
-// which build of the bf16 trunk IPSX_PRECISION=bf16 launches: 0 the second (fused_trunk_bf16v2.h), 1 the first (fused_trunk_split.h)
+// which build of the bf16 trunk IPSX_PRECISION=bf16 launches: 0 the default (the third, fused_trunk_bf16v3.h), 1 the first
+// (fused_trunk_split.h), 2 the second (fused_trunk_bf16v2.h), 3 the third
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_bf16_build(int build) { ipsx::g_bf16_build = build; }
 
 // Diagnostic entry point (not part of include/ipsx.h): the fused trunk with s_memtime stamps,

@@ -153,7 +153,9 @@ def launch_model(net, patch_shape, units=None, precision=None):
     if net.is_image and tuple(patch_shape[-3:]) == (1, 32, 32) and len(net.encoder) == 7:
         # the fused trunk: 8 patches per unit and round.  fp32: 37.26 MFLOP per patch at 0.88 of the unit's pipe; the split
         # trunks on the bf16 pipe: 26 M / 6.8 M patches/s per 256 units
-        t_round = {"bf16": 8 * 256 / 26.0, "fp32x3": 8 * 256 / 6.8}.get(precision, 8 * 37257216 / (_UNIT_FLOPS * 0.88) * 1e6)
+        if precision == "bf16":                   # third build: workgroups of EIGHT patches, two per unit; 36 M patches/s
+            return LaunchModel(round=16 * units, t_round=16 * 256 / 36.0, t_iter=t_iter, kind="fused32:bf16")
+        t_round = {"fp32x3": 8 * 256 / 6.8}.get(precision, 8 * 37257216 / (_UNIT_FLOPS * 0.88) * 1e6)
         return LaunchModel(round=8 * units, t_round=t_round, t_iter=t_iter, kind="fused32:" + precision)
     if net.is_image:
         key = ("macs", tuple(patch_shape[-3:]))

@@ -543,6 +543,13 @@ class Selection:
         edges = None
         if net.is_image and B * N < self.small_batch_limit(dev) and n_iter < 100:
             edges, its = self.small_batch_split(B, N, dev)
+        elif net.is_image and indexed and hip.precision() == "bf16":
+            # the bf16 trunk's workgroups take EIGHT patches (fused_trunk_bf16v3.h): a round is 16 patches per unit, and the
+            # fixed 50 / 30 / 15 / 5 % cut of a 40,000-patch batch is 12 rounds of work for 9.8 - every part a whole number of
+            # rounds instead (dist.plan_iterations: the sharded path's planner, one rank)
+            from .dist import launch_model, plan_iterations
+            its = plan_iterations(N, M, I, 1, B, launch_model(net, tuple(patches.shape[2:]), hip.device_geometry(dev).cus),
+                                  self.OVERLAP_PARTS)
         elif net.is_image:
             its = part_iterations(n_iter, self.OVERLAP_PARTS)
         else:

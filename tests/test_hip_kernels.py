@@ -571,10 +571,11 @@ def test_bf16_trunk_tracks_fp32_within_tolerance(monkeypatch):
 
 @pytest.mark.parametrize("storage", [torch.float32, torch.float16])
 def test_bf16_trunk_builds_agree(monkeypatch, storage):
-    """Round 6: the bf16 trunk's second build (csrc/fused_trunk_bf16v2.h: 8x8 stage by channel tile x patch pair, deep
-    operand rings, ping-pong LDS images) does the FIRST build's arithmetic - same operand rounding, same products in the
-    same order, fp32 identity: the embeddings are bit-identical, whole workgroups and ragged ends, an index list, half-stored
-    patches."""
+    """Round 6: the bf16 trunk's second and third builds (csrc/fused_trunk_bf16v2.h: 8x8 stage by channel tile x patch pair,
+    deep operand rings; fused_trunk_bf16v3.h, the default: eight patches per workgroup, the 4x4 stage once over all eight)
+    do the FIRST build's arithmetic - same operand rounding, same products in the same order, fp32 identity: the embeddings
+    are bit-identical, whole workgroups and ragged ends (1 .. 17 patches: every remainder of 4 and of 8), an index list,
+    half-stored patches."""
     g = Golden("mnist_full")
     net = g.net(DEV)
     plan = hip.EncoderPlan(net.encoder, True)
@@ -583,19 +584,22 @@ def test_bf16_trunk_builds_agree(monkeypatch, storage):
     x_all = g.patches()[0, :1203].to(DEV).to(storage)
     monkeypatch.setenv("IPSX_PRECISION", "bf16")
     try:
-        for n in (1, 2, 3, 4, 5, 7, 8, 203, 1203):
+        for n in (1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 15, 16, 17, 203, 1203):
             x = x_all[:n].contiguous()
             fn(1)
             first = plan.encode(x)
-            fn(0)
+            fn(2)
             second = plan.encode(x)
+            fn(3)
+            third = plan.encode(x)
             assert torch.isfinite(second).all() and torch.equal(first, second), n
+            assert torch.isfinite(third).all() and torch.equal(first, third), n
         idx = torch.randperm(1203, generator=torch.Generator().manual_seed(5))[:333].to(torch.int32).to(DEV)
-        fn(1)
-        first = plan.encode_indexed(x_all, idx)
-        fn(0)
-        second = plan.encode_indexed(x_all, idx)
-        assert torch.equal(first, second) and torch.equal(second, plan.encode(x_all[idx.long()].contiguous()))
+        outs = []
+        for b in (1, 2, 3, 0):
+            fn(b)
+            outs.append(plan.encode_indexed(x_all, idx))
+        assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.equal(outs[0], plan.encode(x_all[idx.long()].contiguous()))
     finally:
         fn(0)
 
