@@ -866,15 +866,18 @@ static int fused_launch(const ipsx_trunk* t, const float* patches, int64_t n, fl
         // the bf16 trunk's builds (round 6): IPSX_BF16_BUILD = 1 first (fused_trunk_split.h), 2 second, 3 third (default)
         static const int bf16_env = [] { const char* e = getenv("IPSX_BF16_BUILD"); return e && e[0] >= '1' && e[0] <= '3' ? e[0] - '0' : 0; }();
         const int bf16_build = g_bf16_build ? g_bf16_build : (bf16_env ? bf16_env : 3);
-        if (!x3 && bf16_build == 3 && !stamps) {
+        if (!x3 && bf16_build == 3) {
             // the third build (fused_trunk_bf16v3.h): eight patches per workgroup, the 4x4 stage once over all eight
             static bool attr_v3 = false;
             if (!attr_v3) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v3_kernel),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v3_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_trunk_bf16v3_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
                 attr_v3 = true;
             }
-            fused_trunk_bf16v3_kernel<<<dim3((unsigned)cdiv(n, 8)), block, V3_LDS, s>>>(a);
+            if (stamps) fused_trunk_bf16v3_kernel<true><<<dim3((unsigned)cdiv(n, 8)), block, V3_LDS, s>>>(a, stamps);
+            else fused_trunk_bf16v3_kernel<false><<<dim3((unsigned)cdiv(n, 8)), block, V3_LDS, s>>>(a, nullptr);
             return launched("fused_trunk_bf16v3");
         }
         if (!x3 && bf16_build != 1) {

@@ -101,11 +101,35 @@ __device__ __forceinline__ void epilogue_l2v3(char* lds, const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a) {
+// STAMP: the diagnostic build (tools/fused_stamps.py): the phase boundaries of quad q on row 8 * workgroup + 4 q + wave; the
+// 4x4 stage's (stamps 11 .. 15) on both quads' rows - the SECOND quad's rows (4 .. 7 of every 8) read like the other builds'
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char ldsx[];
+#undef IPSX_STAMP
+#define IPSX_STAMP(k)                                                                      \
+    do {                                                                                   \
+        if (STAMP) {                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+            if (lane == 0) stamps[((size_t)blockIdx.x * 8 + 4 * q + wave) * 16 + (k)] = t_; \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+        }                                                                                  \
+    } while (0)
+#define IPSX_STAMP2(k)                                                                     \
+    do {                                                                                   \
+        if (STAMP) {                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+            if (lane == 0) {                                                               \
+                stamps[((size_t)blockIdx.x * 8 + wave) * 16 + (k)] = t_;                   \
+                stamps[((size_t)blockIdx.x * 8 + 4 + wave) * 16 + (k)] = t_;               \
+            }                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+        }                                                                                  \
+    } while (0)
     constexpr int R1 = XL<1>::R1, R2 = XL<1>::R2;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rt = wave & 1, pp = wave >> 1;
+    const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long n_valid = a.count ? (long long)*a.count : a.n;
     const long long p_first = (long long)blockIdx.x * 8;
     if (p_first >= n_valid) return;                      // workgroup-uniform
@@ -113,12 +137,19 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a)
     // ---- two quads through stem + layer1, one after the other; the 8x8 images in place
 #pragma unroll 1
     for (int q = 0; q < 2; ++q) {
+        // (lane and wave through an opaque copy per quad: what is derived from them - tap offsets, slab addresses - is formed
+        //  where it is used instead of being carried round the loop in registers the 8x8 stage does not have)
+        int lane = lane0, wave = wave0;
+        asm volatile("" : "+v"(lane));
+        asm volatile("" : "+s"(wave));
+        const int rt = wave & 1, pp = wave >> 1;
         char* const base = ldsx + 4 * q * V2_SLAB;       // this quad's four slabs
         char* const Sb = base + wave * V2_SLAB;          // this wave's own patch: input image, transposition scratch, hand-over
         float* const S = reinterpret_cast<float*>(Sb);
         long long pi = p_first + 4 * q + wave;
         if (pi >= n_valid) pi = n_valid - 1;             // tail: recompute a valid patch, store nothing
         if (a.index) pi = a.index[pi];
+        IPSX_STAMP(0);
         {
             float4 px[4];
             v2_fetch(a, pi, lane, px);
@@ -136,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a)
         }
         wave_fence();
         f32x16 idn[4], acc[4];
+        IPSX_STAMP(1);
         {
             f32x16 st[2][2], tr[2][2];
             stem_pool<1>(a, Sb, st, lane);
@@ -164,21 +196,29 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a)
             for (int z = lane; z < R1 / 4; z += 64) reinterpret_cast<unsigned*>(Sb + XZ1 * R1)[z] = 0u;
         }
         __syncthreads();
+        IPSX_STAMP(2);
         char* const P = base + 2 * pp * V2_SLAB;         // the pair's two slabs
 #pragma unroll 1
         for (int blk = 0; blk < 2; ++blk) {
             conv_l1v2(a.wh[2 * blk], P, rt, acc, lane);
+            IPSX_STAMP(3 + 4 * blk);
             __syncthreads();                             // every wave has read the images: overwrite them
             epilogue_l1v2<0>(P, a.al[2 * blk], a.sh[2 * blk], rt, acc, idn, lane);
             __syncthreads();
+            IPSX_STAMP(4 + 4 * blk);
             conv_l1v2(a.wh[2 * blk + 1], P, rt, acc, lane);
+            IPSX_STAMP(5 + 4 * blk);
             __syncthreads();
             epilogue_l1v2<1>(P, a.al[2 * blk + 1], a.sh[2 * blk + 1], rt, acc, idn, lane);
             __syncthreads();
+            IPSX_STAMP(6 + 4 * blk);
         }
     }
 
     // ---- layer2 over the eight patches: wave = 32 output channels x 128 pixels
+    int lane = lane0, wave = wave0;
+    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+s"(wave));
     char* const setX = ldsx;
     char* const setY = ldsx + 8 * V2_S2;
     f32x16 t2[4], id2[4];
@@ -197,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a)
                 for (int j = 0; j < 4; ++j) id2[ct][4 * g + j] = __builtin_fmaf(id2[ct][4 * g + j], Aa[j], Bb[j]);
         }
     }
+    IPSX_STAMP2(11);
     __syncthreads();                                     // every wave is done with the 8x8 images: their space is the 4x4 stage's
     epilogue_l2v3<0>(setX, a.al[4], a.sh[4], t2, id2, lane, wave);
     for (int p = wave; p < 8; p += 4)                    // the zero (halo) rows of both sets' 4x4 images
@@ -208,13 +249,16 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a)
     conv_l2v3<128, 4, R2, XZ2, 1, 3, V2_S2>(a.wh[5], setX, t2, lane, wave);
     epilogue_l2v3<1>(setY, a.al[5], a.sh[5], t2, id2, lane, wave);
     __syncthreads();
+    IPSX_STAMP2(12);
     conv_l2v3<128, 4, R2, XZ2, 1, 3, V2_S2>(a.wh[6], setY, t2, lane, wave);
     epilogue_l2v3<0>(setX, a.al[6], a.sh[6], t2, id2, lane, wave);
     __syncthreads();
+    IPSX_STAMP2(13);
     conv_l2v3<128, 4, R2, XZ2, 1, 3, V2_S2>(a.wh[7], setX, t2, lane, wave);
     __syncthreads();                                     // the fp32 images of the average pool take the whole space
     epilogue_l2v3<2>(ldsx, a.al[7], a.sh[7], t2, id2, lane, wave);
     __syncthreads();
+    IPSX_STAMP2(14);
     for (int o = threadIdx.x; o < 8 * 128; o += 256) {
         const int pl = o >> 7, n = o & 127;
         const float* sp = reinterpret_cast<const float*>(ldsx + pl * V2_SLAB) + n;
@@ -223,4 +267,5 @@ __global__ __launch_bounds__(256, 2) void fused_trunk_bf16v3_kernel(FusedArgs a)
         for (int k = 0; k < 16; ++k) sum = sum + sp[k * PS2];
         if (p_first + pl < n_valid) a.emb[(size_t)(p_first + pl) * 128 + n] = sum / 16.0f;
     }
+    IPSX_STAMP2(15);
 }

@@ -30,7 +30,7 @@ L = hip.lib()
 fn = L.ipsx_dbg_fused_trunk_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.POINTER(hip.Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-n_wave = ((n + 3) // 4) * 4
+n_wave = ((n + 7) // 8) * 8
 st = torch.zeros((n_wave, 16), dtype=torch.int64, device=dev)
 out = torch.empty_like(ref)
 for _ in range(3):
@@ -39,6 +39,11 @@ for _ in range(3):
 torch.cuda.synchronize()
 assert torch.equal(out, ref)
 s = st.cpu().numpy().astype(np.int64)
+if prec == "bf16" and os.environ.get("IPSX_BF16_BUILD", "3") == "3":
+    # the third build: eight patches per workgroup, two quads one after the other - the SECOND quad's rows (4 .. 7 of every 8)
+    # carry its own phases and, right behind them, the 4x4 stage over all eight (per PATCH: halve those phases)
+    s = s[: (n // 8) * 8].reshape(-1, 8, 16)[:, 4:, :].reshape(-1, 16)
+    print("third build: rows of the second quad of every workgroup; the 4x4 stage's phases (l2.*) are for EIGHT patches")
 names = ["load", "stem+pool", "l1.0.c1", "l1.0.c1 epi", "l1.0.c2", "l1.0.c2 epi", "l1.1.c1", "l1.1.c1 epi",
          "l1.1.c2", "l1.1.c2 epi", "l2.0.c1+down", "l2.0 epi+c2", "l2.1.c1", "l2.1.c2", "avgpool"]
 mfma = [0, 400, 1152, 0, 1152, 0, 1152, 0, 1152, 0, 640, 1152, 1152, 1152, 0]
