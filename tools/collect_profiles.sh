@@ -73,9 +73,11 @@ python tools/fuzz_e2e.py 100 400 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_e2e.tx
 python tools/fuzz_pipelines.py 0 750 2>&1 | grep -v "amdgpu.ids" > "$OUT/fuzz_pipelines.txt"
 # round 6: the bf16 trunk's phases (second build; alone on its unit; the first build), the parity margins, the sharded path
 # with more than one rank on this GPU (fp32 and configs[4]: bf16 pipe + fp16-stored patches)
-python tools/fused_stamps.py 40000 bf16 2>&1 | grep -v "amdgpu.ids" > "$OUT/fused_stamps_bf16v2.txt"
-{ echo "# IPSX_BF16_ONE_WG=1: one workgroup per unit (one wave per SIMD)"; IPSX_BF16_ONE_WG=1 python tools/fused_stamps.py 40000 bf16; } 2>&1 | grep -v "amdgpu.ids" >> "$OUT/fused_stamps_bf16v2.txt"
+python tools/fused_stamps.py 40000 bf16 2>&1 | grep -v "amdgpu.ids" > "$OUT/fused_stamps_bf16v3.txt"
+{ echo "# IPSX_BF16_BUILD=2: the second build (fused_trunk_bf16v2.h)"; IPSX_BF16_BUILD=2 python tools/fused_stamps.py 40000 bf16; } 2>&1 | grep -v "amdgpu.ids" > "$OUT/fused_stamps_bf16v2.txt"
+{ echo "# IPSX_BF16_BUILD=2 IPSX_BF16_ONE_WG=1: one workgroup per unit (one wave per SIMD)"; IPSX_BF16_BUILD=2 IPSX_BF16_ONE_WG=1 python tools/fused_stamps.py 40000 bf16; } 2>&1 | grep -v "amdgpu.ids" >> "$OUT/fused_stamps_bf16v2.txt"
 { echo "# IPSX_BF16_BUILD=1: the first build (fused_trunk_split.h)"; IPSX_BF16_BUILD=1 python tools/fused_stamps.py 40000 bf16; } 2>&1 | grep -v "amdgpu.ids" >> "$OUT/fused_stamps_bf16v2.txt"
+python tools/trunk_bf16_bench.py 2>&1 | grep -v "amdgpu.ids" > "$OUT/trunk_bf16_bench.txt"
 python tools/fused_stamps.py 40000 fp32x3 2>&1 | grep -v "amdgpu.ids" > "$OUT/fused_stamps_x3.txt"
 python -m pytest tests/test_parity_margin.py -q -m gpu -s 2>&1 | grep -v "amdgpu.ids" > "$OUT/parity_margin.txt"
 for w in 2 4; do for ps in "fp32 f32" "bf16 f16"; do set -- $ps
