@@ -157,3 +157,24 @@ def test_partition_gives_every_rank_whole_rounds_of_the_fused_trunk():
     b = ipsd.shard_plan(IPSNet(torch.device("cpu"), conf), 16, conf.N, 4, (1, 32, 32), units=256, precision="fp32")
     assert a.signature() == b.signature()
     assert a.signature() != ipsd.shard_plan(net, 16, conf.N, 4, (1, 32, 32), units=304, precision="fp32").signature()
+
+
+def test_bf16_trunk_parts_are_whole_rounds_of_its_eight_patch_workgroups():
+    """The bf16 trunk's third build takes EIGHT patches per workgroup (two workgroups per unit: a round is 16 patches per
+    unit).  The single-GPU bf16 path cuts its parts with the sharded path's planner (world = 1): every launch but the last a
+    whole number of those rounds - the fixed 50 / 30 / 15 / 5 % cut of the headline batch is 12 rounds' worth of launches
+    for 9.8 rounds of work."""
+    import math
+    from ips_amd import synth
+    from ips_amd.architecture import IPSNet
+    conf, B = synth.bench_workload("mnist")
+    net = IPSNet(torch.device("cpu"), conf)
+    model = ipsd.launch_model(net, (1, 32, 32), units=256, precision="bf16")
+    assert model.round == 16 * 256
+    plan = ipsd.ShardPlan(conf.N, conf.M, conf.I, 1, B, model)
+    n = plan.launches(0)
+    assert sum(n) == B * conf.N and all(v % model.round == 0 for v in n[:-1])
+    fixed = ipsd.ShardPlan(conf.N, conf.M, conf.I, 1, B)
+    assert sum(math.ceil(v / model.round) for v in fixed.launches(0)) == 12 > sum(math.ceil(v / model.round) for v in n)
+    assert ipsd.launch_model(net, (1, 32, 32), units=256, precision="fp32").round == 8 * 256
+
