@@ -273,12 +273,40 @@ def measure_precision(net, x, steps, precision, fixture, storage="f32"):
         os.environ["IPSX_PRECISION"] = "fp32"
     rate = x.shape[0] * x.shape[1] * steps / dt
     peak = {"fp32x3": BF16_MFMA_PEAK_TFLOPS / 6, "bf16": BF16_MFMA_PEAK_TFLOPS}[precision]
+    # the trunk ALONE on the same patches: ONE launch of the whole batch, no selection loop beside it (HIP events on the launch
+    # stream) - inside a call the loops' workgroups take units from it, so the two figures differ
+    os.environ["IPSX_PRECISION"] = precision
+    try:
+        flat = xs.reshape(-1, *xs.shape[2:])
+        for _ in range(2):
+            net._plan.encode(flat)
+        def launches(rows):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                net._plan.encode(rows)
+            e1.record()
+            torch.cuda.synchronize()
+            return rows.shape[0] * 10 / (e0.elapsed_time(e1) * 1e-3)
+        alone = launches(flat)
+        # ... and on whole rounds of the chip only (2 workgroups per CU, 8 patches each for the bf16 build, 4 for fp32x3's):
+        # the batch's 40,000 patches leave 0.77 of a round, which costs 0.8 of one
+        cus = torch.cuda.get_device_properties(flat.device).multi_processor_count
+        whole = flat.shape[0] // (cus * 16) * (cus * 16)
+        alone_whole = launches(flat[:whole]) if whole else alone
+    finally:
+        os.environ["IPSX_PRECISION"] = "fp32"
     return {"value": rate, "unit": "patches/s", "ms_per_step": 1e3 * dt / steps, "patch_storage": storage,
             "same_indices_as_f32": same, "selected_in_common_with_f32": common, "slots_equal_to_f32": float((a == b).mean()),
             "parity": par,
             "roofline_call": {"bound": "mfma", "achieved": rate * FLOP_PER_PATCH["mnist"] / 1e12, "peak": peak, "unit": "TFLOP/s",
                               "frac": rate * FLOP_PER_PATCH["mnist"] / 1e12 / peak,
                               "what": "whole ips() calls back to back x algorithmic encoder FLOP per patch"},
+            "roofline_kernel_alone": {"bound": "mfma", "achieved": alone * FLOP_PER_PATCH["mnist"] / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                      "frac": alone * FLOP_PER_PATCH["mnist"] / 1e12 / peak, "patches_per_s": alone,
+                                      "whole_rounds": {"patches": whole, "patches_per_s": alone_whole,
+                                                       "frac": alone_whole * FLOP_PER_PATCH["mnist"] / 1e12 / peak},
+                                      "what": "the trunk kernel alone: the batch's %d patches in ONE launch, 10 launches between two HIP events" % flat.shape[0]},
             "what": _ALSO[precision] + ("" if storage == "f32" else "; patches stored as %s (BASELINE configs[4])" % storage)}
 
 
