@@ -67,8 +67,10 @@ extern "C" {
  *         ipsx_ips_call_elapsed added
  *   3.01  round 5 (additions only): ipsx_pack_conv_weights_batch, ipsx_conv2d_lds_nhwc_stats (+ _slabs),
  *         ipsx_bn_train_forward_partials, ipsx_stem7x7s2_nhwc (+ _supported), ipsx_conv2d_dgrad_s2_lds_nhwc (+ _supported),
- *         ipsx_maxpool_3x3s2_bwd_nhwc (+ _supported) */
-#define IPSX_VERSION 301
+ *         ipsx_maxpool_3x3s2_bwd_nhwc (+ _supported)
+ *   3.02  round 6 (addition): ipsx_scan_workgroups_per_image - candidate sets beyond the LDS with 8 heads and one token run
+ *         as a team of workgroups per image; ipsx_scan_workspace_bytes grew for those shapes */
+#define IPSX_VERSION 302
 
 #define IPSX_OK            0
 #define IPSX_EINVAL       -1      /* bad argument / unsupported shape */
@@ -402,6 +404,11 @@ int ipsx_scan(const float* logits, int b, int64_t n, int m, int i, int h, int n_
  * ips_net.py:148) - keep only the ranking in LDS and need a caller-owned device workspace of this many bytes (0 = none
  * needed, workspace may be NULL).  ipsx_scan / ipsx_scan_range return IPSX_EWORKSPACE when it is missing or too small. */
 size_t ipsx_scan_workspace_bytes(int b, int m, int i, int h, int n_token);
+/* Workgroups (= compute units) the loop of ONE image occupies for a call of b images: 1 for every LDS-resident shape; the
+ * shapes above with 8 heads and one token - the shipped CAMELYON configuration - run as a TEAM of up to 8 workgroups per
+ * image that share the element-wise passes and pre-sort their shares of the ranking (csrc/scan_large_team.h; same results).
+ * A caller that launches a persistent producer beside persistent loops leaves b x this many units free (3.02). */
+int ipsx_scan_workgroups_per_image(int b, int m, int i, int h, int n_token);
 
 /* Iterations [it_begin, it_end) of the same loop.  it_begin = 0 starts from the first m patches, it_begin > 0
  * resumes from the state a previous call left in mem_idx; only logits rows below m + it_end*i are read, so a

@@ -143,7 +143,20 @@ __device__ __forceinline__ bool ranked_ties_padded(const uint64_t* sorted, int L
                 const long long pa = key_pos(ka), pb = key_pos(kb);
                 const float* ra = rows->lg + (size_t)(pa < rows->m ? rows->mem[pa] : rows->lo + (pa - rows->m)) * rows->R;
                 const float* rb = rows->lg + (size_t)(pb < rows->m ? rows->mem[pb] : rows->lo + (pb - rows->m)) * rows->R;
-                for (int r = 0; r < rows->R; ++r) e = e && as_u32(ra[r]) == as_u32(rb[r]);
+                // (every load issued before the first compare: `e && ...` made them R round trips one after the other -
+                //  with a bit-equal pair of scores in nearly every iteration of 10,000 candidates that was 4 us of each)
+                if ((rows->R & 3) == 0) {
+                    uint32_t diff = 0u;
+                    for (int r = 0; r < rows->R; r += 4) {
+                        const float4 va = *reinterpret_cast<const float4*>(ra + r), vb = *reinterpret_cast<const float4*>(rb + r);
+                        diff |= (as_u32(va.x) ^ as_u32(vb.x)) | (as_u32(va.y) ^ as_u32(vb.y)) | (as_u32(va.z) ^ as_u32(vb.z)) | (as_u32(va.w) ^ as_u32(vb.w));
+                    }
+                    e = diff == 0u;
+                } else {
+                    uint32_t diff = 0u;
+                    for (int r = 0; r < rows->R; ++r) diff |= as_u32(ra[r]) ^ as_u32(rb[r]);
+                    e = diff == 0u;
+                }
             }
             any = any || e;
             if (!by_rows) break;                       // (any tie counts: the neighbour settles it)
@@ -1047,6 +1060,7 @@ bool scan_cam_shape(int m, int i, int h, int n_token);                     // sc
 int launch_scan_cam(const ScanCall& c);                                    // scan_cam.hip
 size_t scan_large_ws_per_image(int m, int i, int h, int n_token);          // scan_large.hip
 int launch_scan_large(const ScanCall& c);                                  // scan_large.hip
+int scan_large_team(int b, int m, int i, int h, int n_token);              // scan_large.hip: workgroups per image (1: no team)
 int launch_topm_large(const TopmArgs& a, int b, void* workspace, size_t workspace_bytes, void* stream);   // scan_large.hip
 size_t topm_large_ws_per_row(int l);                                       // scan_large.hip
 int scan_large_max_l();                                                    // scan_large.hip
@@ -1056,6 +1070,7 @@ extern int g_persist_wait_ms;          // ipsx_set_persistent_wait_ms
 extern bool g_scan_generic;            // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
 extern bool g_replay_stamps_on;        // diagnostic (ipsx_dbg_replay_stamps)
 extern bool g_scan_direct;             // diagnostic (ipsx_dbg_scan_direct)
+extern int g_scan_team;                // diagnostic (ipsx_dbg_scan_team): -1 the default, 0 one workgroup per image, 2 / 4 / 8
 extern bool g_scan_r8;                 // diagnostic (ipsx_dbg_scan_r8): 0 sends scan_cam_kernel's shape through scan_fast_kernel
 extern unsigned long long* g_scan_stamps;      // diagnostic (ipsx_dbg_scan_stamps)
 unsigned long long* persist_log();     // device address of the resident loops' / the gate's log (scorer.hip: g_persist_log)

@@ -306,6 +306,9 @@ struct LargeArgs {
     int* status;           //   bit 0: gave up waiting, bit 1: resident
     const int* cond;       // conditional launch (ipsx_scan_range_if_ws): run only when (*cond & cond_mask) != 0
     int cond_mask;
+    size_t team_off;       // scan_large_team_kernel: where an image's team block (counters, then the sorted runs) starts in its workspace
+    unsigned long long team_ticks;     // ... and the longest wait of one workgroup of a team for another
+    int team_trunc;        // ... 1: the ranking from the top halves of the runs when that is provably enough (IPSX_LARGE_TRUNC=0: never)
 };
 
 // keys (padded) | row maxima, denominators | stack of the sequential fallbacks | leaf bitmap | two range lists + counters
@@ -674,6 +677,8 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
 }
 #undef LARGE_STAMP
 
+#include "scan_large_team.h"
+
 // torch.topk(scores, m)[1] for l <= 16,384 candidates per row: the ranking of scan_large_kernel alone
 __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsigned char* ws, size_t ws_per_row) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -692,9 +697,37 @@ __global__ __launch_bounds__(LARGE_NT) void topm_large_kernel(TopmArgs a, unsign
         a.top[(size_t)b * a.m + j] = replayed ? (long long)q[j].i : (long long)key_pos(keys[large_slot(j)]);
 }
 
-size_t scan_large_ws_per_image(int m, int i, int h, int n_token) {
+static int device_cus() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    return (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+}
+
+// staged logits / exponentials + the tie replay's lists [+ the team's block: counters and sorted runs]
+static size_t large_ws_base(int m, int i, int h, int n_token) {
     const size_t Lp = ((size_t)(m + i) + 63) & ~(size_t)63;
     return ((size_t)h * n_token * Lp * 4 + 2 * Lp * 4 + 255) & ~(size_t)255;
+}
+static bool team_shape(int m, int i, int h, int n_token) {
+    return h == 8 && n_token == 1 && m + i > 4096 && m + i <= LARGE_MAX_L;
+}
+size_t scan_large_ws_per_image(int m, int i, int h, int n_token) {
+    const size_t base = large_ws_base(m, i, h, n_token);
+    if (!team_shape(m, i, h, n_token)) return base;
+    return base + ((team_bytes(std::max(64, next_pow2(m + i))) + 255) & ~(size_t)255);
+}
+
+// Workgroups scan_large_team_kernel gives ONE image of this shape (1: scan_large_kernel, one workgroup).  g_scan_team:
+// -1 the default (8), 0 off, else 2 / 4 / 8 (IPSX_LARGE_TEAM, ipsx_dbg_scan_team).
+int scan_large_team(int b, int m, int i, int h, int n_token) {
+    static const int env = [] { const char* e = std::getenv("IPSX_LARGE_TEAM"); return e && *e ? std::atoi(e) : -1; }();
+    const int want = g_scan_team >= 0 ? g_scan_team : (env >= 0 ? env : 8);
+    if (want < 2 || !g_scan_direct || !team_shape(m, i, h, n_token)) return 1;
+    const int n2 = std::max(64, next_pow2(m + i));
+    int W = want >= 8 ? 8 : (want >= 4 ? 4 : 2);
+    while (W > 1 && n2 / (LARGE_NT * W) < 1) W >>= 1;            // (a run is at least 1,024 slots)
+    if (W < 2 || (long long)b * W > device_cus() / 2) return 1;  // teams must be resident together: half the chip at most
+    return W;
 }
 
 int scan_large_max_l() { return LARGE_MAX_L; }
@@ -738,6 +771,33 @@ int launch_scan_large(const ScanCall& c) {
         la.cond = cond; la.cond_mask = cond_mask;
         const size_t lds = large_lds_bytes(n2, R);
         IPSX_REQUIRE(lds <= kLdsLimit, "scan: internal - %zu B of LDS", lds);
+        // a team of workgroups per image (scan_large_team.h) - not the conditional recovery launch, which must not wait on anyone
+        const int W = cond ? 1 : scan_large_team(b, m, i, h, n_token);
+        if (W > 1 && !(g_scan_stamps && n2 / (LARGE_NT * W) != 2)) {
+            la.team_off = large_ws_base(m, i, h, n_token);
+            la.team_ticks = la.wait_ticks * (ready ? 1ull : 20ull);
+            static const bool trunc = [] { const char* e = std::getenv("IPSX_LARGE_TRUNC"); return !(e && e[0] == '0'); }();
+            la.team_trunc = trunc ? 1 : 0;
+            unsigned char* ctl0 = la.ws + la.team_off;
+            if (hipMemset2DAsync(ctl0, la.ws_per_image, 0, (size_t)TEAM_CTL_INTS * 4, (size_t)b, as_stream(stream)) != hipSuccess)
+                return fail(IPSX_EHIP, "scan: clearing the team counters: %s", hipGetErrorString(hipGetLastError()));
+            const dim3 grid((unsigned)(b * W)), block(LARGE_NT);
+#define IPSX_TEAM_LAUNCH(CPT, ST)                                                                                              \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_large_team_kernel<CPT, ST>),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                        \
+        scan_large_team_kernel<CPT, ST><<<grid, block, lds, as_stream(stream)>>>(la, ST ? g_scan_stamps : nullptr);             \
+    } while (0)
+            switch (n2 / (LARGE_NT * W)) {
+                case 1: IPSX_TEAM_LAUNCH(1, false); break;
+                case 2: if (g_scan_stamps) IPSX_TEAM_LAUNCH(2, true); else IPSX_TEAM_LAUNCH(2, false); break;
+                case 4: IPSX_TEAM_LAUNCH(4, false); break;
+                case 8: IPSX_TEAM_LAUNCH(8, false); break;
+                default: return fail(IPSX_EINVAL, "scan: internal - team of %d workgroups for %d slots", W, n2);
+            }
+#undef IPSX_TEAM_LAUNCH
+            return launched("scan");
+        }
         if (g_scan_stamps) {                                           // diagnostic build (tools/scan_stamps.py large)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_large_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             scan_large_kernel<true><<<dim3((unsigned)b), dim3(LARGE_NT), lds, as_stream(stream)>>>(la, g_scan_stamps);

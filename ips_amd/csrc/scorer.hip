@@ -32,6 +32,7 @@ int g_tie_order = 1;     // 0 canonical; 1 (default) torch.topk's order where bi
 int g_persist_wait_ms = 50;         // ipsx_set_persistent_wait_ms: longest wait of a persistent loop / its gate without progress
 bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
 bool g_replay_stamps_on = false;    // diagnostic (ipsx_dbg_replay_stamps): the replay's phases are stamped from the first read on
+int g_scan_team = -1;               // diagnostic (ipsx_dbg_scan_team): workgroups per image of scan_large_team_kernel (-1: default)
 bool g_scan_direct = true;          // diagnostic (ipsx_dbg_scan_direct): 0 = scan_large_kernel's five generic passes for every shape
 bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the shape of scan_cam_kernel through scan_fast_kernel
 unsigned long long* g_scan_stamps = nullptr;   // diagnostic only (ipsx_dbg_scan_stamps)
@@ -85,6 +86,12 @@ IPSX_API size_t ipsx_scan_workspace_bytes(int b, int m, int i, int h, int n_toke
     if (b <= 0 || m <= 0 || i <= 0 || h <= 0 || n_token <= 0) return 0;
     if (scan_fast_plan(m, i, h, n_token).ok && !g_scan_generic) return 0;
     return (size_t)b * scan_large_ws_per_image(m, i, h, n_token);
+}
+
+IPSX_API int ipsx_scan_workgroups_per_image(int b, int m, int i, int h, int n_token) {
+    if (b <= 0 || m <= 0 || i <= 0 || h <= 0 || n_token <= 0) return 0;
+    if (scan_fast_plan(m, i, h, n_token).ok && !g_scan_generic) return 1;
+    return scan_large_team(b, m, i, h, n_token);
 }
 
 __global__ void publish_rows_kernel(int* ready, int value) {
@@ -235,4 +242,6 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_stamps(unsi
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int on) { g_scan_generic = on != 0; }
 
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_direct(int on) { g_scan_direct = on != 0; }
+// Diagnostic: workgroups per image for candidate sets beyond the LDS (-1 the default, 0 / 1 one workgroup, 2 / 4 / 8)
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_team(int w) { g_scan_team = w; }
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_r8(int on) { g_scan_r8 = on != 0; }

@@ -255,6 +255,7 @@ _EXPORTS = {
     "ipsx_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_scan_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "ipsx_scan_workgroups_per_image": (C.c_int, [C.c_int] * 5),
     "ipsx_scan_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ipsx_scan_range_if": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
@@ -468,6 +469,11 @@ def scan_workspace(B, M, I, H, T, device):
     a side stream keeps it between calls (like its other per-call buffers) instead of allocating it there."""
     nb = lib().ipsx_scan_workspace_bytes(B, M, I, H, T)
     return torch.empty(nb, dtype=torch.uint8, device=device) if nb else None
+
+
+def scan_workgroups_per_image(B, M, I, H, T):
+    """Compute units the loop of ONE image occupies in a call of B images (1, or the team of csrc/scan_large_team.h)."""
+    return max(1, int(lib().ipsx_scan_workgroups_per_image(B, M, I, H, T)))
 
 
 def scan(lg, M, I, H, T, want_scores=False):

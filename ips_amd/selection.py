@@ -445,8 +445,11 @@ class Selection:
         xf, ef, lf = patches.view(B * N, -1), emb_buf.view(B * N, -1), logits.view(1, B * N, R)
         streamed = (not net.use_pos and fused2 and _env_on("IPSX_CAM_STREAM") and (B == 1 or N % 32 == 0)
                     and plan.stream_supported(B * N, R))
+        # (candidate sets beyond the LDS - the shipped M = I = 5000 - run as a TEAM of workgroups per slide, csrc/scan_large_team.h:
+        #  each of them keeps a compute unit)
+        team = hip.scan_workgroups_per_image(B, M, I, ca.H, ca.n_token)
         if streamed and patches.dtype == torch.float32 and self.native_ok(patches, None):
-            free = hip.device_geometry(dev).cus - loops
+            free = hip.device_geometry(dev).cus - loops * team
             wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
             short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-11 if B == 1 else -1)
             return self.native_call("features", patches, None, logits, mem_idx_buf, zeroed, emb_buf, scan_ws, loops, wgs,
@@ -460,17 +463,17 @@ class Selection:
                 # quarters, so that the launch ends evenly (short_first = -11: half the workgroups start with a 32-row tile, one round of single units;
                 # M patches/s per slide synced / back to back: all tiles 32 rows 39.9 / 41.1, this 41.6 / 43.4; without the
                 # quarters the leftover 8-16 units were a round of their own: stream 1.38 -> 1.30 ms)
-                free = hip.device_geometry(dev).cus - loops
+                free = hip.device_geometry(dev).cus - loops * team
                 wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
                 short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-11 if B == 1 else -1)
                 plan.stream(xf, vq, R, ef, logits.view(B * N, R), ctl, ready, workgroups=wgs, slide_rows=N, short_first=short)
                 # (whatever two simultaneous finishers leave to each other is published by the last workgroup out: round 5 -
                 #  it was one publish_rows launch per slide behind the stream)
             else:
-                its = self.feature_parts(loops, N, dev, True)
+                its = self.feature_parts(loops * team, N, dev, True)
                 edges = [0] + [min(N, M + it * I) for it in its[1:]]
                 edges[-1] = N
-                launches = self.feature_launches(B, N, edges, dev, loops)
+                launches = self.feature_launches(B, N, edges, dev, loops * team)
                 if fused2:
                     plan.row_stats(xf[launches[0][0]:launches[0][1]], out=stats[launches[0][0]:launches[0][1]])
                 published = None                       # (slide, rows) whose publication rides on the next GEMM launch

@@ -68,6 +68,38 @@ if kind == "campipe":
     for k, nme in enumerate(names):
         print("  %-30s %9.0f cycles/iter" % (nme, s[k] / n_iter))
     sys.exit(0)
+if kind == "largepipe":
+    # the team loop (scan_large_team_kernel, STAMP build) inside ips() of the shipped CAMELYON sizes: when each iteration's
+    # rows were there and when it ended
+    from ips_amd import synth
+    from ips_amd.architecture import IPSNet
+    dev = torch.device("cuda:0")
+    conf, B = synth.bench_workload("cam_native")
+    net = synth.fill_weights(IPSNet(dev, conf), 7).to(dev).eval()
+    x = synth.make_patches(conf, B, seed=21).to(dev)
+    L = hip.lib()
+    L.ipsx_dbg_scan_stamps.argtypes = [C.c_void_p]
+    st = torch.zeros((B * 8 + 128,), dtype=torch.int64, device=dev)
+    for _ in range(3):
+        net.ips(x)
+    torch.cuda.synchronize()
+    L.ipsx_dbg_scan_stamps(st.data_ptr())
+    net.ips(x)
+    torch.cuda.synchronize()
+    L.ipsx_dbg_scan_stamps(None)
+    n_iter = -(-(x.shape[1] - conf.M) // conf.I)
+    raw = st.cpu().numpy()
+    log = raw[B * 8:B * 8 + 2 * n_iter].reshape(n_iter, 2)
+    t0 = raw[B * 8 + 127]
+    print("team loop inside ips() (main workgroup, STAMP build): us since the loop kernel started")
+    for it in range(n_iter):
+        print("   it %d   rows there %8.1f   end %8.1f   (%.1f us)" % (it, (log[it, 0] - t0) / 100.0, (log[it, 1] - t0) / 100.0,
+                                                                      (log[it, 1] - log[it, 0]) / 100.0))
+    names = ["gather + own maxima (+ rows / memory wait)", "hop A", "exponentials + store + hop B", "row sums + hop C", "scores + own run sorted",
+             "hop D + runs loaded + merged", "tie check + replay", "new memory + hop E"]
+    for k, nme in enumerate(names):
+        print("  %-44s %9.1f k cycles/iter" % (nme, raw[k] / n_iter / 1e3))
+    sys.exit(0)
 if kind == "large":
     # scan_large_kernel (candidate sets beyond the LDS): the reference's shipped CAMELYON sizes, or N M I H T on the command line
     N, M, I, H, T = (int(v) for v in sys.argv[2:7]) if len(sys.argv) >= 7 else (38000, 5000, 5000, 8, 1)
@@ -91,9 +123,15 @@ if kind == "large":
     n_iter = -(-(N - M) // I)
     names = ["stage logits (transposed)", "row maxima", "exponentials", "row sums", "scores + keys", "sort",
              "tie check + replay", "new memory"]
+    team = int(os.environ.get("TEAM", "-1"))              # TEAM=0: one workgroup (scan_large_kernel); 8 (the default): the team's main workgroup
+    L.ipsx_dbg_scan_team(team)
+    if hip.scan_workgroups_per_image(1, M, I, H, T) > 1:
+        names = ["gather + own maxima (+ rows / memory wait)", "hop A: maxima, all to all", "exponentials + store + hop B (all to main)",
+                 "row sums + hop C (main to all)", "scores + own run sorted", "hop D + runs loaded + merged", "tie check + replay",
+                 "new memory + hop E"]
     for mode in ("torch", "canonical"):
         hip.set_tie_order(mode)
-        st = torch.zeros((1, 8), dtype=torch.int64, device=dev)
+        st = torch.zeros((1, 8 + 128), dtype=torch.int64, device=dev)      # (+ the team kernel's per-iteration log)
         hip.scan(lg, M, I, H, T)
         L.ipsx_dbg_scan_stamps(st.data_ptr())
         hip.scan(lg, M, I, H, T)
@@ -104,7 +142,7 @@ if kind == "large":
               "registers the product build does not: its passes over the workspace read slower than they are)"
               % (mode, n_iter, M + I, H * T, s.sum() / n_iter / 1e3))
         for k, nme in enumerate(names):
-            print("  %-28s %9.1f k cycles/iter" % (nme, s[k] / n_iter / 1e3))
+            print("  %-44s %9.1f k cycles/iter" % (nme, s[k] / n_iter / 1e3))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(10):
