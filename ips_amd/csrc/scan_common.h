@@ -1070,6 +1070,7 @@ extern int g_persist_wait_ms;          // ipsx_set_persistent_wait_ms
 extern bool g_scan_generic;            // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
 extern bool g_replay_stamps_on;        // diagnostic (ipsx_dbg_replay_stamps)
 extern bool g_scan_direct;             // diagnostic (ipsx_dbg_scan_direct)
+extern bool g_scan_team_trunc;         // diagnostic (ipsx_dbg_scan_team_trunc): 0 = the team's main workgroup always merges whole runs
 extern int g_scan_team;                // diagnostic (ipsx_dbg_scan_team): -1 the default, 0 one workgroup per image, 2 / 4 / 8
 extern bool g_scan_r8;                 // diagnostic (ipsx_dbg_scan_r8): 0 sends scan_cam_kernel's shape through scan_fast_kernel
 extern unsigned long long* g_scan_stamps;      // diagnostic (ipsx_dbg_scan_stamps)

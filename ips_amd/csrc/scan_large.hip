@@ -308,7 +308,7 @@ struct LargeArgs {
     int cond_mask;
     size_t team_off;       // scan_large_team_kernel: where an image's team block (counters, then the sorted runs) starts in its workspace
     unsigned long long team_ticks;     // ... and the longest wait of one workgroup of a team for another
-    int team_trunc;        // ... 1: the ranking from the top halves of the runs when that is provably enough (IPSX_LARGE_TRUNC=0: never)
+    int team_trunc;        // ... 1: the ranking from the top halves of the runs when that is provably enough (diagnostic ipsx_dbg_scan_team_trunc(0): never)
 };
 
 // keys (padded) | row maxima, denominators | stack of the sequential fallbacks | leaf bitmap | two range lists + counters
@@ -776,8 +776,7 @@ int launch_scan_large(const ScanCall& c) {
         if (W > 1 && !(g_scan_stamps && n2 / (LARGE_NT * W) != 2)) {
             la.team_off = large_ws_base(m, i, h, n_token);
             la.team_ticks = la.wait_ticks * (ready ? 1ull : 20ull);
-            static const bool trunc = [] { const char* e = std::getenv("IPSX_LARGE_TRUNC"); return !(e && e[0] == '0'); }();
-            la.team_trunc = trunc ? 1 : 0;
+            la.team_trunc = g_scan_team_trunc ? 1 : 0;
             unsigned char* ctl0 = la.ws + la.team_off;
             if (hipMemset2DAsync(ctl0, la.ws_per_image, 0, (size_t)TEAM_CTL_INTS * 4, (size_t)b, as_stream(stream)) != hipSuccess)
                 return fail(IPSX_EHIP, "scan: clearing the team counters: %s", hipGetErrorString(hipGetLastError()));

@@ -32,6 +32,7 @@ int g_tie_order = 1;     // 0 canonical; 1 (default) torch.topk's order where bi
 int g_persist_wait_ms = 50;         // ipsx_set_persistent_wait_ms: longest wait of a persistent loop / its gate without progress
 bool g_scan_generic = false;        // diagnostic (ipsx_dbg_scan_generic): every shape through scan_large_kernel
 bool g_replay_stamps_on = false;    // diagnostic (ipsx_dbg_replay_stamps): the replay's phases are stamped from the first read on
+bool g_scan_team_trunc = true;      // diagnostic (ipsx_dbg_scan_team_trunc)
 int g_scan_team = -1;               // diagnostic (ipsx_dbg_scan_team): workgroups per image of scan_large_team_kernel (-1: default)
 bool g_scan_direct = true;          // diagnostic (ipsx_dbg_scan_direct): 0 = scan_large_kernel's five generic passes for every shape
 bool g_scan_r8 = true;              // diagnostic (ipsx_dbg_scan_r8): 0 sends the shape of scan_cam_kernel through scan_fast_kernel
@@ -244,4 +245,6 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_generic(int
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_direct(int on) { g_scan_direct = on != 0; }
 // Diagnostic: workgroups per image for candidate sets beyond the LDS (-1 the default, 0 / 1 one workgroup, 2 / 4 / 8)
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_team(int w) { g_scan_team = w; }
+// Diagnostic: 0 = the team's ranking always from whole runs (the path taken when the runs' top halves are not provably enough)
+extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_team_trunc(int on) { g_scan_team_trunc = on != 0; }
 extern "C" __attribute__((visibility("default"))) void ipsx_dbg_scan_r8(int on) { g_scan_r8 = on != 0; }

@@ -49,6 +49,15 @@ def main():
             M = I = 64
             conf = synth.mnist_conf(N=N, M=M, I=I, use_pos=bool(g.integers(0, 2)))
             B, envs, what = 1, IMAGE_ENVS, "image"
+        elif seed % 7 == 6 or os.environ.get("LARGE") == "1":
+            # feature slides with a candidate set beyond the LDS (the reference's shipped M = I = 5000 and neighbours): the
+            # loop is a TEAM of workgroups per slide (csrc/scan_large_team.h) in every schedule that has resident loops
+            M = int(g.choice([5000, 4200, 2300]))
+            I = int(g.choice([M, 5000, 3000]))
+            B = int(g.choice([1, 1, 2, 3]))
+            N = int(g.integers(M + 1, 45000 if B == 1 else 20000))
+            conf = synth.camelyon_conf(N=N, M=M, I=I)
+            envs, what = FEATURE_ENVS, "features (beyond the LDS)"
         else:                                        # feature slides: the CAMELYON shape or a generic one
             cam = bool(g.integers(0, 2))
             M = I = 256 if cam else int(g.choice([32, 64, 128]))
