@@ -337,7 +337,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
     uint32_t* rmaxkey = reinterpret_cast<uint32_t*>(keys + a.n2 + (a.n2 >> 4));   // row maxima as order-preserving keys (max_key)
     float* rden = reinterpret_cast<float*>(rmaxkey + ((R + 1) & ~1));
     const int tail = (a.n2 + (a.n2 >> 4)) * 8 + ((R + 1) & ~1) * 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x;
     constexpr int NW = LARGE_NT / 64;
     const float* lg = a.lg + (size_t)b * a.n * R;
     long long* mem = a.mem_idx + (size_t)b * m;
@@ -358,7 +358,12 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_kernel(LargeArgs a, unsig
     int tie = 0;
     // row maxima in `seg` stretches per row so that every wavefront has one (max is order-free; a NaN wins: max_key)
     const int seg = R >= NW ? 1 : NW / R;
+    const int tid_outer = tid;
     for (long long it = a.it0; it < a.it1; ++it) {
+        // (nothing that depends on the thread's number is carried round the loop - see scan_large_team_kernel)
+        int tid = tid_outer;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
         const long long lo = it * a.i + m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = m + cnt;
@@ -726,8 +731,12 @@ int scan_large_team(int b, int m, int i, int h, int n_token) {
     const int n2 = std::max(64, next_pow2(m + i));
     int W = want >= 8 ? 8 : (want >= 4 ? 4 : 2);
     while (W > 1 && n2 / (LARGE_NT * W) < 1) W >>= 1;            // (a run is at least 1,024 slots)
-    if (W < 2 || (long long)b * W > device_cus() / 2) return 1;  // teams must be resident together: half the chip at most
-    return W;
+    // The teams of a call keep b x W compute units, beside a producer for the whole call - and only the LAST image's loop
+    // is on the critical path of a call of several (the others run beside the producer of the images behind them): 16
+    // units at most (1 / 16 of an MI355X: two images get teams of 8, four of 4, eight of 2).
+    const int cap = std::max(8, device_cus() / 16);
+    while (W > 1 && (long long)b * W > cap) W >>= 1;
+    return W < 2 ? 1 : W;
 }
 
 int scan_large_max_l() { return LARGE_MAX_L; }

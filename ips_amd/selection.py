@@ -451,7 +451,10 @@ class Selection:
         if streamed and patches.dtype == torch.float32 and self.native_ok(patches, None):
             free = hip.device_geometry(dev).cus - loops * team
             wgs = int(os.environ.get("IPSX_CAM_WGS", "0")) or free
-            short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or (-11 if B == 1 else -1)
+            # (a team's iteration is ~55 us and the last TWO of them run behind the producer - the rows of the last chunk all
+            #  complete in its last round - so a finer end of the stream pays: the last 2 x workgroups units as 32-row tiles,
+            #  38,000 rows at M = I = 5000: 39.3 -> 39.6 M patches/s)
+            short = int(os.environ.get("IPSX_CAM_SHORT", "0")) or ((-19 if team > 1 else -11) if B == 1 else -1)
             return self.native_call("features", patches, None, logits, mem_idx_buf, zeroed, emb_buf, scan_ws, loops, wgs,
                                     short_first=short)
         with _no_gc_pause():                       # from the loop's launch to its producers': no host stall
