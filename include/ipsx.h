@@ -68,7 +68,8 @@ extern "C" {
  *   3.01  round 5 (additions only): ipsx_pack_conv_weights_batch, ipsx_conv2d_lds_nhwc_stats (+ _slabs),
  *         ipsx_bn_train_forward_partials, ipsx_stem7x7s2_nhwc (+ _supported), ipsx_conv2d_dgrad_s2_lds_nhwc (+ _supported),
  *         ipsx_maxpool_3x3s2_bwd_nhwc (+ _supported)
- *   3.02  round 6 (addition): ipsx_scan_workgroups_per_image - candidate sets beyond the LDS with 8 heads and one token run
+ *   3.02  round 6 (additions): ipsx_projector_stream_ctl_zero_words (the stream's control words were re-ordered: what must be
+ *         zero comes first); ipsx_scan_workgroups_per_image - candidate sets beyond the LDS with 8 heads and one token run
  *         as a team of workgroups per image; ipsx_scan_workspace_bytes grew for those shapes */
 #define IPSX_VERSION 302
 
@@ -321,7 +322,7 @@ int ipsx_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n_patch
  * (ipsx_fold_query; r = h * n_token <= 32; out: logits (n, r)) are computed in place, and `*ready` - the progress word
  * of the selection loop - is advanced past every completed 32-row unit in order.  Several slides: x holds them one
  * after the other (n rows in all, slide_rows each, a multiple of 32), ready[s] is slide s's word, and the stream of
- * tiles runs across the slides' ends.  Bit-identical to ipsx_projector_stats + ipsx_projector_apply + ipsx_logits.  ctl: ipsx_projector_stream_ctl_words(n) int32 words ZEROED before every call.
+ * tiles runs across the slides' ends.  Bit-identical to ipsx_projector_stats + ipsx_projector_apply + ipsx_logits.  ctl: ipsx_projector_stream_ctl_words(n) int32 words, the first ipsx_projector_stream_ctl_zero_words(n) of them ZEROED before every call (3.02; the rest are hand-over accumulators, written before they are read).
  * workgroups <= 0: 7 of every 8 compute units (the loop's unit stays free); short_first >= 0: that many workgroups
  * start with a 32-row tile, -1: half of them (completions then do not come in bursts), -2: every tile is 32 rows (a
  * steady supply at 12 % less throughput), -3 - (head + 8 tail), head < 8: every workgroup's first `head` pulls and the
@@ -330,6 +331,7 @@ int ipsx_trunk_stream(const ipsx_trunk* t, const float* patches, int64_t n_patch
  * quarters each (the logits' accumulators pass from quarter to quarter: the same bits).  ipsx_projector_stream_supported: 1x1 Linear with
  * 512 outputs and its column sums (lin->colsum), c_in % 32 == 0, 64 <= n < 2^31.                    */
 size_t ipsx_projector_stream_ctl_words(int64_t n);
+size_t ipsx_projector_stream_ctl_zero_words(int64_t n);
 int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r);
 int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t n, int64_t slide_rows, float ln_eps, float* emb,
                           const float* v_packed, int r, float* logits, int32_t* ctl, int32_t* ready,
@@ -510,7 +512,7 @@ int ipsx_ips_finish(const void* patches, int64_t patch_row_bytes, int64_t patch_
  * runtime (an interpreter's collector or allocator) sits between the launch of the loop and the launch of the producer it
  * waits for - a host thread the OS deschedules there still can: the loop's wait is bounded and the call then redoes it.
  *   words: words_total int32 = tie flags [b] | progress words [b] | status | the producer's control words
- *          (ipsx_trunk_stream_ctl_words / ipsx_projector_stream_ctl_words); zeroed by the call.
+ *          (ipsx_trunk_stream_ctl_words / ipsx_projector_stream_ctl_words); zeroed by the call (what has to be: see ipsx_projector_stream_ctl_zero_words).
  *   timing_slot in [0, 64): the producer's launch is bracketed by a library-owned HIP event pair; ipsx_ips_call_elapsed
  *          (slot, &ms) reads it once the stream has been synchronised.  -1: no events.
  * The two hand-over events are the library's, one pair per device; the call enqueues under a per-device lock, so calls

@@ -80,7 +80,10 @@ IPSX_API int ipsx_ips_call_run(const ipsx_ips_call* c) {
     const int64_t n_iter = cdiv(c->n - c->m, c->i);
     auto hip_ok = [](hipError_t e, const char* what) { return e == hipSuccess ? IPSX_OK : fail(IPSX_EHIP, "ips_call: %s: %s", what, hipGetErrorString(e)); };
 
-    IPSX_TRY(hip_ok(hipMemsetAsync(c->words, 0, (size_t)c->words_total * sizeof(int32_t), main), "fill"));
+    // (the projector stream's control words end in 786 KB of hand-over accumulators that need no zeroing)
+    const int64_t zero_words = c->lin ? std::min<int64_t>(c->words_total, 2 * (int64_t)c->b + 1 + (int64_t)ipsx_projector_stream_ctl_zero_words((int64_t)c->b * c->n))
+                                      : c->words_total;
+    IPSX_TRY(hip_ok(hipMemsetAsync(c->words, 0, (size_t)zero_words * sizeof(int32_t), main), "fill"));
     IPSX_TRY(hip_ok(hipEventRecord(ev->fork, main), "event"));
     IPSX_TRY(hip_ok(hipStreamWaitEvent(side, ev->fork, 0), "wait"));
     const unsigned long long h0 = host_ns();

@@ -322,7 +322,11 @@ struct StreamArgs {
 // accumulators pass from quarter to quarter through memory (ctl: a flag and 1,024 floats per hand-over) - the same chain
 // in the same order, so embeddings and logits stay bit-identical.  The last quarter publishes the unit.
 constexpr int SPLIT_P = 4, SPLIT_TAIL = 16, SPLIT_HEAD = 48, SPLIT_MAX = SPLIT_TAIL + SPLIT_HEAD;
-constexpr int SPLIT_WORDS = 1 + SPLIT_MAX * (SPLIT_P - 1) * (1 + 1024);
+// control words of the quarters: [next quarter | a hand-over flag per (unit, part)] - ZEROED by the caller like the words in
+// front of them and the two exit words behind them - then the hand-over accumulators, which are written before they are
+// read and need no zeroing (786 KB of the 790 KB the caller used to fill in front of every call: advisor, round 5)
+constexpr int SPLIT_ZERO_WORDS = 1 + SPLIT_MAX * (SPLIT_P - 1);
+constexpr int SPLIT_WORDS = SPLIT_ZERO_WORDS + SPLIT_MAX * (SPLIT_P - 1) * 1024;
 constexpr int ST_EP = 516;                         // floats per row of the LDS copy of a tile (512 channels + 4 pad)
 constexpr int ST_STATS = 64 * 2;                    // floats: (mean, rstd) of the tile's rows
 constexpr size_t ST_LDS = (size_t)64 * ST_EP * 4 + ST_STATS * 4 + 16;
@@ -533,7 +537,7 @@ __device__ __forceinline__ void stream_tile(const StreamArgs& a, unsigned row0, 
         const float4* vq = reinterpret_cast<const float4*>(a.vp) + lane;
         const int kg0 = part * (64 / P), kg1 = P > 1 ? kg0 + 64 / P : a.vkgs;
         int* const sflag = a.ctl + a.split_base + 1 + split_unit * (SPLIT_P - 1);
-        float* const sacc = reinterpret_cast<float*>(a.ctl + a.split_base + 1 + SPLIT_MAX * (SPLIT_P - 1)) +
+        float* const sacc = reinterpret_cast<float*>(a.ctl + a.split_base + SPLIT_ZERO_WORDS + 2) +     // (behind the two exit words)
                             (size_t)split_unit * (SPLIT_P - 1) * 1024;
         f32x16 lacc;
 #pragma unroll
@@ -854,6 +858,10 @@ extern "C" __attribute__((visibility("default"))) void ipsx_dbg_stream_split(int
 IPSX_API size_t ipsx_projector_stream_ctl_words(int64_t n) {
     return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 + ipsx::SPLIT_WORDS + 2 : 0;
 }
+// ... of which only the FIRST this many must be zero when a call starts (the rest are hand-over accumulators)
+IPSX_API size_t ipsx_projector_stream_ctl_zero_words(int64_t n) {
+    return n > 0 ? (size_t)ipsx::cdiv(n, 32) + 2 + ipsx::SPLIT_ZERO_WORDS + 2 : 0;
+}
 
 IPSX_API int ipsx_projector_stream_supported(const ipsx_conv* lin, int64_t n, int r) {
     if (!lin || !lin->w_packed || lin->kh != 1 || lin->kw != 1 || lin->stride != 1 || lin->pad != 0) return 0;
@@ -889,7 +897,7 @@ IPSX_API int ipsx_projector_stream(const ipsx_conv* lin, const float* x, int64_t
     a.short_pulls = short_first == -2 ? 0x7fffffff : 0;                            // (-2: every tile 32 rows)
     a.tail_start = a.n_units;
     a.split_start = a.n_units; a.split_units = 0; a.split_base = a.n_units + 2;
-    a.exit_word = a.n_units + 2 + (unsigned)ipsx::SPLIT_WORDS;
+    a.exit_word = a.n_units + 2 + (unsigned)ipsx::SPLIT_ZERO_WORDS;
     a.head_units = a.head_wgs = 0;
     if (short_first <= -3) {
         // -3 - (head + 8 tail): every workgroup's first `head` pulls and the last `tail` x workgroups units are 32-row tiles -

@@ -233,6 +233,7 @@ _EXPORTS = {
     "ipsx_trunk_stream": (C.c_int, [C.POINTER(Trunk), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ipsx_projector_stream_ctl_words": (C.c_size_t, [C.c_int64]),
+    "ipsx_projector_stream_ctl_zero_words": (C.c_size_t, [C.c_int64]),
     "ipsx_projector_stream_supported": (C.c_int, [C.POINTER(Conv), C.c_int64, C.c_int]),
     "ipsx_projector_stream": (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -321,6 +321,11 @@ class EncoderPlan:
     def stream_ctl_words(n):
         return int(lib().ipsx_projector_stream_ctl_words(int(n)))
 
+    @staticmethod
+    def stream_ctl_zero_words(n):
+        """... of which only the first this many have to be zero when a call starts."""
+        return int(lib().ipsx_projector_stream_ctl_zero_words(int(n)))
+
     def encode(self, x, nonblank=None, stats=None, out=None, publish=None):
         """(P, C, h, w) or (P, F) float32 on the GPU  ->  (P, D).
 

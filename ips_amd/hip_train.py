@@ -122,6 +122,8 @@ def conv2d_nhwc(x, weight, stride, pad, dgrad_weights=False, packed=None, stats_
         co, ci = (weight.shape[1], weight.shape[0]) if dgrad_weights else (weight.shape[0], weight.shape[1])
     cv = Conv(ci, co, kh, kw, stride, pad, _p(packed), None, None, None)
     y = torch.empty((n, co, ho, wo), dtype=torch.float32, device=x.device, memory_format=_CL)
+    if n == 0:                                  # (an empty batch: nothing to launch)
+        return (y, torch.zeros((1, 2, co), dtype=torch.float32, device=x.device), 0) if stats_shift is not None else y
     if stats_shift is not None:
         slabs = int(lib().ipsx_conv2d_lds_nhwc_stats_slabs(n))
         partial = torch.empty((max(slabs, 1), 2, co), dtype=torch.float32, device=x.device)

@@ -115,7 +115,7 @@ class Selection:
                 and hip.persistent_ok(dev))
 
     # ------------------------------------------------------------------ the persistent loop: begin / end
-    def persistent_begin(self, logits, mem_idx_buf, zeroed, B, dev, loops=0, scan_ws=None):
+    def persistent_begin(self, logits, mem_idx_buf, zeroed, B, dev, loops=0, scan_ws=None, zero_words=None):
         """Zero the call's words (tie flags | a progress word per image | status | producer control words: ONE fill), launch
         the loop on the side stream and hold the main stream until it is resident.  -> (tie, ready, status, ctl).
 
@@ -125,7 +125,9 @@ class Selection:
         host memory, asynchronously, and looked at in the NEXT call - by then it has long arrived: a timeout re-runs the
         device's self-test, and repeated timeouts (``hip.persistent_timed_out``: IPSX_PERSIST_STRIKES, default 3) or a failing
         self-test switch the persistent pipelines off for the rest of the process (the per-part launches take over)."""
-        zeroed.zero_()                             # (first: everything below is host work in front of the call's second launch)
+        # (first: everything below is host work in front of the call's second launch; zero_words: the projector stream's
+        #  control words end in hand-over accumulators that need no zeroing)
+        (zeroed if zero_words is None else zeroed[:zero_words]).zero_()
         hip._PERSIST_CALLS += 1
         net = self.net
         ca = net.transf.crs_attn
@@ -458,7 +460,8 @@ class Selection:
             return self.native_call("features", patches, None, logits, mem_idx_buf, zeroed, emb_buf, scan_ws, loops, wgs,
                                     short_first=short)
         with _no_gc_pause():                       # from the loop's launch to its producers': no host stall
-            tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops, scan_ws)
+            tie, ready, status, ctl = self.persistent_begin(logits, mem_idx_buf, zeroed, B, dev, loops, scan_ws,
+                                                            zero_words=2 * B + 1 + plan.stream_ctl_zero_words(B * N))
             if streamed:
                 # one workgroup per compute unit the loops leave free (with dynamic pulls one that is placed late just starts
                 # late).  Round 4: the loop (3.7 us per iteration) is no longer the bound of a lone slide, the projector is:

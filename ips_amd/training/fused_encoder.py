@@ -150,11 +150,12 @@ class _ConvBnAct(torch.autograd.Function):
         x = x.contiguous(memory_format=_CL)
         if residual is not None:
             residual = residual.contiguous(memory_format=_CL)
-        shift = bn.running_mean
+        shift = _stats_shift(bn, x, weight, stride, pad, packs)
         c, partial, slabs = hip.conv2d_nhwc(x, weight.detach(), stride, pad, packed=packs[0] if packs is not None else None,
                                             stats_shift=shift)
         y, mean, invstd = hip.bn_train_forward_partials(c, residual, gamma, beta, bn.eps, bn.momentum, bn.running_mean,
                                                         bn.running_var, relu, partial, slabs, shift)
+        bn._ipsx_batch_mean = mean                # (a fresh tensor every step: the next step's shift, for free)
         ctx.relu, ctx.has_res, ctx.geom = relu, residual is not None, (stride, pad)
         ctx.packed_dgrad = packs[1] if packs is not None else None
         ctx.save_for_backward(x, weight, c, y if relu else None, gamma, mean, invstd)
@@ -171,9 +172,25 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, dres, None, None, None, None, None
 
 
+def _stats_shift(bn, x, weight, stride, pad, packs):
+    """What the convolution's epilogue subtracts before it sums and squares (fp32, per slab of 4 patches): var = E[d^2] -
+    E[d]^2 keeps its precision only while the shift is near the batch mean.  ``running_mean`` is not - 0 at
+    initialisation, anything after loading foreign statistics (advisor, round 5) - so: the batch mean of this layer's
+    PREVIOUS training step (the tensor that step returned, held by reference: no copy, no launch), and before there is one
+    the channel means of the convolution of the batch's first patch (one extra launch on 1 patch, once per layer)."""
+    prev = getattr(bn, "_ipsx_batch_mean", None)
+    if prev is not None and prev.device == x.device and prev.shape == bn.running_mean.shape:
+        return prev
+    with torch.no_grad():
+        c0 = hip.conv2d_nhwc(x[:1], weight.detach(), stride, pad, packed=packs[0] if packs is not None else None)
+        return c0.mean((0, 2, 3)).contiguous()
+
+
 def conv_bn_act(conv, bn, x, packs=None, residual=None, relu=True):
     """``bn_act(_conv(conv, x), bn, residual, relu)`` - as one node with the statistics off the convolution's epilogue where
     the convolution runs on the LDS-resident kernels."""
+    if x.shape[0] == 0:                          # an empty batch: no slabs, no statistics, nothing to normalise
+        return _conv(conv, x, packs)
     if _conv_ok(conv, x) and hip.conv_lds_supported(conv, x.shape[2], x.shape[3]) and bn.momentum is not None:
         return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, relu, conv.stride[0], conv.padding[0],
                                 packs.get(conv) if packs else None)

@@ -392,6 +392,35 @@ def test_conv_bn_node_equals_the_two_nodes(monkeypatch):
         assert _rel(a, b) < 1e-5
 
 
+def test_conv_bn_statistics_do_not_depend_on_where_the_running_mean_is():
+    """The conv+bn node's batch statistics are sums around a SHIFT taken in the convolution's epilogue; the shift is data
+    derived (the first patch's channel means, then the previous step's batch mean) - a ``running_mean`` 50 standard
+    deviations away from the batch mean (foreign statistics loaded into the module) costs no precision (advisor, round 5:
+    the shift used to be ``running_mean`` itself)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    P, ci, co, H = 96, 64, 64, 8
+    conv = torch.nn.Conv2d(ci, co, 3, 1, 1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(co).to(dev).train()
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn((co, ci, 3, 3), generator=g) * (2.0 / (ci * 9)) ** 0.5).to(dev))
+    x = (torch.randn((P, ci, H, H), generator=g) + 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    c = torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, 1, 1)
+    ref_mean, ref_var = c.mean((0, 2, 3)), c.var((0, 2, 3), unbiased=False)
+    ref = (c - ref_mean.view(1, -1, 1, 1)) / torch.sqrt(ref_var.view(1, -1, 1, 1) + bn.eps)
+    with torch.no_grad():
+        bn.running_mean.copy_((ref_mean + 50.0 * torch.sqrt(ref_var)).float())
+    for step in range(2):                       # the first step's shift: the first patch; the second's: the first step's mean
+        y = fused_encoder.conv_bn_act(conv, bn, x, relu=False)
+        assert hasattr(bn, "_ipsx_batch_mean")
+        assert _rel(bn._ipsx_batch_mean.double(), ref_mean) < 1e-6
+        assert _rel(y.double(), ref) < 2e-5, step
+    # an empty batch: an empty output, the statistics untouched (it used to raise out of the convolution's launch)
+    rm = bn.running_mean.clone()
+    empty = fused_encoder.conv_bn_act(conv, bn, x[:0], relu=False)
+    assert empty.shape == (0, co, H, H) and torch.equal(bn.running_mean, rm)
+
+
 def test_training_forward_uses_the_fused_path_and_env_switches_it_off(monkeypatch):
     dev = torch.device("cuda:0")
     conf = synth.mnist_conf(N=64, M=8, I=8)
