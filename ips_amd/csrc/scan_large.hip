@@ -719,7 +719,7 @@ static bool team_shape(int m, int i, int h, int n_token) {
 size_t scan_large_ws_per_image(int m, int i, int h, int n_token) {
     const size_t base = large_ws_base(m, i, h, n_token);
     if (!team_shape(m, i, h, n_token)) return base;
-    return base + ((team_bytes(std::max(64, next_pow2(m + i))) + 255) & ~(size_t)255);
+    return base + ((team_bytes(std::max(64, next_pow2(m + i)), m) + 255) & ~(size_t)255);
 }
 
 // Workgroups scan_large_team_kernel gives ONE image of this shape (1: scan_large_kernel, one workgroup).  g_scan_team:

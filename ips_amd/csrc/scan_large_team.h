@@ -7,28 +7,40 @@
 // workgroups (2, 4 or 8; on W compute units) share an image:
 //
 //   every workgroup   owns the candidates of the 64-blocks  w, w + W, w + 2 W, ...  (memory and chunk candidates alike):
-//                     gathers their 8 logits ONCE (they stay in registers), takes its row maxima, [hop A: all to all]
-//                     exponentials -> workspace (transposed, for the row sums) [hop B: all to main]
-//   main (w = 0)      the 8 denominators in the pinned order of the contract - lane j of a wavefront adds elements j, j + 64,
-//                     ... ascending, then the butterfly: 512 sequential chains that cannot be cut [hop C: main to all]
+//                     gathers their 8 logits ONCE (they stay in registers), takes its row maxima [hop A: all to all]
+//                     exponentials -> workspace (transposed, for the row sums) [hop B: all to all]
+//   workgroup w       the denominators of the rows [w * 8 / W, (w + 1) * 8 / W) in the pinned order of the contract - lane j
+//                     of a wavefront adds elements j, j + 64, ... ascending, then the butterfly: 512 sequential chains that
+//                     cannot be cut, but whose LOADS can (all wavefronts load, the sum is handed on) [hop C: all to all]
 //   every workgroup   scores and ranking keys of its candidates from the registers, SORTS them (its run: n2 / W slots, in
-//                     its own LDS) and hands the sorted run over [hop D: all to main]
-//   main              merges the W runs (log2 W rounds instead of log2(n2 / 16)), tie test, torch.topk replay, new memory
-//                     [hop E: main to all - the next iteration's memory rows]
+//                     its own LDS) and publishes the sorted run [hop D: all to all]
+//   every workgroup   RANKS its own run among all candidates - a key's rank is its place in its run plus, for every other
+//                     run, the number of keys there that are larger (a binary search per run) - and writes the patches of
+//                     its ranks below m into the new memory (a second buffer: the old one is still being read)
+//                     [hop E: all to all - the next iteration's memory rows]
+//   main (w = 0)      only when an iteration is flagged - two of the first m + 1 ranks tie in a way that calls for
+//                     torch.topk's order, or the runs' top halves turned out not to be enough - merges the runs and
+//                     replays the order alone, the way scan_large_kernel ends an iteration (team_redo) [hop E2]
 //
-// Same values, same order of every sum, same keys as scan_large_kernel (keys are unique, so the merged order is the sorted
-// order whoever sorted what): tools/scan_compare.py and tests/test_hip_scan_team.py hold the two against each other.
+// Same values, same order of every sum, same keys as scan_large_kernel (keys are unique, so ranks are ranks whoever counts
+// them): tools/scan_team_check.py and tests/test_hip_scan_team.py hold the two against each other.
 //
 // A hop = release fence + a counter in the workspace (monotonic within a launch: target = arrivals per iteration x the
-// iteration's number; zeroed by the launch) + acquire fence.  Every wait is bounded: a persistent launch reports through its
-// status word like every resident loop (the recovery launch redoes the work), a plain launch traps.  Workgroups of a team
-// are neighbours in the grid, so the in-order dispatcher never holds a team's first members on units its last members need.
+// iteration's number; zeroed by the launch) + acquire fence; where the data is 8-64 words (hops A, C) it rides in the
+// polled word itself (epoch << 32 | value) and there is no fence.  Every wait is bounded: a persistent launch reports
+// through its status word like every resident loop (the recovery launch, always one workgroup per image, redoes the
+// work), a plain launch traps.  Workgroups of a team are neighbours in the grid, so the in-order dispatcher never holds a
+// team's first members on units its last members need.
 
 constexpr int TEAM_CTL_INTS = 512;                 // per image, at LargeArgs::team_off of its workspace; the runs follow
 constexpr int TC_RESIDENT = 0, TC_A = 32, TC_B = 64, TC_C = 96, TC_D = 128, TC_E = 160;     // (a 128-byte line each)
 constexpr int TC_PMAX = 192;                       // 8 workgroups x 8 row maxima: 64-bit words, epoch << 32 | order-preserving key
 constexpr int TC_RDEN = 320;                       // 8 reciprocal denominators: epoch << 32 | float bits
-static size_t team_bytes(int n2) { return (size_t)TEAM_CTL_INTS * 4 + (size_t)n2 * 8; }
+constexpr int TC_FLAG = 384;                       // the last iteration (its number + 1) whose ranking the main workgroup must redo alone
+constexpr int TC_TIE = 448;                        // the last iteration (its number + 1) with equal scores at ranks m - 1 and m
+constexpr int TC_E2 = 416;                         // ... how many of those it has redone
+// counters | the W sorted runs (n2 keys) | the memory's second buffer (m patch numbers: an iteration reads one, writes the other)
+static size_t team_bytes(int n2, int m) { return (size_t)TEAM_CTL_INTS * 4 + (size_t)n2 * 8 + (((size_t)m * 8 + 255) & ~(size_t)255); }
 
 // candidates of workgroup w of W among the first L: the 64-blocks w, w + W, ...
 __device__ __forceinline__ int team_count(int L, int w, int W) {
@@ -193,6 +205,64 @@ __device__ __forceinline__ bool team_poll_words(const unsigned long long* words,
     }
 }
 
+// The main workgroup alone: the ranking of iteration `itf` again, from the W sorted runs in the workspace, the way
+// scan_large_kernel ends an iteration - all runs merged, the tie test, torch.topk's order replayed where the loops' rule asks
+// for it, the new memory (all m slots: what the team wrote from its own ranks is overwritten).  -> the boundary tie bit.
+template <int CPT>
+__device__ __attribute__((noinline)) int team_redo(const LargeArgs& a, long long itf, int b, int W, const float* lg, long long* mem_out,
+                                                   long long* mem_alt, float* xT, int* lists, const uint64_t* gkeys, int tail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RUN = LARGE_NT * CPT;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    int* const pre = reinterpret_cast<int*>(smem + tail) + 8 + (LARGE_NT / 64) * 8;
+    const int tid = threadIdx.x, m = a.m;
+    const long long lo = itf * a.i + m;
+    const int cnt = (int)std::min<long long>(a.i, a.n - lo);
+    const int L = m + cnt;
+    const long long* const src = ((itf - a.it0) & 1) ? mem_alt : mem_out;
+    long long* const dst = ((itf - a.it0) & 1) ? mem_out : mem_alt;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int u = 0; u < W; ++u) { pre[u] = run; run += team_count(L, u, W); }
+        pre[W] = run;
+    }
+    __syncthreads();
+    for (int j0 = tid; j0 < a.n2; j0 += 8 * LARGE_NT) {
+        uint64_t t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * LARGE_NT;
+            const int u_ = j / RUN;
+            t[u] = (j < a.n2 && j - u_ * RUN < pre[u_ + 1] - pre[u_]) ? gkeys[j] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u * LARGE_NT < a.n2) keys[large_slot(j0 + u * LARGE_NT)] = t[u];
+    }
+    merge_sorted_runs(0, a.n2, RUN, (int)(reinterpret_cast<unsigned char*>(pre) - smem) >> 2);
+    const int tie = (L > m && (keys[large_slot(m - 1)] >> 32) == (keys[large_slot(m)] >> 32)) ? 1 : 0;
+    const TieRows rows = {lg, src, lo, m, 8};
+    const bool replayed = large_tie_replay(L, m, a.n2, a.tie_order, lists, tail, reinterpret_cast<uint64_t*>(xT), a.rstamp != 0, &rows);
+    const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
+    const bool want_score = a.mem_score != nullptr && itf + 1 == a.it1;
+    for (int j = tid; j < m; j += LARGE_NT) {
+        int pos;
+        float sc;
+        if (replayed) {
+            pos = q[j].i;
+            sc = key_score(rank_key(q[j].v, 0u));
+        } else {
+            pos = (int)key_pos(keys[large_slot(j)]);
+            sc = key_score(keys[large_slot(j)]);
+        }
+        if (want_score) a.mem_score[(size_t)b * m + j] = sc;
+        dst[j] = pos < m ? src[pos] : lo + (pos - m);
+    }
+    __syncthreads();
+    return tie;
+}
+
 #define TEAM_STAMP(k)                                                              \
     do {                                                                           \
         if (STAMP) {                                                               \
@@ -232,12 +302,13 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / W, w = blockIdx.x - b * W;
     const float* lg = a.lg + (size_t)b * a.n * 8;
-    long long* mem = a.mem_idx + (size_t)b * m;
+    long long* const mem_out = a.mem_idx + (size_t)b * m;
     unsigned char* wsb = a.ws + (size_t)b * a.ws_per_image;
     float* xT = reinterpret_cast<float*>(wsb);
     int* lists = reinterpret_cast<int*>(xT + (size_t)8 * Lp);
     int* ctl = reinterpret_cast<int*>(wsb + a.team_off);
     uint64_t* gkeys = reinterpret_cast<uint64_t*>(ctl + TEAM_CTL_INTS);
+    long long* const mem_alt = reinterpret_cast<long long*>(gkeys + a.n2);
     // (the replay's stack, 192 ints, is free outside the replay: wait verdicts, the wavefronts' row maxima, the runs' counts)
     int* const wword = reinterpret_cast<int*>(smem + tail);
     uint32_t* const wmax = reinterpret_cast<uint32_t*>(wword + 8);          // 16 wavefronts x 8 rows
@@ -258,8 +329,9 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
     if (STAMP && w == 0 && tid == 0) stamps[(size_t)gridDim.x / W * 8 + 127] = __builtin_amdgcn_s_memrealtime();
     long long ready_known = 0;
     if (w == 0 && a.it0 == 0)
-        for (int j = tid; j < m; j += LARGE_NT) mem[j] = j;
+        for (int j = tid; j < m; j += LARGE_NT) mem_out[j] = j;      // (only the main workgroup's own redo reads it in iteration 0)
     __syncthreads();
+    int redone = 0;                                                  // iterations the main workgroup has redone alone
     int tie = 0;
     const int tid_outer = tid;
     for (long long it = a.it0; it < a.it1; ++it) {
@@ -272,11 +344,14 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
         const long long lo = it * a.i + m;
         const int cnt = (int)std::min<long long>(a.i, a.n - lo);
         const int L = m + cnt;
-        // ---- what this iteration reads: its chunk's rows (persistent: published by the producer) and - helpers - the memory
-        // the main workgroup wrote at the end of the iteration before
+        // the memory's patch numbers: an iteration reads one buffer and every workgroup writes its ranks into the other
+        const long long* const mem = ((it - a.it0) & 1) ? mem_alt : mem_out;
+        long long* const mem_new = ((it - a.it0) & 1) ? mem_out : mem_alt;
+        // ---- what this iteration reads: its chunk's rows (persistent: published by the producer) and the memory the team
+        // wrote at the end of the iteration before [hop E: all to all]
         {
             const bool need_rows = a.ready && lo + cnt > ready_known;
-            const bool need_mem = w != 0 && it > a.it0;
+            const bool need_mem = it > a.it0;
             if (wave == 0) {
                 int v = 1;
                 if (need_rows) {
@@ -295,7 +370,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
                 }
                 // (the main workgroup may still be sorting the iteration before: its own progress is the producer's clock,
                 //  so the bound here is the team's)
-                if (v >= 0 && need_mem && !team_poll(&ctl[TC_E], e - 1, a.team_ticks)) v = -1;
+                if (v >= 0 && need_mem && !team_poll(&ctl[TC_E], W * (e - 1), a.team_ticks)) v = -1;
                 if (lane == 0) wword[1] = v;
             }
             __syncthreads();
@@ -307,6 +382,19 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
             }
             if (need_rows || need_mem) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (need_rows) ready_known = v;
+            // the iteration before asked for the one-workgroup ranking (torch.topk's order to replay, or the runs' top halves
+            // were not enough): the main workgroup redoes it from the runs, the others wait for its memory [hop E2]
+            if (need_mem && __hip_atomic_load(&ctl[TC_FLAG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e - 1) {
+                ++redone;
+                if (w == 0) {
+                    tie |= team_redo<CPT>(a, it - 1, b, W, lg, mem_out, mem_alt, xT, lists, gkeys, tail);
+                    team_arrive(&ctl[TC_E2]);
+                } else {
+                    TEAM_WAIT(6, &ctl[TC_E2], redone);
+                }
+            } else if (need_mem && w == 0 && __hip_atomic_load(&ctl[TC_TIE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e - 1) {
+                tie = 1;
+            }
         }
         if (tid == 0) {
             int run = 0;
@@ -460,133 +548,141 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
             }
         }
         team_sort_run<CPT>(key, keys, tid, lane);
-        if (w != 0) {
+        TEAM_STAMP(4);
+        // ---- hop D (all to all): every workgroup's sorted run through the workspace
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) gkeys[(size_t)w * RUN + tid + c * LARGE_NT] = keys[large_slot(tid + c * LARGE_NT)];
+        team_arrive(&ctl[TC_D]);
+        TEAM_WAIT(4, &ctl[TC_D], W * e);
+        // ---- the ranking, by every workgroup for its OWN run: a key's rank among all L candidates is its place in its run
+        // plus, for every other run, the number of keys there that are larger (keys are unique) - a branch-free lower bound
+        // per run, in LDS.  Only the first m + 1 ranks are ever used, and with candidates dealt by 64-blocks every run holds
+        // about its share of them: the runs' TOP HALVES are loaded and searched when (m + 1) x 1.25 fits them; the ranks are
+        // then the true ones down to rank m if the score at rank m is above every score left out (the largest is its run's
+        // key KT) - the thread that holds rank m checks.  Otherwise, or when two of the first m + 1 ranks tie in a way that
+        // calls for torch.topk's order (a replay wants all L candidates in one place), the iteration is flagged and the
+        // main workgroup redoes its ranking alone from the runs (team_redo: the ranking of scan_large_kernel).
+        int trunc_total = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) trunc_total += u < W ? min(RUN / 2, pre[u + 1] - pre[u]) : 0;
+        const bool trunc = a.team_trunc && L > m + 1 && (long long)(m + 1) * 5 <= (long long)(a.n2 >> 1) * 4 && trunc_total > m;
+        const int KT = trunc ? RUN / 2 : RUN;
+        const int ksh = 31 - __clz(KT);
+        uint64_t* const T = keys + (RUN + (RUN >> 4));             // the other runs, unpadded, behind this workgroup's own
+        unsigned long long* const exclw = reinterpret_cast<unsigned long long*>(wword + 164);
+        if (wave == 0) {                                           // the largest key left out
+            unsigned long long ex = 0ull;
+            if (trunc && lane < W && pre[lane + 1] - pre[lane] > KT) ex = gkeys[(size_t)lane * RUN + KT];
+            for (int o = 32; o >= 1; o >>= 1) {
+                const unsigned long long other = __shfl_xor(ex, o, 64);
+                ex = other > ex ? other : ex;
+            }
+            if (lane == 0) *exclw = ex;
+        }
+        for (int i0 = tid; i0 < (W - 1) * KT; i0 += 8 * LARGE_NT) {
+            uint64_t t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * LARGE_NT;
+                const int tv = i >> ksh, v_ = tv < w ? tv : tv + 1, il = i - (tv << ksh);
+                t[u] = (i < (W - 1) * KT && il < pre[v_ + 1] - pre[v_]) ? gkeys[(size_t)v_ * RUN + il] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * LARGE_NT < (W - 1) * KT) T[i0 + u * LARGE_NT] = t[u];
+        }
+        __syncthreads();
+        TEAM_STAMP(5);
+        {
+            const int mine = min(KT, pre[w + 1] - pre[w]), mine_all = pre[w + 1] - pre[w];
+            const int nmax = m < L - 1 ? m : L - 1;                 // ranks whose ties matter (ranked_ties_padded)
+            const bool want_score = a.mem_score != nullptr && it + 1 == a.it1;
+            bool flag = false;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const int j = tid + c * LARGE_NT;
-                gkeys[(size_t)w * RUN + j] = keys[large_slot(j)];
+                if (j < mine) {                                      // (wave-uniform up to the run's last block)
+                    const uint64_t ka = keys[large_slot(j)];
+                    int pos[7];
+#pragma unroll
+                    for (int tv = 0; tv < 7; ++tv) pos[tv] = 0;
+                    for (int half = KT >> 1; half >= 1; half >>= 1) {
+#pragma unroll
+                        for (int tv = 0; tv < 7; ++tv)
+                            if (tv < W - 1) pos[tv] += T[(tv << ksh) + pos[tv] + half - 1] > ka ? half : 0;
+                    }
+                    int g = j;
+                    // the next smaller key of every run (0: none): an equal score there is a tie of this rank
+                    uint64_t nxt = j + 1 < mine_all ? keys[large_slot(j + 1)] : 0ull;
+                    bool eq = nxt != 0ull && (nxt >> 32) == (ka >> 32);
+#pragma unroll
+                    for (int tv = 0; tv < 7; ++tv)
+                        if (tv < W - 1) {
+                            const uint64_t last = T[(tv << ksh) + pos[tv]];
+                            pos[tv] += last > ka ? 1 : 0;
+                            const uint64_t s_ = last > ka ? (pos[tv] < KT ? T[(tv << ksh) + pos[tv]] : 0ull) : last;
+                            eq = eq || (s_ != 0ull && (s_ >> 32) == (ka >> 32));
+                            g += pos[tv];
+                        }
+                    if (trunc && g == m && !((ka >> 32) > (*exclw >> 32))) flag = true;
+                    if (g < m) {
+                        const int p_ = (int)key_pos(ka);
+                        mem_new[g] = p_ < m ? (it == 0 ? (long long)p_ : mem[p_]) : lo + (p_ - m);
+                        if (want_score) a.mem_score[(size_t)b * m + g] = key_score(ka);
+                    }
+                    // (the score at rank m equals this one; counted by the main workgroup unless the iteration is redone)
+                    if (eq && g == m - 1 && L > m) __hip_atomic_fetch_max(&ctl[TC_TIE], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (eq && g < nmax && a.tie_order != 0) {
+                        // equal scores among the first m + 1 ranks (rare: a few pairs among 10,000 candidates).  The loops' rule
+                        // (oracle orc_topm_loop): torch.topk's order where two members of the run of equal scores have
+                        // bit-identical logit rows; tie_order 2: wherever scores tie
+                        bool rep = a.tie_order != 1;
+                        if (!rep) {
+                            const long long pa = key_pos(ka);
+                            const float* ra = lg + (size_t)(pa < m ? (it == 0 ? pa : mem[pa]) : lo + (pa - m)) * 8;
+                            const float4 a0 = *reinterpret_cast<const float4*>(ra), a1 = *reinterpret_cast<const float4*>(ra + 4);
+                            for (int tv = -1; tv < W - 1 && !rep; ++tv) {
+                                for (int q = tv < 0 ? j + 1 : pos[tv]; q < (tv < 0 ? mine_all : KT) && !rep; ++q) {
+                                    const uint64_t kb = tv < 0 ? keys[large_slot(q)] : T[(tv << ksh) + q];
+                                    if (kb == 0ull || (kb >> 32) != (ka >> 32)) break;
+                                    const long long pb = key_pos(kb);
+                                    const float* rb = lg + (size_t)(pb < m ? (it == 0 ? pb : mem[pb]) : lo + (pb - m)) * 8;
+                                    const float4 b0 = *reinterpret_cast<const float4*>(rb), b1 = *reinterpret_cast<const float4*>(rb + 4);
+                                    const uint32_t diff = (as_u32(a0.x) ^ as_u32(b0.x)) | (as_u32(a0.y) ^ as_u32(b0.y)) | (as_u32(a0.z) ^ as_u32(b0.z)) |
+                                                          (as_u32(a0.w) ^ as_u32(b0.w)) | (as_u32(a1.x) ^ as_u32(b1.x)) | (as_u32(a1.y) ^ as_u32(b1.y)) |
+                                                          (as_u32(a1.z) ^ as_u32(b1.z)) | (as_u32(a1.w) ^ as_u32(b1.w));
+                                    rep = diff == 0u;
+                                }
+                            }
+                        }
+                        flag = flag || rep;
+                    }
+                }
             }
-            team_arrive(&ctl[TC_D]);
-            continue;
+            if (flag) __hip_atomic_fetch_max(&ctl[TC_FLAG], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        TEAM_STAMP(4);
-        TEAM_WAIT(4, &ctl[TC_D], (W - 1) * e);
-        const TieRows rows = {lg, mem, lo, m, 8};
-        // ---- the ranking.  Only the first m + 1 ranks are ever used in order (new memory, tie test) - and with candidates
-        // dealt to the workgroups by 64-blocks every run holds about its share (m + 1) / W of them.  So first the TOP HALF
-        // of every run only (KT = RUN / 2 keys; n2 / 2 slots, half the merge - and half the wavefronts contending for the
-        // issue slots the merge is bound by); the result is the true ranking down to rank m if the (m + 1)-th score of it
-        // is above every score left out (the largest is its run's key KT), ties of the first m + 1 ranks included.  Otherwise
-        // - or when torch.topk's order has to be replayed, which wants all L candidates - everything is merged as before.
-        constexpr int KT = RUN / 2;
-        int* const pret = pre + 9;
-        unsigned long long* const exclw = reinterpret_cast<unsigned long long*>(wword + 164);
-        int kboff = 0;                                       // (an offset, not a second pointer: LDS loads stay LDS loads)
-        bool full = !(a.team_trunc && L > m + 1 && (long long)(m + 1) * 5 <= (long long)(a.n2 >> 1) * 4);
-        if (!full) {
-            kboff = large_slot(a.n2 >> 1);
-            uint64_t* const kb = keys + kboff;
-            if (wave == 0) {
-                // (counts of the halves; the largest key left out)
-                int c_ = lane < W ? pre[lane + 1] - pre[lane] : 0;
-                unsigned long long ex = 0ull;
-                if (lane < W && c_ > KT) ex = lane == 0 ? keys[large_slot(KT)] : gkeys[(size_t)lane * RUN + KT];
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const unsigned long long other = __shfl_xor(ex, o, 64);
-                    ex = other > ex ? other : ex;
-                }
-                c_ = min(c_, KT);
-                int incl = c_;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int up = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += up;
-                }
-                const int before = __shfl_up(incl, 1, 64);               // (every lane takes part: an inactive source lane reads as 0)
-                if (lane <= W) pret[lane] = lane == 0 ? 0 : before;
-                if (lane == 0) *exclw = ex;
-            }
-            __syncthreads();
-            {
-                uint64_t t[8];
-                uint64_t own[(KT + LARGE_NT - 1) / LARGE_NT];
-#pragma unroll
-                for (int u = 0; u < (KT + LARGE_NT - 1) / LARGE_NT; ++u) {
-                    const int j = tid + u * LARGE_NT;
-                    own[u] = j < KT ? keys[large_slot(j)] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = KT + tid + u * LARGE_NT;                 // slot of the half-size array
-                    const int u_ = j / KT, jl = j - u_ * KT;
-                    t[u] = (j < W * KT && jl < pret[u_ + 1] - pret[u_]) ? gkeys[(size_t)u_ * RUN + jl] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < (KT + LARGE_NT - 1) / LARGE_NT; ++u)
-                    if (tid + u * LARGE_NT < KT) kb[large_slot(tid + u * LARGE_NT)] = own[u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (KT + tid + u * LARGE_NT < W * KT) kb[large_slot(KT + tid + u * LARGE_NT)] = t[u];
-            }
-            merge_sorted_runs(large_slot(a.n2 >> 1), W * KT, KT, (int)(reinterpret_cast<unsigned char*>(pret) - smem) >> 2);
-            const int Lt = pret[W];
-            const bool good = Lt > m && (kb[large_slot(m)] >> 32) > (*exclw >> 32);
-            // (workgroup-uniform: every thread reads the same two words)
-            full = !good || (a.tie_order != 0 && ranked_ties_padded(kb, Lt, m, lane, a.tie_order, &rows));
-            if (full) kboff = 0;
-        }
-        if (full) {
-            // (the real keys of the other runs only, eight loads of a thread in flight)
-            for (int j0 = RUN + tid; j0 < a.n2; j0 += 8 * LARGE_NT) {
-                uint64_t t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u * LARGE_NT;
-                    const int u_ = j / RUN;
-                    t[u] = (j < a.n2 && j - u_ * RUN < pre[u_ + 1] - pre[u_]) ? gkeys[j] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (j0 + u * LARGE_NT < a.n2) keys[large_slot(j0 + u * LARGE_NT)] = t[u];
-            }
-            merge_sorted_runs(0, a.n2, RUN, (int)(reinterpret_cast<unsigned char*>(pre) - smem) >> 2);
-        }
-        TEAM_STAMP(5);
-        if (tid == 0 && L > m && (keys[kboff + large_slot(m - 1)] >> 32) == (keys[kboff + large_slot(m)] >> 32)) tie = 1;
-        const bool replayed = full && large_tie_replay(L, m, a.n2, a.tie_order, lists, tail, reinterpret_cast<uint64_t*>(xT), a.rstamp != 0, &rows);
         TEAM_STAMP(6);
-        const stdorder::E* q = reinterpret_cast<const stdorder::E*>(keys);
-        const bool want_score = a.mem_score != nullptr && it + 1 == a.it1;
-        int nw[LARGE_KPT];
-#pragma unroll
-        for (int s = 0; s < LARGE_KPT; ++s) {
-            const int j = tid + s * LARGE_NT;
-            nw[s] = 0;
-            if (j < m) {
-                int pos;
-                float sc;
-                if (replayed) {
-                    pos = q[j].i;
-                    sc = key_score(rank_key(q[j].v, 0u));
-                } else {
-                    pos = (int)key_pos(keys[kboff + large_slot(j)]);
-                    sc = key_score(keys[kboff + large_slot(j)]);
-                }
-                if (want_score) a.mem_score[(size_t)b * m + j] = sc;
-                nw[s] = pos < m ? (int)mem[pos] : (int)(lo + (pos - m));
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < LARGE_KPT; ++s) {
-            const int j = tid + s * LARGE_NT;
-            if (j < m) mem[j] = nw[s];
-        }
         team_arrive(&ctl[TC_E]);
         TEAM_STAMP(7);
-        if (STAMP && tid == 0 && it - a.it0 < 64) stamps[(size_t)gridDim.x / W * 8 + 2 * (it - a.it0) + 1] = __builtin_amdgcn_s_memrealtime();
+        if (STAMP && w == 0 && tid == 0 && it - a.it0 < 64) stamps[(size_t)gridDim.x / W * 8 + 2 * (it - a.it0) + 1] = __builtin_amdgcn_s_memrealtime();
     }
-    if (w == 0 && a.tie && tid == 0 && tie) a.tie[b] = 1;
-    if (STAMP && w == 0 && tid == 0)
+    // ---- the end: the main workgroup sees the last iteration through (everybody's ranks written; redone if it was flagged)
+    // and leaves the memory in the caller's buffer
+    if (w != 0 || a.it1 <= a.it0) return;
+    {
+        const int e = (int)(a.it1 - a.it0);
+        TEAM_WAIT(7, &ctl[TC_E], W * e);
+        if (__hip_atomic_load(&ctl[TC_FLAG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e)
+            tie |= team_redo<CPT>(a, a.it1 - 1, b, W, lg, mem_out, mem_alt, xT, lists, gkeys, tail);
+        else if (__hip_atomic_load(&ctl[TC_TIE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e)
+            tie = 1;
+        if (a.tie && tid == 0 && tie) a.tie[b] = 1;
+        if (e & 1) {                                               // an odd number of iterations: the last one wrote the second buffer
+            __syncthreads();
+            for (int j = tid; j < m; j += LARGE_NT) mem_out[j] = mem_alt[j];
+        }
+    }
+    if (STAMP && tid == 0)
         for (int k = 0; k < 8; ++k) stamps[(size_t)b * 8 + k] += tacc[k];
 }
 #undef TEAM_STAMP

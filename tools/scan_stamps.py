@@ -95,10 +95,10 @@ if kind == "largepipe":
     for it in range(n_iter):
         print("   it %d   rows there %8.1f   end %8.1f   (%.1f us)" % (it, (log[it, 0] - t0) / 100.0, (log[it, 1] - t0) / 100.0,
                                                                       (log[it, 1] - log[it, 0]) / 100.0))
-    names = ["gather + own maxima (+ rows / memory wait)", "hop A", "exponentials + store + hop B", "row sums + hop C", "scores + own run sorted",
-             "hop D + runs loaded + merged", "tie check + replay", "new memory + hop E"]
+    names = ["rows / hop E of the iteration before + gather + own maxima", "hop A", "exponentials + store + hop B", "row sums + hop C",
+             "scores + own run sorted", "run published + hop D + the other runs loaded", "own run ranked among all, ties, new memory", "arrival at hop E"]
     for k, nme in enumerate(names):
-        print("  %-44s %9.1f k cycles/iter" % (nme, raw[k] / n_iter / 1e3))
+        print("  %-56s %9.1f k cycles/iter" % (nme, raw[k] / n_iter / 1e3))
     sys.exit(0)
 if kind == "large":
     # scan_large_kernel (candidate sets beyond the LDS): the reference's shipped CAMELYON sizes, or N M I H T on the command line
@@ -126,9 +126,9 @@ if kind == "large":
     team = int(os.environ.get("TEAM", "-1"))              # TEAM=0: one workgroup (scan_large_kernel); 8 (the default): the team's main workgroup
     L.ipsx_dbg_scan_team(team)
     if hip.scan_workgroups_per_image(1, M, I, H, T) > 1:
-        names = ["gather + own maxima (+ rows / memory wait)", "hop A: maxima, all to all", "exponentials + store + hop B (all to main)",
-                 "row sums + hop C (main to all)", "scores + own run sorted", "hop D + runs loaded + merged", "tie check + replay",
-                 "new memory + hop E"]
+        names = ["hop E of the iteration before + gather + own maxima", "hop A: maxima, all to all", "exponentials + store + hop B (all to all)",
+                 "row sums of my row + hop C (all to all)", "scores + own run sorted", "run published + hop D + the other runs loaded",
+                 "own run ranked among all, ties, new memory", "arrival at hop E"]
     for mode in ("torch", "canonical"):
         hip.set_tie_order(mode)
         st = torch.zeros((1, 8 + 128), dtype=torch.int64, device=dev)      # (+ the team kernel's per-iteration log)
@@ -142,7 +142,7 @@ if kind == "large":
               "registers the product build does not: its passes over the workspace read slower than they are)"
               % (mode, n_iter, M + I, H * T, s.sum() / n_iter / 1e3))
         for k, nme in enumerate(names):
-            print("  %-44s %9.1f k cycles/iter" % (nme, s[k] / n_iter / 1e3))
+            print("  %-56s %9.1f k cycles/iter" % (nme, s[k] / n_iter / 1e3))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(10):
