@@ -41,7 +41,7 @@ IPSX_TRAIN_CONV=0 python tools/train_step_breakdown.py --fused --profile > "$OUT
 python tools/scan_stamps.py cam > "$OUT/scan_stamps_cam.txt" 2>&1
 IPSX_SCAN_R8=0 python tools/scan_stamps.py cam >> "$OUT/scan_stamps_cam.txt" 2>&1
 python tools/scan_stamps.py mnist >> "$OUT/scan_stamps_cam.txt" 2>&1
-python tools/scan_stamps.py large > "$OUT/scan_stamps_large.txt" 2>&1
+bash tools/collect_team_profiles.sh "$OUT"          # scan_stamps_large(pipe), scan_team_check, cam_native widths, soak_team
 { echo; echo "# the same on the logits of the bench workload itself (tools/scan_stamps.py large bench)"; python tools/scan_stamps.py large bench; } >> "$OUT/scan_stamps_large.txt" 2>&1
 python tools/scan_stamps.py campipe > "$OUT/scan_stamps_campipe.txt" 2>&1
 python tools/trunk_pair_bench.py > "$OUT/trunk_pair_bench.txt" 2>&1
