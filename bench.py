@@ -654,7 +654,11 @@ def measure(args, ctx, name, batch=None, steps=20, warmup=5, cpu_seconds=0.0, he
                                       "" if world == 1 else ", %d of the %d patches of every image per GPU" % (n_mine, n_total)),
                        "parallelism": "patch-sharded x%d, %d all-gathers of logits, scan overlapped" % (world, len(shard.its) - 1) if world > 1 else "single GPU",
                        "dedup_blank": bool(args.dedup_blank), "lazy_host_patches": bool(args.lazy),
-                       "patch_storage": args.storage},
+                       "patch_storage": args.storage,
+                       # compute units the selection loop of ONE image keeps (1; a team of up to 8 workgroups for candidate
+                       # sets beyond the LDS - the shipped CAMELYON M = I = 5000: csrc/scan_large_team.h)
+                       "loop_workgroups_per_image": hip.scan_workgroups_per_image(batch, conf.M, conf.I, net.transf.crs_attn.H,
+                                                                                   conf.n_token)},
             "timing": "value = patches per call / median over the %d timed calls, each bracketed by barrier + device sync "
                       "(SURVEY d-1; max over ranks per call); value_pipelined = the same %d calls enqueued back to back "
                       "between two fences" % (steps, steps),

@@ -94,6 +94,30 @@ def test_abi_major_and_the_round_4_additions_are_declared():
     assert lib.ipsx_conv2d_wgrad_nhwc_workspace_bytes(0, 64, 64, 3, 3) == 0
 
 
+def test_round_6_additions_team_width_and_the_words_a_call_has_to_clear():
+    """ABI 3.02 (no GPU needed: both answers are host arithmetic): the loop of candidate sets beyond the LDS keeps a TEAM of
+    compute units per image (csrc/scan_large_team.h) - 16 units of a call at most, its block is part of the workspace - and
+    only the head of the projector stream's control words has to be zero when a call starts."""
+    lib = hip.lib()
+    for name in ("ipsx_scan_workgroups_per_image", "ipsx_projector_stream_ctl_zero_words"):
+        assert name in hip._EXPORTS and hasattr(lib, name)
+    team = lib.ipsx_scan_workgroups_per_image
+    assert [team(b, 5000, 5000, 8, 1) for b in (1, 2, 3, 4, 8, 9, 16)] == [8, 8, 4, 4, 2, 1, 1]
+    assert team(1, 256, 256, 8, 1) == 1 and team(1, 64, 64, 8, 4) == 1          # LDS-resident loops
+    assert team(1, 3000, 6000, 8, 4) == 1 and team(1, 8192, 8192, 2, 1) == 1    # beyond the LDS, but not 8 heads x one token
+    assert team(1, 2000, 2000, 8, 1) == 1                                       # 4,000 candidates
+    assert team(0, 5000, 5000, 8, 1) == 0
+    ws = lib.ipsx_scan_workspace_bytes
+    lp, n2 = 10048, 16384
+    assert ws(1, 5000, 5000, 8, 1) >= 8 * lp * 4 + 2 * lp * 4 + 2048 + n2 * 8 + 5000 * 8     # ... + counters, runs, second memory buffer
+    assert ws(3, 5000, 5000, 8, 1) == 3 * ws(1, 5000, 5000, 8, 1) and ws(1, 256, 256, 8, 1) == 0
+    words, zero = lib.ipsx_projector_stream_ctl_words, lib.ipsx_projector_stream_ctl_zero_words
+    for n in (64, 38000, 65536, 16 * 65536):
+        assert 0 < zero(n) <= words(n) and zero(n) < n // 32 + 1024             # a flag per 32 rows and a few hundred words
+        assert words(n) - zero(n) == words(64) - zero(64)                       # the hand-over accumulators: a fixed block
+    assert zero(0) == 0
+
+
 def test_plan_signature_sees_nested_module_swaps_and_new_entries():
     """EncoderPlan._signature (CPU: it only reads pointers and version counters): in-place writes, replaced tensors, a child
     module exchanged BELOW the top level, a buffer that was None and appears, an entry that is removed - each changes the
