@@ -787,7 +787,8 @@ int launch_scan_large(const ScanCall& c) {
             la.team_ticks = la.wait_ticks * (ready ? 1ull : 20ull);
             la.team_trunc = g_scan_team_trunc ? 1 : 0;
             unsigned char* ctl0 = la.ws + la.team_off;
-            if (hipMemset2DAsync(ctl0, la.ws_per_image, 0, (size_t)TEAM_CTL_INTS * 4, (size_t)b, as_stream(stream)) != hipSuccess)
+            // (the counters, and the runs' words behind them: a key on its way carries its iteration's number - team_key_out)
+            if (hipMemset2DAsync(ctl0, la.ws_per_image, 0, (size_t)TEAM_CTL_INTS * 4 + (size_t)n2 * 8, (size_t)b, as_stream(stream)) != hipSuccess)
                 return fail(IPSX_EHIP, "scan: clearing the team counters: %s", hipGetErrorString(hipGetLastError()));
             const dim3 grid((unsigned)(b * W)), block(LARGE_NT);
 #define IPSX_TEAM_LAUNCH(CPT, ST)                                                                                              \

@@ -192,6 +192,17 @@ __device__ __forceinline__ void team_sort_run(uint64_t (&key)[CPT], uint64_t* ke
     __syncthreads();
 }
 
+// A ranking key on its way through the workspace carries the iteration's number in the 18 bits of its low word that are
+// all ones in every key (the low word is 0xFFFFFFFF - position, positions below 16,384): data and flag in ONE 64-bit word,
+// one relaxed agent-scope store, polled by whoever needs it - hop D has no fence and no counter.  The launch clears the
+// runs' words, a key's score word is never 0, and a slot is rewritten every iteration: a word that carries this
+// iteration's number is this iteration's key.
+__device__ __forceinline__ uint64_t team_key_out(uint64_t key, uint32_t tag) { return key ^ ((uint64_t)(0x3FFFFu ^ (tag & 0x3FFFFu)) << 14); }
+__device__ __forceinline__ bool team_key_in(uint64_t word, uint32_t tag, uint64_t* key) {
+    *key = word | (0x3FFFFull << 14);
+    return (uint32_t)((word >> 14) & 0x3FFFFull) == (tag & 0x3FFFFu) && (word >> 32) != 0ull;
+}
+
 // wave 0: wait until the W * 8 (or 8) words at `words` all carry epoch e in their upper halves; the lower halves of the
 // lanes' words come back in `low`.  Data and flag are ONE 64-bit word, written with one relaxed agent-scope store: no fence.
 __device__ __forceinline__ bool team_poll_words(const unsigned long long* words, int n, int e, unsigned long long ticks,
@@ -234,7 +245,7 @@ __device__ __attribute__((noinline)) int team_redo(const LargeArgs& a, long long
         for (int u = 0; u < 8; ++u) {
             const int j = j0 + u * LARGE_NT;
             const int u_ = j / RUN;
-            t[u] = (j < a.n2 && j - u_ * RUN < pre[u_ + 1] - pre[u_]) ? gkeys[j] : 0ull;
+            t[u] = (j < a.n2 && j - u_ * RUN < pre[u_ + 1] - pre[u_]) ? (gkeys[j] | (0x3FFFFull << 14)) : 0ull;     // (tagged: team_key_out)
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -549,11 +560,18 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
         }
         team_sort_run<CPT>(key, keys, tid, lane);
         TEAM_STAMP(4);
-        // ---- hop D (all to all): every workgroup's sorted run through the workspace
+        // ---- hop D (all to all): every workgroup's sorted run through the workspace - the real keys only, each with the
+        // iteration's number in it (team_key_out): no fence, no counter; the readers below poll the words they need
+        {
+            const int mine_all = pre[w + 1] - pre[w];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) gkeys[(size_t)w * RUN + tid + c * LARGE_NT] = keys[large_slot(tid + c * LARGE_NT)];
-        team_arrive(&ctl[TC_D]);
-        TEAM_WAIT(4, &ctl[TC_D], W * e);
+            for (int c = 0; c < CPT; ++c) {
+                const int j = tid + c * LARGE_NT;
+                if (j < mine_all)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(gkeys) + (size_t)w * RUN + j,
+                                       (unsigned long long)team_key_out(keys[large_slot(j)], (uint32_t)e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         // ---- the ranking, by every workgroup for its OWN run: a key's rank among all L candidates is its place in its run
         // plus, for every other run, the number of keys there that are larger (keys are unique) - a branch-free lower bound
         // per run, in LDS.  Only the first m + 1 ranks are ever used, and with candidates dealt by 64-blocks every run holds
@@ -570,9 +588,19 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
         const int ksh = 31 - __clz(KT);
         uint64_t* const T = keys + (RUN + (RUN >> 4));             // the other runs, unpadded, behind this workgroup's own
         unsigned long long* const exclw = reinterpret_cast<unsigned long long*>(wword + 164);
+        bool late = false;                                         // a word that never came (bounded like every wait)
         if (wave == 0) {                                           // the largest key left out
             unsigned long long ex = 0ull;
-            if (trunc && lane < W && pre[lane + 1] - pre[lane] > KT) ex = gkeys[(size_t)lane * RUN + KT];
+            if (trunc && lane < W && pre[lane + 1] - pre[lane] > KT) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                uint64_t k_ = 0ull;
+                while (!team_key_in(__hip_atomic_load(reinterpret_cast<const unsigned long long*>(gkeys) + (size_t)lane * RUN + KT,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (uint32_t)e, &k_)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.team_ticks) { late = true; break; }
+                }
+                ex = k_;
+            }
             for (int o = 32; o >= 1; o >>= 1) {
                 const unsigned long long other = __shfl_xor(ex, o, 64);
                 ex = other > ex ? other : ex;
@@ -581,17 +609,42 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
         }
         for (int i0 = tid; i0 < (W - 1) * KT; i0 += 8 * LARGE_NT) {
             uint64_t t[8];
+            const unsigned long long* src[8];
+            uint32_t need = 0u;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * LARGE_NT;
                 const int tv = i >> ksh, v_ = tv < w ? tv : tv + 1, il = i - (tv << ksh);
-                t[u] = (i < (W - 1) * KT && il < pre[v_ + 1] - pre[v_]) ? gkeys[(size_t)v_ * RUN + il] : 0ull;
+                const bool real = i < (W - 1) * KT && il < pre[v_ + 1] - pre[v_];
+                src[u] = reinterpret_cast<const unsigned long long*>(gkeys) + (real ? (size_t)v_ * RUN + il : (size_t)0);
+                t[u] = 0ull;
+                need |= real ? 1u << u : 0u;
+            }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (need != 0u) {                                      // (all eight in flight; the ones that have come drop out)
+                unsigned long long wd[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wd[u] = (need >> u) & 1u ? __hip_atomic_load(src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if ((need >> u) & 1u) {
+                        uint64_t k_;
+                        if (team_key_in(wd[u], (uint32_t)e, &k_)) { t[u] = k_; need &= ~(1u << u); }
+                    }
+                if (need != 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.team_ticks) { late = true; break; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (i0 + u * LARGE_NT < (W - 1) * KT) T[i0 + u * LARGE_NT] = t[u];
         }
-        __syncthreads();
+        if (__syncthreads_or(late ? 1 : 0)) {
+            if (!a.status) __builtin_trap();
+            if (tid == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         TEAM_STAMP(5);
         {
             const int mine = min(KT, pre[w + 1] - pre[w]), mine_all = pre[w + 1] - pre[w];
