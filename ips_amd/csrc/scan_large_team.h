@@ -26,8 +26,9 @@
 // them): tools/scan_team_check.py and tests/test_hip_scan_team.py hold the two against each other.
 //
 // A hop = release fence + a counter in the workspace (monotonic within a launch: target = arrivals per iteration x the
-// iteration's number; zeroed by the launch) + acquire fence; where the data is 8-64 words (hops A, C) it rides in the
-// polled word itself (epoch << 32 | value) and there is no fence.  Every wait is bounded: a persistent launch reports
+// iteration's number; zeroed by the launch) + acquire fence (hops B, E); where the data can carry the iteration's number
+// itself - hops A and C: 8-64 words, epoch << 32 | value; hop D: the sorted runs, team_key_out - it is ONE relaxed store
+// per word, polled by its readers, and there is no fence and no counter.  Every wait is bounded: a persistent launch reports
 // through its status word like every resident loop (the recovery launch, always one workgroup per image, redoes the
 // work), a plain launch traps.  Workgroups of a team are neighbours in the grid, so the in-order dispatcher never holds a
 // team's first members on units its last members need.
