@@ -60,8 +60,10 @@ __device__ __forceinline__ bool team_poll(const int* word, int target, unsigned 
 }
 
 // every thread: what it stored before is visible to whoever sees the counter move (all threads call; one barrier)
+// (ONE L2 write-back per workgroup, not sixteen: every wavefront waits until its own stores have reached the L2 - the compute
+//  unit's waves share it -, the barrier collects them, and the first thread's release covers what the barrier collected)
 __device__ __forceinline__ void team_arrive(int* word) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -290,6 +292,7 @@ __device__ __attribute__((noinline)) int team_redo(const LargeArgs& a, long long
         if (wave == 0) {                                                                               \
             const bool ok_ = team_poll((word), (target), a.team_ticks);                               \
             if (lane == 0) wword[site] = ok_ ? 1 : 0;                                                  \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     /* (one invalidate per compute unit, before the barrier) */ \
         }                                                                                              \
         __syncthreads();                                                                               \
         if (!wword[site]) {                                                                            \
@@ -297,7 +300,6 @@ __device__ __attribute__((noinline)) int team_redo(const LargeArgs& a, long long
             if (tid == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
             return;                                                                                    \
         }                                                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                             \
     } while (0)
 
 // CPT = candidates per thread: a workgroup's run is 1024 * CPT slots, the team W = n2 / (1024 * CPT) workgroups.
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
                 //  so the bound here is the team's)
                 if (v >= 0 && need_mem && !team_poll(&ctl[TC_E], W * (e - 1), a.team_ticks)) v = -1;
                 if (lane == 0) wword[1] = v;
+                if (need_rows || need_mem) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
             const int v = wword[1];
@@ -392,7 +395,6 @@ __global__ __launch_bounds__(LARGE_NT) void scan_large_team_kernel(LargeArgs a, 
                 if (tid == 0) __hip_atomic_fetch_or(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
-            if (need_rows || need_mem) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (need_rows) ready_known = v;
             // the iteration before asked for the one-workgroup ranking (torch.topk's order to replay, or the runs' top halves
             // were not enough): the main workgroup redoes it from the runs, the others wait for its memory [hop E2]
