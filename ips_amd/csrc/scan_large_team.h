@@ -25,8 +25,9 @@
 // Same values, same order of every sum, same keys as scan_large_kernel (keys are unique, so ranks are ranks whoever counts
 // them): tools/scan_team_check.py and tests/test_hip_scan_team.py hold the two against each other.
 //
-// A hop = release fence + a counter in the workspace (monotonic within a launch: target = arrivals per iteration x the
-// iteration's number; zeroed by the launch) + acquire fence (hops B, E); where the data can carry the iteration's number
+// A hop = release + a counter in the workspace (monotonic within a launch: target = arrivals per iteration x the iteration's
+// number; zeroed by the launch) + acquire (hops B, E) - ONE L2 write-back and ONE invalidate per workgroup, not one per
+// wavefront: team_arrive, TEAM_WAIT; where the data can carry the iteration's number
 // itself - hops A and C: 8-64 words, epoch << 32 | value; hop D: the sorted runs, team_key_out - it is ONE relaxed store
 // per word, polled by its readers, and there is no fence and no counter.  Every wait is bounded: a persistent launch reports
 // through its status word like every resident loop (the recovery launch, always one workgroup per image, redoes the
