@@ -82,6 +82,18 @@ def test_team_of_workgroups_equals_one_workgroup(B, N, M, I, kind):
         L.ipsx_dbg_scan_team_trunc(1)
 
 
+def test_team_on_random_shapes():
+    """tools/scan_team_check.py fuzz, a short stretch of it: random M, I with 4,096 < M + I <= 16,384, ragged ends, one to
+    six iterations, every kind of logits above - widths 2 / 4 / 8, top halves and whole runs, resumed ranges."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scan_team_check.py"), "fuzz", "40000", "150"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "150 failures" not in out.stdout and ": 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_team_shapes_and_the_workspace_they_need():
     L = hip.lib()
     assert hip.scan_workgroups_per_image(1, 5000, 5000, 8, 1) == 8          # the shipped CAMELYON sizes

@@ -54,7 +54,55 @@ def run(lg, M, I, cut=None):
     return idx.cpu().numpy(), None, tie.cpu().numpy()
 
 
+def fuzz(first, n):
+    """Random shapes beyond the LDS (8 heads, one token), random kinds of logits, every team width and the ranking from whole
+    runs too, against the one-workgroup kernel:  python tools/scan_team_check.py fuzz [first seed] [seeds]"""
+    L = hip.lib()
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + n):
+        g = np.random.default_rng(9000 + seed)
+        while True:
+            M = int(g.integers(1, 9000))
+            I = int(g.integers(1, 9000))
+            if 4096 < M + I <= 16384:
+                break
+        B = int(g.choice([1, 1, 2, 3]))
+        n_iter = int(g.integers(1, 7))
+        N = M + (n_iter - 1) * I + int(g.integers(1, I + 1))                 # a ragged last chunk more often than not
+        kind = [0, 0, 4096, 256, 64, -1, -6, -40, "blocks"][int(g.integers(0, 9))]
+        lg = torch.from_numpy(logits(B, N, kind, seed)).cuda()
+        cut = max(1, n_iter // 2) if n_iter > 1 else None
+        L.ipsx_dbg_scan_team(0)
+        want = run(lg, M, I)
+        line = []
+        for W in (2, 4, 8):
+            for trunc in (1, 0):
+                L.ipsx_dbg_scan_team(W)
+                L.ipsx_dbg_scan_team_trunc(trunc)
+                got = run(lg, M, I)
+                ok = np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.int32), want[1].view(np.int32)) and np.array_equal(got[2], want[2])
+                if ok and cut is not None:
+                    got2 = run(lg, M, I, cut=cut)
+                    ok = np.array_equal(got2[0], want[0]) and np.array_equal(got2[2], want[2])
+                if not ok:
+                    line.append("W=%d trunc=%d" % (W, trunc))
+        if seed - first < 5:
+            L.ipsx_dbg_scan_team(-1)
+            print("seed %d: B %d N %d M %d I %d (%d iterations) kind %s, default team %d" % (
+                seed, B, N, M, I, n_iter, kind, hip.scan_workgroups_per_image(B, M, I, 8, 1)), flush=True)
+        if line:
+            bad += 1
+            print("seed %d (B %d N %d M %d I %d kind %s): DIFFERENT at %s" % (seed, B, N, M, I, kind, ", ".join(line)), flush=True)
+    L.ipsx_dbg_scan_team(-1)
+    L.ipsx_dbg_scan_team_trunc(1)
+    print("team fuzz, seeds %d..%d: %d failures (%.2f s per seed)" % (first, first + n - 1, bad, (time.time() - t0) / max(n, 1)))
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fuzz":
+        return fuzz(int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[3]) if len(sys.argv) > 3 else 100)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     L = hip.lib()
     bad = 0
