@@ -29,6 +29,7 @@ M, I = conf.M, conf.I
 mem = np.arange(M)
 n_iter = math.ceil((N - M) / I)
 inv_adj, maxdisp, surv, sortedok, ninv = [], [], [], 0, []
+heads_same, prev_md = [], None   # round 5's review, item 5: heads whose (max, denominator) did not move
 for it in range(n_iter):
     lo = M + it * I; hi = min(N, lo + I)
     cand = np.concatenate([mem, np.arange(lo, hi)])
@@ -36,6 +37,10 @@ for it in range(n_iter):
     e = np.exp(xl - xl.max(0, keepdims=True)); w = e / e.sum(0, keepdims=True)
     sc = w.mean(1).mean(1)
     ms = sc[:M]
+    md = np.stack([xl.max(0), e.sum(0)])            # (2,H,T): what a memory row's weight depends on beside its own logit
+    if prev_md is not None:
+        heads_same.append(int((md == prev_md).all(0).sum()))
+    prev_md = md
     if it > 0:
         adj = int((ms[:-1] < ms[1:]).sum()); inv_adj.append(adj)
         order = np.argsort(-ms, kind="stable"); rank = np.empty(M, int); rank[order] = np.arange(M)
@@ -47,4 +52,6 @@ for it in range(n_iter):
 print(name, "N", N, "iters", n_iter)
 for nm, a in (("adjacent inversions in carried memory", inv_adj), ("max displacement", maxdisp), ("survivors", surv)):
     a = np.array(a); print("%-40s mean %.1f median %.0f p90 %.0f max %d" % (nm, a.mean(), np.median(a), np.percentile(a, 90), a.max()))
+a = np.array(heads_same); print("(head, token) rows whose (max, denominator) is bit-equal to the previous iteration's: mean %.2f max %d of %d rows, in %d of %d iterations any"
+                              % (a.mean(), a.max(), H * T, int((a > 0).sum()), len(a)))
 print("iterations with carried memory exactly sorted:", sortedok, "of", n_iter - 1)
